@@ -1,0 +1,11 @@
+"""dang_amd -- MI355X-native Gibbs inner loop for the `dang` component-separation sampler.
+
+Only the hot path lives here: HIP kernels + C ABI (csrc/, lib/libdangx.so), the host-side
+mirror of the reference's module API (api.py), pixel sharding / reductions (dist.py) and the
+synthetic-sky generator used by tests and bench.py (synth.py).
+"""
+from . import _lib  # noqa: F401
+from .api import (BandInfo, DangCGGroup, DangComps, DangData, DangParams, DangxError, Engine,  # noqa: F401
+                  compute_chisq, initialize, sample_cg_groups, sample_spectral_parameters, stream_id)
+
+__version__ = "0.1.0"

@@ -1,0 +1,89 @@
+"""Build helpers: compile the HIP library (gfx950), the Fortran binding module and the oracle.
+
+Everything is built IN-TREE (dang_amd/lib/, oracle/) so that the shared objects travel
+with the source snapshot.  hipcc cross-compiles gfx950 without a GPU.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "dang_amd", "csrc")
+LIBDIR = os.path.join(ROOT, "dang_amd", "lib")
+LIB = os.path.join(LIBDIR, "libdangx.so")
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "libdang_oracle.so")
+FORTRAN_DIR = os.path.join(ROOT, "fortran")
+FLANG = "/opt/rocm/lib/llvm/bin/flang"
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd, **kw):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, **kw)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout)
+        raise RuntimeError("command failed: " + " ".join(cmd))
+    return r.stdout
+
+
+def hip_sources():
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(ROOT, "include", "dangx.h")]
+
+
+def build_hip(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> dang_amd/lib/libdangx.so (+ kernel resource report)."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    if not force and not _newer(LIB, hip_sources()):
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
+           "-I" + os.path.join(ROOT, "include"), "-Rpass-analysis=kernel-resource-usage",
+           "-o", LIB, os.path.join(CSRC, "dangx.hip")]
+    out = _run(cmd)
+    with open(os.path.join(LIBDIR, "kernel_resource_usage.txt"), "w") as f:
+        f.write(out)
+    if verbose:
+        print(out)
+    return LIB
+
+
+def build_oracle(force=False):
+    """gcc -> oracle/libdang_oracle.so (the CPU checker; test infrastructure only)."""
+    src = [os.path.join(ORACLE_DIR, "dang_oracle.c"), os.path.join(ORACLE_DIR, "dang_oracle.h")]
+    if not force and not _newer(ORACLE_LIB, src):
+        return ORACLE_LIB
+    _run(["make", "-C", ORACLE_DIR, "-s"])
+    return ORACLE_LIB
+
+
+def build_fortran(force=False):
+    """flang -> fortran/dangx_fsmoke (ISO_C_BINDING module + smoke driver), if flang is present."""
+    if not os.path.exists(FLANG) or not os.path.isdir(FORTRAN_DIR):
+        return None
+    exe = os.path.join(FORTRAN_DIR, "dangx_fsmoke")
+    src = [os.path.join(FORTRAN_DIR, f) for f in ("dangx_mod.f90", "dangx_fsmoke.f90")]
+    if not all(os.path.exists(s) for s in src):
+        return None
+    if not force and not _newer(exe, src + [LIB]):
+        return exe
+    _run([FLANG, "-O2", "-J", FORTRAN_DIR, "-o", exe] + src +
+         ["-L" + LIBDIR, "-ldangx", "-Wl,-rpath," + LIBDIR])
+    return exe
+
+
+def build_all(force=False):
+    build_hip(force)
+    build_oracle(force)
+    build_fortran(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)
+    print("built:", LIB, ORACLE_LIB)

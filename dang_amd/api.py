@@ -1,0 +1,391 @@
+"""Host-side mirror of the reference's module API for the Gibbs inner loop.
+
+The reference is a Fortran program whose hot path is reached through two calls,
+`call sample_cg_groups(dpar, ddata)` (src/dang.f90:101, src/dang_cg_mod.f90:142-177) and
+`call sample_spectral_parameters(dpar, ddata)` (src/dang.f90:106, src/dang_sample_mod.f90:21-86).
+This module keeps those names, argument meanings and the state they read/write
+(`dang_params`, `dang_data`, `dang_comps`, `dang_cg_group`, `bandinfo`), and routes the work
+through the C ABI of libdangx.so (include/dangx.h).  It is the Python twin of
+fortran/dangx_mod.f90 + the wrapper shown in INTEGRATION.md; tests and bench.py use it.
+
+Arrays keep the Fortran memory order, i.e. numpy/torch shape [band][map][pix] for
+sig_map/rms_map, [map][pix] for masks/amplitude and [ind][map][pix] for indices.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from . import _lib as L
+from . import dist as _dist
+
+MISSVAL = -1.6375e30  # src/dang_util_mod.f90:19
+
+
+# --------------------------------------------------------------------------- state types
+
+@dataclass
+class BandInfo:
+    """type bandinfo, src/dang_bp_mod.f90:7-12."""
+    label: str
+    nu_c: float                      # GHz (<1e9) or Hz, src/dang_bp_mod.f90:35-37
+    id: str = "delta"
+    nu0: Optional[np.ndarray] = None  # Hz
+    tau0: Optional[np.ndarray] = None
+
+
+@dataclass
+class DangComps:
+    """type dang_comps, src/dang_component_mod.f90:12-48 (fields the hot path reads/writes)."""
+    label: str
+    type: str                         # 'power-law' | 'mbb' | 'freefree' | 'lognormal' | 'cmb'
+    nu_ref: float                     # GHz (<1e7) or Hz, src/dang_param_mod.f90:571-573
+    cg_group: int = 1
+    sample_amplitude: bool = True
+    nindices: int = 0
+    ind_label: List[str] = field(default_factory=list)
+    sample_index: List[bool] = field(default_factory=list)
+    index_mode: List[int] = field(default_factory=list)      # 2 = per-pixel (the built path)
+    lnl_type: List[str] = field(default_factory=list)        # 'chisq' | 'marginal' | 'prior'
+    prior_type: List[str] = field(default_factory=list)      # 'gaussian' | 'uniform' | 'jeffreys'
+    gauss_prior: List[List[float]] = field(default_factory=list)  # [mean, std]
+    uni_prior: List[List[float]] = field(default_factory=list)    # [low, high]
+    step_size: List[float] = field(default_factory=list)
+    pol_flag: List[List[int]] = field(default_factory=list)  # per index: list of poltype bit flags
+    amplitude: Optional[np.ndarray] = None                   # [nmaps][npix]
+    indices: Optional[np.ndarray] = None                     # [nindices][nmaps][npix]
+
+
+@dataclass
+class DangCGGroup:
+    """type dang_cg_group, src/dang_cg_mod.f90:16-42."""
+    cg_group: int
+    i_max: int = 100
+    converge: float = 1e-8
+    sample: bool = True
+    pol_flag: List[int] = field(default_factory=lambda: [L.FLAG_T])
+
+
+@dataclass
+class DangParams:
+    """The dang_params fields that drive the hot path (src/dang_param_mod.f90:370-400)."""
+    ml_mode: str = "sample"           # ML_MODE
+    nsample: int = 10                 # NUMSAMPLE
+    cg_groups: List[DangCGGroup] = field(default_factory=list)
+    # builder-added knobs (the reference has no seed: RANDOM_SEED() is unseeded, src/dang.f90:67)
+    seed: int = 1234
+    solver: str = "direct"            # 'direct' (MI355X block solve) | 'cg' (reference algorithm on device)
+    fluct_mode: str = "reference"     # 'reference' reproduces compute_sample_vector's quirks | 'correct'
+
+
+@dataclass
+class DangData:
+    """type dang_data, src/dang_data_mod.f90:9-61 (hot-path fields)."""
+    sig_map: object                   # [nbands][nmaps][npix]  numpy (host) or torch cuda tensor
+    rms_map: object
+    masks: object                     # [nmaps][npix]
+    gain: np.ndarray = None
+    offset: np.ndarray = None
+    pol_type: List[int] = field(default_factory=lambda: [1])
+    nump: float = 0.0                 # number of unmasked (pixel, map) entries; an INPUT
+    chisq: float = 0.0
+    engine: object = None
+
+
+def stream_id(it, phase, a=0, b=0, c=0):
+    """64-bit random-stream label: Gibbs iteration, phase (0 amp / 1 index), and up to three small ids."""
+    return ((int(it) & 0xFFFFFFFF) << 32) | ((phase & 0xF) << 28) | ((a & 0xFFF) << 16) | ((b & 0xFF) << 8) | (c & 0xFF)
+
+
+# --------------------------------------------------------------------------- engine
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class DangxError(RuntimeError):
+    pass
+
+
+class Engine:
+    """Owns one dangx context = one pixel shard on one MI355X."""
+
+    def __init__(self, bands, component_list, ddata, npix_global=None, pix0=0, device=-1, stream=None, tcmb=None):
+        self.lib = L.load()
+        self.bands = bands
+        self.component_list = component_list
+        self.ddata = ddata
+        sig = ddata.sig_map
+        nb, nmaps, npix = (int(s) for s in sig.shape)
+        self.npix, self.nmaps, self.nbands, self.ncomp = npix, nmaps, nb, len(component_list)
+        self.pix0 = int(pix0)
+        self.npix_global = int(npix_global if npix_global is not None else npix)
+        self._keep = []
+        dims = L.Dims(npix, nmaps, nb, self.ncomp, self.pix0, self.npix_global, device, 0)
+        h = C.c_void_p()
+        rc = self.lib.dangx_create(C.byref(h), C.byref(dims))
+        if rc != 0:
+            raise DangxError("dangx_create failed with status %d (3 = no HIP device: the product path has no CPU fallback)" % rc)
+        self.h = h
+        if stream is not None:
+            self._chk(self.lib.dangx_set_stream(self.h, C.c_void_p(stream)))
+        for j, b in enumerate(bands):
+            if b.id == "delta" or b.nu0 is None:
+                self._chk(self.lib.dangx_set_band(self.h, j, float(b.nu_c), 0, None, None))
+            else:
+                nu0 = np.ascontiguousarray(b.nu0, dtype=np.float64)
+                tau0 = np.ascontiguousarray(b.tau0, dtype=np.float64)
+                self._chk(self.lib.dangx_set_band(self.h, j, float(b.nu_c), len(nu0), nu0.ctypes.data, tau0.ctypes.data))
+        if tcmb is not None:
+            self._chk(self.lib.dangx_set_tcmb(self.h, float(tcmb)))
+        for l, c in enumerate(component_list):
+            self._chk(self.lib.dangx_set_component(self.h, l, C.byref(comp_desc(c))))
+        gain = np.ones(nb) if ddata.gain is None else np.ascontiguousarray(ddata.gain, dtype=np.float64)
+        off = np.zeros(nb) if ddata.offset is None else np.ascontiguousarray(ddata.offset, dtype=np.float64)
+        self._chk(self.lib.dangx_set_calibration(self.h, gain.ctypes.data, off.ctypes.data))
+        if _is_torch(sig):
+            for t in (ddata.sig_map, ddata.rms_map, ddata.masks):
+                assert t.is_cuda and t.is_contiguous() and t.dtype.is_floating_point and t.element_size() == 8
+            self._keep += [ddata.sig_map, ddata.rms_map, ddata.masks]
+            self._chk(self.lib.dangx_adopt_device_data(self.h, ddata.sig_map.data_ptr(), ddata.rms_map.data_ptr(),
+                                                       ddata.masks.data_ptr()))
+        else:
+            s, r, m = (np.ascontiguousarray(a, dtype=np.float64) for a in (ddata.sig_map, ddata.rms_map, ddata.masks))
+            self._chk(self.lib.dangx_upload_data(self.h, s.ctypes.data, r.ctypes.data, m.ctypes.data))
+        self._adopted = {}
+        for l, c in enumerate(component_list):
+            if c.amplitude is not None and _is_torch(c.amplitude) and c.amplitude.is_cuda:
+                # torch owns the HBM buffers; the library works on them in place
+                amp = c.amplitude
+                idx = c.indices if c.nindices > 0 else None
+                assert amp.is_contiguous() and tuple(amp.shape) == (nmaps, npix) and amp.element_size() == 8
+                if idx is not None:
+                    assert idx.is_cuda and idx.is_contiguous() and tuple(idx.shape) == (c.nindices, nmaps, npix)
+                self._adopted[l] = (amp, idx)
+                self._chk(self.lib.dangx_adopt_device_state(self.h, l, amp.data_ptr(),
+                                                            idx.data_ptr() if idx is not None else None))
+                continue
+            if c.amplitude is not None:
+                self.put_amplitude(l, c.amplitude)
+            if c.nindices > 0 and c.indices is not None:
+                self.put_indices(l, c.indices)
+
+    # -- plumbing
+    def _chk(self, rc):
+        if rc != 0:
+            raise DangxError(self.lib.dangx_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dangx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._chk(self.lib.dangx_synchronize(self.h))
+
+    def put_amplitude(self, l, a):
+        if _is_torch(a):
+            a = a.cpu().numpy()
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.shape == (self.nmaps, self.npix)
+        self._chk(self.lib.dangx_put_amplitude(self.h, l, a.ctypes.data))
+
+    def get_amplitude(self, l):
+        if l in self._adopted:
+            self.synchronize()
+            return self._adopted[l][0].cpu().numpy()
+        a = np.empty((self.nmaps, self.npix))
+        self._chk(self.lib.dangx_get_amplitude(self.h, l, a.ctypes.data))
+        return a
+
+    def put_indices(self, l, x):
+        if _is_torch(x):
+            x = x.cpu().numpy()
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.shape == (self.component_list[l].nindices, self.nmaps, self.npix)
+        self._chk(self.lib.dangx_put_indices(self.h, l, x.ctypes.data))
+
+    def get_indices(self, l):
+        if l in self._adopted:
+            self.synchronize()
+            return self._adopted[l][1].cpu().numpy()
+        x = np.empty((self.component_list[l].nindices, self.nmaps, self.npix))
+        self._chk(self.lib.dangx_get_indices(self.h, l, x.ctypes.data))
+        return x
+
+    def pull_state(self):
+        """Copy the resident amplitude / index maps back into component_list (before output)."""
+        for l, c in enumerate(self.component_list):
+            c.amplitude = self.get_amplitude(l)
+            if c.nindices > 0:
+                c.indices = self.get_indices(l)
+
+    # -- hot path
+    def amp_sample(self, group, flag, ml_mode, seed, stream, solver="direct", fluct_mode="reference",
+                   i_max=100, converge=1e-8, want_counts=True):
+        it, bad = C.c_int(0), C.c_int64(0)
+        self._chk(self.lib.dangx_amp_sample(
+            self.h, group, flag, L.ML_CODES[ml_mode], L.SOLVER_CG if solver == "cg" else L.SOLVER_DIRECT,
+            L.FLUCT_REFERENCE if fluct_mode == "reference" else L.FLUCT_CORRECT, seed, stream, i_max, converge,
+            C.byref(it) if want_counts else None, C.byref(bad) if want_counts else None))
+        return it.value, bad.value
+
+    def index_sample(self, comp, nind, map_n, nsample, ml_mode, seed, stream, want_counts=True):
+        acc = C.c_int64(0)
+        self._chk(self.lib.dangx_index_sample(self.h, comp, nind, map_n, nsample, L.ML_CODES[ml_mode], seed, stream,
+                                              C.byref(acc) if want_counts else None))
+        return acc.value
+
+    def sky_model_chisq(self, pol_lo, pol_hi, want_maps=False):
+        s = C.c_double(0.0)
+        if want_maps:
+            sky = np.empty((self.nbands, self.nmaps, self.npix))
+            res = np.empty_like(sky)
+            chi = np.empty((self.nmaps, self.npix))
+            self._chk(self.lib.dangx_sky_model_chisq(self.h, pol_lo, pol_hi, C.byref(s), sky.ctypes.data,
+                                                     res.ctypes.data, chi.ctypes.data))
+            return s.value, sky, res, chi
+        self._chk(self.lib.dangx_sky_model_chisq(self.h, pol_lo, pol_hi, C.byref(s), None, None, None))
+        return s.value
+
+    def sky_model_chisq_dev(self, pol_lo, pol_hi, out_tensor):
+        """Asynchronous local chi^2 sum into a 1-element cuda fp64 tensor (for the RCCL all-reduce)."""
+        self._chk(self.lib.dangx_sky_model_chisq_dev(self.h, pol_lo, pol_hi, out_tensor.data_ptr()))
+
+    # -- secondary seams
+    def group_size(self, group, flag):
+        n = self.lib.dangx_group_size(self.h, group, flag)
+        if n < 0:
+            raise DangxError(self.lib.dangx_last_error(self.h).decode())
+        return n
+
+    def compute_rhs(self, group, flag):
+        b = np.empty(self.group_size(group, flag))
+        self._chk(self.lib.dangx_compute_rhs(self.h, group, flag, b.ctypes.data))
+        return b
+
+    def compute_Ax(self, group, flag, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        res = np.empty_like(x)
+        assert x.size == self.group_size(group, flag)
+        self._chk(self.lib.dangx_compute_Ax(self.h, group, flag, x.ctypes.data, res.ctypes.data))
+        return res
+
+    def compute_sample_vector(self, group, flag, eta):
+        eta = np.ascontiguousarray(eta, dtype=np.float64)
+        res = np.empty(self.group_size(group, flag))
+        assert eta.size == (2 if flag == L.FLAG_QU else 1) * self.npix
+        self._chk(self.lib.dangx_compute_sample_vector(self.h, group, flag, eta.ctypes.data, res.ctypes.data))
+        return res
+
+    def eval_sed(self, comp, band, map_n):
+        out = np.empty(self.npix)
+        self._chk(self.lib.dangx_eval_sed(self.h, comp, band, map_n, out.ctypes.data))
+        return out
+
+    # -- profiling
+    def profile(self, on=True):
+        self._chk(self.lib.dangx_profile_enable(self.h, 1 if on else 0))
+        self._chk(self.lib.dangx_profile_reset(self.h))
+
+    def profile_get(self):
+        out = {}
+        for kid, name in L.KERNEL_NAMES.items():
+            ms, n = C.c_double(0.0), C.c_int64(0)
+            self._chk(self.lib.dangx_profile_get(self.h, kid, C.byref(ms), C.byref(n)))
+            if n.value:
+                out[name] = {"total_ms": ms.value, "launches": n.value, "avg_ms": ms.value / n.value}
+        return out
+
+
+def comp_desc(c: DangComps):
+    d = L.CompDesc()
+    if c.type not in L.TYPE_CODES:
+        raise DangxError("Error - unrecognized component type '%s' (template/monopole/hi_fit/T_cmb: not built)" % c.type)
+    d.type = L.TYPE_CODES[c.type]
+    d.is_synch = 1 if c.label.strip() == "synch" else 0
+    d.nindices = c.nindices
+    d.cg_group = c.cg_group
+    d.sample_amplitude = 1 if c.sample_amplitude else 0
+    d.nu_ref = float(c.nu_ref)
+    for q in range(c.nindices):
+        d.lnl_type[q] = L.LNL_CODES[c.lnl_type[q]] if q < len(c.lnl_type) else L.LNL_CHISQ
+        d.prior_type[q] = L.PRIOR_CODES[c.prior_type[q]] if q < len(c.prior_type) else L.PRIOR_UNIFORM
+        gp = c.gauss_prior[q] if q < len(c.gauss_prior) else [0.0, 1.0]
+        up = c.uni_prior[q] if q < len(c.uni_prior) else [-1e300, 1e300]
+        d.gauss_prior[q][0], d.gauss_prior[q][1] = gp
+        d.uni_prior[q][0], d.uni_prior[q][1] = up
+        d.step_size[q] = c.step_size[q] if q < len(c.step_size) else 0.0
+    return d
+
+
+# --------------------------------------------------------------------------- the two entry points
+
+def initialize(bands, component_list, ddata, **kw):
+    """What the driver does once after src/dang.f90:73: hand the static state to the device."""
+    ddata.engine = Engine(bands, component_list, ddata, **kw)
+    return ddata.engine
+
+
+def compute_chisq(ddata):
+    """update_sky_model + compute_chisq (src/dang_data_mod.f90:339-396, 494-526); all-reduced over shards."""
+    eng = ddata.engine
+    s = eng.sky_model_chisq(ddata.pol_type[0], ddata.pol_type[-1])
+    s = _dist.allreduce_sum_float(s)
+    ddata.chisq = s / eng.nbands / ddata.nump
+    return ddata.chisq
+
+
+def sample_cg_groups(dpar: DangParams, ddata: DangData, it=1, verbose=False):
+    """sample_cg_groups(dpar, ddata), src/dang_cg_mod.f90:142-177."""
+    eng = ddata.engine
+    info = []
+    for g in dpar.cg_groups:
+        if not g.sample:
+            continue
+        for f in g.pol_flag:
+            cg_it, bad = eng.amp_sample(g.cg_group, f, dpar.ml_mode, dpar.seed, stream_id(it, 0, g.cg_group, 0, f),
+                                        solver=dpar.solver, fluct_mode=dpar.fluct_mode, i_max=g.i_max,
+                                        converge=g.converge)
+            info.append((g.cg_group, f, cg_it, bad))
+        compute_chisq(ddata)  # update_sky_model + write_stats_to_term, :172-173
+        if verbose:
+            print("%6d - Chisq: %16.5E" % (it, ddata.chisq))
+    return info
+
+
+_MAPN = {L.FLAG_T: 1, L.FLAG_Q: 2, L.FLAG_U: 3, L.FLAG_QU: -1}  # src/dang_sample_mod.f90:53-64
+
+
+def sample_spectral_parameters(dpar: DangParams, ddata: DangData, it=2, verbose=False):
+    """sample_spectral_parameters(dpar, ddata), src/dang_sample_mod.f90:21-86 (per-pixel index_mode)."""
+    eng = ddata.engine
+    sampled = False
+    info = []
+    for l, c in enumerate(eng.component_list):
+        if c.nindices == 0 or not any(c.sample_index):
+            continue
+        sampled = True
+        for j in range(c.nindices):
+            if not c.sample_index[j]:
+                continue
+            if c.index_mode and c.index_mode[j] != 2:
+                raise DangxError("index_mode 1 (full-sky) is not built yet (SURVEY 8f rank 2)")
+            for f in c.pol_flag[j]:
+                if f not in _MAPN:
+                    raise DangxError("There is something wrong with the poltype flag for component " + c.label)
+                acc = eng.index_sample(l, j, _MAPN[f], dpar.nsample, dpar.ml_mode, dpar.seed,
+                                       stream_id(it, 1, l, j, f))
+                info.append((l, j, f, acc))
+    if sampled:
+        compute_chisq(ddata)  # :81-84
+        if verbose:
+            print("%6d - Chisq: %16.5E" % (it, ddata.chisq))
+    return info

@@ -1,0 +1,1318 @@
+// dangx.hip -- libdangx.so: hand-written HIP (gfx950 / CDNA4) kernels for dang's
+// Gibbs inner loop and the C ABI declared in include/dangx.h.
+//
+// Design: one thread owns one (pixel, Stokes plane) unit -- the
+// reference's global CG system is block diagonal for diffuse components, so the
+// amplitude phase is a single streaming pass (mixing rows -> normal equations ->
+// Cholesky) and the index phase a single pass with the Metropolis chain held in
+// LDS/registers.  All map arrays are pixel-major, so a wavefront's 64 lanes read 64
+// consecutive doubles (512 B) per load.  Everything is fp64.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dangx.h"
+#include "dx_model.h"
+#include "dx_rng.h"
+#include "dx_sed.h"
+
+using namespace dx;
+
+// ======================================================================= kernels
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+struct GroupArgs {
+    int ng;          // sampled diffuse components of the group
+    int gc[MAXG];    // their component indices, in component_list order
+    int no;          // components NOT solved for (removed from the data)
+    int oc[MAXC];
+    int flag;        // one poltype bit
+    int ml_mode, fluct;
+    unsigned long long seed, stream;
+};
+
+__device__ __forceinline__ int flag_nplanes(int flag) { return (flag & DANGX_FLAG_QU) ? 2 : 1; }
+// src/dang_cg_mod.f90:357-363 and the flag-8 branches (:488-494): plane p -> map number
+__device__ __forceinline__ int flag_map(int flag, int p) {
+    if (flag & DANGX_FLAG_QU) return 2 + p;
+    if (flag & DANGX_FLAG_T) return 1;
+    if (flag & DANGX_FLAG_Q) return 2;
+    return 3;
+}
+
+// data(i,k,j) of compute_rhs (src/dang_cg_mod.f90:367-378, 427-443): the band map with
+// every component that is not solved for removed.  Zero-amplitude components are
+// skipped (0*sed; differs from the reference only if that sed is not finite).
+__device__ __forceinline__ double rhs_data(const Model& M, const GroupArgs& a, int i, int k, int j) {
+    double d = M.sig[((long long)j * M.nmaps + (k - 1)) * M.npix + i];
+    if (k == 1) d = d / M.gain[j];
+    for (int o = 0; o < a.no; ++o) {
+        const Comp& c = M.comp[a.oc[o]];
+        const double amp = c.amp[(long long)(k - 1) * M.npix + i];
+        if (amp != 0.0) {
+            double t0, t1;
+            load_theta(M, c, i, k, t0, t1);
+            d = d - amp * sed_eval(M, c, j, sed_prep(c, t0, t1));
+        }
+    }
+    return d;
+}
+
+// ---------------------------------------------------------------------------
+// Amplitude phase, direct solve.  Replaces compute_rhs + cg_search (compute_Ax,
+// compute_sample_vector) + unpack_amplitudes (src/dang_cg_mod.f90:166-171) for
+// groups of diffuse components: every term of compute_Ax couples only index i
+// (:697-704, :813-820), so A^t N^-1 A is one NG x NG SPD block per (pixel, plane).
+// Per unit: stream the nb bands once, accumulate the lower triangle of the block
+// and the right-hand side in registers, Cholesky, two triangular solves, store.
+template <int NG>
+__global__ __launch_bounds__(BLOCK) void k_amp_direct(const Model* __restrict__ Mp, GroupArgs a,
+                                                      unsigned long long* __restrict__ not_spd) {
+    const Model& M = *Mp;
+    const int npix = M.npix;
+    const long long u = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (u >= (long long)flag_nplanes(a.flag) * npix) return;
+    const int p = (int)(u / npix);
+    const int i = (int)(u - (long long)p * npix);
+    const int k = flag_map(a.flag, p);
+    if (is_masked(M.mask[i])) return;  // masked rows/cols are zero: x keeps its value (:695)
+
+    Prep pr[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const Comp& c = M.comp[a.gc[g]];
+        double t0, t1;
+        load_theta(M, c, i, k, t0, t1);
+        pr[g] = sed_prep(c, t0, t1);
+    }
+    double A[NG * (NG + 1) / 2], bv[NG], mrow[NG];
+#pragma unroll
+    for (int q = 0; q < NG * (NG + 1) / 2; ++q) A[q] = 0.0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) bv[g] = 0.0;
+
+    const bool sample = (a.ml_mode == DANGX_ML_SAMPLE);
+    const unsigned long long gpix = (unsigned long long)(M.pix0 + i);
+    double eta = 0.0, f0 = 0.0;
+    if (sample && a.fluct == DANGX_FLUCT_REFERENCE) {
+        double u1, u2;
+        uniform2(a.seed, a.stream, gpix, (uint32_t)k, u1, u2);
+        eta = rand_normal(0.0, 1.0, u1, u2);  // eta(i), :258-260: ONE draw per unit, reused per band
+    }
+    for (int j = 0; j < M.nbands; ++j) {
+        const double d = rhs_data(M, a, i, k, j);
+        const double is = 1.0 / M.rms[((long long)j * M.nmaps + (k - 1)) * npix + i];
+        const double inv = is * is;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) mrow[g] = sed_eval(M, M.comp[a.gc[g]], j, pr[g]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const double t = mrow[g] * inv;
+            bv[g] += d * t;  // b = T^t N^-1 d, :489-508
+#pragma unroll
+            for (int h = 0; h <= g; ++h) A[g * (g + 1) / 2 + h] += t * mrow[h];  // T^t N^-1 T
+        }
+        if (sample) {
+            if (a.fluct == DANGX_FLUCT_REFERENCE) {
+                // :1033-1040 '=' without component offset: only slot 0 receives the term,
+                // holding the LAST component's SED product
+                f0 += (eta * is) * mrow[NG - 1];
+            } else {
+                double u1, u2;
+                uniform2(a.seed, a.stream, gpix, (uint32_t)(k + 4 * (j + 1)), u1, u2);
+                const double ej = rand_normal(0.0, 1.0, u1, u2) * is;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) bv[g] += ej * mrow[g];
+            }
+        }
+    }
+    bv[0] += f0;
+
+    // Cholesky A = L L^t in place (packed lower triangle)
+    bool ok = true;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int h = 0; h <= g; ++h) {
+            double s = A[g * (g + 1) / 2 + h];
+#pragma unroll
+            for (int t = 0; t < h; ++t) s -= A[g * (g + 1) / 2 + t] * A[h * (h + 1) / 2 + t];
+            if (h == g) {
+                if (!(s > 0.0)) ok = false;
+                A[g * (g + 1) / 2 + g] = sqrt(s);
+            } else {
+                A[g * (g + 1) / 2 + h] = s / A[h * (h + 1) / 2 + h];
+            }
+        }
+    }
+    if (!ok) {
+        atomicAdd(not_spd, 1ull);
+        return;
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        double s = bv[g];
+#pragma unroll
+        for (int t = 0; t < g; ++t) s -= A[g * (g + 1) / 2 + t] * bv[t];
+        bv[g] = s / A[g * (g + 1) / 2 + g];
+    }
+#pragma unroll
+    for (int g = NG - 1; g >= 0; --g) {
+        double s = bv[g];
+#pragma unroll
+        for (int t = g + 1; t < NG; ++t) s -= A[t * (t + 1) / 2 + g] * bv[t];
+        bv[g] = s / A[g * (g + 1) / 2 + g];
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) M.comp[a.gc[g]].amp[(long long)(k - 1) * npix + i] = bv[g];  // unpack, :1327-1354
+}
+
+// ---------------------------------------------------------------------------
+// Secondary seams on the reference's packed vectors (device CG = parity mode).
+// Packing (src/dang_cg_mod.f90:1216-1243): x = [c1: plane0(npix), plane1(npix) | c2: ...],
+// so element (comp g, unit u) is x[g*S*npix + u] with u = p*npix + i.
+
+// compute_rhs, src/dang_cg_mod.f90:326-596 (diffuse branch)
+template <int NG>
+__global__ __launch_bounds__(BLOCK) void k_rhs(const Model* __restrict__ Mp, GroupArgs a, double* __restrict__ b) {
+    const Model& M = *Mp;
+    const int npix = M.npix;
+    const long long SN = (long long)flag_nplanes(a.flag) * npix;
+    const long long u = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (u >= SN) return;
+    const int p = (int)(u / npix), i = (int)(u - (long long)p * npix), k = flag_map(a.flag, p);
+    double acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = 0.0;
+    if (M.mask[i] != 0.0) {  // :474 tests ==0 only
+        const bool removed = !is_masked(M.mask[i]);  // :434 other components are removed only off-mask
+        Prep pr[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            double t0, t1;
+            load_theta(M, M.comp[a.gc[g]], i, k, t0, t1);
+            pr[g] = sed_prep(M.comp[a.gc[g]], t0, t1);
+        }
+        for (int j = 0; j < M.nbands; ++j) {
+            double d;
+            if (removed) d = rhs_data(M, a, i, k, j);
+            else {
+                d = M.sig[((long long)j * M.nmaps + (k - 1)) * npix + i];
+                if (k == 1) d = d / M.gain[j];
+            }
+            const double rms = M.rms[((long long)j * M.nmaps + (k - 1)) * npix + i];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g] = acc[g] + (d * sed_eval(M, M.comp[a.gc[g]], j, pr[g])) / (rms * rms);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) b[(long long)g * SN + u] = acc[g];
+}
+
+// compute_Ax, src/dang_cg_mod.f90:598-911 (diffuse branch), same operation order per unit:
+// temp1 = sum_c x_c*sed_c ; temp1 /= rms**2 ; res_c += temp1*sed_c, band by band.
+// Also returns the block-local partial of dot(x, res) for cg_search's sum(d*q) (:297).
+template <int NG>
+__global__ __launch_bounds__(BLOCK) void k_Ax(const Model* __restrict__ Mp, GroupArgs a, const double* __restrict__ x,
+                                              double* __restrict__ res, double* __restrict__ dot_partial) {
+    const Model& M = *Mp;
+    const int npix = M.npix;
+    const long long SN = (long long)flag_nplanes(a.flag) * npix;
+    const long long u = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    double dotv = 0.0;
+    if (u < SN) {
+        const int p = (int)(u / npix), i = (int)(u - (long long)p * npix), k = flag_map(a.flag, p);
+        double acc[NG], xv[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { acc[g] = 0.0; xv[g] = x[(long long)g * SN + u]; }
+        if (!is_masked(M.mask[i])) {
+            Prep pr[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                double t0, t1;
+                load_theta(M, M.comp[a.gc[g]], i, k, t0, t1);
+                pr[g] = sed_prep(M.comp[a.gc[g]], t0, t1);
+            }
+            for (int j = 0; j < M.nbands; ++j) {
+                double mrow[NG], temp1 = 0.0;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    mrow[g] = sed_eval(M, M.comp[a.gc[g]], j, pr[g]);
+                    temp1 = temp1 + xv[g] * mrow[g];
+                }
+                const double rms = M.rms[((long long)j * M.nmaps + (k - 1)) * npix + i];
+                temp1 = temp1 / (rms * rms);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = acc[g] + temp1 * mrow[g];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            res[(long long)g * SN + u] = acc[g];
+            dotv += xv[g] * acc[g];
+        }
+    }
+    if (dot_partial) {
+        __shared__ double sh[BLOCK / 64];
+        for (int o = 32; o > 0; o >>= 1) dotv += __shfl_down(dotv, o, 64);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = dotv;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = 0.0;
+            for (int w = 0; w < BLOCK / 64; ++w) s += sh[w];
+            dot_partial[blockIdx.x] = s;
+        }
+    }
+}
+
+// compute_sample_vector, src/dang_cg_mod.f90:913-1100 (diffuse branch, with its quirks)
+template <int NG>
+__global__ __launch_bounds__(BLOCK) void k_sample_vector(const Model* __restrict__ Mp, GroupArgs a,
+                                                         const double* __restrict__ eta, double* __restrict__ res) {
+    const Model& M = *Mp;
+    const int npix = M.npix;
+    const long long SN = (long long)flag_nplanes(a.flag) * npix;
+    const long long u = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (u >= SN) return;
+    const int p = (int)(u / npix), i = (int)(u - (long long)p * npix), k = flag_map(a.flag, p);
+    double acc = 0.0;
+    if (!is_masked(M.mask[i])) {
+        const Comp& c = M.comp[a.gc[NG - 1]];
+        double t0, t1;
+        load_theta(M, c, i, k, t0, t1);
+        const Prep pr = sed_prep(c, t0, t1);
+        const double e = eta[u];
+        for (int j = 0; j < M.nbands; ++j) {
+            const double temp1 = e / M.rms[((long long)j * M.nmaps + (k - 1)) * npix + i];
+            acc = acc + temp1 * sed_eval(M, c, j, pr);
+        }
+    }
+    res[u] = acc;
+#pragma unroll
+    for (int g = 1; g < NG; ++g) res[(long long)g * SN + u] = 0.0;
+}
+
+// eta(i) = rand_normal(0,1), src/dang_cg_mod.f90:256-262, from the keyed stream
+__global__ __launch_bounds__(BLOCK) void k_draw_eta(const Model* __restrict__ Mp, GroupArgs a, double* __restrict__ eta) {
+    const Model& M = *Mp;
+    const long long SN = (long long)flag_nplanes(a.flag) * M.npix;
+    const long long u = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (u >= SN) return;
+    const int p = (int)(u / M.npix), i = (int)(u - (long long)p * M.npix), k = flag_map(a.flag, p);
+    double u1, u2;
+    uniform2(a.seed, a.stream, (unsigned long long)(M.pix0 + i), (uint32_t)k, u1, u2);
+    eta[u] = rand_normal(0.0, 1.0, u1, u2);
+}
+
+// pack / unpack between c%amplitude and x (initialize_x :1173-1282, unpack_amplitudes :1284-1396)
+__global__ __launch_bounds__(BLOCK) void k_pack(const Model* __restrict__ Mp, GroupArgs a, double* __restrict__ x, int unpack) {
+    const Model& M = *Mp;
+    const long long SN = (long long)flag_nplanes(a.flag) * M.npix;
+    const long long u = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (u >= SN) return;
+    const int p = (int)(u / M.npix), i = (int)(u - (long long)p * M.npix), k = flag_map(a.flag, p);
+    for (int g = 0; g < a.ng; ++g) {
+        double* amp = M.comp[a.gc[g]].amp + (long long)(k - 1) * M.npix + i;
+        if (unpack) *amp = x[(long long)g * SN + u];
+        else x[(long long)g * SN + u] = *amp;
+    }
+}
+
+// CG vector updates (src/dang_cg_mod.f90:283-305) with block partials of sum(r*r)
+//  mode 0: r = b2 - q ; d = r                        -> partial sum(r*r)
+//  mode 1: x += alpha*d ; r -= alpha*q               -> partial sum(r*r)
+//  mode 2: d = r + beta*d
+//  mode 3: b2 = b + f
+__global__ __launch_bounds__(BLOCK) void k_cg_vec(int mode, long long n, double alpha, double* __restrict__ x,
+                                                  double* __restrict__ r, double* __restrict__ d,
+                                                  const double* __restrict__ q, const double* __restrict__ b2,
+                                                  double* __restrict__ partial) {
+    const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    double rr = 0.0;
+    if (t < n) {
+        if (mode == 0) {
+            const double rv = b2[t] - q[t];
+            r[t] = rv; d[t] = rv; rr = rv * rv;
+        } else if (mode == 1) {
+            x[t] = x[t] + alpha * d[t];
+            const double rv = r[t] - alpha * q[t];
+            r[t] = rv; rr = rv * rv;
+        } else if (mode == 2) {
+            d[t] = r[t] + alpha * d[t];
+        } else {
+            x[t] = b2[t] + q[t];
+        }
+    }
+    if (partial) {
+        __shared__ double sh[BLOCK / 64];
+        for (int o = 32; o > 0; o >>= 1) rr += __shfl_down(rr, o, 64);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = rr;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = 0.0;
+            for (int w = 0; w < BLOCK / 64; ++w) s += sh[w];
+            partial[blockIdx.x] = s;
+        }
+    }
+}
+
+// deterministic second stage: out[0] = sum(partial[0..n)) in a fixed order
+__global__ __launch_bounds__(BLOCK) void k_reduce(const double* __restrict__ partial, long long n, double* __restrict__ out) {
+    __shared__ double sh[BLOCK];
+    double s = 0.0;
+    for (long long t = threadIdx.x; t < n; t += BLOCK) s += partial[t];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = BLOCK / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+// ---------------------------------------------------------------------------
+// Index phase: sample_index_mh, per-pixel branch (src/dang_sample_mod.f90:332-481) with
+// update_sample_model (:548-553), evaluate_lnL / evaluate_marginal_lnL
+// (src/dang_lnl_mod.f90:126-182, 47-124) and the priors (:394-400) fused.
+// One thread per pixel.  The pixel's cleaned data d(k,j) and 1/rms(k,j) are staged once
+// into LDS columns [slot][thread] (conflict-free: lane l touches bank pair 2l), the
+// chain state lives in registers, and the index map is written once at the end.
+struct IndexArgs {
+    int comp, nind, s1, s2, nsample, ml_mode;
+    unsigned long long seed, stream;
+};
+
+__device__ __forceinline__ double index_prior(const Model& M, const Comp& c, const IndexArgs& a, int i, double val,
+                                              const double* amp, const double* lds_is, int BS, int tid) {
+    const int t = c.prior_type[a.nind];
+    if (t == DANGX_PRIOR_GAUSSIAN) {  // eval_normal_prior, src/dang_util_mod.f90:112-121
+        const double mean = c.gauss[a.nind][0], std = c.gauss[a.nind][1];
+        const double var = std * std;
+        const double num = exp(-((val - mean) * (val - mean)) / (2 * var));
+        const double denom = std * sqrt(2.0 * PI);
+        return log(num / denom);
+    }
+    if (t == DANGX_PRIOR_JEFFREYS) {  // eval_jeffreys_prior, src/dang_lnl_mod.f90:242-304
+        double sum = 0.0;
+        if (c.is_synch) {
+            const Prep pr = sed_prep(c, val, 0.0);
+            const int Sp = a.s2 - a.s1 + 1;
+            for (int kk = 0; kk < Sp; ++kk)
+                for (int j = 0; j < M.nbands; ++j) {
+                    const double ss = amp[kk] * sed_eval(M, c, j, pr);
+                    const double rr = lds_is[((Sp + kk) * M.nbands + j) * BS + tid];  // 1/rms
+                    const double tt = (rr * rr) * (ss / amp[kk]) * c.lnr[j];
+                    sum = sum + tt * tt;
+                }
+        }
+        return log(sqrt(sum));
+    }
+    return 0.0;
+}
+
+__global__ void k_index_mh(const Model* __restrict__ Mp, IndexArgs a, unsigned long long* __restrict__ accepted) {
+    extern __shared__ double lds[];
+    const Model& M = *Mp;
+    const int BS = blockDim.x, tid = threadIdx.x;
+    const int npix = M.npix, nb = M.nbands;
+    const int i = blockIdx.x * BS + tid;
+    if (i >= npix) return;
+    const Comp& c = M.comp[a.comp];
+    const int Sp = a.s2 - a.s1 + 1;
+    double* out = c.idx + ((long long)a.nind * M.nmaps) * npix + i;
+    if (is_masked(M.mask[i])) {  // :362 cycle; index_map stays 0 (:223) and is copied back (:480-483)
+        for (int k = a.s1; k <= a.s2; ++k) out[(long long)(k - 1) * npix] = 0.0;
+        return;
+    }
+    // --- stage data_raw minus every OTHER component (:173-196) and 1/rms
+    double amp[2] = {0.0, 0.0};
+    for (int kk = 0; kk < Sp; ++kk) {
+        const int k = a.s1 + kk;
+        amp[kk] = c.amp[(long long)(k - 1) * npix + i];
+        for (int j = 0; j < nb; ++j) {
+            double d = M.sig[((long long)j * M.nmaps + (k - 1)) * npix + i];
+            if (k == 1) d = (d - M.offset[j]) / M.gain[j];
+            lds[(kk * nb + j) * BS + tid] = d;
+            lds[((Sp + kk) * nb + j) * BS + tid] = 1.0 / M.rms[((long long)j * M.nmaps + (k - 1)) * npix + i];
+        }
+        for (int l = 0; l < M.ncomp; ++l) {
+            if (l == a.comp) continue;
+            const Comp& c2 = M.comp[l];
+            const double a2 = c2.amp[(long long)(k - 1) * npix + i];
+            if (a2 == 0.0) continue;  // 0*sed
+            double t0, t1;
+            load_theta(M, c2, i, k, t0, t1);
+            const Prep pr = sed_prep(c2, t0, t1);
+            for (int j = 0; j < nb; ++j) lds[(kk * nb + j) * BS + tid] -= a2 * sed_eval(M, c2, j, pr);
+        }
+    }
+    // --- chain state: sample(l) = c%indices(i, map_inds(1), l)  (:372-377)
+    double sample[2], theta[2];
+    load_theta(M, c, i, a.s1, sample[0], sample[1]);
+    theta[0] = sample[0]; theta[1] = sample[1];
+    const int lnl_type = c.lnl_type[a.nind];
+    const bool unmasked_lnl = true;  // evaluate_lnL tests mask(i) again (:171): already unmasked here
+
+    auto lnl_of = [&](const double th[2]) -> double {
+        if (lnl_type == DANGX_LNL_PRIOR) return 0.0;
+        const Prep pr = sed_prep(c, th[0], th[1]);
+        if (lnl_type == DANGX_LNL_CHISQ) {  // -0.5*sum ((d-m)/rms)^2, one accumulator per plane
+            double acc0 = 0.0, acc1 = 0.0;
+            for (int j = 0; j < nb; ++j) {
+                const double s = sed_eval(M, c, j, pr);
+                const double t = (lds[j * BS + tid] - amp[0] * s) * lds[(Sp * nb + j) * BS + tid];
+                acc0 = acc0 - 0.5 * (t * t);
+                if (Sp == 2) {
+                    const double t2 = (lds[(nb + j) * BS + tid] - amp[1] * s) * lds[((Sp + 1) * nb + j) * BS + tid];
+                    acc1 = acc1 - 0.5 * (t2 * t2);
+                }
+            }
+            return unmasked_lnl ? acc0 + acc1 : 0.0;
+        }
+        double lnL = 0.0;  // marginal: -0.5*TNd*invTNT*TNd per (band, plane), src/dang_lnl_mod.f90:113-122
+        for (int j = 0; j < nb; ++j) {
+            const double s = sed_eval(M, c, j, pr);
+            for (int kk = 0; kk < Sp; ++kk) {
+                const double m = amp[kk] * s;
+                const double is = lds[((Sp + kk) * nb + j) * BS + tid];
+                const double TN = m * (is * is);
+                const double TNd = TN * lds[(kk * nb + j) * BS + tid];
+                const double TNT = TN * m;
+                lnL = lnL - 0.5 * TNd * (1.0 / TNT) * TNd;
+            }
+        }
+        return lnL;
+    };
+
+    const unsigned long long gpix = (unsigned long long)(M.pix0 + i);
+    unsigned long long nacc = 0;
+    double lnl = lnl_of(sample);
+    bool sample_it = true;
+    if (lnl_type == DANGX_LNL_PRIOR) {  // :389-392
+        double u1, u2;
+        sample_it = false;
+        uniform2(a.seed, a.stream, gpix, 0u, u1, u2);
+        sample[a.nind] = rand_normal(c.gauss[a.nind][0], c.gauss[a.nind][1], u1, u2);
+    }
+    double lnl_old = lnl + index_prior(M, c, a, i, sample[a.nind], amp, lds, BS, tid);
+    if (sample_it) {
+        const double step = c.step[a.nind];
+        const double lo = c.uni[a.nind][0], hi = c.uni[a.nind][1];
+        for (int l = 1; l <= a.nsample; ++l) {
+            double u1, u2;
+            uniform2(a.seed, a.stream, gpix, (uint32_t)l, u1, u2);
+            const double prop = sample[a.nind] + rand_normal(0.0, step, u1, u2);  // :414
+            theta[a.nind] = prop;
+            if (prop < lo || prop > hi) continue;  // :415 (no accept draw consumed)
+            lnl = lnl_of(theta);
+            const double lnl_new = lnl + index_prior(M, c, a, i, prop, amp, lds, BS, tid);
+            const double diff = lnl_new - lnl_old;
+            bool acc;
+            if (a.ml_mode == DANGX_ML_OPTIMIZE) {
+                acc = diff > 0.0;  // :443-447
+            } else {
+                double v1, v2;
+                uniform2(a.seed, a.stream, gpix, (uint32_t)l | 0x80000000u, v1, v2);
+                acc = diff > log(v1);  // :448-454
+            }
+            if (acc) {
+                sample[a.nind] = prop;
+                lnl_old = lnl_new;
+                ++nacc;
+            }
+        }
+    }
+    for (int k = a.s1; k <= a.s2; ++k) out[(long long)(k - 1) * npix] = sample[a.nind];  // :465, :483
+    if (accepted) {
+        for (int o = 32; o > 0; o >>= 1) nacc += __shfl_down(nacc, o, 64);
+        if ((tid & 63) == 0 && nacc) atomicAdd(accepted, nacc);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// update_sky_model + compute_chisq (src/dang_data_mod.f90:339-396, 494-526), one thread per
+// pixel.  sky(i,k,j) is accumulated over components in component_list order in an LDS column;
+// the residual and chi^2 follow the reference's expressions.  Block partials of
+// sum_k sum_j res^2/rms^2 go to `partial` (second stage: k_reduce).
+__global__ void k_sky_chisq(const Model* __restrict__ Mp, int pol_lo, int pol_hi, double* __restrict__ sky,
+                            double* __restrict__ res, double* __restrict__ chi_map, double* __restrict__ partial) {
+    extern __shared__ double lds[];  // [nb][BS]
+    const Model& M = *Mp;
+    const int BS = blockDim.x, tid = threadIdx.x;
+    const int npix = M.npix, nb = M.nbands;
+    const int i = blockIdx.x * BS + tid;
+    double chi_sum = 0.0;
+    if (i < npix) {
+        const bool msk = is_masked(M.mask[i]);
+        const bool want_maps = (sky != nullptr) || (res != nullptr);
+        if (!msk || want_maps) {
+            for (int k = 1; k <= M.nmaps; ++k) {
+                const bool in_pol = (k >= pol_lo && k <= pol_hi);
+                if (!want_maps && !in_pol) continue;
+                for (int j = 0; j < nb; ++j) lds[j * BS + tid] = 0.0;
+                for (int l = 0; l < M.ncomp; ++l) {
+                    const Comp& c = M.comp[l];
+                    const double amp = c.amp[(long long)(k - 1) * npix + i];
+                    if (amp == 0.0 && !want_maps) continue;
+                    double t0, t1;
+                    load_theta(M, c, i, k, t0, t1);
+                    const Prep pr = sed_prep(c, t0, t1);
+                    for (int j = 0; j < nb; ++j) lds[j * BS + tid] = lds[j * BS + tid] + amp * sed_eval(M, c, j, pr);
+                }
+                double chi = 0.0;
+                for (int j = 0; j < nb; ++j) {
+                    const long long q = ((long long)j * M.nmaps + (k - 1)) * npix + i;
+                    const double s = lds[j * BS + tid];
+                    const double r = (k == 1) ? (M.sig[q] - M.offset[j]) / M.gain[j] - s : M.sig[q] - s;
+                    if (sky) sky[q] = s;
+                    if (res) res[q] = r;
+                    if (!msk && in_pol) {
+                        const double rms = M.rms[q];
+                        chi = chi + (r * r) / (rms * rms);
+                    }
+                }
+                if (!msk && in_pol) {
+                    chi_sum += chi;
+                    if (chi_map) chi_map[(long long)(k - 1) * npix + i] = chi / nb;
+                }
+            }
+        }
+    }
+    __shared__ double sh[16];
+    for (int o = 32; o > 0; o >>= 1) chi_sum += __shfl_down(chi_sum, o, 64);
+    if ((tid & 63) == 0) sh[tid >> 6] = chi_sum;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int w = 0; w < BS / 64; ++w) s += sh[w];
+        partial[blockIdx.x] = s;
+    }
+}
+
+// eval_sed(band, pix, map_n) over the shard (src/dang_component_mod.f90:778-813)
+__global__ __launch_bounds__(BLOCK) void k_eval_sed(const Model* __restrict__ Mp, int comp, int band, int map_n,
+                                                    double* __restrict__ out) {
+    const Model& M = *Mp;
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= M.npix) return;
+    const Comp& c = M.comp[comp];
+    double t0, t1;
+    load_theta(M, c, i, map_n, t0, t1);
+    out[i] = sed_eval(M, c, band, sed_prep(c, t0, t1));
+}
+
+}  // namespace
+
+// ======================================================================= host side
+
+struct dangx_ctx {
+    dangx_dims dims{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // host mirror of the model + device copy
+    Model hm{};
+    Model* dm = nullptr;
+    bool dirty = true;
+    bool comp_set[MAXC] = {};
+    bool band_set[MAXB] = {};
+    dangx_comp_desc desc[MAXC] = {};
+    // owned device buffers
+    double *sig = nullptr, *rms = nullptr, *mask = nullptr;
+    bool own_data = false;
+    double* amp[MAXC] = {};
+    double* idx[MAXC] = {};
+    bool own_amp[MAXC] = {};
+    bool own_idx[MAXC] = {};
+    std::vector<double> bp_nu0, bp_tau0;
+    double *d_bp_nu0 = nullptr, *d_bp_tau0 = nullptr;
+    // scratch
+    double* partial = nullptr;
+    long long partial_cap = 0;
+    double* scalars = nullptr;              // device scalars [8]
+    unsigned long long* counters = nullptr; // device counters [4]
+    double* work[6] = {};                   // CG vectors
+    long long work_cap = 0;
+    // profiling
+    bool prof = false;
+    struct Ev { hipEvent_t a, b; int kid; };
+    std::vector<Ev> events;
+    double prof_ms[DANGX_K_COUNT] = {};
+    long long prof_n[DANGX_K_COUNT] = {};
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
+            return 1;                                                                             \
+        }                                                                                         \
+    } while (0)
+
+int fail(dangx_ctx* ctx, const std::string& msg) {
+    ctx->err = msg;
+    return 1;
+}
+
+// a2t(bp), src/dang_bp_mod.f90:211-243
+double host_a2t(const dangx_ctx* ctx, int j) {
+    const Band& b = ctx->hm.band[j];
+    double sum = 0.0, y;
+    if (b.n == 0) {
+        if (b.nu_c > 1e7f) y = (H_PLANCK * b.nu_c) / (K_B * ctx->hm.tcmb);
+        else y = (H_PLANCK * b.nu_c * 1e9) / (K_B * ctx->hm.tcmb);
+        sum = ((std::exp(y) - 1.0) * (std::exp(y) - 1.0)) / ((y * y) * std::exp(y));
+    } else {
+        for (int i = 0; i < b.n; ++i) {
+            const double nu = ctx->bp_nu0[b.off + i], tau = ctx->bp_tau0[b.off + i];
+            if (nu == 0.0) continue;
+            if (nu > 1e7f) y = (H_PLANCK * nu) / (K_B * ctx->hm.tcmb);
+            else y = (H_PLANCK * nu * 1e9) / (K_B * ctx->hm.tcmb);
+            sum = sum + tau * ((std::exp(y) - 1.0) * (std::exp(y) - 1.0)) / ((y * y) * std::exp(y));
+        }
+    }
+    return sum;
+}
+
+int sync_model(dangx_ctx* ctx) {
+    if (!ctx->dirty) return 0;
+    Model& M = ctx->hm;
+    for (int j = 0; j < M.nbands; ++j)
+        if (!ctx->band_set[j]) return fail(ctx, "band " + std::to_string(j) + " not set");
+    for (int l = 0; l < M.ncomp; ++l)
+        if (!ctx->comp_set[l]) return fail(ctx, "component " + std::to_string(l) + " not set");
+    if (!ctx->sig || !ctx->rms || !ctx->mask) return fail(ctx, "map data not uploaded");
+    M.sig = ctx->sig; M.rms = ctx->rms; M.mask = ctx->mask;
+    if (!ctx->bp_nu0.empty()) {
+        if (ctx->d_bp_nu0) { (void)hipFree(ctx->d_bp_nu0); (void)hipFree(ctx->d_bp_tau0); }
+        const size_t nbytes = ctx->bp_nu0.size() * sizeof(double);
+        HIPCHK(ctx, hipMalloc(&ctx->d_bp_nu0, nbytes));
+        HIPCHK(ctx, hipMalloc(&ctx->d_bp_tau0, nbytes));
+        HIPCHK(ctx, hipMemcpy(ctx->d_bp_nu0, ctx->bp_nu0.data(), nbytes, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(ctx->d_bp_tau0, ctx->bp_tau0.data(), nbytes, hipMemcpyHostToDevice));
+    }
+    M.bp_nu0 = ctx->d_bp_nu0; M.bp_tau0 = ctx->d_bp_tau0;
+    for (int l = 0; l < M.ncomp; ++l) {
+        Comp& c = M.comp[l];
+        const dangx_comp_desc& d = ctx->desc[l];
+        c.type = d.type; c.nind = d.nindices; c.group = d.cg_group; c.sample_amp = d.sample_amplitude;
+        c.is_synch = d.is_synch; c.nu_ref = d.nu_ref;
+        c.amp = ctx->amp[l]; c.idx = ctx->idx[l];
+        for (int q = 0; q < MAXI; ++q) {
+            c.lnl_type[q] = d.lnl_type[q]; c.prior_type[q] = d.prior_type[q];
+            c.gauss[q][0] = d.gauss_prior[q][0]; c.gauss[q][1] = d.gauss_prior[q][1];
+            c.uni[q][0] = d.uni_prior[q][0]; c.uni[q][1] = d.uni_prior[q][1];
+            c.step[q] = d.step_size[q];
+        }
+        c.nuref9 = 1.0 * c.nu_ref / 1.0e9;
+        for (int j = 0; j < M.nbands; ++j) {
+            const double nu = M.band[j].nu_c;
+            const double r = nu / c.nu_ref;
+            c.lnr[j] = std::log(r);
+            c.nu9[j] = 1.0 * nu / 1.0e9;
+            c.cst[j] = 0.0;
+            if (c.type == DANGX_CMB) c.cst[j] = 1.0 / host_a2t(ctx, j);
+            else if (c.type == DANGX_FREEFREE) c.cst[j] = 1.0 / (r * r);
+            else if (c.type == DANGX_LOGNORMAL) { const double q = c.nu_ref / nu; c.cst[j] = q * q; }
+        }
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dm, &ctx->hm, sizeof(Model), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->dirty = false;
+    return 0;
+}
+
+struct Timed {
+    dangx_ctx* ctx;
+    dangx_ctx::Ev ev{};
+    bool on;
+    Timed(dangx_ctx* c, int kid) : ctx(c), on(c->prof) {
+        if (!on) return;
+        ev.kid = kid;
+        (void)hipEventCreate(&ev.a);
+        (void)hipEventCreate(&ev.b);
+        (void)hipEventRecord(ev.a, ctx->stream);
+    }
+    ~Timed() {
+        if (!on) return;
+        (void)hipEventRecord(ev.b, ctx->stream);
+        ctx->events.push_back(ev);
+    }
+};
+
+int prof_collect(dangx_ctx* ctx) {
+    for (auto& e : ctx->events) {
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventSynchronize(e.b));
+        HIPCHK(ctx, hipEventElapsedTime(&ms, e.a, e.b));
+        ctx->prof_ms[e.kid] += ms;
+        ctx->prof_n[e.kid] += 1;
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    ctx->events.clear();
+    return 0;
+}
+
+int ensure_partial(dangx_ctx* ctx, long long n) {
+    if (n <= ctx->partial_cap) return 0;
+    if (ctx->partial) (void)hipFree(ctx->partial);
+    HIPCHK(ctx, hipMalloc(&ctx->partial, sizeof(double) * (size_t)n));
+    ctx->partial_cap = n;
+    return 0;
+}
+
+int ensure_work(dangx_ctx* ctx, long long n) {
+    if (n <= ctx->work_cap) return 0;
+    for (auto& w : ctx->work) {
+        if (w) (void)hipFree(w);
+        w = nullptr;
+        HIPCHK(ctx, hipMalloc(&w, sizeof(double) * (size_t)n));
+    }
+    ctx->work_cap = n;
+    return 0;
+}
+
+int flag_planes_h(int flag) { return (flag & DANGX_FLAG_QU) ? 2 : 1; }
+
+int make_group(dangx_ctx* ctx, int group, int flag, GroupArgs& a) {
+    if (flag != DANGX_FLAG_T && flag != DANGX_FLAG_Q && flag != DANGX_FLAG_U && flag != DANGX_FLAG_QU)
+        return fail(ctx, "flag must be exactly one of T(1), Q(2), U(4), Q+U(8)");
+    if (ctx->dims.nmaps < 3 && flag != DANGX_FLAG_T) return fail(ctx, "polarisation flag needs nmaps == 3");
+    std::memset(&a, 0, sizeof(a));
+    a.flag = flag;
+    for (int l = 0; l < ctx->hm.ncomp; ++l) {
+        const dangx_comp_desc& d = ctx->desc[l];
+        if (d.cg_group == group && d.sample_amplitude) {
+            if (a.ng >= MAXG) return fail(ctx, "too many components in CG group");
+            a.gc[a.ng++] = l;
+        } else {
+            a.oc[a.no++] = l;
+        }
+    }
+    if (a.ng == 0) return fail(ctx, "Woah there, number of CG components = 0 for CG group " + std::to_string(group));
+    return 0;
+}
+
+template <template <int> class L, typename... Args>
+int dispatch_ng(dangx_ctx* ctx, int ng, Args&&... args) {
+    switch (ng) {
+    case 1: return L<1>::run(ctx, args...);
+    case 2: return L<2>::run(ctx, args...);
+    case 3: return L<3>::run(ctx, args...);
+    case 4: return L<4>::run(ctx, args...);
+    case 5: return L<5>::run(ctx, args...);
+    case 6: return L<6>::run(ctx, args...);
+    case 7: return L<7>::run(ctx, args...);
+    case 8: return L<8>::run(ctx, args...);
+    default: return fail(ctx, "unsupported group size");
+    }
+}
+
+inline unsigned nblocks(long long n, int bs = BLOCK) { return (unsigned)((n + bs - 1) / bs); }
+
+template <int NG>
+struct LaunchAmp {
+    static int run(dangx_ctx* ctx, const GroupArgs& a, long long SN) {
+        Timed t(ctx, DANGX_K_AMP_DIRECT);
+        hipLaunchKernelGGL(k_amp_direct<NG>, dim3(nblocks(SN)), dim3(BLOCK), 0, ctx->stream, ctx->dm, a, ctx->counters);
+        return 0;
+    }
+};
+template <int NG>
+struct LaunchRhs {
+    static int run(dangx_ctx* ctx, const GroupArgs& a, long long SN, double* b) {
+        Timed t(ctx, DANGX_K_CG_VEC);
+        hipLaunchKernelGGL(k_rhs<NG>, dim3(nblocks(SN)), dim3(BLOCK), 0, ctx->stream, ctx->dm, a, b);
+        return 0;
+    }
+};
+template <int NG>
+struct LaunchAx {
+    static int run(dangx_ctx* ctx, const GroupArgs& a, long long SN, const double* x, double* res, double* part) {
+        Timed t(ctx, DANGX_K_CG_AX);
+        hipLaunchKernelGGL(k_Ax<NG>, dim3(nblocks(SN)), dim3(BLOCK), 0, ctx->stream, ctx->dm, a, x, res, part);
+        return 0;
+    }
+};
+template <int NG>
+struct LaunchSv {
+    static int run(dangx_ctx* ctx, const GroupArgs& a, long long SN, const double* eta, double* res) {
+        Timed t(ctx, DANGX_K_CG_VEC);
+        hipLaunchKernelGGL(k_sample_vector<NG>, dim3(nblocks(SN)), dim3(BLOCK), 0, ctx->stream, ctx->dm, a, eta, res);
+        return 0;
+    }
+};
+
+// sum of block partials -> host double (deterministic order)
+int reduce_to_host(dangx_ctx* ctx, long long nblk, double* out) {
+    {
+        Timed t(ctx, DANGX_K_REDUCE);
+        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->partial, nblk, ctx->scalars);
+    }
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->scalars, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// cg_search on the device, src/dang_cg_mod.f90:179-324.  work[0]=x, [1]=r, [2]=d, [3]=q, [4]=b2, [5]=eta/b
+int device_cg(dangx_ctx* ctx, const GroupArgs& a, int i_max, double converge, int* iters) {
+    const long long SN = (long long)flag_planes_h(a.flag) * ctx->hm.npix;
+    const long long n = SN * a.ng;
+    if (ensure_work(ctx, n)) return 1;
+    if (ensure_partial(ctx, nblocks(n))) return 1;
+    double *x = ctx->work[0], *r = ctx->work[1], *d = ctx->work[2], *q = ctx->work[3], *b2 = ctx->work[4], *tmp = ctx->work[5];
+    hipStream_t st = ctx->stream;
+    // b = compute_rhs
+    if (dispatch_ng<LaunchRhs>(ctx, a.ng, a, SN, tmp)) return 1;
+    if (a.ml_mode == DANGX_ML_SAMPLE) {  // b2 = b + compute_sample_vector(eta)
+        hipLaunchKernelGGL(k_draw_eta, dim3(nblocks(SN)), dim3(BLOCK), 0, st, ctx->dm, a, r);
+        if (dispatch_ng<LaunchSv>(ctx, a.ng, a, SN, r, q)) return 1;
+        hipLaunchKernelGGL(k_cg_vec, dim3(nblocks(n)), dim3(BLOCK), 0, st, 3, n, 0.0, b2, nullptr, nullptr, q, tmp, nullptr);
+    } else {
+        HIPCHK(ctx, hipMemcpyAsync(b2, tmp, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    }
+    // x0 = current amplitudes (the reference keeps self%x; identical as amplitudes only change via unpack)
+    hipLaunchKernelGGL(k_pack, dim3(nblocks(SN)), dim3(BLOCK), 0, st, ctx->dm, a, x, 0);
+    if (dispatch_ng<LaunchAx>(ctx, a.ng, a, SN, x, q, nullptr)) return 1;
+    hipLaunchKernelGGL(k_cg_vec, dim3(nblocks(n)), dim3(BLOCK), 0, st, 0, n, 0.0, x, r, d, q, b2, ctx->partial);
+    double delta_new = 0.0, delta_old, dq = 0.0;
+    if (reduce_to_host(ctx, nblocks(n), &delta_new)) return 1;
+    int i = 1;
+    while (i < i_max && delta_new > converge) {
+        if (ensure_partial(ctx, nblocks(SN))) return 1;
+        if (dispatch_ng<LaunchAx>(ctx, a.ng, a, SN, d, q, ctx->partial)) return 1;
+        if (reduce_to_host(ctx, nblocks(SN), &dq)) return 1;
+        const double alpha = delta_new / dq;
+        {
+            Timed t(ctx, DANGX_K_CG_VEC);
+            hipLaunchKernelGGL(k_cg_vec, dim3(nblocks(n)), dim3(BLOCK), 0, st, 1, n, alpha, x, r, d, q, b2, ctx->partial);
+        }
+        delta_old = delta_new;
+        if (reduce_to_host(ctx, nblocks(n), &delta_new)) return 1;
+        const double beta = delta_new / delta_old;
+        {
+            Timed t(ctx, DANGX_K_CG_VEC);
+            hipLaunchKernelGGL(k_cg_vec, dim3(nblocks(n)), dim3(BLOCK), 0, st, 2, n, beta, x, r, d, q, b2, nullptr);
+        }
+        i = i + 1;
+    }
+    hipLaunchKernelGGL(k_pack, dim3(nblocks(SN)), dim3(BLOCK), 0, st, ctx->dm, a, x, 1);
+    if (iters) *iters = i;
+    return 0;
+}
+
+int check_comp(dangx_ctx* ctx, int comp) {
+    if (comp < 0 || comp >= ctx->dims.ncomp) return fail(ctx, "component index out of range");
+    return 0;
+}
+
+}  // namespace
+
+// ======================================================================= C ABI
+
+extern "C" {
+
+const char* dangx_version(void) { return "dangx 0.1 (gfx950)"; }
+
+int dangx_create(dangx_ctx** out, const dangx_dims* dims) {
+    if (!out || !dims) return 1;
+    *out = nullptr;
+    if (dims->npix <= 0 || (dims->nmaps != 1 && dims->nmaps != 3) || dims->nbands <= 0 || dims->nbands > MAXB ||
+        dims->ncomp <= 0 || dims->ncomp > MAXC)
+        return 2;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return 3;  // no HIP device: fail loudly, no CPU fallback
+    dangx_ctx* ctx = new dangx_ctx();
+    ctx->dims = *dims;
+    if (dims->device >= 0) {
+        if (hipSetDevice(dims->device) != hipSuccess) { delete ctx; return 4; }
+        ctx->device = dims->device;
+    } else {
+        (void)hipGetDevice(&ctx->device);
+    }
+    Model& M = ctx->hm;
+    std::memset(&M, 0, sizeof(M));
+    M.npix = dims->npix; M.nmaps = dims->nmaps; M.nbands = dims->nbands; M.ncomp = dims->ncomp;
+    M.pix0 = dims->pix0; M.tcmb = 2.7255;  // src/dang_util_mod.f90:15
+    for (int j = 0; j < MAXB; ++j) { M.gain[j] = 1.0; M.offset[j] = 0.0; }  // src/dang_data_mod.f90:127-128
+    if (hipMalloc(&ctx->dm, sizeof(Model)) != hipSuccess || hipMalloc(&ctx->scalars, 8 * sizeof(double)) != hipSuccess ||
+        hipMalloc(&ctx->counters, 4 * sizeof(unsigned long long)) != hipSuccess) {
+        delete ctx;
+        return 5;
+    }
+    *out = ctx;
+    return 0;
+}
+
+int dangx_destroy(dangx_ctx* ctx) {
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    if (ctx->own_data) { (void)hipFree(ctx->sig); (void)hipFree(ctx->rms); (void)hipFree(ctx->mask); }
+    for (int l = 0; l < MAXC; ++l) {
+        if (ctx->amp[l] && ctx->own_amp[l]) (void)hipFree(ctx->amp[l]);
+        if (ctx->idx[l] && ctx->own_idx[l]) (void)hipFree(ctx->idx[l]);
+    }
+    for (auto& w : ctx->work) if (w) (void)hipFree(w);
+    if (ctx->partial) (void)hipFree(ctx->partial);
+    if (ctx->d_bp_nu0) { (void)hipFree(ctx->d_bp_nu0); (void)hipFree(ctx->d_bp_tau0); }
+    (void)hipFree(ctx->dm); (void)hipFree(ctx->scalars); (void)hipFree(ctx->counters);
+    for (auto& e : ctx->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    delete ctx;
+    return 0;
+}
+
+const char* dangx_last_error(const dangx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int dangx_set_stream(dangx_ctx* ctx, void* s) {
+    if (!ctx) return 1;
+    ctx->stream = (hipStream_t)s;
+    return 0;
+}
+
+int dangx_synchronize(dangx_ctx* ctx) {
+    if (!ctx) return 1;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int dangx_set_band(dangx_ctx* ctx, int band, double nu_c, int n, const double* nu0, const double* tau0) {
+    if (!ctx) return 1;
+    if (band < 0 || band >= ctx->dims.nbands) return fail(ctx, "band index out of range");
+    if (n < 0 || (n > 0 && (!nu0 || !tau0))) return fail(ctx, "bad bandpass arrays");
+    Band& b = ctx->hm.band[band];
+    b.nu_c = (nu_c < 1e9) ? nu_c * 1e9 : nu_c;  // src/dang_bp_mod.f90:35-37
+    b.n = n;
+    b.off = (int)ctx->bp_nu0.size();
+    for (int i = 0; i < n; ++i) { ctx->bp_nu0.push_back(nu0[i]); ctx->bp_tau0.push_back(tau0[i]); }
+    ctx->band_set[band] = true;
+    ctx->dirty = true;
+    return 0;
+}
+
+int dangx_set_component(dangx_ctx* ctx, int comp, const dangx_comp_desc* d) {
+    if (!ctx || !d) return 1;
+    if (check_comp(ctx, comp)) return 1;
+    if (d->type < DANGX_POWERLAW || d->type > DANGX_CMB)
+        return fail(ctx, "Error - unrecognized component type (only diffuse types are built)");
+    const int want = (d->type == DANGX_MBB || d->type == DANGX_LOGNORMAL) ? 2 : (d->type == DANGX_CMB ? 0 : 1);
+    if (d->nindices != want) return fail(ctx, "nindices does not match the component type");
+    (void)hipSetDevice(ctx->device);
+    const size_t plane = (size_t)ctx->dims.npix * ctx->dims.nmaps * sizeof(double);
+    if (!ctx->amp[comp]) {
+        HIPCHK(ctx, hipMalloc(&ctx->amp[comp], plane));
+        HIPCHK(ctx, hipMemset(ctx->amp[comp], 0, plane));
+        ctx->own_amp[comp] = true;
+    }
+    if (d->nindices > 0 && !ctx->idx[comp]) {
+        HIPCHK(ctx, hipMalloc(&ctx->idx[comp], plane * d->nindices));
+        HIPCHK(ctx, hipMemset(ctx->idx[comp], 0, plane * d->nindices));
+        ctx->own_idx[comp] = true;
+    }
+    ctx->desc[comp] = *d;
+    if (ctx->desc[comp].nu_ref < 1e7) ctx->desc[comp].nu_ref *= 1e9;  // src/dang_param_mod.f90:571-573
+    ctx->comp_set[comp] = true;
+    ctx->dirty = true;
+    return 0;
+}
+
+int dangx_set_tcmb(dangx_ctx* ctx, double T) {
+    if (!ctx) return 1;
+    ctx->hm.tcmb = T;
+    ctx->dirty = true;
+    return 0;
+}
+
+int dangx_set_calibration(dangx_ctx* ctx, const double* gain, const double* offset) {
+    if (!ctx) return 1;
+    for (int j = 0; j < ctx->dims.nbands; ++j) {
+        if (gain) ctx->hm.gain[j] = gain[j];
+        if (offset) ctx->hm.offset[j] = offset[j];
+    }
+    ctx->dirty = true;
+    return 0;
+}
+
+int dangx_upload_data(dangx_ctx* ctx, const double* sig, const double* rms, const double* mask) {
+    if (!ctx || !sig || !rms || !mask) return 1;
+    (void)hipSetDevice(ctx->device);
+    const size_t nmap = (size_t)ctx->dims.npix * ctx->dims.nmaps * sizeof(double);
+    const size_t nall = nmap * ctx->dims.nbands;
+    if (!ctx->own_data) {
+        ctx->sig = ctx->rms = ctx->mask = nullptr;
+        HIPCHK(ctx, hipMalloc(&ctx->sig, nall));
+        HIPCHK(ctx, hipMalloc(&ctx->rms, nall));
+        HIPCHK(ctx, hipMalloc(&ctx->mask, nmap));
+        ctx->own_data = true;
+    }
+    HIPCHK(ctx, hipMemcpy(ctx->sig, sig, nall, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->rms, rms, nall, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->mask, mask, nmap, hipMemcpyHostToDevice));
+    ctx->dirty = true;
+    return 0;
+}
+
+int dangx_adopt_device_data(dangx_ctx* ctx, const double* sig, const double* rms, const double* mask) {
+    if (!ctx || !sig || !rms || !mask) return 1;
+    if (ctx->own_data) { (void)hipFree(ctx->sig); (void)hipFree(ctx->rms); (void)hipFree(ctx->mask); ctx->own_data = false; }
+    ctx->sig = const_cast<double*>(sig);
+    ctx->rms = const_cast<double*>(rms);
+    ctx->mask = const_cast<double*>(mask);
+    ctx->dirty = true;
+    return 0;
+}
+
+int dangx_put_amplitude(dangx_ctx* ctx, int comp, const double* amp) {
+    if (!ctx || !amp || check_comp(ctx, comp)) return 1;
+    if (!ctx->amp[comp]) return fail(ctx, "component not set");
+    HIPCHK(ctx, hipMemcpyAsync(ctx->amp[comp], amp, (size_t)ctx->dims.npix * ctx->dims.nmaps * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int dangx_get_amplitude(dangx_ctx* ctx, int comp, double* amp) {
+    if (!ctx || !amp || check_comp(ctx, comp)) return 1;
+    if (!ctx->amp[comp]) return fail(ctx, "component not set");
+    HIPCHK(ctx, hipMemcpyAsync(amp, ctx->amp[comp], (size_t)ctx->dims.npix * ctx->dims.nmaps * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int dangx_put_indices(dangx_ctx* ctx, int comp, const double* ind) {
+    if (!ctx || !ind || check_comp(ctx, comp)) return 1;
+    if (!ctx->idx[comp]) return fail(ctx, "component has no indices");
+    HIPCHK(ctx, hipMemcpyAsync(ctx->idx[comp], ind, (size_t)ctx->dims.npix * ctx->dims.nmaps * ctx->desc[comp].nindices * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int dangx_get_indices(dangx_ctx* ctx, int comp, double* ind) {
+    if (!ctx || !ind || check_comp(ctx, comp)) return 1;
+    if (!ctx->idx[comp]) return fail(ctx, "component has no indices");
+    HIPCHK(ctx, hipMemcpyAsync(ind, ctx->idx[comp], (size_t)ctx->dims.npix * ctx->dims.nmaps * ctx->desc[comp].nindices * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int dangx_adopt_device_state(dangx_ctx* ctx, int comp, double* amp_dev, double* idx_dev) {
+    if (!ctx || !amp_dev || check_comp(ctx, comp)) return 1;
+    if (!ctx->comp_set[comp]) return fail(ctx, "component not set");
+    if (ctx->desc[comp].nindices > 0 && !idx_dev) return fail(ctx, "component has indices: idx_dev required");
+    if (ctx->amp[comp] && ctx->own_amp[comp]) (void)hipFree(ctx->amp[comp]);
+    if (ctx->idx[comp] && ctx->own_idx[comp]) (void)hipFree(ctx->idx[comp]);
+    ctx->amp[comp] = amp_dev; ctx->own_amp[comp] = false;
+    ctx->idx[comp] = (ctx->desc[comp].nindices > 0) ? idx_dev : nullptr; ctx->own_idx[comp] = false;
+    ctx->dirty = true;
+    return 0;
+}
+void* dangx_amplitude_devptr(dangx_ctx* ctx, int comp) { return (ctx && comp >= 0 && comp < MAXC) ? ctx->amp[comp] : nullptr; }
+void* dangx_indices_devptr(dangx_ctx* ctx, int comp) { return (ctx && comp >= 0 && comp < MAXC) ? ctx->idx[comp] : nullptr; }
+
+int64_t dangx_group_size(dangx_ctx* ctx, int group, int flag) {
+    GroupArgs a;
+    if (!ctx || make_group(ctx, group, flag, a)) return -1;
+    return (int64_t)a.ng * flag_planes_h(flag) * ctx->hm.npix;
+}
+
+int dangx_amp_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed,
+                     uint64_t stream, int i_max, double converge, int* cg_iters, int64_t* n_not_spd) {
+    if (!ctx) return 1;
+    (void)hipSetDevice(ctx->device);
+    if (ml_mode != DANGX_ML_SAMPLE && ml_mode != DANGX_ML_OPTIMIZE) return fail(ctx, "bad ml_mode");
+    GroupArgs a;
+    if (make_group(ctx, group, flag, a) || sync_model(ctx)) return 1;
+    a.ml_mode = ml_mode; a.fluct = fluct_mode; a.seed = seed; a.stream = stream;
+    const long long SN = (long long)flag_planes_h(flag) * ctx->hm.npix;
+    if (cg_iters) *cg_iters = 0;
+    if (n_not_spd) *n_not_spd = 0;
+    if (solver == DANGX_SOLVER_CG) {
+        if (fluct_mode != DANGX_FLUCT_REFERENCE && ml_mode == DANGX_ML_SAMPLE)
+            return fail(ctx, "the CG solver reproduces the reference's fluctuation term only");
+        return device_cg(ctx, a, i_max, converge, cg_iters);
+    }
+    if (n_not_spd) HIPCHK(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));
+    if (dispatch_ng<LaunchAmp>(ctx, a.ng, a, SN)) return 1;
+    HIPCHK(ctx, hipGetLastError());
+    if (n_not_spd) {
+        unsigned long long v = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&v, ctx->counters, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        *n_not_spd = (int64_t)v;
+    }
+    return 0;
+}
+
+int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed,
+                       uint64_t stream, int64_t* accepted) {
+    if (!ctx || check_comp(ctx, comp)) return 1;
+    (void)hipSetDevice(ctx->device);
+    if (sync_model(ctx)) return 1;
+    const dangx_comp_desc& d = ctx->desc[comp];
+    if (nind < 0 || nind >= d.nindices) return fail(ctx, "index number out of range");
+    IndexArgs a;
+    a.comp = comp; a.nind = nind; a.nsample = nsample; a.ml_mode = ml_mode; a.seed = seed; a.stream = stream;
+    if (map_n == -1) { a.s1 = 2; a.s2 = 3; }                       // src/dang_sample_mod.f90:157-163
+    else if (map_n >= 1 && map_n <= 3) { a.s1 = a.s2 = map_n; }
+    else return fail(ctx, "There is something wrong with the poltype flag (map_n must be 1,2,3 or -1)");
+    if (a.s2 > ctx->dims.nmaps) return fail(ctx, "map_n exceeds nmaps");
+    if (d.lnl_type[nind] < DANGX_LNL_CHISQ || d.lnl_type[nind] > DANGX_LNL_PRIOR) return fail(ctx, "bad lnl_type");
+    if (ml_mode != DANGX_ML_SAMPLE && ml_mode != DANGX_ML_OPTIMIZE) return fail(ctx, "bad ml_mode");
+    const int Sp = a.s2 - a.s1 + 1;
+    // LDS columns: 2*Sp*nb doubles per thread; pick the block so that >= 2 blocks fit in 160 KiB
+    int bs = 256;
+    while (bs > 64 && (size_t)2 * Sp * ctx->hm.nbands * bs * sizeof(double) > 72 * 1024) bs >>= 1;
+    const size_t lds = (size_t)2 * Sp * ctx->hm.nbands * bs * sizeof(double);
+    if (accepted) HIPCHK(ctx, hipMemsetAsync(ctx->counters + 1, 0, sizeof(unsigned long long), ctx->stream));
+    {
+        Timed t(ctx, DANGX_K_INDEX_MH);
+        hipLaunchKernelGGL(k_index_mh, dim3(nblocks(ctx->hm.npix, bs)), dim3(bs), lds, ctx->stream, ctx->dm, a,
+                           accepted ? ctx->counters + 1 : nullptr);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    if (accepted) {
+        unsigned long long v = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&v, ctx->counters + 1, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        *accepted = (int64_t)v;
+    }
+    return 0;
+}
+
+static int sky_chisq_launch(dangx_ctx* ctx, int pol_lo, int pol_hi, double* sky_d, double* res_d, double* chi_d, double* out_dev) {
+    if (pol_lo < 1 || pol_hi > ctx->dims.nmaps || pol_lo > pol_hi) return fail(ctx, "bad pol_type range");
+    int bs = 256;
+    while (bs > 64 && (size_t)ctx->hm.nbands * bs * sizeof(double) > 32 * 1024) bs >>= 1;
+    const unsigned nblk = nblocks(ctx->hm.npix, bs);
+    if (ensure_partial(ctx, nblk)) return 1;
+    {
+        Timed t(ctx, DANGX_K_SKY_CHISQ);
+        hipLaunchKernelGGL(k_sky_chisq, dim3(nblk), dim3(bs), (size_t)ctx->hm.nbands * bs * sizeof(double), ctx->stream,
+                           ctx->dm, pol_lo, pol_hi, sky_d, res_d, chi_d, ctx->partial);
+    }
+    {
+        Timed t(ctx, DANGX_K_REDUCE);
+        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->partial, (long long)nblk, out_dev);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+int dangx_sky_model_chisq_dev(dangx_ctx* ctx, int pol_lo, int pol_hi, double* chisq_sum_dev) {
+    if (!ctx || !chisq_sum_dev) return 1;
+    (void)hipSetDevice(ctx->device);
+    if (sync_model(ctx)) return 1;
+    return sky_chisq_launch(ctx, pol_lo, pol_hi, nullptr, nullptr, nullptr, chisq_sum_dev);
+}
+
+int dangx_sky_model_chisq(dangx_ctx* ctx, int pol_lo, int pol_hi, double* chisq_sum, double* sky, double* res, double* chi_map) {
+    if (!ctx) return 1;
+    (void)hipSetDevice(ctx->device);
+    if (sync_model(ctx)) return 1;
+    const size_t nmap = (size_t)ctx->dims.npix * ctx->dims.nmaps * sizeof(double);
+    const size_t nall = nmap * ctx->dims.nbands;
+    double *sky_d = nullptr, *res_d = nullptr, *chi_d = nullptr;
+    int rc = 0;
+    if (sky) HIPCHK(ctx, hipMalloc(&sky_d, nall));
+    if (res) HIPCHK(ctx, hipMalloc(&res_d, nall));
+    if (chi_map) { HIPCHK(ctx, hipMalloc(&chi_d, nmap)); HIPCHK(ctx, hipMemsetAsync(chi_d, 0, nmap, ctx->stream)); }
+    rc = sky_chisq_launch(ctx, pol_lo, pol_hi, sky_d, res_d, chi_d, ctx->scalars);
+    if (!rc) {
+        double v = 0.0;
+        if (hipMemcpyAsync(&v, ctx->scalars, sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = 1;
+        if (sky && hipMemcpyAsync(sky, sky_d, nall, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = 1;
+        if (res && hipMemcpyAsync(res, res_d, nall, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = 1;
+        if (chi_map && hipMemcpyAsync(chi_map, chi_d, nmap, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = 1;
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = 1;
+        if (rc) ctx->err = "copy-back failed in dangx_sky_model_chisq";
+        if (chisq_sum) *chisq_sum = v;
+    }
+    if (sky_d) (void)hipFree(sky_d);
+    if (res_d) (void)hipFree(res_d);
+    if (chi_d) (void)hipFree(chi_d);
+    return rc;
+}
+
+// ---- secondary seams, host vectors ------------------------------------------------
+
+static int seam_common(dangx_ctx* ctx, int group, int flag, GroupArgs& a, long long& SN, long long& n) {
+    (void)hipSetDevice(ctx->device);
+    if (make_group(ctx, group, flag, a) || sync_model(ctx)) return 1;
+    SN = (long long)flag_planes_h(flag) * ctx->hm.npix;
+    n = SN * a.ng;
+    if (ensure_work(ctx, n)) return 1;
+    return 0;
+}
+
+int dangx_compute_rhs(dangx_ctx* ctx, int group, int flag, double* b) {
+    if (!ctx || !b) return 1;
+    GroupArgs a; long long SN, n;
+    if (seam_common(ctx, group, flag, a, SN, n)) return 1;
+    if (dispatch_ng<LaunchRhs>(ctx, a.ng, a, SN, ctx->work[0])) return 1;
+    HIPCHK(ctx, hipMemcpyAsync(b, ctx->work[0], sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int dangx_compute_Ax(dangx_ctx* ctx, int group, int flag, const double* x, double* res) {
+    if (!ctx || !x || !res) return 1;
+    GroupArgs a; long long SN, n;
+    if (seam_common(ctx, group, flag, a, SN, n)) return 1;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->work[0], x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    if (dispatch_ng<LaunchAx>(ctx, a.ng, a, SN, ctx->work[0], ctx->work[1], nullptr)) return 1;
+    HIPCHK(ctx, hipMemcpyAsync(res, ctx->work[1], sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int dangx_compute_sample_vector(dangx_ctx* ctx, int group, int flag, const double* eta, double* res) {
+    if (!ctx || !eta || !res) return 1;
+    GroupArgs a; long long SN, n;
+    if (seam_common(ctx, group, flag, a, SN, n)) return 1;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->work[0], eta, sizeof(double) * (size_t)SN, hipMemcpyHostToDevice, ctx->stream));
+    if (dispatch_ng<LaunchSv>(ctx, a.ng, a, SN, ctx->work[0], ctx->work[1])) return 1;
+    HIPCHK(ctx, hipMemcpyAsync(res, ctx->work[1], sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int dangx_eval_sed(dangx_ctx* ctx, int comp, int band, int map_n, double* out) {
+    if (!ctx || !out || check_comp(ctx, comp)) return 1;
+    (void)hipSetDevice(ctx->device);
+    if (band < 0 || band >= ctx->dims.nbands || map_n < 1 || map_n > ctx->dims.nmaps) return fail(ctx, "bad band/map");
+    if (sync_model(ctx) || ensure_work(ctx, ctx->hm.npix)) return 1;
+    hipLaunchKernelGGL(k_eval_sed, dim3(nblocks(ctx->hm.npix)), dim3(BLOCK), 0, ctx->stream, ctx->dm, comp, band, map_n, ctx->work[0]);
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->work[0], sizeof(double) * (size_t)ctx->hm.npix, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---- profiling ---------------------------------------------------------------------
+
+int dangx_profile_enable(dangx_ctx* ctx, int on) {
+    if (!ctx) return 1;
+    ctx->prof = on != 0;
+    return 0;
+}
+int dangx_profile_reset(dangx_ctx* ctx) {
+    if (!ctx) return 1;
+    if (prof_collect(ctx)) return 1;
+    for (int k = 0; k < DANGX_K_COUNT; ++k) { ctx->prof_ms[k] = 0.0; ctx->prof_n[k] = 0; }
+    return 0;
+}
+int dangx_profile_get(dangx_ctx* ctx, int kid, double* total_ms, int64_t* launches) {
+    if (!ctx || kid < 0 || kid >= DANGX_K_COUNT) return 1;
+    if (prof_collect(ctx)) return 1;
+    if (total_ms) *total_ms = ctx->prof_ms[kid];
+    if (launches) *launches = ctx->prof_n[kid];
+    return 0;
+}
+
+}  // extern "C"

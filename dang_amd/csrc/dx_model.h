@@ -1,0 +1,63 @@
+// dx_model.h -- device-resident description of one pixel shard (gfx950 only).
+//
+// The reference keeps this state in module globals and derived types
+// (src/dang_util_mod.f90:16-37, src/dang_component_mod.f90:12-48,
+// src/dang_bp_mod.f90:7-15, src/dang_data_mod.f90:23-45).  Here it is one POD
+// block in HBM that every kernel receives by pointer; all fields are
+// wave-uniform, so the compiler reads them through the scalar cache (s_load).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dangx.h"
+
+namespace dx {
+
+constexpr int MAXB = DANGX_MAX_BANDS;
+constexpr int MAXC = DANGX_MAX_COMPS;
+constexpr int MAXI = DANGX_MAX_IND;
+constexpr int MAXG = DANGX_MAX_GROUP;
+
+// constants, src/dang_util_mod.f90:12-15,19 (exact literals)
+constexpr double PI = 3.141592653589793238462643383279502884197;
+constexpr double K_B = 1.3806503e-23;
+constexpr double C_LIGHT = 2.99792458e8;
+constexpr double MISSVAL = -1.6375e30;
+constexpr double H_PLANCK = 1.0545726691251021e-34 * 2.0 * PI;
+
+struct Band {
+    double nu_c;  // Hz
+    int n;        // 0 = delta
+    int off;      // offset into bp_nu0 / bp_tau0
+};
+
+struct Comp {
+    int type, nind, group, sample_amp, is_synch, pad;
+    double nu_ref;
+    double* amp;  // [nmaps][npix]
+    double* idx;  // [nind][nmaps][npix]
+    int lnl_type[MAXI], prior_type[MAXI];
+    double gauss[MAXI][2], uni[MAXI][2], step[MAXI];
+    // per-band host-precomputed scalars (delta bandpass fast path)
+    double lnr[MAXB];   // log(nu_c/nu_ref)
+    double cst[MAXB];   // cmb: 1/a2t(bp) ; freefree: 1/(r*r) ; lognormal: (nu_ref/nu_c)^2
+    double nu9[MAXB];   // freefree: 1.0*nu_c/1e9
+    double nuref9;      // freefree: 1.0*nu_ref/1e9
+};
+
+struct Model {
+    int npix, nmaps, nbands, ncomp;
+    long long pix0;
+    const double* sig;   // [nbands][nmaps][npix]
+    const double* rms;   // [nbands][nmaps][npix]
+    const double* mask;  // [nmaps][npix]
+    const double* bp_nu0;
+    const double* bp_tau0;
+    double tcmb;
+    double gain[MAXB], offset[MAXB];
+    Band band[MAXB];
+    Comp comp[MAXC];
+};
+
+__host__ __device__ inline bool is_masked(double m) { return m == 0.0 || m == MISSVAL; }
+
+}  // namespace dx

@@ -1,0 +1,59 @@
+// dx_rng.h -- counter-based random streams for the sampler kernels.
+//
+// The reference draws from the compiler's RANDOM_NUMBER after an unseeded
+// RANDOM_SEED() (src/dang.f90:67; rand_normal src/dang_util_mod.f90:100-110),
+// which is irreproducible and thread-order dependent.  The MI355X path keys
+// every draw by (seed, stream, GLOBAL pixel, draw slot) through Philox4x32-10,
+// so a sample does not depend on launch geometry or on how pixels are sharded.
+//
+//   counter = { pixel[31:0], draw ^ (pixel[63:32] << 16), stream[31:0], stream[63:32] }
+//   key     = { seed[31:0], seed[63:32] }
+//   u1 = words(0,1), u2 = words(2,3), each mapped to (0,1) with 53 bits.
+// Draw slots:
+//   amplitude phase, reference fluctuation term : draw = map number k (1..3)
+//   amplitude phase, textbook fluctuation term  : draw = k + 4*(band+1)
+//   index phase, step l (1..nsample): proposal  : draw = l         (u1,u2 -> normal)
+//                                     accept    : draw = l | 2^31  (u1)
+//   index phase, lnl_type=='prior' draw         : draw = 0
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dx_model.h"
+
+namespace dx {
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
+    const unsigned long long x = ((unsigned long long)hi << 32) | lo;
+    return ((double)(x >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+__device__ __forceinline__ void uniform2(unsigned long long seed, unsigned long long stream,
+                                         unsigned long long pix, uint32_t draw, double& u1, double& u2) {
+    uint32_t o[4];
+    philox4x32_10((uint32_t)pix, draw ^ ((uint32_t)(pix >> 32) << 16), (uint32_t)stream, (uint32_t)(stream >> 32),
+                  (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    u1 = u53(o[0], o[1]);
+    u2 = u53(o[2], o[3]);
+}
+
+// rand_normal, src/dang_util_mod.f90:100-110 (Box-Muller, sine branch only)
+__device__ __forceinline__ double rand_normal(double mean, double stdev, double u1, double u2) {
+    const double r = sqrt(-2.0 * log(u1));
+    const double theta = 2.0 * PI * u2;
+    return mean + stdev * r * sin(theta);
+}
+
+}  // namespace dx

@@ -1,0 +1,116 @@
+// dx_sed.h -- mixing-matrix elements (SEDs) on the device.
+//
+// Restates eval_sed / eval_signal and the SED kernels of the reference
+// (src/dang_component_mod.f90:754-813, 886-1040; cmb: src/dang_bp_mod.f90:211-243).
+// The reference re-dispatches on the type string and calls pow/exp for every
+// (pixel, band, component) and every CG iteration.  Here the evaluation is split:
+//   sed_prep()  -- everything that depends only on the pixel's spectral indices
+//                  (once per pixel, or once per Metropolis proposal);
+//   sed_eval()  -- the per-band part, using host-precomputed band scalars.
+// (nu/nu_ref)**beta is evaluated as exp(beta*log(nu/nu_ref)) with the logarithm
+// precomputed on the host; this differs from pow() by a few ulp (|beta*ln r| * eps).
+#pragma once
+#include "dx_model.h"
+
+namespace dx {
+
+struct Prep {
+    double p0, p1, p2;
+};
+
+// src/dang_component_mod.f90:1024-1027 -- Gaunt-factor form, literal constants kept
+__device__ __forceinline__ double ff_gaunt(double nu9, double t15) {
+    constexpr double S3PI = 1.7320508075688772 / PI;  // sqrt(3.d0)/pi
+    return log(exp(5.960 - S3PI * log(nu9 * t15)) + 2.71828);
+}
+
+__device__ __forceinline__ Prep sed_prep(const Comp& c, double th0, double th1) {
+    Prep p = {0.0, 0.0, 0.0};
+    switch (c.type) {
+    case DANGX_POWERLAW:  // :901-905
+        p.p0 = th0;
+        break;
+    case DANGX_MBB: {  // :936-943
+        const double z = H_PLANCK / (K_B * th1);
+        p.p0 = th0 + 1.0;
+        p.p1 = z;
+        p.p2 = exp(z * c.nu_ref) - 1.0;
+        break;
+    }
+    case DANGX_FREEFREE: {  // :1017-1024
+        const double t15 = pow(th0 / 1.0e4, -1.5);
+        p.p0 = t15;
+        p.p1 = ff_gaunt(c.nuref9, t15);  // S_ref
+        break;
+    }
+    case DANGX_LOGNORMAL:  // :978-984
+        p.p0 = th0 * 1e9;
+        p.p1 = th1;
+        break;
+    default:
+        break;
+    }
+    return p;
+}
+
+// bandpass-integrated forms (bp%id /= 'delta'): tau0-weighted sums, e.g. :909-913
+__device__ inline double sed_bandpass(const Model& M, const Comp& c, int j, const Prep& p) {
+    const Band& b = M.band[j];
+    double s = 0.0;
+    for (int i = 0; i < b.n; ++i) {
+        const double nu = M.bp_nu0[b.off + i];
+        const double tau = M.bp_tau0[b.off + i];
+        if (nu == 0.0) continue;
+        switch (c.type) {
+        case DANGX_POWERLAW:
+            s = s + tau * pow(nu / c.nu_ref, p.p0);
+            break;
+        case DANGX_MBB:
+            s = s + tau * p.p2 / (exp(p.p1 * nu) - 1.0) * pow(nu / c.nu_ref, p.p0);
+            break;
+        case DANGX_FREEFREE: {
+            const double r = nu / c.nu_ref;
+            s = s + tau * ff_gaunt(1.0 * nu / 1.0e9, p.p0) / p.p1 * (1.0 / (r * r));
+            break;
+        }
+        case DANGX_LOGNORMAL: {
+            const double l = log(nu / p.p0) / p.p1;
+            const double q = c.nu_ref / nu;
+            s = s + tau * exp(-0.5 * (l * l)) * (q * q);
+            break;
+        }
+        default:
+            break;
+        }
+    }
+    return s;
+}
+
+// eval_sed for band j given the prepared pixel state (src/dang_component_mod.f90:778-813)
+__device__ __forceinline__ double sed_eval(const Model& M, const Comp& c, int j, const Prep& p) {
+    if (c.type == DANGX_CMB) return c.cst[j];  // 1.0/a2t(bp(band)), :799-800
+    if (M.band[j].n != 0) return sed_bandpass(M, c, j, p);
+    switch (c.type) {
+    case DANGX_POWERLAW:  // :908
+        return exp(p.p0 * c.lnr[j]);
+    case DANGX_MBB:  // :947-948
+        return p.p2 / (exp(p.p1 * M.band[j].nu_c) - 1.0) * exp(p.p0 * c.lnr[j]);
+    case DANGX_FREEFREE:  // :1026-1027
+        return ff_gaunt(c.nu9[j], p.p0) / p.p1 * c.cst[j];
+    case DANGX_LOGNORMAL: {  // :988
+        const double l = log(M.band[j].nu_c / p.p0) / p.p1;
+        return exp(-0.5 * (l * l)) * c.cst[j];
+    }
+    default:
+        return 0.0;
+    }
+}
+
+// spectral indices of component c at (pixel i, map k): c%indices(i,k,:)
+__device__ __forceinline__ void load_theta(const Model& M, const Comp& c, int i, int k, double& th0, double& th1) {
+    const long long plane = (long long)M.npix;
+    th0 = (c.nind > 0) ? c.idx[((long long)0 * M.nmaps + (k - 1)) * plane + i] : 0.0;
+    th1 = (c.nind > 1) ? c.idx[((long long)1 * M.nmaps + (k - 1)) * plane + i] : 0.0;
+}
+
+}  // namespace dx

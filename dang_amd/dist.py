@@ -1,0 +1,56 @@
+"""Pixel sharding across ranks (one process per GPU) and the global reductions.
+
+The reference is single-process; its "collectives" are serial `sum()` intrinsics over
+full-sky vectors (e.g. chi^2, src/dang_data_mod.f90:523-524).  With pixels sharded as
+contiguous RING ranges these become scalar all-reduces (RCCL over xGMI when the
+process group's backend is "nccl"; gloo on CPU in the tests).  Every BASELINE config
+is per-pixel independent, so there is no other data-path collective.
+"""
+import torch
+import torch.distributed as td
+
+
+def world():
+    if td.is_available() and td.is_initialized():
+        return td.get_rank(), td.get_world_size()
+    return 0, 1
+
+
+def shard_range(npix_global, rank, nranks):
+    """Contiguous range [pix0, pix0+npix) of RING pixels owned by `rank`."""
+    base, rem = divmod(int(npix_global), int(nranks))
+    pix0 = rank * base + min(rank, rem)
+    return pix0, base + (1 if rank < rem else 0)
+
+
+def allreduce_sum_float(x, device=None):
+    """Sum a Python float over all ranks (returns the same value on every rank)."""
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return float(x)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if td.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+    td.all_reduce(t, op=td.ReduceOp.SUM)
+    return float(t.item())
+
+
+def allreduce_sum_(t):
+    """In-place sum of a tensor over all ranks (device tensors go through RCCL)."""
+    if td.is_available() and td.is_initialized() and td.get_world_size() > 1:
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+    return t
+
+
+def gather_maps(local, npix_global, dst=0):
+    """Gather pixel-sharded maps [..., npix_local] to `dst` as [..., npix_global] (map output)."""
+    rank, n = world()
+    if n == 1:
+        return local
+    sizes = [shard_range(npix_global, r, n)[1] for r in range(n)]
+    lead = local.shape[:-1]
+    if rank == dst:
+        parts = [torch.empty(*lead, s, dtype=local.dtype, device=local.device) for s in sizes]
+    else:
+        parts = None
+    td.gather(local.contiguous(), parts, dst=dst)
+    return torch.cat(parts, dim=-1) if rank == dst else None

@@ -1,0 +1,174 @@
+/*
+ * dangx.h -- C ABI of libdangx.so, the MI355X (gfx950) implementation of dang's
+ * Gibbs inner loop.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * The reference (hermda02/dang, Fortran 90) has no FFI layer; the seam is its
+ * module API.  Each entry point below names the reference procedure whose work it
+ * replaces.  A Fortran driver binds these through ISO_C_BINDING
+ * (fortran/dangx_mod.f90); INTEGRATION.md shows the reference-side wrapper.
+ *
+ * Array layouts are the Fortran arrays as they sit in memory (no transposition):
+ *   sig_map/rms_map (0:npix-1, nmaps, nbands)  == C [band][map][pix]
+ *   masks           (0:npix-1, nmaps)          == C [map][pix]   (plane 1 is tested,
+ *                                                 as everywhere in the reference)
+ *   c%amplitude     (0:npix-1, nmaps)          == C [map][pix]
+ *   c%indices       (0:npix-1, nmaps, nind)    == C [ind][map][pix]
+ * All reals are IEEE fp64 (real(dp)); map numbers are 1-based (1=T,2=Q,3=U).
+ *
+ * A context holds ONE pixel shard [pix0, pix0+npix) of the sky on ONE device.
+ * Every per-pixel operation is shard-local; the random streams are keyed by the
+ * GLOBAL pixel index, so results do not depend on how the sky is sharded.
+ * Global reductions (chi^2) are returned as un-normalised local sums for the
+ * caller to all-reduce.
+ *
+ * Return value: 0 on success, non-zero on error (message: dangx_last_error).
+ * The reference's convention is print + stop (e.g. src/dang_cg_mod.f90:97-101);
+ * the Fortran wrapper reproduces that from the status code.
+ */
+#ifndef DANGX_H
+#define DANGX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DANGX_MAX_BANDS 32
+#define DANGX_MAX_COMPS 16
+#define DANGX_MAX_IND 2
+#define DANGX_MAX_GROUP 8
+
+/* component type == c%type string, src/dang_component_mod.f90:791-809 */
+enum { DANGX_POWERLAW = 1, DANGX_MBB = 2, DANGX_FREEFREE = 3, DANGX_LOGNORMAL = 4, DANGX_CMB = 5 };
+/* c%lnl_type / c%prior_type strings, src/dang_sample_mod.f90:383-400 */
+enum { DANGX_LNL_CHISQ = 1, DANGX_LNL_MARGINAL = 2, DANGX_LNL_PRIOR = 3 };
+enum { DANGX_PRIOR_GAUSSIAN = 1, DANGX_PRIOR_UNIFORM = 2, DANGX_PRIOR_JEFFREYS = 3 };
+/* ml_mode string, src/dang_cg_mod.f90:254-267 */
+enum { DANGX_ML_SAMPLE = 1, DANGX_ML_OPTIMIZE = 2 };
+/* poltype bit flags, src/dang_util_mod.f90:228-292 */
+enum { DANGX_FLAG_T = 1, DANGX_FLAG_Q = 2, DANGX_FLAG_U = 4, DANGX_FLAG_QU = 8 };
+/* amplitude solver: DIRECT = per-(pixel,plane) Cholesky block solve (MI355X path);
+ * CG = the reference's global conjugate-gradient iteration run on the device. */
+enum { DANGX_SOLVER_DIRECT = 0, DANGX_SOLVER_CG = 1 };
+/* fluctuation term: REFERENCE reproduces compute_sample_vector exactly, including
+ * its two quirks (src/dang_cg_mod.f90:1008-1015 one eta for all bands; :1033-1040 no
+ * component offset); CORRECT draws the textbook sum_nu T^t N^-1/2 eta_nu. */
+enum { DANGX_FLUCT_CORRECT = 0, DANGX_FLUCT_REFERENCE = 1 };
+
+/* kernel ids for dangx_profile_get */
+enum {
+    DANGX_K_AMP_DIRECT = 0, DANGX_K_INDEX_MH = 1, DANGX_K_SKY_CHISQ = 2, DANGX_K_REDUCE = 3,
+    DANGX_K_CG_AX = 4, DANGX_K_CG_VEC = 5, DANGX_K_GIBBS_FUSED = 6, DANGX_K_COUNT = 8
+};
+
+typedef struct dangx_ctx dangx_ctx;
+
+typedef struct {
+    int32_t npix;         /* pixels in this shard */
+    int32_t nmaps;        /* 1 or 3 (global nmaps, src/dang.f90:49-63) */
+    int32_t nbands;       /* global nbands */
+    int32_t ncomp;        /* global ncomp */
+    int64_t pix0;         /* global index of this shard's first pixel */
+    int64_t npix_global;  /* 12*nside^2 */
+    int32_t device;       /* HIP device ordinal, -1 = current device */
+    int32_t reserved;
+} dangx_dims;
+
+/* mirrors the fields of type(dang_comps) the hot path reads, src/dang_component_mod.f90:12-48 */
+typedef struct {
+    int32_t type;              /* DANGX_POWERLAW ... */
+    int32_t is_synch;          /* trim(c%label)=='synch' (jeffreys prior, src/dang_lnl_mod.f90:289) */
+    int32_t nindices;
+    int32_t cg_group;          /* c%cg_group (1-based as in the parameter file) */
+    int32_t sample_amplitude;  /* c%sample_amplitude */
+    int32_t reserved;
+    double nu_ref;             /* Hz */
+    int32_t lnl_type[DANGX_MAX_IND];
+    int32_t prior_type[DANGX_MAX_IND];
+    double gauss_prior[DANGX_MAX_IND][2]; /* mean, std */
+    double uni_prior[DANGX_MAX_IND][2];   /* low, high */
+    double step_size[DANGX_MAX_IND];
+} dangx_comp_desc;
+
+/* ---- lifetime ------------------------------------------------------------ */
+int dangx_create(dangx_ctx **ctx, const dangx_dims *dims);
+int dangx_destroy(dangx_ctx *ctx);
+const char *dangx_last_error(const dangx_ctx *ctx);
+const char *dangx_version(void);
+/* run all work of this context on the given hipStream_t (NULL = default stream) */
+int dangx_set_stream(dangx_ctx *ctx, void *hip_stream);
+int dangx_synchronize(dangx_ctx *ctx);
+
+/* ---- static description (once, after src/dang.f90:73) ------------------------ */
+/* bp(j): src/dang_bp_mod.f90:7-15,31-57.  n = 0 for a 'delta' bandpass, else n
+ * samples nu0[] (Hz) with normalised weights tau0[].  band is 0-based. */
+int dangx_set_band(dangx_ctx *ctx, int band, double nu_c_hz, int n, const double *nu0, const double *tau0);
+int dangx_set_component(dangx_ctx *ctx, int comp /*0-based*/, const dangx_comp_desc *desc);
+/* global T_CMB used by the 'cmb' SED through a2t (src/dang_util_mod.f90:15) */
+int dangx_set_tcmb(dangx_ctx *ctx, double T_cmb);
+/* ddata%gain(:), ddata%offset(:) (src/dang_data_mod.f90:31-32) */
+int dangx_set_calibration(dangx_ctx *ctx, const double *gain, const double *offset);
+
+/* ---- map data ------------------------------------------------------------------ */
+/* ddata%sig_map, rms_map, masks: host pointers, copied to HBM */
+int dangx_upload_data(dangx_ctx *ctx, const double *sig, const double *rms, const double *mask);
+/* same arrays already resident in HBM (borrowed, not copied, not freed) */
+int dangx_adopt_device_data(dangx_ctx *ctx, const double *sig_dev, const double *rms_dev, const double *mask_dev);
+/* c%amplitude(:, :) and c%indices(:, :, :) of component comp; host pointers */
+int dangx_put_amplitude(dangx_ctx *ctx, int comp, const double *amp);
+int dangx_get_amplitude(dangx_ctx *ctx, int comp, double *amp);
+int dangx_put_indices(dangx_ctx *ctx, int comp, const double *ind);
+int dangx_get_indices(dangx_ctx *ctx, int comp, double *ind);
+/* let caller-owned HBM buffers BE the resident amplitude / index maps of a component
+ * (borrowed, not freed; idx_dev may be NULL when the component has no indices) */
+int dangx_adopt_device_state(dangx_ctx *ctx, int comp, double *amp_dev, double *idx_dev);
+/* device addresses of the resident copies ([map][pix] and [ind][map][pix]) */
+void *dangx_amplitude_devptr(dangx_ctx *ctx, int comp);
+void *dangx_indices_devptr(dangx_ctx *ctx, int comp);
+
+/* ---- amplitude phase: one (group, flag) pass of sample_cg_groups ---------------
+ * replaces compute_rhs + cg_search + unpack_amplitudes (src/dang_cg_mod.f90:166-171).
+ * flag is one poltype bit (T, Q, U or Q+U).  seed/stream select the keyed random
+ * stream (the reference uses an unseeded RANDOM_NUMBER, src/dang.f90:67).
+ * cg_iters (nullable): CG iteration counter as printed by the reference (CG solver),
+ * 0 for DIRECT.  n_not_spd (nullable): units whose block was not SPD (left unchanged). */
+int dangx_amp_sample(dangx_ctx *ctx, int group, int flag, int ml_mode, int solver, int fluct_mode,
+                     uint64_t seed, uint64_t stream, int i_max, double converge,
+                     int *cg_iters, int64_t *n_not_spd);
+
+/* ---- index phase: sample_index_mh, per-pixel branch (src/dang_sample_mod.f90:88-485,
+ * index_mode==2, sample_nside==nside).  nind 0-based; map_n = 1,2,3 or -1 (Q+U).
+ * accepted (nullable): number of accepted proposals over the shard. */
+int dangx_index_sample(dangx_ctx *ctx, int comp, int nind, int map_n, int nsample, int ml_mode,
+                       uint64_t seed, uint64_t stream, int64_t *accepted);
+
+/* ---- sky model + chi^2: update_sky_model + compute_chisq
+ * (src/dang_data_mod.f90:339-396, 494-526).  pol_lo..pol_hi = ddata%pol_type range.
+ * chisq_sum receives the LOCAL sum over unmasked pixels and planes of
+ * sum_j res^2/rms^2 (not divided by nbands or nump); the reference's chisq is
+ * allreduce(chisq_sum)/nbands/nump.  sky/res ([band][map][pix]) and chi_map
+ * ([map][pix], already divided by nbands as in the reference) are optional host outputs. */
+int dangx_sky_model_chisq(dangx_ctx *ctx, int pol_lo, int pol_hi, double *chisq_sum,
+                          double *sky, double *res, double *chi_map);
+/* asynchronous form: writes the local sum to a device double (for an RCCL all-reduce) */
+int dangx_sky_model_chisq_dev(dangx_ctx *ctx, int pol_lo, int pol_hi, double *chisq_sum_dev);
+
+/* ---- secondary seams (type-bound procedures of dang_cg_group), host vectors in the
+ * reference's packing [c1: plane1(npix), plane2(npix) | c2: ... ] -------------------- */
+int64_t dangx_group_size(dangx_ctx *ctx, int group, int flag);
+int dangx_compute_rhs(dangx_ctx *ctx, int group, int flag, double *b);                       /* :326 */
+int dangx_compute_Ax(dangx_ctx *ctx, int group, int flag, const double *x, double *res);     /* :598 */
+int dangx_compute_sample_vector(dangx_ctx *ctx, int group, int flag, const double *eta, double *res); /* :913 */
+/* eval_sed(band, pix, map_n) for all local pixels of one component/band/map -> out[npix] (:778) */
+int dangx_eval_sed(dangx_ctx *ctx, int comp, int band, int map_n, double *out);
+
+/* ---- per-kernel timing with HIP events on the context's stream ----------------- */
+int dangx_profile_enable(dangx_ctx *ctx, int on);
+int dangx_profile_reset(dangx_ctx *ctx);
+int dangx_profile_get(dangx_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

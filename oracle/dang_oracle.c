@@ -1,0 +1,727 @@
+/*
+ * dang_oracle.c -- CPU restatement of the dang Gibbs inner loop.
+ * TEST INFRASTRUCTURE ONLY -- see dang_oracle.h.  PARITY UNPINNED (see header).
+ *
+ * Every routine restates the cited reference lines (paths relative to the
+ * reference checkout, e.g. src/dang_cg_mod.f90:598-911) with the same loop
+ * structure and the same order of floating-point operations, so that it can
+ * stand in for the reference's CPU path both as the checker and as the
+ * `cpu_baseline` ("port") timing.  Global-amplitude component types
+ * (template / monopole / hi_fit) are not restated yet.
+ */
+#include "dang_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---- constants: src/dang_util_mod.f90:12-15,19; pi: HEALPix healpix_types ---- */
+static const double PI_ = 3.141592653589793238462643383279502884197;
+static const double K_B = 1.3806503e-23;
+static const double C_LIGHT = 2.99792458e8;
+static const double MISSVAL = -1.6375e30;
+static double planck_h(void) { return 1.0545726691251021e-34 * 2.0 * PI_; }
+
+double dgo_const_h(void) { return planck_h(); }
+double dgo_const_kB(void) { return K_B; }
+double dgo_const_c(void) { return C_LIGHT; }
+double dgo_missval(void) { return MISSVAL; }
+
+static int masked(double m) { return m == 0.0 || m == MISSVAL; }
+
+static void set_threads(const dgo_ctx *ctx) {
+#ifdef _OPENMP
+    if (ctx->nthreads > 0) omp_set_num_threads(ctx->nthreads);
+#else
+    (void)ctx;
+#endif
+}
+
+/* ------------------------------------------------------------------ RNG */
+
+/* Philox4x32-10 (Salmon et al. 2011, Random123).  Builder-defined stream:
+ * the reference calls the compiler's RANDOM_NUMBER after an unseeded
+ * RANDOM_SEED() (src/dang.f90:67), which is irreproducible by construction. */
+void dgo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static double u53(uint32_t hi, uint32_t lo) {
+    uint64_t x = ((uint64_t)hi << 32) | lo;
+    return ((double)(x >> 11) + 0.5) * (1.0 / 9007199254740992.0); /* (0,1) */
+}
+
+void dgo_uniform2(uint64_t seed, uint64_t stream, uint64_t pix, uint32_t draw, double u[2]) {
+    uint32_t ctr[4] = {(uint32_t)pix, draw, (uint32_t)stream, (uint32_t)(stream >> 32)};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t o[4];
+    /* pixel indices above 2^32 fold their high word into the draw slot */
+    ctr[1] ^= (uint32_t)(pix >> 32) << 16;
+    dgo_philox4x32_10(ctr, key, o);
+    u[0] = u53(o[0], o[1]);
+    u[1] = u53(o[2], o[3]);
+}
+
+/* src/dang_util_mod.f90:100-110: Box-Muller, sine branch only */
+double dgo_rand_normal(double mean, double stdev, double u1, double u2) {
+    double r = sqrt(-2.0 * log(u1));
+    double theta = 2.0 * PI_ * u2;
+    return mean + stdev * r * sin(theta);
+}
+
+/* src/dang_util_mod.f90:112-121 */
+double dgo_eval_normal_prior(double prop, double mean, double std) {
+    double var = std * std;
+    double num = exp(-((prop - mean) * (prop - mean)) / (2 * var));
+    double denom = std * sqrt(2.0 * PI_);
+    return num / denom;
+}
+
+/* ------------------------------------------------------------------ sky model */
+
+#define IDX3(ctx, j, k, i) (((int64_t)(j) * (ctx)->nmaps + ((k)-1)) * (int64_t)(ctx)->npix + (i))
+#define IDX2(ctx, k, i) (((int64_t)((k)-1)) * (int64_t)(ctx)->npix + (i))
+
+/* src/dang_bp_mod.f90:211-243 */
+double dgo_a2t(const dgo_ctx *ctx, int band) {
+    const dgo_band *b = &ctx->bands[band];
+    const double h = planck_h();
+    double sum = 0.0, y;
+    if (b->n == 0) {
+        if (b->nu_c > 1e7f) y = (h * b->nu_c) / (K_B * ctx->T_CMB);
+        else y = (h * b->nu_c * 1e9) / (K_B * ctx->T_CMB);
+        sum = ((exp(y) - 1.0) * (exp(y) - 1.0)) / ((y * y) * exp(y));
+    } else {
+        for (int i = 0; i < b->n; ++i) {
+            if (b->nu0[i] == 0.0) continue;
+            if (b->nu0[i] > 1e7f) y = (h * b->nu0[i]) / (K_B * ctx->T_CMB);
+            else y = (h * b->nu0[i] * 1e9) / (K_B * ctx->T_CMB);
+            sum = sum + b->tau0[i] * ((exp(y) - 1.0) * (exp(y) - 1.0)) / ((y * y) * exp(y));
+        }
+    }
+    return sum;
+}
+
+static void get_theta(const dgo_ctx *ctx, const dgo_comp *c, int pix, int map_n, const double *theta, double th[DGO_MAX_IND]) {
+    for (int l = 0; l < c->nindices && l < DGO_MAX_IND; ++l)
+        th[l] = theta ? theta[l] : c->indices[((int64_t)l * ctx->nmaps + (map_n - 1)) * (int64_t)ctx->npix + pix];
+}
+
+/* src/dang_component_mod.f90:886-918 */
+static double sed_powerlaw(const dgo_band *b, double nu_ref, double beta) {
+    if (b->n == 0) return pow(b->nu_c / nu_ref, beta);
+    double s = 0.0;
+    for (int i = 0; i < b->n; ++i) {
+        if (b->nu0[i] == 0.0) continue;
+        s = s + b->tau0[i] * pow(b->nu0[i] / nu_ref, beta);
+    }
+    return s;
+}
+
+/* src/dang_component_mod.f90:920-958 */
+static double sed_mbb(const dgo_band *b, double nu_ref, double beta, double td) {
+    const double z = planck_h() / (K_B * td);
+    if (b->n == 0)
+        return (exp(z * nu_ref) - 1.0) / (exp(z * b->nu_c) - 1.0) * pow(b->nu_c / nu_ref, beta + 1.0);
+    double s = 0.0;
+    for (int i = 0; i < b->n; ++i) {
+        if (b->nu0[i] == 0.0) continue;
+        s = s + b->tau0[i] * (exp(z * nu_ref) - 1.0) / (exp(z * b->nu0[i]) - 1.0) * pow(b->nu0[i] / nu_ref, beta + 1.0);
+    }
+    return s;
+}
+
+/* src/dang_component_mod.f90:960-999 */
+static double sed_lognormal(const dgo_band *b, double nu_ref, double nu_p, double w) {
+    if (b->n == 0) {
+        double l = log(b->nu_c / (nu_p * 1e9)) / w;
+        double q = nu_ref / b->nu_c;
+        return exp(-0.5 * (l * l)) * (q * q);
+    }
+    double s = 0.0;
+    for (int i = 0; i < b->n; ++i) {
+        if (b->nu0[i] == 0.0) continue;
+        double l = log(b->nu0[i] / (nu_p * 1e9)) / w;
+        double q = nu_ref / b->nu0[i];
+        s = s + b->tau0[i] * exp(-0.5 * (l * l)) * (q * q);
+    }
+    return s;
+}
+
+/* src/dang_component_mod.f90:1001-1040 */
+static double ff_gaunt(double nu, double T_e) {
+    return log(exp(5.960 - sqrt(3.0) / PI_ * log(1.0 * nu / 1.0e9 * pow(T_e / 1.0e4, -1.5))) + 2.71828);
+}
+static double sed_freefree(const dgo_band *b, double nu_ref, double T_e) {
+    const double S_ref = ff_gaunt(nu_ref, T_e);
+    if (b->n == 0) {
+        double r = b->nu_c / nu_ref;
+        return ff_gaunt(b->nu_c, T_e) / S_ref * (1.0 / (r * r));
+    }
+    double s = 0.0;
+    for (int i = 0; i < b->n; ++i) {
+        if (b->nu0[i] == 0.0) continue;
+        double r = b->nu0[i] / nu_ref;
+        s = s + b->tau0[i] * ff_gaunt(b->nu0[i], T_e) / S_ref * (1.0 / (r * r));
+    }
+    return s;
+}
+
+/* src/dang_component_mod.f90:778-813 */
+double dgo_eval_sed(const dgo_ctx *ctx, int comp, int band, int pix, int map_n, const double *theta) {
+    const dgo_comp *c = &ctx->comps[comp];
+    const dgo_band *b = &ctx->bands[band];
+    double th[DGO_MAX_IND] = {0.0, 0.0};
+    get_theta(ctx, c, pix, map_n, theta, th);
+    switch (c->type) {
+    case DGO_POWERLAW: return sed_powerlaw(b, c->nu_ref, th[0]);
+    case DGO_MBB: return sed_mbb(b, c->nu_ref, th[0], th[1]);
+    case DGO_FREEFREE: return sed_freefree(b, c->nu_ref, th[0]);
+    case DGO_LOGNORMAL: return sed_lognormal(b, c->nu_ref, th[0], th[1]);
+    case DGO_CMB: return 1.0 / dgo_a2t(ctx, band);
+    default: return NAN;
+    }
+}
+
+/* src/dang_component_mod.f90:754-776 (diffuse branch, :773) */
+double dgo_eval_signal(const dgo_ctx *ctx, int comp, int band, int pix, int map_n, const double *theta) {
+    const dgo_comp *c = &ctx->comps[comp];
+    return c->amplitude[IDX2(ctx, map_n, pix)] * dgo_eval_sed(ctx, comp, band, pix, map_n, theta);
+}
+
+/* ------------------------------------------------------------------ amplitude phase */
+
+static int flag_nplanes(int flag) { return (flag & DGO_FLAG_QU) ? 2 : 1; }
+/* map number of plane p (0/1) for a flag: src/dang_cg_mod.f90:357-363, 488-508 */
+static int flag_map(int flag, int p) {
+    if (flag & DGO_FLAG_QU) return 2 + p;
+    if (flag & DGO_FLAG_T) return 1;
+    if (flag & DGO_FLAG_Q) return 2;
+    return 3;
+}
+static int in_group(const dgo_comp *c, int group) { return c->cg_group == group && c->sample_amplitude; }
+
+int64_t dgo_group_size(const dgo_ctx *ctx, int group, int flag, int *ncg) {
+    int n = 0;
+    for (int l = 0; l < ctx->ncomp; ++l)
+        if (in_group(&ctx->comps[l], group)) ++n;
+    if (ncg) *ncg = n;
+    return (int64_t)n * flag_nplanes(flag) * ctx->npix;
+}
+
+/* src/dang_cg_mod.f90:326-596 */
+void dgo_compute_rhs(const dgo_ctx *ctx, int group, int flag, double *b) {
+    const int npix = ctx->npix, nb = ctx->nbands, nmaps = ctx->nmaps;
+    const int S = flag_nplanes(flag);
+    set_threads(ctx);
+    double *data = (double *)malloc(sizeof(double) * (size_t)nb * nmaps * npix);
+    /* :367-378  T is divided by the gain, the offset is NOT removed here */
+    for (int k = 1; k <= nmaps; ++k)
+        for (int j = 0; j < nb; ++j)
+            for (int i = 0; i < npix; ++i)
+                data[IDX3(ctx, j, k, i)] = (k == 1) ? ctx->sig[IDX3(ctx, j, k, i)] / ctx->gain[j] : ctx->sig[IDX3(ctx, j, k, i)];
+    /* :427-443 remove components that are not solved for in this group */
+    for (int l = 0; l < ctx->ncomp; ++l) {
+        if (in_group(&ctx->comps[l], group)) continue;
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < npix; ++i) {
+            if (masked(ctx->mask[i])) continue;
+            for (int k = 1; k <= nmaps; ++k)
+                for (int j = 0; j < nb; ++j)
+                    data[IDX3(ctx, j, k, i)] = data[IDX3(ctx, j, k, i)] - dgo_eval_signal(ctx, l, j, i, k, NULL);
+        }
+    }
+    int64_t n = dgo_group_size(ctx, group, flag, NULL);
+    for (int64_t q = 0; q < n; ++q) b[q] = 0.0;
+    /* :464-521 */
+    int64_t offset = 0;
+    for (int l = 0; l < ctx->ncomp; ++l) {
+        if (!in_group(&ctx->comps[l], group)) continue;
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < npix; ++i) {
+            for (int j = 0; j < nb; ++j) {
+                if (ctx->mask[i] == 0.0) { /* :474 -- only the ==0 test here */
+                    for (int p = 0; p < S; ++p) b[(int64_t)p * npix + i] = 0.0;
+                    continue;
+                }
+                for (int p = 0; p < S; ++p) {
+                    int k = flag_map(flag, p);
+                    double rms = ctx->rms[IDX3(ctx, j, k, i)];
+                    b[offset + (int64_t)p * npix + i] = b[offset + (int64_t)p * npix + i] +
+                        (data[IDX3(ctx, j, k, i)] * dgo_eval_sed(ctx, l, j, i, k, NULL)) / (rms * rms);
+                }
+            }
+        }
+        offset += (int64_t)S * npix;
+    }
+    free(data);
+}
+
+/* src/dang_cg_mod.f90:598-911 */
+void dgo_compute_Ax(const dgo_ctx *ctx, int group, int flag, const double *x, double *res) {
+    const int npix = ctx->npix, nb = ctx->nbands;
+    const int S = flag_nplanes(flag);
+    const int64_t m = (int64_t)S * npix;
+    const int64_t n = dgo_group_size(ctx, group, flag, NULL);
+    set_threads(ctx);
+    double *temp1 = (double *)malloc(sizeof(double) * (size_t)m);
+    double *temp3 = (double *)malloc(sizeof(double) * (size_t)n);
+    for (int64_t q = 0; q < n; ++q) res[q] = 0.0;
+    for (int j = 0; j < nb; ++j) {
+        for (int64_t q = 0; q < m; ++q) temp1[q] = 0.0;
+        for (int64_t q = 0; q < n; ++q) temp3[q] = 0.0;
+        int64_t offset = 0;
+        /* :685-769 temp1 = T_nu x */
+        for (int l = 0; l < ctx->ncomp; ++l) {
+            if (!in_group(&ctx->comps[l], group)) continue;
+#pragma omp parallel for schedule(static)
+            for (int i = 0; i < npix; ++i) {
+                if (masked(ctx->mask[i])) continue;
+                for (int p = 0; p < S; ++p)
+                    temp1[(int64_t)p * npix + i] = temp1[(int64_t)p * npix + i] +
+                        x[offset + (int64_t)p * npix + i] * dgo_eval_sed(ctx, l, j, i, flag_map(flag, p), NULL);
+            }
+            offset += m;
+        }
+        /* :775-791 temp1 = N^-1 temp1 */
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < npix; ++i) {
+            if (masked(ctx->mask[i])) continue;
+            for (int p = 0; p < S; ++p) {
+                double rms = ctx->rms[IDX3(ctx, j, flag_map(flag, p), i)];
+                temp1[(int64_t)p * npix + i] = temp1[(int64_t)p * npix + i] / (rms * rms);
+            }
+        }
+        /* :801-894 temp3 = T_nu^t temp1 */
+        offset = 0;
+        for (int l = 0; l < ctx->ncomp; ++l) {
+            if (!in_group(&ctx->comps[l], group)) continue;
+#pragma omp parallel for schedule(static)
+            for (int i = 0; i < npix; ++i) {
+                if (masked(ctx->mask[i])) continue;
+                for (int p = 0; p < S; ++p)
+                    temp3[offset + (int64_t)p * npix + i] =
+                        temp1[(int64_t)p * npix + i] * dgo_eval_sed(ctx, l, j, i, flag_map(flag, p), NULL);
+            }
+            offset += m;
+        }
+        for (int64_t q = 0; q < n; ++q) res[q] = res[q] + temp3[q]; /* :904 */
+    }
+    free(temp1);
+    free(temp3);
+}
+
+/* src/dang_cg_mod.f90:913-1100.  NOTE (quirks 2,3): the diffuse branch writes
+ * temp2(i)/temp2(npix+i) WITHOUT the component offset and with '=' (:1033-1040),
+ * and the same eta is used for every band (:1008-1015). */
+void dgo_compute_sample_vector(const dgo_ctx *ctx, int group, int flag, const double *eta, double *res) {
+    const int npix = ctx->npix, nb = ctx->nbands;
+    const int S = flag_nplanes(flag);
+    const int64_t m = (int64_t)S * npix;
+    const int64_t n = dgo_group_size(ctx, group, flag, NULL);
+    set_threads(ctx);
+    double *temp1 = (double *)malloc(sizeof(double) * (size_t)m);
+    double *temp2 = (double *)malloc(sizeof(double) * (size_t)n);
+    for (int64_t q = 0; q < n; ++q) res[q] = 0.0;
+    for (int j = 0; j < nb; ++j) {
+        for (int64_t q = 0; q < m; ++q) temp1[q] = 0.0;
+        for (int64_t q = 0; q < n; ++q) temp2[q] = 0.0;
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < npix; ++i) {
+            if (masked(ctx->mask[i])) continue;
+            for (int p = 0; p < S; ++p)
+                temp1[(int64_t)p * npix + i] = eta[(int64_t)p * npix + i] / ctx->rms[IDX3(ctx, j, flag_map(flag, p), i)];
+        }
+        for (int l = 0; l < ctx->ncomp; ++l) {
+            if (!in_group(&ctx->comps[l], group)) continue;
+#pragma omp parallel for schedule(static)
+            for (int i = 0; i < npix; ++i) {
+                if (masked(ctx->mask[i])) continue;
+                for (int p = 0; p < S; ++p)
+                    temp2[(int64_t)p * npix + i] =
+                        temp1[(int64_t)p * npix + i] * dgo_eval_sed(ctx, l, j, i, flag_map(flag, p), NULL);
+            }
+        }
+        for (int64_t q = 0; q < n; ++q) res[q] = res[q] + temp2[q];
+    }
+    free(temp1);
+    free(temp2);
+}
+
+/* src/dang_cg_mod.f90:1173-1282 (diffuse branch) */
+void dgo_initialize_x(const dgo_ctx *ctx, int group, int flag, double *x) {
+    const int S = flag_nplanes(flag);
+    int64_t offset = 0;
+    for (int l = 0; l < ctx->ncomp; ++l) {
+        if (!in_group(&ctx->comps[l], group)) continue;
+        for (int p = 0; p < S; ++p) {
+            for (int i = 0; i < ctx->npix; ++i) x[offset + i] = ctx->comps[l].amplitude[IDX2(ctx, flag_map(flag, p), i)];
+            offset += ctx->npix;
+        }
+    }
+}
+
+/* src/dang_cg_mod.f90:1284-1396 (diffuse branch) */
+void dgo_unpack_amplitudes(dgo_ctx *ctx, int group, int flag, const double *x) {
+    const int S = flag_nplanes(flag);
+    int64_t offset = 0;
+    for (int l = 0; l < ctx->ncomp; ++l) {
+        if (!in_group(&ctx->comps[l], group)) continue;
+        for (int p = 0; p < S; ++p) {
+            for (int i = 0; i < ctx->npix; ++i) ctx->comps[l].amplitude[IDX2(ctx, flag_map(flag, p), i)] = x[offset + i];
+            offset += ctx->npix;
+        }
+    }
+}
+
+/* src/dang_cg_mod.f90:254-262: eta(i)=rand_normal(0,1), i=1..m.  The keyed
+ * stream uses (pixel, draw = map number) so that eta does not depend on sharding. */
+void dgo_draw_eta(const dgo_ctx *ctx, int flag, uint64_t seed, uint64_t stream, double *eta) {
+    const int S = flag_nplanes(flag);
+    for (int p = 0; p < S; ++p)
+        for (int i = 0; i < ctx->npix; ++i) {
+            double u[2];
+            dgo_uniform2(seed, stream, (uint64_t)(ctx->pix0 + i), (uint32_t)flag_map(flag, p), u);
+            eta[(int64_t)p * ctx->npix + i] = dgo_rand_normal(0.0, 1.0, u[0], u[1]);
+        }
+}
+
+static double dot(const double *a, const double *b, int64_t n) {
+    double s = 0.0;
+    for (int64_t q = 0; q < n; ++q) s += a[q] * b[q];
+    return s;
+}
+
+/* src/dang_cg_mod.f90:179-324 (Shewchuk B2, no preconditioner) */
+int dgo_cg_search(const dgo_ctx *ctx, int group, int flag, const double *b, int ml_mode, const double *eta,
+                  double *x, int i_max, double converge, double *delta_trace) {
+    const int64_t n = dgo_group_size(ctx, group, flag, NULL);
+    double *b2 = (double *)malloc(sizeof(double) * (size_t)n);
+    double *r = (double *)malloc(sizeof(double) * (size_t)n);
+    double *d = (double *)malloc(sizeof(double) * (size_t)n);
+    double *q = (double *)malloc(sizeof(double) * (size_t)n);
+    if (ml_mode == DGO_ML_SAMPLE) { /* :254-264 */
+        dgo_compute_sample_vector(ctx, group, flag, eta, q);
+        for (int64_t t = 0; t < n; ++t) b2[t] = b[t] + q[t];
+    } else {
+        for (int64_t t = 0; t < n; ++t) b2[t] = b[t];
+    }
+    dgo_compute_Ax(ctx, group, flag, x, q); /* :283 */
+    for (int64_t t = 0; t < n; ++t) { r[t] = b2[t] - q[t]; d[t] = r[t]; }
+    double delta_new = dot(r, r, n), delta_old;
+    int i = 1;
+    if (delta_trace) delta_trace[0] = delta_new;
+    while (i < i_max && delta_new > converge) { /* :293 */
+        dgo_compute_Ax(ctx, group, flag, d, q);
+        double alpha = delta_new / dot(d, q, n);
+        for (int64_t t = 0; t < n; ++t) x[t] = x[t] + alpha * d[t];
+        for (int64_t t = 0; t < n; ++t) r[t] = r[t] - alpha * q[t];
+        delta_old = delta_new;
+        delta_new = dot(r, r, n);
+        double beta = delta_new / delta_old;
+        for (int64_t t = 0; t < n; ++t) d[t] = r[t] + beta * d[t];
+        if (delta_trace) delta_trace[i] = delta_new;
+        i = i + 1;
+    }
+    free(b2); free(r); free(d); free(q);
+    return i;
+}
+
+/* one (group, flag) pass of sample_cg_groups, src/dang_cg_mod.f90:166-171 */
+int dgo_amp_sample_cg(dgo_ctx *ctx, int group, int flag, int ml_mode, uint64_t seed, uint64_t stream,
+                      int i_max, double converge, double *x_state) {
+    const int64_t n = dgo_group_size(ctx, group, flag, NULL);
+    const int64_t m = (int64_t)flag_nplanes(flag) * ctx->npix;
+    double *b = (double *)malloc(sizeof(double) * (size_t)n);
+    double *eta = (double *)calloc((size_t)m, sizeof(double));
+    double *x = x_state ? x_state : (double *)malloc(sizeof(double) * (size_t)n);
+    dgo_compute_rhs(ctx, group, flag, b);
+    if (!x_state) dgo_initialize_x(ctx, group, flag, x); /* iter==1, :227-239 */
+    if (ml_mode == DGO_ML_SAMPLE) dgo_draw_eta(ctx, flag, seed, stream, eta);
+    int it = dgo_cg_search(ctx, group, flag, b, ml_mode, eta, x, i_max, converge, NULL);
+    dgo_unpack_amplitudes(ctx, group, flag, x);
+    free(b); free(eta);
+    if (!x_state) free(x);
+    return it;
+}
+
+/* Direct block solve: the system of compute_rhs/compute_Ax/compute_sample_vector is
+ * block diagonal with one ncg x ncg SPD block per (pixel, plane) when all group
+ * components are diffuse (every term of :697-704, :813-820 couples only index i).
+ * This restates the arithmetic order of the HIP kernel, so GPU-vs-oracle agreement
+ * is at rounding level; agreement with dgo_amp_sample_cg is at CG-residual level. */
+#define DGO_MAX_NC 8
+int dgo_amp_sample_direct(dgo_ctx *ctx, int group, int flag, int ml_mode, int fluct_mode, uint64_t seed,
+                          uint64_t stream, int64_t *n_not_spd) {
+    const int npix = ctx->npix, nb = ctx->nbands, S = flag_nplanes(flag);
+    int gc[DGO_MAX_NC], oc[64], ng = 0, no = 0;
+    for (int l = 0; l < ctx->ncomp; ++l) {
+        if (in_group(&ctx->comps[l], group)) { if (ng >= DGO_MAX_NC) return -1; gc[ng++] = l; }
+        else { if (no >= 64) return -1; oc[no++] = l; }
+    }
+    if (ng == 0) return -1;
+    int64_t bad = 0;
+    set_threads(ctx);
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+    for (int i = 0; i < npix; ++i) {
+        if (masked(ctx->mask[i])) continue;
+        for (int p = 0; p < S; ++p) {
+            const int k = flag_map(flag, p);
+            double A[DGO_MAX_NC][DGO_MAX_NC], bv[DGO_MAX_NC], mrow[DGO_MAX_NC];
+            double f0 = 0.0, eta = 0.0;
+            for (int a = 0; a < ng; ++a) { bv[a] = 0.0; for (int c = 0; c <= a; ++c) A[a][c] = 0.0; }
+            if (ml_mode == DGO_ML_SAMPLE && fluct_mode == DGO_FLUCT_REFERENCE) {
+                double u[2];
+                dgo_uniform2(seed, stream, (uint64_t)(ctx->pix0 + i), (uint32_t)k, u);
+                eta = dgo_rand_normal(0.0, 1.0, u[0], u[1]);
+            }
+            for (int j = 0; j < nb; ++j) {
+                double d = (k == 1) ? ctx->sig[IDX3(ctx, j, k, i)] / ctx->gain[j] : ctx->sig[IDX3(ctx, j, k, i)];
+                for (int o = 0; o < no; ++o) d = d - dgo_eval_signal(ctx, oc[o], j, i, k, NULL);
+                for (int a = 0; a < ng; ++a) mrow[a] = dgo_eval_sed(ctx, gc[a], j, i, k, NULL);
+                const double is = 1.0 / ctx->rms[IDX3(ctx, j, k, i)];
+                const double inv = is * is;
+                for (int a = 0; a < ng; ++a) {
+                    const double t = mrow[a] * inv;
+                    bv[a] += d * t;
+                    for (int c = 0; c <= a; ++c) A[a][c] += t * mrow[c];
+                }
+                if (ml_mode == DGO_ML_SAMPLE) {
+                    if (fluct_mode == DGO_FLUCT_REFERENCE) {
+                        f0 += (eta * is) * mrow[ng - 1];
+                    } else {
+                        double u[2];
+                        dgo_uniform2(seed, stream, (uint64_t)(ctx->pix0 + i), (uint32_t)(k + 4 * (j + 1)), u);
+                        const double ej = dgo_rand_normal(0.0, 1.0, u[0], u[1]) * is;
+                        for (int a = 0; a < ng; ++a) bv[a] += ej * mrow[a];
+                    }
+                }
+            }
+            bv[0] += f0;
+            /* in-place Cholesky A = L L^t (lower), then two triangular solves */
+            int ok = 1;
+            for (int a = 0; a < ng && ok; ++a) {
+                for (int c = 0; c <= a; ++c) {
+                    double s = A[a][c];
+                    for (int t = 0; t < c; ++t) s -= A[a][t] * A[c][t];
+                    if (a == c) {
+                        if (!(s > 0.0)) { ok = 0; break; }
+                        A[a][a] = sqrt(s);
+                    } else {
+                        A[a][c] = s / A[c][c];
+                    }
+                }
+            }
+            if (!ok) { bad += 1; continue; }
+            for (int a = 0; a < ng; ++a) {
+                double s = bv[a];
+                for (int t = 0; t < a; ++t) s -= A[a][t] * bv[t];
+                bv[a] = s / A[a][a];
+            }
+            for (int a = ng - 1; a >= 0; --a) {
+                double s = bv[a];
+                for (int t = a + 1; t < ng; ++t) s -= A[t][a] * bv[t];
+                bv[a] = s / A[a][a];
+            }
+            for (int a = 0; a < ng; ++a) ctx->comps[gc[a]].amplitude[IDX2(ctx, k, i)] = bv[a];
+        }
+    }
+    if (n_not_spd) *n_not_spd = bad;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ sky model + chisq */
+
+/* src/dang_data_mod.f90:339-396 */
+void dgo_update_sky_model(const dgo_ctx *ctx, double *sky, double *res) {
+    const int npix = ctx->npix, nb = ctx->nbands, nmaps = ctx->nmaps;
+    set_threads(ctx);
+    for (int64_t q = 0; q < (int64_t)nb * nmaps * npix; ++q) sky[q] = 0.0;
+    for (int l = 0; l < ctx->ncomp; ++l) {
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < npix; ++i)
+            for (int k = 1; k <= nmaps; ++k)
+                for (int j = 0; j < nb; ++j)
+                    sky[IDX3(ctx, j, k, i)] = sky[IDX3(ctx, j, k, i)] + dgo_eval_signal(ctx, l, j, i, k, NULL);
+    }
+    if (!res) return;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < npix; ++i)
+        for (int k = 1; k <= nmaps; ++k)
+            for (int j = 0; j < nb; ++j) {
+                if (k == 1) res[IDX3(ctx, j, 1, i)] = (ctx->sig[IDX3(ctx, j, 1, i)] - ctx->offset[j]) / ctx->gain[j] - sky[IDX3(ctx, j, 1, i)];
+                else res[IDX3(ctx, j, k, i)] = ctx->sig[IDX3(ctx, j, k, i)] - sky[IDX3(ctx, j, k, i)];
+            }
+}
+
+/* src/dang_data_mod.f90:494-526; nump is an input (quirk 9) */
+double dgo_compute_chisq(const dgo_ctx *ctx, const double *sky, int pol_lo, int pol_hi, double nump, double *chi_map) {
+    const int npix = ctx->npix, nb = ctx->nbands, nmaps = ctx->nmaps;
+    double *cm = chi_map ? chi_map : (double *)malloc(sizeof(double) * (size_t)nmaps * npix);
+    for (int64_t q = 0; q < (int64_t)nmaps * npix; ++q) cm[q] = 0.0;
+    for (int i = 0; i < npix; ++i) {
+        if (masked(ctx->mask[i])) continue;
+        for (int k = pol_lo; k <= pol_hi; ++k)
+            for (int j = 0; j < nb; ++j) {
+                double rms = ctx->rms[IDX3(ctx, j, k, i)];
+                double r = (k == 1) ? (ctx->sig[IDX3(ctx, j, k, i)] - ctx->offset[j]) / ctx->gain[j] - sky[IDX3(ctx, j, k, i)]
+                                    : ctx->sig[IDX3(ctx, j, k, i)] - sky[IDX3(ctx, j, k, i)];
+                cm[IDX2(ctx, k, i)] = cm[IDX2(ctx, k, i)] + (r * r) / (rms * rms);
+            }
+    }
+    double s = 0.0;
+    for (int64_t q = 0; q < (int64_t)nmaps * npix; ++q) { cm[q] = cm[q] / nb; s += cm[q]; }
+    if (!chi_map) free(cm);
+    return s / nump;
+}
+
+/* ------------------------------------------------------------------ index phase */
+
+/* src/dang_lnl_mod.f90:126-182, single-pixel call.  data/rms/model point at
+ * element (band 0, map 1, pixel 0) of arrays with the given strides. */
+double dgo_evaluate_lnL(int nbands, int s1, int s2, const double *data, const double *rms, const double *model,
+                        int64_t band_stride, int64_t map_stride, int pix, double maskval) {
+    double lnL_local = 0.0;
+    if (masked(maskval)) return 0.0;
+    for (int k = s1; k <= s2; ++k)
+        for (int j = 0; j < nbands; ++j) {
+            int64_t q = (int64_t)j * band_stride + (int64_t)(k - 1) * map_stride + pix;
+            double t = (data[q] - model[q]) / rms[q];
+            lnL_local = lnL_local - 0.5 * (t * t);
+        }
+    return 0.0 + lnL_local;
+}
+
+/* src/dang_lnl_mod.f90:47-124, single-pixel call (no mask test, no log-det term) */
+double dgo_evaluate_marginal_lnL(int nbands, int s1, int s2, const double *data, const double *rms, const double *model,
+                                 int64_t band_stride, int64_t map_stride, int pix) {
+    double lnL = 0.0;
+    for (int j = 0; j < nbands; ++j)
+        for (int k = s1; k <= s2; ++k) {
+            int64_t q = (int64_t)j * band_stride + (int64_t)(k - 1) * map_stride + pix;
+            double TN = model[q] / (rms[q] * rms[q]);
+            double TNd = TN * data[q];
+            double TNT = TN * model[q];
+            double invTNT = 1.0 / TNT;
+            lnL = lnL - 0.5 * TNd * invTNT * TNd;
+        }
+    return lnL;
+}
+
+/* src/dang_lnl_mod.f90:242-304, single-pixel call */
+static double jeffreys_prior(const dgo_ctx *ctx, int comp, int s1, int s2, int pix, double val) {
+    const dgo_comp *c = &ctx->comps[comp];
+    double sum = 0.0, theta[DGO_MAX_IND] = {val, 0.0};
+    if (c->is_synch) {
+        if (!masked(ctx->mask[pix])) {
+            for (int k = s1; k <= s2; ++k)
+                for (int j = 0; j < ctx->nbands; ++j) {
+                    double ss = dgo_eval_signal(ctx, comp, j, pix, k, theta);
+                    double rr = 1.0 / ctx->rms[IDX3(ctx, j, k, pix)];
+                    double t = ((rr * rr) * (ss / c->amplitude[IDX2(ctx, k, pix)]) * log(ctx->bands[j].nu_c / c->nu_ref));
+                    sum = sum + t * t;
+                }
+        }
+    }
+    return sqrt(sum);
+}
+
+static double index_prior(const dgo_ctx *ctx, int comp, int nind, int s1, int s2, int pix, double val) {
+    const dgo_comp *c = &ctx->comps[comp];
+    switch (c->prior_type[nind]) {
+    case DGO_PRIOR_GAUSSIAN: return log(dgo_eval_normal_prior(val, c->gauss_prior[nind][0], c->gauss_prior[nind][1]));
+    case DGO_PRIOR_JEFFREYS: return log(jeffreys_prior(ctx, comp, s1, s2, pix, val));
+    default: return 0.0;
+    }
+}
+
+/* src/dang_sample_mod.f90:88-485, index_mode==2 with sample_nside==nside */
+int64_t dgo_sample_index_mh(dgo_ctx *ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed,
+                            uint64_t stream) {
+    dgo_comp *c = &ctx->comps[comp];
+    const int npix = ctx->npix, nb = ctx->nbands;
+    const int s1 = (map_n == -1) ? 2 : (map_n == -2 ? 1 : map_n); /* :157-163 */
+    const int s2 = (map_n == -1) ? 3 : (map_n == -2 ? 3 : map_n);
+    const int64_t ms = npix, bs = (int64_t)ctx->nmaps * npix;
+    int64_t accepted = 0;
+    set_threads(ctx);
+    double *index_map = (double *)calloc((size_t)3 * npix, sizeof(double)); /* :221-223 zero-initialised */
+#pragma omp parallel for schedule(static) reduction(+ : accepted)
+    for (int i = 0; i < npix; ++i) {
+        if (masked(ctx->mask[i])) continue; /* :362 */
+        double data[3 * 64], model[3 * 64], rmsl[3 * 64];
+        double sample[DGO_MAX_IND] = {0, 0}, theta[DGO_MAX_IND] = {0, 0};
+        /* :173-196 data_raw minus every OTHER component, evaluated for this pixel */
+        for (int k = s1; k <= s2; ++k)
+            for (int j = 0; j < nb; ++j) {
+                double d = (k == 1) ? (ctx->sig[IDX3(ctx, j, 1, i)] - ctx->offset[j]) / ctx->gain[j] : ctx->sig[IDX3(ctx, j, k, i)];
+                for (int l = 0; l < ctx->ncomp; ++l)
+                    if (l != comp) d = d - dgo_eval_signal(ctx, l, j, i, k, NULL);
+                data[(k - 1) * 64 + j] = d;
+                rmsl[(k - 1) * 64 + j] = ctx->rms[IDX3(ctx, j, k, i)];
+            }
+        for (int l = 0; l < c->nindices; ++l) sample[l] = c->indices[((int64_t)l * ctx->nmaps + (s1 - 1)) * (int64_t)npix + i]; /* :372-374 */
+        for (int l = 0; l < DGO_MAX_IND; ++l) theta[l] = sample[l];
+#define FILL_MODEL(th)                                                                     \
+        for (int k = s1; k <= s2; ++k)                                                     \
+            for (int j = 0; j < nb; ++j) model[(k - 1) * 64 + j] = dgo_eval_signal(ctx, comp, j, i, k, (th));
+#define LNL()                                                                              \
+        (c->lnl_type[nind] == DGO_LNL_CHISQ    ? dgo_evaluate_lnL(nb, s1, s2, data, rmsl, model, 1, 64, 0, ctx->mask[i]) \
+         : c->lnl_type[nind] == DGO_LNL_MARGINAL ? dgo_evaluate_marginal_lnL(nb, s1, s2, data, rmsl, model, 1, 64, 0)    \
+                                                 : 0.0)
+        FILL_MODEL(sample) /* :380 */
+        int sample_it = 1;
+        double lnl = LNL();
+        if (c->lnl_type[nind] == DGO_LNL_PRIOR) { /* :389-392 */
+            double u[2];
+            sample_it = 0;
+            dgo_uniform2(seed, stream, (uint64_t)(ctx->pix0 + i), 0u, u);
+            sample[nind] = dgo_rand_normal(c->gauss_prior[nind][0], c->gauss_prior[nind][1], u[0], u[1]);
+        }
+        double lnl_old = lnl + index_prior(ctx, comp, nind, s1, s2, i, sample[nind]); /* :394-402 */
+        if (sample_it) {
+            for (int l = 1; l <= nsample; ++l) {
+                double u[2];
+                dgo_uniform2(seed, stream, (uint64_t)(ctx->pix0 + i), (uint32_t)l, u);
+                theta[nind] = sample[nind] + dgo_rand_normal(0.0, c->step_size[nind], u[0], u[1]); /* :414 */
+                if (theta[nind] < c->uni_prior[nind][0] || theta[nind] > c->uni_prior[nind][1]) continue; /* :415 */
+                FILL_MODEL(theta)
+                lnl = LNL();
+                double lnl_new = lnl + index_prior(ctx, comp, nind, s1, s2, i, theta[nind]);
+                double diff = lnl_new - lnl_old;
+                if (ml_mode == DGO_ML_OPTIMIZE) { /* :443-447 */
+                    if (diff > 0.0) { sample[nind] = theta[nind]; lnl_old = lnl_new; accepted += 1; }
+                } else { /* :448-454 */
+                    double v[2];
+                    dgo_uniform2(seed, stream, (uint64_t)(ctx->pix0 + i), (uint32_t)l | 0x80000000u, v);
+                    if (diff > log(v[0])) { sample[nind] = theta[nind]; lnl_old = lnl_new; accepted += 1; }
+                }
+            }
+        }
+        for (int k = s1; k <= s2; ++k) index_map[(int64_t)(k - 1) * npix + i] = sample[nind]; /* :465 */
+#undef FILL_MODEL
+#undef LNL
+    }
+    /* :480-483 udgrade_ring at equal Nside is a copy; masked pixels receive 0 */
+    for (int k = s1; k <= s2; ++k)
+        for (int i = 0; i < npix; ++i)
+            c->indices[((int64_t)nind * ctx->nmaps + (k - 1)) * (int64_t)npix + i] = index_map[(int64_t)(k - 1) * npix + i];
+    free(index_map);
+    (void)ms; (void)bs;
+    return accepted;
+}
