@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- Gibbs iterations/sec of the MI355X path on synthetic HEALPix-shaped maps.
+
+One "step" = one full Gibbs iteration of the hot path: `sample_cg_groups` (amplitude solve for
+every CG group / poltype flag, then update_sky_model + compute_chisq) followed by
+`sample_spectral_parameters` (per-pixel Metropolis sweep of every sampled spectral index, then
+update_sky_model + compute_chisq) -- src/dang.f90:101-106 without FITS/ASCII output.
+
+Workload at N=1: BASELINE config "C3" = Nside 1024, 10 bands, 4 components (cmb, synch, dust,
+free-free), IQU, fp64.  For N>1 the SAME sky is pixel-sharded over the ranks (strong scaling,
+BASELINE config 4); the only collective is the scalar chi^2 all-reduce (RCCL).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")  # oracle leg: no spinning OpenMP workers
+
+import torch  # noqa: E402
+import torch.distributed as td  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(meta, comps, kernel, units):
+    """Algorithmic HBM bytes of one launch (DESIGN.md 'Algorithmic bytes'), 8 B per double.
+
+    amplitude solve, per (pixel, plane) unit: read d and sigma for every band (2 nb), the group's
+      spectral indices (nidx_g) and the mask (1); write the group's nc amplitudes.
+    index sweep, per unit: read d and sigma (2 nb), every amplitude that enters the model on that
+      plane (nc_g), the group's indices (nidx_g) and the mask (1); write 1 index value.
+    """
+    nb = meta["nbands"]
+    nphys = len(meta["phys"])
+    nidx = sum(c.nindices for c in comps[:nphys])
+    if kernel == "k_amp_direct":
+        per_unit = 2 * nb + nidx + 1 + nphys
+    elif kernel == "k_index_mh":
+        per_unit = 2 * nb + nphys + nidx + 1 + 1
+    else:  # k_sky_chisq: read d, sigma, amplitudes, indices, mask
+        per_unit = 2 * nb + nphys + nidx + 1
+    return 8.0 * per_unit * units
+
+
+def log(msg):
+    sys.stderr.write("[bench %.1fs] %s\n" % (time.time() - _T0, msg))
+    sys.stderr.flush()
+
+
+_T0 = time.time()
+
+
+def cpu_baseline(config_name, nsample, nside_sample=64):
+    """Time the CPU oracle ("port" of the reference algorithm: global CG with per-iteration SED
+    re-evaluation + per-pixel Metropolis) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ffi as O
+    import dang_amd as da
+    from dang_amd import synth
+
+    # the GPU box gives one GPU's share of the host: at most 16 cores (never oversubscribe OpenMP)
+    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    dpar, ddata, bands, comps, meta = synth.make_sky(config_name, nside=nside_sample, nsample=nsample)
+    full_npix = 12 * synth.CONFIGS[config_name]["nside"] ** 2
+    orc = O.Oracle(bands, comps, ddata, nthreads=cores)
+    mapn = {1: 1, 2: 2, 4: 3, 8: -1}
+    t0 = time.time()
+    cg_iters = []
+    for g in dpar.cg_groups:
+        for f in g.pol_flag:
+            cg_iters.append(orc.amp_sample_cg(g.cg_group, f, "sample", dpar.seed, da.stream_id(1, 0, g.cg_group, 0, f),
+                                              i_max=g.i_max, converge=g.converge))
+    orc.chisq(1, meta["nmaps"], ddata.nump)
+    for l, c in enumerate(comps):
+        for j in range(c.nindices):
+            if c.sample_index[j]:
+                for f in c.pol_flag[j]:
+                    orc.sample_index_mh(l, j, mapn[f], dpar.nsample, "sample", dpar.seed, da.stream_id(2, 1, l, j, f))
+    orc.chisq(1, meta["nmaps"], ddata.nump)
+    dt = time.time() - t0
+    scale = full_npix / meta["npix_global"]
+    return {"value": 1.0 / (dt * scale), "unit": "it/s", "cores": cores, "kind": "port",
+            "sample": "1 Gibbs iteration of config %s at Nside=%d (%d px; CG iterations %s at i_max=100, converge=1e-8) "
+                      "took %.2f s on %d OpenMP threads; scaled by pixel count x%d to Nside=%d"
+                      % (config_name, nside_sample, meta["npix_global"], cg_iters, dt, cores, int(scale),
+                         synth.CONFIGS[config_name]["nside"])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--nside", type=int, default=None)
+    ap.add_argument("--nsample", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        td.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import dang_amd as da
+    from dang_amd import synth
+
+    log("building synthetic sky %s on %s" % (args.config, dev))
+    dpar, ddata, bands, comps, meta = synth.make_sky(args.config, nside=args.nside, device=dev, rank=rank, nranks=world,
+                                                     nsample=args.nsample, as_numpy=False)
+    stream = torch.cuda.current_stream().cuda_stream
+    eng = da.initialize(bands, comps, ddata, npix_global=meta["npix_global"], pix0=meta["pix0"], device=local_rank,
+                        stream=stream if stream else None)
+    nmaps, nb = meta["nmaps"], meta["nbands"]
+    chisq_buf = torch.zeros(2, dtype=torch.float64, device=dev)
+    mapn = {1: 1, 2: 2, 4: 3, 8: -1}
+
+    def gibbs_iteration(it):
+        # sample_cg_groups (src/dang_cg_mod.f90:142-177)
+        for g in dpar.cg_groups:
+            for f in g.pol_flag:
+                eng.amp_sample(g.cg_group, f, dpar.ml_mode, dpar.seed, da.stream_id(it, 0, g.cg_group, 0, f),
+                               solver="direct", fluct_mode=dpar.fluct_mode, want_counts=False)
+        eng.sky_model_chisq_dev(1, nmaps, chisq_buf[0:1])
+        # sample_spectral_parameters (src/dang_sample_mod.f90:21-86)
+        for l, c in enumerate(comps):
+            for j in range(c.nindices):
+                if c.sample_index[j]:
+                    for f in c.pol_flag[j]:
+                        eng.index_sample(l, j, mapn[f], dpar.nsample, dpar.ml_mode, dpar.seed,
+                                         da.stream_id(it, 1, l, j, f), want_counts=False)
+        eng.sky_model_chisq_dev(1, nmaps, chisq_buf[1:2])
+        if world > 1:
+            td.all_reduce(chisq_buf)  # global chi^2 (RCCL over xGMI); 16-byte message
+
+    def fence():
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    log("engine ready: npix(local)=%d nbands=%d ncomp=%d" % (meta["npix"], nb, meta["ncomp"]))
+    it = 1
+    for _ in range(args.warmup):
+        gibbs_iteration(it)
+        it += 1
+    eng.profile(True)
+    fence()
+    log("warmup done, timing %d steps" % args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gibbs_iteration(it)
+        it += 1
+    fence()
+    elapsed = time.perf_counter() - t0
+    log("timed region: %.3f s" % elapsed)
+    prof = eng.profile_get()
+    eng.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        elapsed = float(t.item())
+    chisq = (chisq_buf / nb / ddata.nump).tolist()
+
+    if rank == 0:
+        # dominant kernel (largest total time on this rank) and its HBM roofline fraction
+        dom = max(prof, key=lambda k: prof[k]["total_ms"])
+        units_per_step = {"k_amp_direct": meta["npix"] * nmaps,
+                          "k_index_mh": sum(meta["npix"] * (2 if f == 8 else 1) for c in comps for j in range(c.nindices)
+                                            if c.sample_index[j] for f in c.pol_flag[j]),
+                          "k_sky_chisq": 2 * meta["npix"] * nmaps}
+        launches_per_step = max(prof[dom]["launches"] // args.steps, 1)
+        bytes_per_launch = algorithmic_bytes(meta, comps, dom, units_per_step.get(dom, meta["npix"] * nmaps)) / launches_per_step
+        achieved = bytes_per_launch / (prof[dom]["avg_ms"] * 1e-3) / 1e9
+        out = {
+            "metric": "gibbs_iterations_per_sec", "value": args.steps / elapsed, "unit": "it/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: Nside=%d, %d bands, %d components (%s), %s, NUMSAMPLE=%d, per-pixel indices, "
+                                   "direct block solve, reference fluctuation term; pixel-sharded over %d rank(s)"
+                                   % (args.config, meta["nside"], nb, len(meta["phys"]), "+".join(meta["phys"]),
+                                      "IQU" if nmaps == 3 else "I", args.nsample, world),
+                       "npix": meta["npix_global"], "chisq_after_amp": chisq[0], "chisq_after_index": chisq[1]},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": prof[dom]["avg_ms"], "bytes_per_launch": bytes_per_launch},
+            "kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"],
+                            "ms_per_step": round(v["total_ms"] / args.steps, 4)} for k, v in prof.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                log("timing the CPU oracle (cpu_baseline)")
+                out["cpu_baseline"] = cpu_baseline(args.config, args.nsample)
+                log("cpu_baseline done")
+            except Exception as e:  # the oracle is optional infrastructure; never let it break the bench line
+                out["cpu_baseline"] = {"value": None, "unit": "it/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    if world > 1:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

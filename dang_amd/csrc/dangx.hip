@@ -418,19 +418,15 @@ __device__ __forceinline__ double index_prior(const Model& M, const Comp& c, con
     return 0.0;
 }
 
-__global__ void k_index_mh(const Model* __restrict__ Mp, IndexArgs a, unsigned long long* __restrict__ accepted) {
-    extern __shared__ double lds[];
-    const Model& M = *Mp;
-    const int BS = blockDim.x, tid = threadIdx.x;
+// the chain of one pixel; returns the number of accepted proposals
+__device__ __forceinline__ unsigned long long index_chain(const Model& M, const IndexArgs& a, double* lds, int BS, int tid, int i) {
     const int npix = M.npix, nb = M.nbands;
-    const int i = blockIdx.x * BS + tid;
-    if (i >= npix) return;
     const Comp& c = M.comp[a.comp];
     const int Sp = a.s2 - a.s1 + 1;
     double* out = c.idx + ((long long)a.nind * M.nmaps) * npix + i;
     if (is_masked(M.mask[i])) {  // :362 cycle; index_map stays 0 (:223) and is copied back (:480-483)
         for (int k = a.s1; k <= a.s2; ++k) out[(long long)(k - 1) * npix] = 0.0;
-        return;
+        return 0ull;
     }
     // --- stage data_raw minus every OTHER component (:173-196) and 1/rms
     double amp[2] = {0.0, 0.0};
@@ -455,15 +451,16 @@ __global__ void k_index_mh(const Model* __restrict__ Mp, IndexArgs a, unsigned l
         }
     }
     // --- chain state: sample(l) = c%indices(i, map_inds(1), l)  (:372-377)
-    double sample[2], theta[2];
-    load_theta(M, c, i, a.s1, sample[0], sample[1]);
-    theta[0] = sample[0]; theta[1] = sample[1];
+    // (scalars, not arrays: a runtime-indexed array would live in scratch memory)
+    double sample0, sample1;
+    load_theta(M, c, i, a.s1, sample0, sample1);
+    const bool first = (a.nind == 0);
     const int lnl_type = c.lnl_type[a.nind];
     const bool unmasked_lnl = true;  // evaluate_lnL tests mask(i) again (:171): already unmasked here
 
-    auto lnl_of = [&](const double th[2]) -> double {
+    auto lnl_of = [&](double th0, double th1) -> double {
         if (lnl_type == DANGX_LNL_PRIOR) return 0.0;
-        const Prep pr = sed_prep(c, th[0], th[1]);
+        const Prep pr = sed_prep(c, th0, th1);
         if (lnl_type == DANGX_LNL_CHISQ) {  // -0.5*sum ((d-m)/rms)^2, one accumulator per plane
             double acc0 = 0.0, acc1 = 0.0;
             for (int j = 0; j < nb; ++j) {
@@ -494,25 +491,25 @@ __global__ void k_index_mh(const Model* __restrict__ Mp, IndexArgs a, unsigned l
 
     const unsigned long long gpix = (unsigned long long)(M.pix0 + i);
     unsigned long long nacc = 0;
-    double lnl = lnl_of(sample);
+    double lnl = lnl_of(sample0, sample1);
+    double cur = first ? sample0 : sample1;  // sample(nind)
     bool sample_it = true;
     if (lnl_type == DANGX_LNL_PRIOR) {  // :389-392
         double u1, u2;
         sample_it = false;
         uniform2(a.seed, a.stream, gpix, 0u, u1, u2);
-        sample[a.nind] = rand_normal(c.gauss[a.nind][0], c.gauss[a.nind][1], u1, u2);
+        cur = rand_normal(c.gauss[a.nind][0], c.gauss[a.nind][1], u1, u2);
     }
-    double lnl_old = lnl + index_prior(M, c, a, i, sample[a.nind], amp, lds, BS, tid);
+    double lnl_old = lnl + index_prior(M, c, a, i, cur, amp, lds, BS, tid);
     if (sample_it) {
         const double step = c.step[a.nind];
         const double lo = c.uni[a.nind][0], hi = c.uni[a.nind][1];
         for (int l = 1; l <= a.nsample; ++l) {
             double u1, u2;
             uniform2(a.seed, a.stream, gpix, (uint32_t)l, u1, u2);
-            const double prop = sample[a.nind] + rand_normal(0.0, step, u1, u2);  // :414
-            theta[a.nind] = prop;
+            const double prop = cur + rand_normal(0.0, step, u1, u2);  // :414
             if (prop < lo || prop > hi) continue;  // :415 (no accept draw consumed)
-            lnl = lnl_of(theta);
+            lnl = lnl_of(first ? prop : sample0, first ? sample1 : prop);
             const double lnl_new = lnl + index_prior(M, c, a, i, prop, amp, lds, BS, tid);
             const double diff = lnl_new - lnl_old;
             bool acc;
@@ -524,14 +521,23 @@ __global__ void k_index_mh(const Model* __restrict__ Mp, IndexArgs a, unsigned l
                 acc = diff > log(v1);  // :448-454
             }
             if (acc) {
-                sample[a.nind] = prop;
+                cur = prop;
                 lnl_old = lnl_new;
                 ++nacc;
             }
         }
     }
-    for (int k = a.s1; k <= a.s2; ++k) out[(long long)(k - 1) * npix] = sample[a.nind];  // :465, :483
-    if (accepted) {
+    for (int k = a.s1; k <= a.s2; ++k) out[(long long)(k - 1) * npix] = cur;  // :465, :483
+    return nacc;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_index_mh(const Model* __restrict__ Mp, IndexArgs a, unsigned long long* __restrict__ accepted) {
+    extern __shared__ double lds[];
+    const Model& M = *Mp;
+    const int BS = blockDim.x, tid = threadIdx.x;
+    const int i = blockIdx.x * BS + tid;
+    unsigned long long nacc = (i < M.npix) ? index_chain(M, a, lds, BS, tid, i) : 0ull;
+    if (accepted) {  // every lane takes part in the wave reduction
         for (int o = 32; o > 0; o >>= 1) nacc += __shfl_down(nacc, o, 64);
         if ((tid & 63) == 0 && nacc) atomicAdd(accepted, nacc);
     }
@@ -542,7 +548,7 @@ __global__ void k_index_mh(const Model* __restrict__ Mp, IndexArgs a, unsigned l
 // pixel.  sky(i,k,j) is accumulated over components in component_list order in an LDS column;
 // the residual and chi^2 follow the reference's expressions.  Block partials of
 // sum_k sum_j res^2/rms^2 go to `partial` (second stage: k_reduce).
-__global__ void k_sky_chisq(const Model* __restrict__ Mp, int pol_lo, int pol_hi, double* __restrict__ sky,
+__global__ __launch_bounds__(BLOCK) void k_sky_chisq(const Model* __restrict__ Mp, int pol_lo, int pol_hi, double* __restrict__ sky,
                             double* __restrict__ res, double* __restrict__ chi_map, double* __restrict__ partial) {
     extern __shared__ double lds[];  // [nb][BS]
     const Model& M = *Mp;
