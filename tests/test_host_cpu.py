@@ -1,0 +1,48 @@
+"""Host-side logic: stream labels, descriptor marshalling, synthetic sky, sharding."""
+import numpy as np
+
+import dang_amd as da
+from dang_amd import _lib as L
+from dang_amd import dist, synth
+from dang_amd.api import comp_desc
+
+
+def test_stream_ids_are_distinct():
+    ids = {da.stream_id(it, ph, a, b, c) for it in (1, 2, 77) for ph in (0, 1) for a in (0, 1, 5) for b in (0, 1) for c in (1, 2, 4, 8)}
+    assert len(ids) == 3 * 2 * 3 * 2 * 4
+    assert da.stream_id(3, 1, 2, 1, 8) < 2 ** 64
+
+
+def test_comp_desc_marshalling():
+    dpar, ddata, bands, comps, meta = synth.make_sky("C2", nside=1)
+    d = comp_desc(comps[2])  # dust
+    assert (d.type, d.nindices, d.cg_group, d.sample_amplitude, d.is_synch) == (L.MBB, 2, 1, 1, 0)
+    assert d.lnl_type[0] == L.LNL_CHISQ and d.prior_type[1] == L.PRIOR_GAUSSIAN
+    assert (d.gauss_prior[1][0], d.gauss_prior[1][1]) == (19.6, 1.5)
+    assert abs(d.step_size[0] - 0.05) < 1e-15
+    assert comp_desc(comps[1]).is_synch == 1 and comp_desc(comps[4]).is_synch == 0  # 'synch' vs 'synch_P'
+
+
+def test_shard_ranges_tile_the_sky():
+    for npix in (12, 49152, 12582912, 1000003):
+        for n in (1, 2, 3, 4, 8):
+            r = [dist.shard_range(npix, k, n) for k in range(n)]
+            assert r[0][0] == 0 and sum(s for _, s in r) == npix
+            for (a0, s0), (a1, _) in zip(r, r[1:]):
+                assert a0 + s0 == a1
+
+
+def test_synthetic_sky_is_shard_invariant_and_well_formed():
+    full = synth.make_sky("C2", nside=4)
+    parts = [synth.make_sky("C2", nside=4, rank=r, nranks=3) for r in range(3)]
+    assert np.array_equal(np.concatenate([p[1].sig_map for p in parts], -1), full[1].sig_map)
+    assert np.array_equal(np.concatenate([p[1].rms_map for p in parts], -1), full[1].rms_map)
+    assert np.array_equal(np.concatenate([p[1].masks for p in parts], -1), full[1].masks)
+    assert all(p[1].nump == full[1].nump for p in parts)
+    dpar, ddata, bands, comps, meta = full
+    assert ddata.sig_map.shape == (5, 3, 192) and len(comps) == 6
+    assert ddata.nump == 3 * (ddata.masks[0] != 0).sum()
+    assert [g.pol_flag for g in dpar.cg_groups] == [[L.FLAG_T], [L.FLAG_QU]]
+    assert (ddata.rms_map > 0).all()
+    f = synth.band_freqs_ghz(10)
+    assert abs(f[0] - 20) < 1e-12 and abs(f[-1] - 857) < 1e-9
