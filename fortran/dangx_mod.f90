@@ -1,0 +1,159 @@
+! dangx_mod.f90 -- ISO_C_BINDING interface to libdangx.so (include/dangx.h).
+!
+! This is the thin Fortran layer the north star asks for: the dang driver keeps its
+! parameter files, HEALPix/CFITSIO I/O and dang_component_mod API and reaches the
+! MI355X path through these bind(C) interfaces.  The wrapper with the reference's
+! own signatures, sample_cg_groups_gpu(dpar, ddata) / sample_spectral_parameters_gpu
+! (dpar, ddata), lives in fortran/reference_side/dang_gpu_mod.f90 (it `use`s the
+! reference's modules and is compiled inside the reference's build).
+!
+! Array arguments are the reference's arrays passed as-is (c_loc of the first element):
+!   sig_map/rms_map(0:npix-1,nmaps,nbands), masks(0:npix-1,nmaps),
+!   c%amplitude(0:npix-1,nmaps), c%indices(0:npix-1,nmaps,nindices).
+module dangx_mod
+  use, intrinsic :: iso_c_binding
+  implicit none
+
+  integer(c_int), parameter :: DANGX_POWERLAW = 1, DANGX_MBB = 2, DANGX_FREEFREE = 3, &
+       DANGX_LOGNORMAL = 4, DANGX_CMB = 5
+  integer(c_int), parameter :: DANGX_LNL_CHISQ = 1, DANGX_LNL_MARGINAL = 2, DANGX_LNL_PRIOR = 3
+  integer(c_int), parameter :: DANGX_PRIOR_GAUSSIAN = 1, DANGX_PRIOR_UNIFORM = 2, DANGX_PRIOR_JEFFREYS = 3
+  integer(c_int), parameter :: DANGX_ML_SAMPLE = 1, DANGX_ML_OPTIMIZE = 2
+  integer(c_int), parameter :: DANGX_FLAG_T = 1, DANGX_FLAG_Q = 2, DANGX_FLAG_U = 4, DANGX_FLAG_QU = 8
+  integer(c_int), parameter :: DANGX_SOLVER_DIRECT = 0, DANGX_SOLVER_CG = 1
+  integer(c_int), parameter :: DANGX_FLUCT_CORRECT = 0, DANGX_FLUCT_REFERENCE = 1
+
+  type, bind(C) :: dangx_dims
+     integer(c_int32_t) :: npix, nmaps, nbands, ncomp
+     integer(c_int64_t) :: pix0, npix_global
+     integer(c_int32_t) :: device, reserved
+  end type dangx_dims
+
+  ! C: double gauss_prior[ind][2]  <->  Fortran gauss_prior(2, ind)  (mean/std fastest)
+  type, bind(C) :: dangx_comp_desc
+     integer(c_int32_t) :: type, is_synch, nindices, cg_group, sample_amplitude, reserved
+     real(c_double)     :: nu_ref
+     integer(c_int32_t) :: lnl_type(2), prior_type(2)
+     real(c_double)     :: gauss_prior(2,2), uni_prior(2,2), step_size(2)
+  end type dangx_comp_desc
+
+  interface
+     integer(c_int) function dangx_create(ctx, dims) bind(C, name='dangx_create')
+       import :: c_int, c_ptr, dangx_dims
+       type(c_ptr), intent(out) :: ctx
+       type(dangx_dims), intent(in) :: dims
+     end function
+     integer(c_int) function dangx_destroy(ctx) bind(C, name='dangx_destroy')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function
+     type(c_ptr) function dangx_last_error(ctx) bind(C, name='dangx_last_error')
+       import :: c_ptr
+       type(c_ptr), value :: ctx
+     end function
+     integer(c_int) function dangx_set_band(ctx, band, nu_c, n, nu0, tau0) bind(C, name='dangx_set_band')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: band, n
+       real(c_double), value :: nu_c
+       type(c_ptr), value :: nu0, tau0
+     end function
+     integer(c_int) function dangx_set_component(ctx, comp, desc) bind(C, name='dangx_set_component')
+       import :: c_int, c_ptr, dangx_comp_desc
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: comp
+       type(dangx_comp_desc), intent(in) :: desc
+     end function
+     integer(c_int) function dangx_set_tcmb(ctx, T) bind(C, name='dangx_set_tcmb')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), value :: T
+     end function
+     integer(c_int) function dangx_set_calibration(ctx, gain, offset) bind(C, name='dangx_set_calibration')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, gain, offset
+     end function
+     integer(c_int) function dangx_upload_data(ctx, sig, rms, mask) bind(C, name='dangx_upload_data')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, sig, rms, mask
+     end function
+     integer(c_int) function dangx_put_amplitude(ctx, comp, amp) bind(C, name='dangx_put_amplitude')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, amp
+       integer(c_int), value :: comp
+     end function
+     integer(c_int) function dangx_get_amplitude(ctx, comp, amp) bind(C, name='dangx_get_amplitude')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, amp
+       integer(c_int), value :: comp
+     end function
+     integer(c_int) function dangx_put_indices(ctx, comp, ind) bind(C, name='dangx_put_indices')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, ind
+       integer(c_int), value :: comp
+     end function
+     integer(c_int) function dangx_get_indices(ctx, comp, ind) bind(C, name='dangx_get_indices')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, ind
+       integer(c_int), value :: comp
+     end function
+     integer(c_int) function dangx_amp_sample(ctx, group, flag, ml_mode, solver, fluct_mode, seed, stream, &
+          i_max, converge, cg_iters, n_not_spd) bind(C, name='dangx_amp_sample')
+       import :: c_int, c_ptr, c_double, c_int64_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: group, flag, ml_mode, solver, fluct_mode, i_max
+       integer(c_int64_t), value :: seed, stream
+       real(c_double), value :: converge
+       integer(c_int), intent(out) :: cg_iters
+       integer(c_int64_t), intent(out) :: n_not_spd
+     end function
+     integer(c_int) function dangx_index_sample(ctx, comp, nind, map_n, nsample, ml_mode, seed, stream, accepted) &
+          bind(C, name='dangx_index_sample')
+       import :: c_int, c_ptr, c_int64_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: comp, nind, map_n, nsample, ml_mode
+       integer(c_int64_t), value :: seed, stream
+       integer(c_int64_t), intent(out) :: accepted
+     end function
+     integer(c_int) function dangx_sky_model_chisq(ctx, pol_lo, pol_hi, chisq_sum, sky, res, chi_map) &
+          bind(C, name='dangx_sky_model_chisq')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: pol_lo, pol_hi
+       real(c_double), intent(out) :: chisq_sum
+       type(c_ptr), value :: sky, res, chi_map
+     end function
+  end interface
+
+contains
+
+  ! the reference's error convention is print + stop (e.g. src/dang_cg_mod.f90:97-101)
+  subroutine dangx_check(ctx, status, where)
+    type(c_ptr), intent(in) :: ctx
+    integer(c_int), intent(in) :: status
+    character(len=*), intent(in) :: where
+    character(kind=c_char), pointer :: msg(:)
+    integer :: n
+    if (status == 0) return
+    write(*,*) 'dangx error in ', where, ' status = ', status
+    if (c_associated(ctx)) then
+       call c_f_pointer(dangx_last_error(ctx), msg, [512])
+       n = 1
+       do while (n < 512 .and. msg(n) /= c_null_char)
+          n = n + 1
+       end do
+       write(*,*) msg(1:n-1)
+    end if
+    stop 1
+  end subroutine dangx_check
+
+  ! 64-bit random-stream label: Gibbs iteration, phase (0 amp / 1 index), three small ids
+  ! (same packing as dang_amd.api.stream_id)
+  function dangx_stream_id(iter, phase, a, b, c) result(s)
+    integer, intent(in) :: iter, phase, a, b, c
+    integer(c_int64_t) :: s
+    s = ior(ior(ior(ior(shiftl(int(iter, c_int64_t), 32), shiftl(int(iand(phase, 15), c_int64_t), 28)), &
+         shiftl(int(iand(a, 4095), c_int64_t), 16)), shiftl(int(iand(b, 255), c_int64_t), 8)), int(iand(c, 255), c_int64_t))
+  end function dangx_stream_id
+
+end module dangx_mod
