@@ -135,7 +135,7 @@ def main():
             for f in g.pol_flag:
                 eng.amp_sample(g.cg_group, f, dpar.ml_mode, dpar.seed, da.stream_id(it, 0, g.cg_group, 0, f),
                                solver="direct", fluct_mode=dpar.fluct_mode, want_counts=False)
-        eng.sky_model_chisq_dev(1, nmaps, chisq_buf[0:1])
+        # the chi^2 after the amplitude phase is captured by the first index sweep on each plane (fused);
         # sample_spectral_parameters (src/dang_sample_mod.f90:21-86)
         for l, c in enumerate(comps):
             for j in range(c.nindices):
@@ -143,7 +143,10 @@ def main():
                     for f in c.pol_flag[j]:
                         eng.index_sample(l, j, mapn[f], dpar.nsample, dpar.ml_mode, dpar.seed,
                                          da.stream_id(it, 1, l, j, f), want_counts=False)
-        eng.sky_model_chisq_dev(1, nmaps, chisq_buf[1:2])
+        # update_sky_model + compute_chisq after each phase (src/dang_cg_mod.f90:172-173,
+        # src/dang_sample_mod.f90:81-84): both values come out of the sweeps, no extra pass over the maps
+        if not (eng.chisq_cached_dev(0, 1, nmaps, chisq_buf[0:1]) and eng.chisq_cached_dev(1, 1, nmaps, chisq_buf[1:2])):
+            eng.sky_model_chisq_dev(1, nmaps, chisq_buf[1:2])  # a plane without a sampled index: explicit pass
         if world > 1:
             td.all_reduce(chisq_buf)  # global chi^2 (RCCL over xGMI); 16-byte message
 

@@ -71,6 +71,8 @@ SYMBOLS = {
                                      C.POINTER(C.c_int64)]),
     "dangx_sky_model_chisq": (C.c_int, [_P, C.c_int, C.c_int, _D, _P, _P, _P]),
     "dangx_sky_model_chisq_dev": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "dangx_chisq_cached": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _D]),
+    "dangx_chisq_cached_dev": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "dangx_group_size": (C.c_int64, [_P, C.c_int, C.c_int]),
     "dangx_compute_rhs": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "dangx_compute_Ax": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),

@@ -90,6 +90,7 @@ class DangData:
     pol_type: List[int] = field(default_factory=lambda: [1])
     nump: float = 0.0                 # number of unmasked (pixel, map) entries; an INPUT
     chisq: float = 0.0
+    chisq_after_amp: float = 0.0      # chi^2 of the state the amplitude phase left (when deferred)
     engine: object = None
 
 
@@ -255,6 +256,23 @@ class Engine:
         self._chk(self.lib.dangx_sky_model_chisq(self.h, pol_lo, pol_hi, C.byref(s), None, None, None))
         return s.value
 
+    def chisq_cached(self, which, pol_lo, pol_hi):
+        """chi^2 sum fused into the index sweeps (which: 0 = state left by the amplitude phase, 1 = current);
+        returns None when a plane was not covered by a sweep (caller falls back to sky_model_chisq)."""
+        s = C.c_double(0.0)
+        rc = self.lib.dangx_chisq_cached(self.h, which, pol_lo, pol_hi, C.byref(s))
+        if rc == 2:
+            return None
+        self._chk(rc)
+        return s.value
+
+    def chisq_cached_dev(self, which, pol_lo, pol_hi, out_tensor):
+        rc = self.lib.dangx_chisq_cached_dev(self.h, which, pol_lo, pol_hi, out_tensor.data_ptr())
+        if rc == 2:
+            return False
+        self._chk(rc)
+        return True
+
     def sky_model_chisq_dev(self, pol_lo, pol_hi, out_tensor):
         """Asynchronous local chi^2 sum into a 1-element cuda fp64 tensor (for the RCCL all-reduce)."""
         self._chk(self.lib.dangx_sky_model_chisq_dev(self.h, pol_lo, pol_hi, out_tensor.data_ptr()))
@@ -343,8 +361,11 @@ def compute_chisq(ddata):
     return ddata.chisq
 
 
-def sample_cg_groups(dpar: DangParams, ddata: DangData, it=1, verbose=False):
-    """sample_cg_groups(dpar, ddata), src/dang_cg_mod.f90:142-177."""
+def sample_cg_groups(dpar: DangParams, ddata: DangData, it=1, verbose=False, defer_chisq=False):
+    """sample_cg_groups(dpar, ddata), src/dang_cg_mod.f90:142-177.
+
+    defer_chisq=True skips the chi^2 pass after the amplitude phase; sample_spectral_parameters then
+    reports it (ddata.chisq_after_amp) from the value its first sweeps compute as a by-product."""
     eng = ddata.engine
     info = []
     for g in dpar.cg_groups:
@@ -355,9 +376,10 @@ def sample_cg_groups(dpar: DangParams, ddata: DangData, it=1, verbose=False):
                                         solver=dpar.solver, fluct_mode=dpar.fluct_mode, i_max=g.i_max,
                                         converge=g.converge)
             info.append((g.cg_group, f, cg_it, bad))
-        compute_chisq(ddata)  # update_sky_model + write_stats_to_term, :172-173
-        if verbose:
-            print("%6d - Chisq: %16.5E" % (it, ddata.chisq))
+        if not defer_chisq:
+            compute_chisq(ddata)  # update_sky_model + write_stats_to_term, :172-173
+            if verbose:
+                print("%6d - Chisq: %16.5E" % (it, ddata.chisq))
     return info
 
 
@@ -385,7 +407,14 @@ def sample_spectral_parameters(dpar: DangParams, ddata: DangData, it=2, verbose=
                                        stream_id(it, 1, l, j, f))
                 info.append((l, j, f, acc))
     if sampled:
-        compute_chisq(ddata)  # :81-84
+        lo, hi = ddata.pol_type[0], ddata.pol_type[-1]
+        before, after = eng.chisq_cached(0, lo, hi), eng.chisq_cached(1, lo, hi)
+        if before is not None:
+            ddata.chisq_after_amp = _dist.allreduce_sum_float(before) / eng.nbands / ddata.nump
+        if after is not None:  # every plane was swept: chi^2 came for free
+            ddata.chisq = _dist.allreduce_sum_float(after) / eng.nbands / ddata.nump
+        else:
+            compute_chisq(ddata)  # :81-84
         if verbose:
             print("%6d - Chisq: %16.5E" % (it, ddata.chisq))
     return info

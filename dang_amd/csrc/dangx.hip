@@ -382,34 +382,152 @@ __global__ __launch_bounds__(BLOCK) void k_reduce(const double* __restrict__ par
 // Index phase: sample_index_mh, per-pixel branch (src/dang_sample_mod.f90:332-481) with
 // update_sample_model (:548-553), evaluate_lnL / evaluate_marginal_lnL
 // (src/dang_lnl_mod.f90:126-182, 47-124) and the priors (:394-400) fused.
-// One thread per pixel.  The pixel's cleaned data d(k,j) and 1/rms(k,j) are staged once
-// into LDS columns [slot][thread] (conflict-free: lane l touches bank pair 2l), the
-// chain state lives in registers, and the index map is written once at the end.
+// One thread per pixel.  The pixel's cleaned data d(k,j), 1/rms(k,j) and the chain-invariant
+// SED factor F(j) are staged once into LDS columns [slot][thread] (conflict-free: lane l
+// touches bank pair 2l), the chain state lives in registers, the index map is written once.
+//
+// Chain modes: the SED of the sampled component factorises into a part that is constant
+// along the chain (F_j, evaluated once) and a part that depends on the proposal, with the
+// reference's multiplication order kept, e.g. mbb (:947-948) = (A/B_j) * P_j:
+//   CH_POW       power-law beta     : exp(beta*lnr_j)
+//   CH_MBB_BETA  mbb beta (T fixed) : F_j = A/B_j ; sed = F_j * exp((beta+1)*lnr_j)
+//   CH_MBB_T     mbb T (beta fixed) : F_j = P_j   ; sed = (A(T)/B_j(T)) * F_j
+//   CH_LOGN_NUP  lognormal nu_p     : sed = exp(-0.5*(log(nu_j/(nu_p*1e9))/w)^2) * cst_j
+//   CH_LOGN_W    lognormal w        : F_j = log(nu_j/(nu_p*1e9)) ; sed = exp(-0.5*(F_j/w)^2) * cst_j
+//   CH_GENERIC   anything else (free-free T_e, bandpass-integrated bands): sed_prep + sed_eval
+enum { CH_GENERIC = 0, CH_POW = 1, CH_MBB_BETA = 2, CH_MBB_T = 3, CH_LOGN_NUP = 4, CH_LOGN_W = 5 };
+
 struct IndexArgs {
-    int comp, nind, s1, s2, nsample, ml_mode;
+    int comp, nind, s1, s2, nsample, ml_mode, mode;
     unsigned long long seed, stream;
 };
 
-__device__ __forceinline__ double index_prior(const Model& M, const Comp& c, const IndexArgs& a, int i, double val,
-                                              const double* amp, const double* lds_is, int BS, int tid) {
-    const int t = c.prior_type[a.nind];
-    if (t == DANGX_PRIOR_GAUSSIAN) {  // eval_normal_prior, src/dang_util_mod.f90:112-121
-        const double mean = c.gauss[a.nind][0], std = c.gauss[a.nind][1];
-        const double var = std * std;
-        const double num = exp(-((val - mean) * (val - mean)) / (2 * var));
-        const double denom = std * sqrt(2.0 * PI);
-        return log(num / denom);
+struct ChainCtx {
+    const Model& M;
+    const Comp& c;
+    const IndexArgs& a;
+    double* lds;
+    int BS, tid, nb, Sp;
+    double amp0, amp1, other;  // amplitudes on the planes; the index that is NOT sampled
+    __device__ __forceinline__ double& D(int kk, int j) const { return lds[(kk * nb + j) * BS + tid]; }
+    __device__ __forceinline__ double& IS(int kk, int j) const { return lds[((Sp + kk) * nb + j) * BS + tid]; }
+    __device__ __forceinline__ double& F(int j) const { return lds[(2 * Sp * nb + j) * BS + tid]; }
+};
+
+// -1/2 sum ((d-m)/rms)^2 per plane (evaluate_lnL) or the marginal form; acc0/acc1 = per-plane parts
+__device__ __forceinline__ double chain_lnl(const ChainCtx& C, double th, int lnl_type, double& acc0, double& acc1) {
+    const Model& M = C.M;
+    const Comp& c = C.c;
+    const bool first = (C.a.nind == 0);
+    acc0 = 0.0; acc1 = 0.0;
+    if (lnl_type == DANGX_LNL_PRIOR) return 0.0;
+    double s0 = 0.0, s1 = 0.0;
+    Prep pr = {0.0, 0.0, 0.0};
+    switch (C.a.mode) {
+    case CH_POW: s0 = th; break;
+    case CH_MBB_BETA: s0 = th + 1.0; break;
+    case CH_MBB_T: s0 = H_PLANCK / (K_B * th); s1 = exp(s0 * c.nu_ref) - 1.0; break;
+    case CH_LOGN_NUP: s0 = th * 1e9; s1 = C.other; break;
+    case CH_LOGN_W: s1 = th; break;
+    default: pr = sed_prep(c, first ? th : C.other, first ? C.other : th); break;
+    }
+    double lnL = 0.0;
+    for (int j = 0; j < C.nb; ++j) {
+        double s;
+        switch (C.a.mode) {
+        case CH_POW: s = exp(s0 * c.lnr[j]); break;
+        case CH_MBB_BETA: s = C.F(j) * exp(s0 * c.lnr[j]); break;
+        case CH_MBB_T: s = s1 / (exp(s0 * M.band[j].nu_c) - 1.0) * C.F(j); break;
+        case CH_LOGN_NUP: { const double l = log_pos(M.band[j].nu_c / s0) / s1; s = exp(-0.5 * (l * l)) * c.cst[j]; break; }
+        case CH_LOGN_W: { const double l = C.F(j) / s1; s = exp(-0.5 * (l * l)) * c.cst[j]; break; }
+        default: s = sed_eval(M, c, j, pr); break;
+        }
+        if (lnl_type == DANGX_LNL_CHISQ) {
+            const double t = (C.D(0, j) - C.amp0 * s) * C.IS(0, j);
+            acc0 = acc0 - 0.5 * (t * t);
+            if (C.Sp == 2) {
+                const double t2 = (C.D(1, j) - C.amp1 * s) * C.IS(1, j);
+                acc1 = acc1 - 0.5 * (t2 * t2);
+            }
+        } else {  // marginal: -0.5*TNd*invTNT*TNd per (band, plane), src/dang_lnl_mod.f90:113-122
+            for (int kk = 0; kk < C.Sp; ++kk) {
+                const double m = (kk ? C.amp1 : C.amp0) * s;
+                const double is = C.IS(kk, j);
+                const double TN = m * (is * is);
+                const double TNd = TN * C.D(kk, j);
+                const double TNT = TN * m;
+                lnL = lnL - 0.5 * TNd * (1.0 / TNT) * TNd;
+            }
+        }
+    }
+    return (lnl_type == DANGX_LNL_CHISQ) ? acc0 + acc1 : lnL;
+}
+
+// Fast path of evaluate_lnL for the chain: chisq likelihood, delta bandpasses, compile-time chain mode
+// (CH_POW / CH_MBB_BETA / CH_MBB_T), plane count SP and band tile TB (nb % TB == 0).  A tile first issues
+// every LDS / scalar load of its TB bands, then runs the TB independent exp chains interleaved, then
+// accumulates in band order (same summation order as the plain loop).
+template <int MODE, int SP, int TB>
+__device__ __forceinline__ double chain_lnl_tiled(const ChainCtx& C, double th, double& acc0, double& acc1) {
+    const Model& M = C.M;
+    const Comp& c = C.c;
+    double s0 = 0.0, s1 = 0.0;
+    if (MODE == CH_POW) s0 = th;
+    else if (MODE == CH_MBB_BETA) s0 = th + 1.0;
+    else { s0 = H_PLANCK / (K_B * th); s1 = exp(s0 * c.nu_ref) - 1.0; }
+    acc0 = 0.0; acc1 = 0.0;
+    for (int j0 = 0; j0 < C.nb; j0 += TB) {
+        double f[TB], d0[TB], i0[TB], d1[TB], i1[TB], x[TB], s[TB];
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+            const int j = j0 + t;
+            x[t] = (MODE == CH_MBB_T) ? s0 * M.band[j].nu_c : s0 * c.lnr[j];
+            f[t] = (MODE == CH_POW) ? 1.0 : C.F(j);
+            d0[t] = C.D(0, j); i0[t] = C.IS(0, j);
+            if (SP == 2) { d1[t] = C.D(1, j); i1[t] = C.IS(1, j); }
+        }
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+            const double e = exp(x[t]);
+            if (MODE == CH_POW) s[t] = e;
+            else if (MODE == CH_MBB_BETA) s[t] = f[t] * e;
+            else s[t] = s1 / (e - 1.0) * f[t];
+        }
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+            const double r0 = (d0[t] - C.amp0 * s[t]) * i0[t];
+            acc0 = acc0 - 0.5 * (r0 * r0);
+            if (SP == 2) {
+                const double r1 = (d1[t] - C.amp1 * s[t]) * i1[t];
+                acc1 = acc1 - 0.5 * (r1 * r1);
+            }
+        }
+    }
+    return acc0 + acc1;
+}
+
+__device__ __forceinline__ double index_prior(const ChainCtx& C, double val) {
+    const Comp& c = C.c;
+    const int q = C.a.nind;
+    const int t = c.prior_type[q];
+    if (t == DANGX_PRIOR_GAUSSIAN) {
+        // log(eval_normal_prior) (src/dang_util_mod.f90:112-121, src/dang_sample_mod.f90:395):
+        // log(exp(-(x-m)^2/(2 var))/(std*sqrt(2 pi))) = -(x-m)^2/(2 var) - log(std*sqrt(2 pi));
+        // the reference's exp() underflows to 0 (log -> -inf) beyond ~745
+        const double mean = c.gauss[q][0], std = c.gauss[q][1];
+        const double arg = ((val - mean) * (val - mean)) / (2 * (std * std));
+        return (arg > 745.0) ? -INFINITY : -arg - c.lgden[q];
     }
     if (t == DANGX_PRIOR_JEFFREYS) {  // eval_jeffreys_prior, src/dang_lnl_mod.f90:242-304
         double sum = 0.0;
         if (c.is_synch) {
             const Prep pr = sed_prep(c, val, 0.0);
-            const int Sp = a.s2 - a.s1 + 1;
-            for (int kk = 0; kk < Sp; ++kk)
-                for (int j = 0; j < M.nbands; ++j) {
-                    const double ss = amp[kk] * sed_eval(M, c, j, pr);
-                    const double rr = lds_is[((Sp + kk) * M.nbands + j) * BS + tid];  // 1/rms
-                    const double tt = (rr * rr) * (ss / amp[kk]) * c.lnr[j];
+            for (int kk = 0; kk < C.Sp; ++kk)
+                for (int j = 0; j < C.nb; ++j) {
+                    const double amp = kk ? C.amp1 : C.amp0;
+                    const double ss = amp * sed_eval(C.M, c, j, pr);
+                    const double rr = C.IS(kk, j);  // 1/rms
+                    const double tt = (rr * rr) * (ss / amp) * c.lnr[j];
                     sum = sum + tt * tt;
                 }
         }
@@ -418,8 +536,13 @@ __device__ __forceinline__ double index_prior(const Model& M, const Comp& c, con
     return 0.0;
 }
 
-// the chain of one pixel; returns the number of accepted proposals
-__device__ __forceinline__ unsigned long long index_chain(const Model& M, const IndexArgs& a, double* lds, int BS, int tid, int i) {
+// the chain of one pixel; returns the number of accepted proposals; chi[0..3] = chi^2 of the touched
+// planes before (plane0, plane1) and after (plane0, plane1) the sweep
+// MODE == CH_GENERIC: everything decided at run time (a.mode, lnl type, plane count, any nb);
+// otherwise the chisq fast path above with compile-time MODE / SP / TB.
+template <int MODE, int SP, int TB>
+__device__ __forceinline__ unsigned long long index_chain(const Model& M, const IndexArgs& a, double* lds, int BS, int tid,
+                                                          int i, double chi[4]) {
     const int npix = M.npix, nb = M.nbands;
     const Comp& c = M.comp[a.comp];
     const int Sp = a.s2 - a.s1 + 1;
@@ -428,16 +551,21 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
         for (int k = a.s1; k <= a.s2; ++k) out[(long long)(k - 1) * npix] = 0.0;
         return 0ull;
     }
+    // chain state: sample(l) = c%indices(i, map_inds(1), l)  (:372-377)
+    double sample0, sample1;
+    load_theta(M, c, i, a.s1, sample0, sample1);
+    const bool first = (a.nind == 0);
+    ChainCtx C{M, c, a, lds, BS, tid, nb, Sp, 0.0, 0.0, first ? sample1 : sample0};
     // --- stage data_raw minus every OTHER component (:173-196) and 1/rms
-    double amp[2] = {0.0, 0.0};
     for (int kk = 0; kk < Sp; ++kk) {
         const int k = a.s1 + kk;
-        amp[kk] = c.amp[(long long)(k - 1) * npix + i];
+        const double ak = c.amp[(long long)(k - 1) * npix + i];
+        if (kk) C.amp1 = ak; else C.amp0 = ak;
         for (int j = 0; j < nb; ++j) {
             double d = M.sig[((long long)j * M.nmaps + (k - 1)) * npix + i];
             if (k == 1) d = (d - M.offset[j]) / M.gain[j];
-            lds[(kk * nb + j) * BS + tid] = d;
-            lds[((Sp + kk) * nb + j) * BS + tid] = 1.0 / M.rms[((long long)j * M.nmaps + (k - 1)) * npix + i];
+            C.D(kk, j) = d;
+            C.IS(kk, j) = 1.0 / M.rms[((long long)j * M.nmaps + (k - 1)) * npix + i];
         }
         for (int l = 0; l < M.ncomp; ++l) {
             if (l == a.comp) continue;
@@ -447,52 +575,36 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
             double t0, t1;
             load_theta(M, c2, i, k, t0, t1);
             const Prep pr = sed_prep(c2, t0, t1);
-            for (int j = 0; j < nb; ++j) lds[(kk * nb + j) * BS + tid] -= a2 * sed_eval(M, c2, j, pr);
+            for (int j = 0; j < nb; ++j) C.D(kk, j) -= a2 * sed_eval(M, c2, j, pr);
         }
     }
-    // --- chain state: sample(l) = c%indices(i, map_inds(1), l)  (:372-377)
-    // (scalars, not arrays: a runtime-indexed array would live in scratch memory)
-    double sample0, sample1;
-    load_theta(M, c, i, a.s1, sample0, sample1);
-    const bool first = (a.nind == 0);
-    const int lnl_type = c.lnl_type[a.nind];
-    const bool unmasked_lnl = true;  // evaluate_lnL tests mask(i) again (:171): already unmasked here
-
-    auto lnl_of = [&](double th0, double th1) -> double {
-        if (lnl_type == DANGX_LNL_PRIOR) return 0.0;
-        const Prep pr = sed_prep(c, th0, th1);
-        if (lnl_type == DANGX_LNL_CHISQ) {  // -0.5*sum ((d-m)/rms)^2, one accumulator per plane
-            double acc0 = 0.0, acc1 = 0.0;
-            for (int j = 0; j < nb; ++j) {
-                const double s = sed_eval(M, c, j, pr);
-                const double t = (lds[j * BS + tid] - amp[0] * s) * lds[(Sp * nb + j) * BS + tid];
-                acc0 = acc0 - 0.5 * (t * t);
-                if (Sp == 2) {
-                    const double t2 = (lds[(nb + j) * BS + tid] - amp[1] * s) * lds[((Sp + 1) * nb + j) * BS + tid];
-                    acc1 = acc1 - 0.5 * (t2 * t2);
-                }
-            }
-            return unmasked_lnl ? acc0 + acc1 : 0.0;
-        }
-        double lnL = 0.0;  // marginal: -0.5*TNd*invTNT*TNd per (band, plane), src/dang_lnl_mod.f90:113-122
-        for (int j = 0; j < nb; ++j) {
-            const double s = sed_eval(M, c, j, pr);
-            for (int kk = 0; kk < Sp; ++kk) {
-                const double m = amp[kk] * s;
-                const double is = lds[((Sp + kk) * nb + j) * BS + tid];
-                const double TN = m * (is * is);
-                const double TNd = TN * lds[(kk * nb + j) * BS + tid];
-                const double TNT = TN * m;
-                lnL = lnL - 0.5 * TNd * (1.0 / TNT) * TNd;
-            }
-        }
-        return lnL;
-    };
-
+    // --- chain-invariant SED factor
+    if (a.mode == CH_MBB_BETA) {
+        const double z = H_PLANCK / (K_B * sample1);
+        const double A = exp(z * c.nu_ref) - 1.0;
+        for (int j = 0; j < nb; ++j) C.F(j) = A / (exp(z * M.band[j].nu_c) - 1.0);
+    } else if (a.mode == CH_MBB_T) {
+        for (int j = 0; j < nb; ++j) C.F(j) = exp((sample0 + 1.0) * c.lnr[j]);
+    } else if (a.mode == CH_LOGN_W) {
+        for (int j = 0; j < nb; ++j) C.F(j) = log_pos(M.band[j].nu_c / (sample0 * 1e9));
+    }
+    const int lnl_type = (MODE == CH_GENERIC) ? c.lnl_type[a.nind] : DANGX_LNL_CHISQ;
     const unsigned long long gpix = (unsigned long long)(M.pix0 + i);
     unsigned long long nacc = 0;
-    double lnl = lnl_of(sample0, sample1);
     double cur = first ? sample0 : sample1;  // sample(nind)
+    double a0, a1, c0, c1;                   // per-plane likelihood parts: current / proposal
+    auto lnl_of = [&](double th, double& p0, double& p1) -> double {
+        if (MODE == CH_GENERIC) return chain_lnl(C, th, lnl_type, p0, p1);
+        return chain_lnl_tiled<MODE == CH_GENERIC ? CH_POW : MODE, SP, TB>(C, th, p0, p1);
+    };
+    double lnl = lnl_of(cur, a0, a1);
+    if (lnl_type != DANGX_LNL_CHISQ) {       // chi^2 bookkeeping needs the chisq form
+        double t0, t1;
+        chain_lnl(C, cur, DANGX_LNL_CHISQ, t0, t1);
+        chi[0] = -2.0 * t0; chi[1] = -2.0 * t1;
+    } else {
+        chi[0] = -2.0 * a0; chi[1] = -2.0 * a1;
+    }
     bool sample_it = true;
     if (lnl_type == DANGX_LNL_PRIOR) {  // :389-392
         double u1, u2;
@@ -500,48 +612,122 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
         uniform2(a.seed, a.stream, gpix, 0u, u1, u2);
         cur = rand_normal(c.gauss[a.nind][0], c.gauss[a.nind][1], u1, u2);
     }
-    double lnl_old = lnl + index_prior(M, c, a, i, cur, amp, lds, BS, tid);
+    double lnl_old = lnl + index_prior(C, cur);
     if (sample_it) {
         const double step = c.step[a.nind];
         const double lo = c.uni[a.nind][0], hi = c.uni[a.nind][1];
         for (int l = 1; l <= a.nsample; ++l) {
-            double u1, u2;
-            uniform2(a.seed, a.stream, gpix, (uint32_t)l, u1, u2);
+            double u1, u2, u3;
+            uniform3(a.seed, a.stream, gpix, (uint32_t)l, u1, u2, u3);  // one Philox call per step
             const double prop = cur + rand_normal(0.0, step, u1, u2);  // :414
-            if (prop < lo || prop > hi) continue;  // :415 (no accept draw consumed)
-            lnl = lnl_of(first ? prop : sample0, first ? sample1 : prop);
-            const double lnl_new = lnl + index_prior(M, c, a, i, prop, amp, lds, BS, tid);
+            if (prop < lo || prop > hi) continue;  // :415 (the accept draw is not used)
+            lnl = lnl_of(prop, c0, c1);
+            const double lnl_new = lnl + index_prior(C, prop);
             const double diff = lnl_new - lnl_old;
             bool acc;
             if (a.ml_mode == DANGX_ML_OPTIMIZE) {
                 acc = diff > 0.0;  // :443-447
             } else {
-                double v1, v2;
-                uniform2(a.seed, a.stream, gpix, (uint32_t)l | 0x80000000u, v1, v2);
-                acc = diff > log(v1);  // :448-454
+                // :448-454  diff > log(u)  <=>  diff >= 0 or exp(diff) > u   (u in (0,1))
+                acc = (diff >= 0.0) || (exp(diff) > u3);
             }
             if (acc) {
                 cur = prop;
                 lnl_old = lnl_new;
+                a0 = c0; a1 = c1;
                 ++nacc;
             }
         }
     }
     for (int k = a.s1; k <= a.s2; ++k) out[(long long)(k - 1) * npix] = cur;  // :465, :483
+    if (lnl_type != DANGX_LNL_CHISQ) chain_lnl(C, cur, DANGX_LNL_CHISQ, a0, a1);
+    chi[2] = -2.0 * a0; chi[3] = -2.0 * a1;
     return nacc;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_index_mh(const Model* __restrict__ Mp, IndexArgs a, unsigned long long* __restrict__ accepted) {
+// chi_partial (nullable): [4][gridDim.x] block sums of chi[0..3]
+template <int MODE, int SP, int TB>
+__global__ __launch_bounds__(BLOCK) void k_index_mh(const Model* __restrict__ Mp, IndexArgs a,
+                                                    unsigned long long* __restrict__ accepted,
+                                                    double* __restrict__ chi_partial) {
     extern __shared__ double lds[];
     const Model& M = *Mp;
     const int BS = blockDim.x, tid = threadIdx.x;
     const int i = blockIdx.x * BS + tid;
-    unsigned long long nacc = (i < M.npix) ? index_chain(M, a, lds, BS, tid, i) : 0ull;
+    double chi[4] = {0.0, 0.0, 0.0, 0.0};
+    unsigned long long nacc = (i < M.npix) ? index_chain<MODE, SP, TB>(M, a, lds, BS, tid, i, chi) : 0ull;
     if (accepted) {  // every lane takes part in the wave reduction
         for (int o = 32; o > 0; o >>= 1) nacc += __shfl_down(nacc, o, 64);
         if ((tid & 63) == 0 && nacc) atomicAdd(accepted, nacc);
     }
+    if (chi_partial) {
+        __shared__ double sh[4][BLOCK / 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double v = chi[q];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            if ((tid & 63) == 0) sh[q][tid >> 6] = v;
+        }
+        __syncthreads();
+        if (tid < 4) {
+            double s = 0.0;
+            for (int w = 0; w < BS / 64; ++w) s += sh[tid][w];
+            chi_partial[(long long)tid * gridDim.x + blockIdx.x] = s;
+        }
+    }
 }
+
+// first stage of a deterministic row-wise reduction: in[q][0..n) -> out[q][0..gridDim.x), fixed chunking
+__global__ __launch_bounds__(BLOCK) void k_reduce_rows(const double* __restrict__ in, long long n, int rows,
+                                                       double* __restrict__ out) {
+    __shared__ double sh[BLOCK];
+    const long long chunk = (n + gridDim.x - 1) / gridDim.x;
+    const long long lo = (long long)blockIdx.x * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+    for (int q = 0; q < rows; ++q) {
+        double s = 0.0;
+        for (long long t = lo + threadIdx.x; t < hi; t += BLOCK) s += in[(long long)q * n + t];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = BLOCK / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[(long long)q * gridDim.x + blockIdx.x] = sh[0];
+        __syncthreads();
+    }
+}
+
+// second stage for the fused chi^2: cache[0..2] = chi^2 "before" of planes 1..3, cache[3..5] = "after".
+// rows of `partial`: before(plane s1), before(plane s2), after(s1), after(s2); write_before = first sweep
+// on these planes since the last amplitude update.
+__global__ __launch_bounds__(BLOCK) void k_reduce_chi(const double* __restrict__ partial, long long n, int s1, int s2,
+                                                      int write_before, double* __restrict__ cache) {
+    __shared__ double sh[BLOCK];
+    for (int q = 0; q < 4; ++q) {
+        double s = 0.0;
+        for (long long t = threadIdx.x; t < n; t += BLOCK) s += partial[(long long)q * n + t];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = BLOCK / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const int plane = (q & 1) ? s2 : s1;
+            const bool after = q >= 2;
+            if (!((q & 1) && s1 == s2) && (after || write_before)) cache[(after ? 3 : 0) + plane - 1] = sh[0];
+        }
+        __syncthreads();
+    }
+}
+
+// out[0] = sum over planes pol_lo..pol_hi of cache[which*3 + plane-1]
+__global__ void k_chi_from_cache(const double* __restrict__ cache, int which, int pol_lo, int pol_hi, double* __restrict__ out) {
+    double s = 0.0;
+    for (int k = pol_lo; k <= pol_hi; ++k) s += cache[which * 3 + k - 1];
+    out[0] = s;
+}
+
 
 // ---------------------------------------------------------------------------
 // update_sky_model + compute_chisq (src/dang_data_mod.f90:339-396, 494-526), one thread per
@@ -644,6 +830,8 @@ struct dangx_ctx {
     double* partial = nullptr;
     long long partial_cap = 0;
     double* scalars = nullptr;              // device scalars [8]
+    double* chi_cache = nullptr;            // device [6]: chi^2 before/after of planes 1..3 (fused in k_index_mh)
+    bool chi_before_valid[3] = {}, chi_after_valid[3] = {}, touched_since_amp[3] = {};
     unsigned long long* counters = nullptr; // device counters [4]
     double* work[6] = {};                   // CG vectors
     long long work_cap = 0;
@@ -720,13 +908,14 @@ int sync_model(dangx_ctx* ctx) {
             c.gauss[q][0] = d.gauss_prior[q][0]; c.gauss[q][1] = d.gauss_prior[q][1];
             c.uni[q][0] = d.uni_prior[q][0]; c.uni[q][1] = d.uni_prior[q][1];
             c.step[q] = d.step_size[q];
+            c.lgden[q] = std::log(d.gauss_prior[q][1] * std::sqrt(2.0 * PI));
         }
-        c.nuref9 = 1.0 * c.nu_ref / 1.0e9;
+        c.lnuref9 = std::log(1.0 * c.nu_ref / 1.0e9);
         for (int j = 0; j < M.nbands; ++j) {
             const double nu = M.band[j].nu_c;
             const double r = nu / c.nu_ref;
             c.lnr[j] = std::log(r);
-            c.nu9[j] = 1.0 * nu / 1.0e9;
+            c.lnu9[j] = std::log(1.0 * nu / 1.0e9);
             c.cst[j] = 0.0;
             if (c.type == DANGX_CMB) c.cst[j] = 1.0 / host_a2t(ctx, j);
             else if (c.type == DANGX_FREEFREE) c.cst[j] = 1.0 / (r * r);
@@ -954,6 +1143,7 @@ int dangx_create(dangx_ctx** out, const dangx_dims* dims) {
     M.pix0 = dims->pix0; M.tcmb = 2.7255;  // src/dang_util_mod.f90:15
     for (int j = 0; j < MAXB; ++j) { M.gain[j] = 1.0; M.offset[j] = 0.0; }  // src/dang_data_mod.f90:127-128
     if (hipMalloc(&ctx->dm, sizeof(Model)) != hipSuccess || hipMalloc(&ctx->scalars, 8 * sizeof(double)) != hipSuccess ||
+        hipMalloc(&ctx->chi_cache, 6 * sizeof(double)) != hipSuccess ||
         hipMalloc(&ctx->counters, 4 * sizeof(unsigned long long)) != hipSuccess) {
         delete ctx;
         return 5;
@@ -974,7 +1164,7 @@ int dangx_destroy(dangx_ctx* ctx) {
     for (auto& w : ctx->work) if (w) (void)hipFree(w);
     if (ctx->partial) (void)hipFree(ctx->partial);
     if (ctx->d_bp_nu0) { (void)hipFree(ctx->d_bp_nu0); (void)hipFree(ctx->d_bp_tau0); }
-    (void)hipFree(ctx->dm); (void)hipFree(ctx->scalars); (void)hipFree(ctx->counters);
+    (void)hipFree(ctx->dm); (void)hipFree(ctx->scalars); (void)hipFree(ctx->counters); (void)hipFree(ctx->chi_cache);
     for (auto& e : ctx->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     delete ctx;
     return 0;
@@ -1137,6 +1327,10 @@ int dangx_amp_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solve
     if (make_group(ctx, group, flag, a) || sync_model(ctx)) return 1;
     a.ml_mode = ml_mode; a.fluct = fluct_mode; a.seed = seed; a.stream = stream;
     const long long SN = (long long)flag_planes_h(flag) * ctx->hm.npix;
+    for (int pl = 0; pl < flag_planes_h(flag); ++pl) {  // the planes' cached chi^2 is stale now
+        const int k = (flag & DANGX_FLAG_QU) ? 2 + pl : (flag & DANGX_FLAG_T) ? 1 : (flag & DANGX_FLAG_Q) ? 2 : 3;
+        ctx->chi_before_valid[k - 1] = ctx->chi_after_valid[k - 1] = ctx->touched_since_amp[k - 1] = false;
+    }
     if (cg_iters) *cg_iters = 0;
     if (n_not_spd) *n_not_spd = 0;
     if (solver == DANGX_SOLVER_CG) {
@@ -1172,15 +1366,57 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
     if (d.lnl_type[nind] < DANGX_LNL_CHISQ || d.lnl_type[nind] > DANGX_LNL_PRIOR) return fail(ctx, "bad lnl_type");
     if (ml_mode != DANGX_ML_SAMPLE && ml_mode != DANGX_ML_OPTIMIZE) return fail(ctx, "bad ml_mode");
     const int Sp = a.s2 - a.s1 + 1;
-    // LDS columns: 2*Sp*nb doubles per thread; pick the block so that >= 2 blocks fit in 160 KiB
+    // chain mode: factorised SED when every band is a delta bandpass
+    bool all_delta = true;
+    for (int j = 0; j < ctx->hm.nbands; ++j) all_delta = all_delta && ctx->hm.band[j].n == 0;
+    a.mode = CH_GENERIC;
+    if (all_delta) {
+        if (d.type == DANGX_POWERLAW) a.mode = CH_POW;
+        else if (d.type == DANGX_MBB) a.mode = nind == 0 ? CH_MBB_BETA : CH_MBB_T;
+        else if (d.type == DANGX_LOGNORMAL) a.mode = nind == 0 ? CH_LOGN_NUP : CH_LOGN_W;
+    }
+    // LDS columns: (2*Sp+1)*nb doubles per thread; pick the block so that >= 2 blocks fit in 160 KiB
+    const size_t per_thread = (size_t)(2 * Sp + 1) * ctx->hm.nbands * sizeof(double);
     int bs = 256;
-    while (bs > 64 && (size_t)2 * Sp * ctx->hm.nbands * bs * sizeof(double) > 72 * 1024) bs >>= 1;
-    const size_t lds = (size_t)2 * Sp * ctx->hm.nbands * bs * sizeof(double);
+    while (bs > 64 && per_thread * bs > 72 * 1024) bs >>= 1;
+    const size_t lds = per_thread * bs;
+    const unsigned nblk = nblocks(ctx->hm.npix, bs);
+    constexpr int RSTAGE = 128;  // blocks of the first reduction stage
+    if (ensure_partial(ctx, 4ll * nblk + 4ll * RSTAGE)) return 1;
     if (accepted) HIPCHK(ctx, hipMemsetAsync(ctx->counters + 1, 0, sizeof(unsigned long long), ctx->stream));
     {
         Timed t(ctx, DANGX_K_INDEX_MH);
-        hipLaunchKernelGGL(k_index_mh, dim3(nblocks(ctx->hm.npix, bs)), dim3(bs), lds, ctx->stream, ctx->dm, a,
-                           accepted ? ctx->counters + 1 : nullptr);
+        unsigned long long* accp = accepted ? ctx->counters + 1 : nullptr;
+        const int nb = ctx->hm.nbands;
+        const int tb = (nb % 5 == 0) ? 5 : (nb % 4 == 0) ? 4 : (nb % 3 == 0) ? 3 : 1;
+        const bool fast = d.lnl_type[nind] == DANGX_LNL_CHISQ &&
+                          (a.mode == CH_POW || a.mode == CH_MBB_BETA || a.mode == CH_MBB_T);
+#define DX_LAUNCH_MH(MODE_, SP_, TB_)                                                                            \
+        hipLaunchKernelGGL((k_index_mh<MODE_, SP_, TB_>), dim3(nblk), dim3(bs), lds, ctx->stream, ctx->dm, a, accp, ctx->partial)
+#define DX_MH_TB(MODE_, SP_)                                                                                     \
+        do { if (tb == 5) DX_LAUNCH_MH(MODE_, SP_, 5); else if (tb == 4) DX_LAUNCH_MH(MODE_, SP_, 4);            \
+             else if (tb == 3) DX_LAUNCH_MH(MODE_, SP_, 3); else DX_LAUNCH_MH(MODE_, SP_, 1); } while (0)
+#define DX_MH_SP(MODE_) do { if (Sp == 2) DX_MH_TB(MODE_, 2); else DX_MH_TB(MODE_, 1); } while (0)
+        if (!fast) DX_LAUNCH_MH(CH_GENERIC, 1, 1);
+        else if (a.mode == CH_POW) DX_MH_SP(CH_POW);
+        else if (a.mode == CH_MBB_BETA) DX_MH_SP(CH_MBB_BETA);
+        else DX_MH_SP(CH_MBB_T);
+#undef DX_MH_SP
+#undef DX_MH_TB
+#undef DX_LAUNCH_MH
+    }
+    {   // fused chi^2 of the touched planes (before = state left by the amplitude phase, after = new state)
+        const bool wb = !ctx->touched_since_amp[a.s1 - 1];
+        Timed t(ctx, DANGX_K_REDUCE);
+        double* stage = ctx->partial + 4ll * nblk;
+        hipLaunchKernelGGL(k_reduce_rows, dim3(RSTAGE), dim3(BLOCK), 0, ctx->stream, ctx->partial, (long long)nblk, 4, stage);
+        hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(BLOCK), 0, ctx->stream, stage, (long long)RSTAGE, a.s1, a.s2,
+                           wb ? 1 : 0, ctx->chi_cache);
+        for (int k = a.s1; k <= a.s2; ++k) {
+            if (wb) ctx->chi_before_valid[k - 1] = true;
+            ctx->chi_after_valid[k - 1] = true;
+            ctx->touched_since_amp[k - 1] = true;
+        }
     }
     HIPCHK(ctx, hipGetLastError());
     if (accepted) {
@@ -1192,12 +1428,38 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
     return 0;
 }
 
+// chi^2 of planes pol_lo..pol_hi from the values fused into the index sweeps: which = 0 -> the state the
+// amplitude phase left (captured by the first sweep on each plane), 1 -> the current state.  Fails (status 2)
+// if some plane has not been covered by a sweep since its last amplitude update: use dangx_sky_model_chisq.
+int dangx_chisq_cached_dev(dangx_ctx* ctx, int which, int pol_lo, int pol_hi, double* out_dev) {
+    if (!ctx || !out_dev || (which != 0 && which != 1)) return 1;
+    if (pol_lo < 1 || pol_hi > ctx->dims.nmaps || pol_lo > pol_hi) return fail(ctx, "bad pol_type range");
+    for (int k = pol_lo; k <= pol_hi; ++k)
+        if (!(which ? ctx->chi_after_valid[k - 1] : ctx->chi_before_valid[k - 1])) {
+            ctx->err = "cached chi^2 not available for plane " + std::to_string(k);
+            return 2;
+        }
+    hipLaunchKernelGGL(k_chi_from_cache, dim3(1), dim3(1), 0, ctx->stream, ctx->chi_cache, which, pol_lo, pol_hi, out_dev);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+int dangx_chisq_cached(dangx_ctx* ctx, int which, int pol_lo, int pol_hi, double* chisq_sum) {
+    if (!ctx || !chisq_sum) return 1;
+    const int rc = dangx_chisq_cached_dev(ctx, which, pol_lo, pol_hi, ctx->scalars + 1);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(chisq_sum, ctx->scalars + 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 static int sky_chisq_launch(dangx_ctx* ctx, int pol_lo, int pol_hi, double* sky_d, double* res_d, double* chi_d, double* out_dev) {
     if (pol_lo < 1 || pol_hi > ctx->dims.nmaps || pol_lo > pol_hi) return fail(ctx, "bad pol_type range");
     int bs = 256;
     while (bs > 64 && (size_t)ctx->hm.nbands * bs * sizeof(double) > 32 * 1024) bs >>= 1;
     const unsigned nblk = nblocks(ctx->hm.npix, bs);
-    if (ensure_partial(ctx, nblk)) return 1;
+    constexpr int RSTAGE = 128;
+    if (ensure_partial(ctx, (long long)nblk + RSTAGE)) return 1;
     {
         Timed t(ctx, DANGX_K_SKY_CHISQ);
         hipLaunchKernelGGL(k_sky_chisq, dim3(nblk), dim3(bs), (size_t)ctx->hm.nbands * bs * sizeof(double), ctx->stream,
@@ -1205,7 +1467,9 @@ static int sky_chisq_launch(dangx_ctx* ctx, int pol_lo, int pol_hi, double* sky_
     }
     {
         Timed t(ctx, DANGX_K_REDUCE);
-        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->partial, (long long)nblk, out_dev);
+        double* stage = ctx->partial + nblk;
+        hipLaunchKernelGGL(k_reduce_rows, dim3(RSTAGE), dim3(BLOCK), 0, ctx->stream, ctx->partial, (long long)nblk, 1, stage);
+        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(BLOCK), 0, ctx->stream, stage, (long long)RSTAGE, out_dev);
     }
     HIPCHK(ctx, hipGetLastError());
     return 0;

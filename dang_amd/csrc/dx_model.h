@@ -37,11 +37,12 @@ struct Comp {
     double* idx;  // [nind][nmaps][npix]
     int lnl_type[MAXI], prior_type[MAXI];
     double gauss[MAXI][2], uni[MAXI][2], step[MAXI];
+    double lgden[MAXI];  // log(std*sqrt(2*pi)) of the gaussian prior (eval_normal_prior's denominator)
     // per-band host-precomputed scalars (delta bandpass fast path)
     double lnr[MAXB];   // log(nu_c/nu_ref)
     double cst[MAXB];   // cmb: 1/a2t(bp) ; freefree: 1/(r*r) ; lognormal: (nu_ref/nu_c)^2
-    double nu9[MAXB];   // freefree: 1.0*nu_c/1e9
-    double nuref9;      // freefree: 1.0*nu_ref/1e9
+    double lnu9[MAXB];  // freefree: log(1.0*nu_c/1e9)
+    double lnuref9;     // freefree: log(1.0*nu_ref/1e9)
 };
 
 struct Model {

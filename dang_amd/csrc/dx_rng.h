@@ -12,12 +12,14 @@
 // Draw slots:
 //   amplitude phase, reference fluctuation term : draw = map number k (1..3)
 //   amplitude phase, textbook fluctuation term  : draw = k + 4*(band+1)
-//   index phase, step l (1..nsample): proposal  : draw = l         (u1,u2 -> normal)
-//                                     accept    : draw = l | 2^31  (u1)
-//   index phase, lnl_type=='prior' draw         : draw = 0
+//   index phase, step l (1..nsample)            : draw = l, ONE Philox call per step (uniform3):
+//        proposal normal from u1 = words(0,1) [53 bits] and u2 = word 2 [32 bits];
+//        accept uniform u3 = word 3 [32 bits]  (each 32-bit word maps to (w + 0.5) * 2^-32)
+//   index phase, lnl_type=='prior' draw         : draw = 0 (uniform2)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "dx_math.h"
 #include "dx_model.h"
 
 namespace dx {
@@ -49,11 +51,24 @@ __device__ __forceinline__ void uniform2(unsigned long long seed, unsigned long 
     u2 = u53(o[2], o[3]);
 }
 
-// rand_normal, src/dang_util_mod.f90:100-110 (Box-Muller, sine branch only)
+__device__ __forceinline__ double u32(uint32_t w) { return ((double)w + 0.5) * (1.0 / 4294967296.0); }
+
+__device__ __forceinline__ void uniform3(unsigned long long seed, unsigned long long stream, unsigned long long pix,
+                                         uint32_t draw, double& u1, double& u2, double& u3) {
+    uint32_t o[4];
+    philox4x32_10((uint32_t)pix, draw ^ ((uint32_t)(pix >> 32) << 16), (uint32_t)stream, (uint32_t)(stream >> 32),
+                  (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    u1 = u53(o[0], o[1]);
+    u2 = u32(o[2]);
+    u3 = u32(o[3]);
+}
+
+// rand_normal, src/dang_util_mod.f90:100-110 (Box-Muller, sine branch only):
+//   r = (-2 log u1)**0.5 ; theta = 2 pi u2 ; c = mean + stdev*r*sin(theta)
+// sin(2 pi u2) is evaluated as sinpi(2 u2) (no rounding of theta); log by log_pos (u1 is normal).
 __device__ __forceinline__ double rand_normal(double mean, double stdev, double u1, double u2) {
-    const double r = sqrt(-2.0 * log(u1));
-    const double theta = 2.0 * PI * u2;
-    return mean + stdev * r * sin(theta);
+    const double r = sqrt(-2.0 * log_pos(u1));
+    return mean + stdev * r * sin_2pi(u2);
 }
 
 }  // namespace dx

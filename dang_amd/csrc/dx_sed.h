@@ -10,6 +10,7 @@
 // (nu/nu_ref)**beta is evaluated as exp(beta*log(nu/nu_ref)) with the logarithm
 // precomputed on the host; this differs from pow() by a few ulp (|beta*ln r| * eps).
 #pragma once
+#include "dx_math.h"
 #include "dx_model.h"
 
 namespace dx {
@@ -18,10 +19,13 @@ struct Prep {
     double p0, p1, p2;
 };
 
-// src/dang_component_mod.f90:1024-1027 -- Gaunt-factor form, literal constants kept
-__device__ __forceinline__ double ff_gaunt(double nu9, double t15) {
+// src/dang_component_mod.f90:1024-1027 -- Gaunt-factor form, literal constants kept:
+//   log(exp(5.960 - sqrt(3)/pi * log(nu/1e9 * (T_e/1e4)**(-1.5))) + 2.71828)
+// with log(nu9*t15) = log(nu9) + log(t15): lnu9 is host-precomputed per band, lt15 = -1.5*log(T_e/1e4)
+// once per pixel (two transcendentals per band instead of three plus a pow per pixel).
+__device__ __forceinline__ double ff_gaunt(double lnu9, double lt15) {
     constexpr double S3PI = 1.7320508075688772 / PI;  // sqrt(3.d0)/pi
-    return log(exp(5.960 - S3PI * log(nu9 * t15)) + 2.71828);
+    return log_pos(exp(5.960 - S3PI * (lnu9 + lt15)) + 2.71828);
 }
 
 __device__ __forceinline__ Prep sed_prep(const Comp& c, double th0, double th1) {
@@ -38,9 +42,9 @@ __device__ __forceinline__ Prep sed_prep(const Comp& c, double th0, double th1) 
         break;
     }
     case DANGX_FREEFREE: {  // :1017-1024
-        const double t15 = pow(th0 / 1.0e4, -1.5);
-        p.p0 = t15;
-        p.p1 = ff_gaunt(c.nuref9, t15);  // S_ref
+        const double lt15 = -1.5 * log_pos(th0 / 1.0e4);  // log((T_e/1e4)**(-1.5))
+        p.p0 = lt15;
+        p.p1 = ff_gaunt(c.lnuref9, lt15);  // S_ref
         break;
     }
     case DANGX_LOGNORMAL:  // :978-984
@@ -70,11 +74,11 @@ __device__ inline double sed_bandpass(const Model& M, const Comp& c, int j, cons
             break;
         case DANGX_FREEFREE: {
             const double r = nu / c.nu_ref;
-            s = s + tau * ff_gaunt(1.0 * nu / 1.0e9, p.p0) / p.p1 * (1.0 / (r * r));
+            s = s + tau * ff_gaunt(log_pos(1.0 * nu / 1.0e9), p.p0) / p.p1 * (1.0 / (r * r));
             break;
         }
         case DANGX_LOGNORMAL: {
-            const double l = log(nu / p.p0) / p.p1;
+            const double l = log_pos(nu / p.p0) / p.p1;
             const double q = c.nu_ref / nu;
             s = s + tau * exp(-0.5 * (l * l)) * (q * q);
             break;
@@ -96,9 +100,9 @@ __device__ __forceinline__ double sed_eval(const Model& M, const Comp& c, int j,
     case DANGX_MBB:  // :947-948
         return p.p2 / (exp(p.p1 * M.band[j].nu_c) - 1.0) * exp(p.p0 * c.lnr[j]);
     case DANGX_FREEFREE:  // :1026-1027
-        return ff_gaunt(c.nu9[j], p.p0) / p.p1 * c.cst[j];
+        return ff_gaunt(c.lnu9[j], p.p0) / p.p1 * c.cst[j];
     case DANGX_LOGNORMAL: {  // :988
-        const double l = log(M.band[j].nu_c / p.p0) / p.p1;
+        const double l = log_pos(M.band[j].nu_c / p.p0) / p.p1;
         return exp(-0.5 * (l * l)) * c.cst[j];
     }
     default:

@@ -154,6 +154,13 @@ int dangx_sky_model_chisq(dangx_ctx *ctx, int pol_lo, int pol_hi, double *chisq_
 /* asynchronous form: writes the local sum to a device double (for an RCCL all-reduce) */
 int dangx_sky_model_chisq_dev(dangx_ctx *ctx, int pol_lo, int pol_hi, double *chisq_sum_dev);
 
+/* chi^2 sums that the index sweeps compute as a by-product (no extra pass over the maps):
+ * which = 0: the state the amplitude phase left (captured by the first sweep on each plane since its last
+ * amplitude update), which = 1: the current state.  Same un-normalised local sum as above.  Returns 2 when
+ * a plane in pol_lo..pol_hi was not covered by a sweep -- fall back to dangx_sky_model_chisq. */
+int dangx_chisq_cached(dangx_ctx *ctx, int which, int pol_lo, int pol_hi, double *chisq_sum);
+int dangx_chisq_cached_dev(dangx_ctx *ctx, int which, int pol_lo, int pol_hi, double *chisq_sum_dev);
+
 /* ---- secondary seams (type-bound procedures of dang_cg_group), host vectors in the
  * reference's packing [c1: plane1(npix), plane2(npix) | c2: ... ] -------------------- */
 int64_t dangx_group_size(dangx_ctx *ctx, int group, int flag);

@@ -77,6 +77,18 @@ void dgo_uniform2(uint64_t seed, uint64_t stream, uint64_t pix, uint32_t draw, d
     u[1] = u53(o[2], o[3]);
 }
 
+/* one Philox call per Metropolis step: u[0] 53 bits (words 0,1), u[1] and u[2] 32 bits (words 2, 3) */
+void dgo_uniform3(uint64_t seed, uint64_t stream, uint64_t pix, uint32_t draw, double u[3]) {
+    uint32_t ctr[4] = {(uint32_t)pix, draw, (uint32_t)stream, (uint32_t)(stream >> 32)};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t o[4];
+    ctr[1] ^= (uint32_t)(pix >> 32) << 16;
+    dgo_philox4x32_10(ctr, key, o);
+    u[0] = u53(o[0], o[1]);
+    u[1] = ((double)o[2] + 0.5) * (1.0 / 4294967296.0);
+    u[2] = ((double)o[3] + 0.5) * (1.0 / 4294967296.0);
+}
+
 /* src/dang_util_mod.f90:100-110: Box-Muller, sine branch only */
 double dgo_rand_normal(double mean, double stdev, double u1, double u2) {
     double r = sqrt(-2.0 * log(u1));
@@ -696,8 +708,8 @@ int64_t dgo_sample_index_mh(dgo_ctx *ctx, int comp, int nind, int map_n, int nsa
         double lnl_old = lnl + index_prior(ctx, comp, nind, s1, s2, i, sample[nind]); /* :394-402 */
         if (sample_it) {
             for (int l = 1; l <= nsample; ++l) {
-                double u[2];
-                dgo_uniform2(seed, stream, (uint64_t)(ctx->pix0 + i), (uint32_t)l, u);
+                double u[3];
+                dgo_uniform3(seed, stream, (uint64_t)(ctx->pix0 + i), (uint32_t)l, u);
                 theta[nind] = sample[nind] + dgo_rand_normal(0.0, c->step_size[nind], u[0], u[1]); /* :414 */
                 if (theta[nind] < c->uni_prior[nind][0] || theta[nind] > c->uni_prior[nind][1]) continue; /* :415 */
                 FILL_MODEL(theta)
@@ -707,9 +719,8 @@ int64_t dgo_sample_index_mh(dgo_ctx *ctx, int comp, int nind, int map_n, int nsa
                 if (ml_mode == DGO_ML_OPTIMIZE) { /* :443-447 */
                     if (diff > 0.0) { sample[nind] = theta[nind]; lnl_old = lnl_new; accepted += 1; }
                 } else { /* :448-454 */
-                    double v[2];
-                    dgo_uniform2(seed, stream, (uint64_t)(ctx->pix0 + i), (uint32_t)l | 0x80000000u, v);
-                    if (diff > log(v[0])) { sample[nind] = theta[nind]; lnl_old = lnl_new; accepted += 1; }
+                    /* :449-450 call RANDOM_NUMBER(num); if (diff > log(num)) */
+                    if (diff > log(u[2])) { sample[nind] = theta[nind]; lnl_old = lnl_new; accepted += 1; }
                 }
             }
         }

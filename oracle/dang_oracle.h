@@ -94,6 +94,8 @@ double dgo_missval(void);
 void dgo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 /* two uniforms in (0,1) for (seed, stream, pixel, draw) */
 void dgo_uniform2(uint64_t seed, uint64_t stream, uint64_t pix, uint32_t draw, double u[2]);
+/* three uniforms from ONE Philox call (Metropolis step): u[0] 53 bits, u[1], u[2] 32 bits */
+void dgo_uniform3(uint64_t seed, uint64_t stream, uint64_t pix, uint32_t draw, double u[3]);
 /* rand_normal, src/dang_util_mod.f90:100-110 */
 double dgo_rand_normal(double mean, double stdev, double u1, double u2);
 /* eval_normal_prior, src/dang_util_mod.f90:112-121 */

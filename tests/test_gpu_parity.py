@@ -273,3 +273,28 @@ def test_sharding_is_bitwise_invariant(built):
     s_full = eng_full.sky_model_chisq(1, 3)
     s_parts = sum(e.sky_model_chisq(1, 3) for e in engs)
     assert abs(s_full - s_parts) <= 1e-12 * s_full
+
+
+def test_fused_chisq_matches_explicit_pass(built):
+    """The chi^2 values the index sweeps produce as a by-product (before = state left by the amplitude
+    phase, after = current state) equal update_sky_model + compute_chisq evaluated explicitly."""
+    case = make_case("C2", nside=8)
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+    assert eng.chisq_cached(1, 1, 3) is None           # nothing swept yet
+    eng.amp_sample(1, L.FLAG_T, "sample", 7, 1)
+    eng.amp_sample(2, L.FLAG_QU, "sample", 7, 2)
+    explicit_before = eng.sky_model_chisq(1, 3)
+    assert eng.chisq_cached(0, 1, 3) is None           # amplitude update invalidated the cache
+    _sweep(eng, orc, comps, dpar)
+    explicit_after = eng.sky_model_chisq(1, 3)
+    before, after = eng.chisq_cached(0, 1, 3), eng.chisq_cached(1, 1, 3)
+    assert abs(before - explicit_before) <= 1e-11 * explicit_before
+    assert abs(after - explicit_after) <= 1e-11 * explicit_after
+    assert abs(eng.chisq_cached(1, 1, 1) + eng.chisq_cached(1, 2, 3) - after) <= 1e-12 * after
+    # the deferred host flow reports the same numbers as the eager one
+    da.sample_cg_groups(dpar, ddata, it=5, defer_chisq=True)
+    eager = eng.sky_model_chisq(1, 3) / meta["nbands"] / ddata.nump
+    da.sample_spectral_parameters(dpar, ddata, it=5)
+    assert abs(ddata.chisq_after_amp - eager) <= 1e-11 * eager
+    assert abs(ddata.chisq - eng.sky_model_chisq(1, 3) / meta["nbands"] / ddata.nump) <= 1e-11 * ddata.chisq
