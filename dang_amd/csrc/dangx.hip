@@ -48,22 +48,24 @@ __device__ __forceinline__ int flag_map(int flag, int p) {
     return 3;
 }
 
-// data(i,k,j) of compute_rhs (src/dang_cg_mod.f90:367-378, 427-443): the band map with
-// every component that is not solved for removed.  Zero-amplitude components are
-// skipped (0*sed; differs from the reference only if that sed is not finite).
-__device__ __forceinline__ double rhs_data(const Model& M, const GroupArgs& a, int i, int k, int j) {
-    double d = M.sig[((long long)j * M.nmaps + (k - 1)) * M.npix + i];
-    if (k == 1) d = d / M.gain[j];
+// data(i,k,j) of compute_rhs (src/dang_cg_mod.f90:367-378, 427-443): the band map with every
+// component that is not solved for removed.  a.oc lists only the components whose amplitude
+// plane may be non-zero (the host tracks all-zero planes; subtracting 0*sed is skipped, which
+// differs from the reference only if that sed is not finite).
+__device__ __forceinline__ double remove_others(const Model& M, const GroupArgs& a, int i, int k, int j, double d) {
     for (int o = 0; o < a.no; ++o) {
         const Comp& c = M.comp[a.oc[o]];
         const double amp = c.amp[(long long)(k - 1) * M.npix + i];
-        if (amp != 0.0) {
-            double t0, t1;
-            load_theta(M, c, i, k, t0, t1);
-            d = d - amp * sed_eval(M, c, j, sed_prep(c, t0, t1));
-        }
+        double t0, t1;
+        load_theta(M, c, i, k, t0, t1);
+        d = d - amp * sed_eval(M, c, j, sed_prep(c, t0, t1));
     }
     return d;
+}
+__device__ __forceinline__ double rhs_data(const Model& M, const GroupArgs& a, int i, int k, int j) {
+    double d = M.sig[((long long)j * M.nmaps + (k - 1)) * M.npix + i];
+    if (k == 1) d = d / M.gain[j];
+    return remove_others(M, a, i, k, j, d);
 }
 
 // ---------------------------------------------------------------------------
@@ -107,30 +109,55 @@ __global__ __launch_bounds__(BLOCK) void k_amp_direct(const Model* __restrict__ 
         uniform2(a.seed, a.stream, gpix, (uint32_t)k, u1, u2);
         eta = rand_normal(0.0, 1.0, u1, u2);  // eta(i), :258-260: ONE draw per unit, reused per band
     }
-    for (int j = 0; j < M.nbands; ++j) {
-        const double d = rhs_data(M, a, i, k, j);
-        const double is = 1.0 / M.rms[((long long)j * M.nmaps + (k - 1)) * npix + i];
-        const double inv = is * is;
+    // Band loop, software pipelined: the (d, rms) loads of band j+PF are in flight while band j is
+    // processed, so a wave does not park on every band's HBM latency.
+    constexpr int PF = 4;
+    const long long bstride = (long long)M.nmaps * npix;
+    const double* sigp = M.sig + (long long)(k - 1) * npix + i;
+    const double* rmsp = M.rms + (long long)(k - 1) * npix + i;
+    double dq[PF], rq[PF];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) mrow[g] = sed_eval(M, M.comp[a.gc[g]], j, pr[g]);
+    for (int t = 0; t < PF; ++t) {
+        const int j = (t < M.nbands) ? t : M.nbands - 1;
+        dq[t] = sigp[j * bstride];
+        rq[t] = rmsp[j * bstride];
+    }
+    for (int j0 = 0; j0 < M.nbands; j0 += PF) {
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const double t = mrow[g] * inv;
-            bv[g] += d * t;  // b = T^t N^-1 d, :489-508
+        for (int t = 0; t < PF; ++t) {
+            const int j = j0 + t;
+            if (j < M.nbands) {
+                double d = dq[t];
+                const double is = 1.0 / rq[t];
+                if (j + PF < M.nbands) {
+                    dq[t] = sigp[(j + PF) * bstride];
+                    rq[t] = rmsp[(j + PF) * bstride];
+                }
+                if (k == 1) d = d / M.gain[j];
+                if (a.no) d = remove_others(M, a, i, k, j, d);
+                const double inv = is * is;
 #pragma unroll
-            for (int h = 0; h <= g; ++h) A[g * (g + 1) / 2 + h] += t * mrow[h];  // T^t N^-1 T
-        }
-        if (sample) {
-            if (a.fluct == DANGX_FLUCT_REFERENCE) {
-                // :1033-1040 '=' without component offset: only slot 0 receives the term,
-                // holding the LAST component's SED product
-                f0 += (eta * is) * mrow[NG - 1];
-            } else {
-                double u1, u2;
-                uniform2(a.seed, a.stream, gpix, (uint32_t)(k + 4 * (j + 1)), u1, u2);
-                const double ej = rand_normal(0.0, 1.0, u1, u2) * is;
+                for (int g = 0; g < NG; ++g) mrow[g] = sed_eval(M, M.comp[a.gc[g]], j, pr[g]);
 #pragma unroll
-                for (int g = 0; g < NG; ++g) bv[g] += ej * mrow[g];
+                for (int g = 0; g < NG; ++g) {
+                    const double t2 = mrow[g] * inv;
+                    bv[g] += d * t2;  // b = T^t N^-1 d, :489-508
+#pragma unroll
+                    for (int h = 0; h <= g; ++h) A[g * (g + 1) / 2 + h] += t2 * mrow[h];  // T^t N^-1 T
+                }
+                if (sample) {
+                    if (a.fluct == DANGX_FLUCT_REFERENCE) {
+                        // :1033-1040 '=' without component offset: only slot 0 receives the term,
+                        // holding the LAST component's SED product
+                        f0 += (eta * is) * mrow[NG - 1];
+                    } else {
+                        double u1, u2;
+                        uniform2(a.seed, a.stream, gpix, (uint32_t)(k + 4 * (j + 1)), u1, u2);
+                        const double ej = rand_normal(0.0, 1.0, u1, u2) * is;
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) bv[g] += ej * mrow[g];
+                    }
+                }
             }
         }
     }
@@ -399,6 +426,7 @@ enum { CH_GENERIC = 0, CH_POW = 1, CH_MBB_BETA = 2, CH_MBB_T = 3, CH_LOGN_NUP = 
 
 struct IndexArgs {
     int comp, nind, s1, s2, nsample, ml_mode, mode;
+    unsigned others;  // bit l: component l (/= comp) may have a non-zero amplitude on planes s1..s2
     unsigned long long seed, stream;
 };
 
@@ -556,26 +584,64 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
     load_theta(M, c, i, a.s1, sample0, sample1);
     const bool first = (a.nind == 0);
     ChainCtx C{M, c, a, lds, BS, tid, nb, Sp, 0.0, 0.0, first ? sample1 : sample0};
-    // --- stage data_raw minus every OTHER component (:173-196) and 1/rms
+    // --- stage data_raw (:173-177) and 1/rms: loads of ST bands are issued together
+    constexpr int ST = (MODE == CH_GENERIC) ? 4 : TB;
     for (int kk = 0; kk < Sp; ++kk) {
         const int k = a.s1 + kk;
         const double ak = c.amp[(long long)(k - 1) * npix + i];
         if (kk) C.amp1 = ak; else C.amp0 = ak;
-        for (int j = 0; j < nb; ++j) {
-            double d = M.sig[((long long)j * M.nmaps + (k - 1)) * npix + i];
-            if (k == 1) d = (d - M.offset[j]) / M.gain[j];
-            C.D(kk, j) = d;
-            C.IS(kk, j) = 1.0 / M.rms[((long long)j * M.nmaps + (k - 1)) * npix + i];
+        const long long bstride = (long long)M.nmaps * npix;
+        const double* sigp = M.sig + (long long)(k - 1) * npix + i;
+        const double* rmsp = M.rms + (long long)(k - 1) * npix + i;
+#pragma unroll 2
+        for (int j0 = 0; j0 < nb; j0 += ST) {
+            double dv[ST], rv[ST];
+#pragma unroll
+            for (int t = 0; t < ST; ++t) {
+                const int j = (j0 + t < nb) ? j0 + t : nb - 1;
+                dv[t] = sigp[j * bstride];
+                rv[t] = rmsp[j * bstride];
+            }
+#pragma unroll
+            for (int t = 0; t < ST; ++t) {
+                const int j = j0 + t;
+                if (j < nb) {
+                    C.D(kk, j) = (k == 1) ? (dv[t] - M.offset[j]) / M.gain[j] : dv[t];
+                    C.IS(kk, j) = 1.0 / rv[t];
+                }
+            }
         }
-        for (int l = 0; l < M.ncomp; ++l) {
-            if (l == a.comp) continue;
+    }
+    // --- remove every OTHER component (:180-196), in component_list order; a.others holds the
+    // components whose amplitude may be non-zero on these planes (an all-zero plane contributes 0*sed).
+    // The next component's amplitude / indices are fetched while the current one is processed.
+    {
+        unsigned om = a.others;
+        double na[2] = {0.0, 0.0}, nt0[2] = {0.0, 0.0}, nt1[2] = {0.0, 0.0};
+        auto fetch = [&](int l) {
             const Comp& c2 = M.comp[l];
-            const double a2 = c2.amp[(long long)(k - 1) * npix + i];
-            if (a2 == 0.0) continue;  // 0*sed
-            double t0, t1;
-            load_theta(M, c2, i, k, t0, t1);
-            const Prep pr = sed_prep(c2, t0, t1);
-            for (int j = 0; j < nb; ++j) C.D(kk, j) -= a2 * sed_eval(M, c2, j, pr);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                if (kk < Sp) {
+                    na[kk] = c2.amp[(long long)(a.s1 + kk - 1) * npix + i];
+                    load_theta(M, c2, i, a.s1 + kk, nt0[kk], nt1[kk]);
+                }
+        };
+        int l = om ? __builtin_ctz(om) : -1;
+        if (l >= 0) fetch(l);
+        while (l >= 0) {
+            const Comp& c2 = M.comp[l];
+            const double ca[2] = {na[0], na[1]}, ct0[2] = {nt0[0], nt0[1]}, ct1[2] = {nt1[0], nt1[1]};
+            om &= om - 1;
+            const int ln = om ? __builtin_ctz(om) : -1;
+            if (ln >= 0) fetch(ln);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                if (kk < Sp) {
+                    const Prep pr = sed_prep(c2, ct0[kk], ct1[kk]);
+                    for (int j = 0; j < nb; ++j) C.D(kk, j) -= ca[kk] * sed_eval(M, c2, j, pr);
+                }
+            l = ln;
         }
     }
     // --- chain-invariant SED factor
@@ -789,6 +855,17 @@ __global__ __launch_bounds__(BLOCK) void k_sky_chisq(const Model* __restrict__ M
     }
 }
 
+// bit k of flags[0] is set when plane k+1 of a [nmaps][npix] amplitude map holds a non-zero value
+__global__ __launch_bounds__(BLOCK) void k_any_nonzero(const double* __restrict__ amp, long long npix, int nmaps,
+                                                       unsigned* __restrict__ flags) {
+    for (int k = 0; k < nmaps; ++k) {
+        bool nz = false;
+        for (long long t = (long long)blockIdx.x * BLOCK + threadIdx.x; t < npix; t += (long long)gridDim.x * BLOCK)
+            nz = nz || (amp[(long long)k * npix + t] != 0.0);
+        if (__ballot(nz) && (threadIdx.x & 63) == 0) atomicOr(flags, 1u << k);
+    }
+}
+
 // eval_sed(band, pix, map_n) over the shard (src/dang_component_mod.f90:778-813)
 __global__ __launch_bounds__(BLOCK) void k_eval_sed(const Model* __restrict__ Mp, int comp, int band, int map_n,
                                                     double* __restrict__ out) {
@@ -824,6 +901,7 @@ struct dangx_ctx {
     double* idx[MAXC] = {};
     bool own_amp[MAXC] = {};
     bool own_idx[MAXC] = {};
+    unsigned plane_nz[MAXC] = {};  // bit k-1: amplitude plane k of the component may be non-zero
     std::vector<double> bp_nu0, bp_tau0;
     double *d_bp_nu0 = nullptr, *d_bp_tau0 = nullptr;
     // scratch
@@ -993,7 +1071,10 @@ int make_group(dangx_ctx* ctx, int group, int flag, GroupArgs& a) {
             if (a.ng >= MAXG) return fail(ctx, "too many components in CG group");
             a.gc[a.ng++] = l;
         } else {
-            a.oc[a.no++] = l;
+            unsigned planes = 0;  // planes this (group, flag) works on
+            for (int pl = 0; pl < flag_planes_h(flag); ++pl)
+                planes |= 1u << (((flag & DANGX_FLAG_QU) ? 2 + pl : (flag & DANGX_FLAG_T) ? 1 : (flag & DANGX_FLAG_Q) ? 2 : 3) - 1);
+            if (ctx->plane_nz[l] & planes) a.oc[a.no++] = l;  // an all-zero plane contributes 0*sed: skipped
         }
     }
     if (a.ng == 0) return fail(ctx, "Woah there, number of CG components = 0 for CG group " + std::to_string(group));
@@ -1273,6 +1354,10 @@ int dangx_adopt_device_data(dangx_ctx* ctx, const double* sig, const double* rms
 int dangx_put_amplitude(dangx_ctx* ctx, int comp, const double* amp) {
     if (!ctx || !amp || check_comp(ctx, comp)) return 1;
     if (!ctx->amp[comp]) return fail(ctx, "component not set");
+    ctx->plane_nz[comp] = 0;
+    for (int k = 0; k < ctx->dims.nmaps; ++k)
+        for (long long t = 0; t < ctx->dims.npix; ++t)
+            if (amp[(long long)k * ctx->dims.npix + t] != 0.0) { ctx->plane_nz[comp] |= 1u << k; break; }
     HIPCHK(ctx, hipMemcpyAsync(ctx->amp[comp], amp, (size_t)ctx->dims.npix * ctx->dims.nmaps * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
@@ -1305,6 +1390,15 @@ int dangx_adopt_device_state(dangx_ctx* ctx, int comp, double* amp_dev, double* 
     if (ctx->amp[comp] && ctx->own_amp[comp]) (void)hipFree(ctx->amp[comp]);
     if (ctx->idx[comp] && ctx->own_idx[comp]) (void)hipFree(ctx->idx[comp]);
     ctx->amp[comp] = amp_dev; ctx->own_amp[comp] = false;
+    {   // which planes hold a non-zero amplitude right now (one small kernel, once)
+        unsigned f = 0;
+        unsigned* df = reinterpret_cast<unsigned*>(ctx->counters + 2);
+        HIPCHK(ctx, hipMemsetAsync(df, 0, sizeof(unsigned), ctx->stream));
+        hipLaunchKernelGGL(k_any_nonzero, dim3(1024), dim3(BLOCK), 0, ctx->stream, amp_dev, (long long)ctx->dims.npix, ctx->dims.nmaps, df);
+        HIPCHK(ctx, hipMemcpyAsync(&f, df, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->plane_nz[comp] = f;
+    }
     ctx->idx[comp] = (ctx->desc[comp].nindices > 0) ? idx_dev : nullptr; ctx->own_idx[comp] = false;
     ctx->dirty = true;
     return 0;
@@ -1330,6 +1424,7 @@ int dangx_amp_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solve
     for (int pl = 0; pl < flag_planes_h(flag); ++pl) {  // the planes' cached chi^2 is stale now
         const int k = (flag & DANGX_FLAG_QU) ? 2 + pl : (flag & DANGX_FLAG_T) ? 1 : (flag & DANGX_FLAG_Q) ? 2 : 3;
         ctx->chi_before_valid[k - 1] = ctx->chi_after_valid[k - 1] = ctx->touched_since_amp[k - 1] = false;
+        for (int g = 0; g < a.ng; ++g) ctx->plane_nz[a.gc[g]] |= 1u << (k - 1);  // about to be written
     }
     if (cg_iters) *cg_iters = 0;
     if (n_not_spd) *n_not_spd = 0;
@@ -1366,6 +1461,9 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
     if (d.lnl_type[nind] < DANGX_LNL_CHISQ || d.lnl_type[nind] > DANGX_LNL_PRIOR) return fail(ctx, "bad lnl_type");
     if (ml_mode != DANGX_ML_SAMPLE && ml_mode != DANGX_ML_OPTIMIZE) return fail(ctx, "bad ml_mode");
     const int Sp = a.s2 - a.s1 + 1;
+    a.others = 0;
+    for (int l = 0; l < ctx->hm.ncomp; ++l)
+        if (l != comp && (ctx->plane_nz[l] & ((1u << (a.s1 - 1)) | (1u << (a.s2 - 1))))) a.others |= 1u << l;
     // chain mode: factorised SED when every band is a delta bandpass
     bool all_delta = true;
     for (int j = 0; j < ctx->hm.nbands; ++j) all_delta = all_delta && ctx->hm.band[j].n == 0;
