@@ -75,32 +75,64 @@ __device__ __forceinline__ double rhs_data(const Model& M, const GroupArgs& a, i
 // (:697-704, :813-820), so A^t N^-1 A is one NG x NG SPD block per (pixel, plane).
 // Per unit: stream the nb bands once, accumulate the lower triangle of the block
 // and the right-hand side in registers, Cholesky, two triangular solves, store.
-template <int NG>
+// FAST: every band is a delta bandpass and nothing has to be removed from the data (the common case);
+// the generic instantiation carries the bandpass-integrated SEDs and the other-component removal.
+template <int NG, bool FAST>
 __global__ __launch_bounds__(BLOCK) void k_amp_direct(const Model* __restrict__ Mp, GroupArgs a,
                                                       unsigned long long* __restrict__ not_spd) {
+    extern __shared__ double lds[];  // [table | D(j) and IS(j) columns: (2*nb) x blockDim]
     const Model& M = *Mp;
-    const int npix = M.npix;
-    const long long u = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    if (u >= (long long)flag_nplanes(a.flag) * npix) return;
-    const int p = (int)(u / npix);
-    const int i = (int)(u - (long long)p * npix);
+    const int npix = M.npix, nb = M.nbands, BS = blockDim.x, tid = threadIdx.x;
+    double* tab = lds;
+    double* col = lds + sed_table_size(M);
+    sed_table_build(M, tab, tid, BS);
+    const long long u = (long long)blockIdx.x * BS + tid;
+    const bool in_range = u < (long long)flag_nplanes(a.flag) * npix;
+    const int p = in_range ? (int)(u / npix) : 0;
+    const int i = in_range ? (int)(u - (long long)p * npix) : 0;
     const int k = flag_map(a.flag, p);
-    if (is_masked(M.mask[i])) return;  // masked rows/cols are zero: x keeps its value (:695)
+    const bool live = in_range && !is_masked(M.mask[i]);  // masked rows/cols are zero: x keeps its value (:695)
 
+    // ---- phase 1: every HBM load of this unit is issued up front (d, rms for all bands in tiles of 5;
+    // the group's spectral indices), results parked in LDS columns
     Prep pr[NG];
+    int ty[NG], gl[NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const Comp& c = M.comp[a.gc[g]];
-        double t0, t1;
-        load_theta(M, c, i, k, t0, t1);
-        pr[g] = sed_prep(c, t0, t1);
+    for (int g = 0; g < NG; ++g) { gl[g] = a.gc[g]; ty[g] = M.comp[gl[g]].type; }
+    if (live) {
+        double th0[NG], th1[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) load_theta(M, M.comp[gl[g]], i, k, th0[g], th1[g]);
+        const long long bstride = (long long)M.nmaps * npix;
+        const double* sigp = M.sig + (long long)(k - 1) * npix + i;
+        const double* rmsp = M.rms + (long long)(k - 1) * npix + i;
+#pragma unroll 2
+        for (int j0 = 0; j0 < nb; j0 += 5) {
+            double dv[5], rv[5];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const int j = (j0 + t < nb) ? j0 + t : nb - 1;
+                dv[t] = sigp[j * bstride];
+                rv[t] = rmsp[j * bstride];
+            }
+#pragma unroll
+            for (int t = 0; t < 5; ++t)
+                if (j0 + t < nb) {
+                    col[(j0 + t) * BS + tid] = dv[t];
+                    col[(nb + j0 + t) * BS + tid] = 1.0 / rv[t];
+                }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) pr[g] = sed_prep(M.comp[gl[g]], th0[g], th1[g]);
     }
+    __syncthreads();  // constant table complete
+    if (!live) return;
+
     double A[NG * (NG + 1) / 2], bv[NG], mrow[NG];
 #pragma unroll
     for (int q = 0; q < NG * (NG + 1) / 2; ++q) A[q] = 0.0;
 #pragma unroll
     for (int g = 0; g < NG; ++g) bv[g] = 0.0;
-
     const bool sample = (a.ml_mode == DANGX_ML_SAMPLE);
     const unsigned long long gpix = (unsigned long long)(M.pix0 + i);
     double eta = 0.0, f0 = 0.0;
@@ -109,55 +141,36 @@ __global__ __launch_bounds__(BLOCK) void k_amp_direct(const Model* __restrict__ 
         uniform2(a.seed, a.stream, gpix, (uint32_t)k, u1, u2);
         eta = rand_normal(0.0, 1.0, u1, u2);  // eta(i), :258-260: ONE draw per unit, reused per band
     }
-    // Band loop, software pipelined: the (d, rms) loads of band j+PF are in flight while band j is
-    // processed, so a wave does not park on every band's HBM latency.
-    constexpr int PF = 4;
-    const long long bstride = (long long)M.nmaps * npix;
-    const double* sigp = M.sig + (long long)(k - 1) * npix + i;
-    const double* rmsp = M.rms + (long long)(k - 1) * npix + i;
-    double dq[PF], rq[PF];
+    // ---- phase 2: rolled band loop (one copy of the SED code per group component)
+    const double* gain = tab + (3 * M.ncomp + 1) * nb;
+#pragma unroll 1
+    for (int j = 0; j < nb; ++j) {
+        double d = col[j * BS + tid];
+        const double is = col[(nb + j) * BS + tid];
+        if (k == 1) d = d / gain[j];
+        if (!FAST) d = remove_others(M, a, i, k, j, d);
+        const double inv = is * is;
 #pragma unroll
-    for (int t = 0; t < PF; ++t) {
-        const int j = (t < M.nbands) ? t : M.nbands - 1;
-        dq[t] = sigp[j * bstride];
-        rq[t] = rmsp[j * bstride];
-    }
-    for (int j0 = 0; j0 < M.nbands; j0 += PF) {
+        for (int g = 0; g < NG; ++g)
+            mrow[g] = FAST ? sed_eval_tab(ty[g], tab, nb, M.ncomp, gl[g], j, pr[g]) : sed_eval(M, M.comp[gl[g]], j, pr[g]);
 #pragma unroll
-        for (int t = 0; t < PF; ++t) {
-            const int j = j0 + t;
-            if (j < M.nbands) {
-                double d = dq[t];
-                const double is = 1.0 / rq[t];
-                if (j + PF < M.nbands) {
-                    dq[t] = sigp[(j + PF) * bstride];
-                    rq[t] = rmsp[(j + PF) * bstride];
-                }
-                if (k == 1) d = d / M.gain[j];
-                if (a.no) d = remove_others(M, a, i, k, j, d);
-                const double inv = is * is;
+        for (int g = 0; g < NG; ++g) {
+            const double t2 = mrow[g] * inv;
+            bv[g] += d * t2;  // b = T^t N^-1 d, :489-508
 #pragma unroll
-                for (int g = 0; g < NG; ++g) mrow[g] = sed_eval(M, M.comp[a.gc[g]], j, pr[g]);
+            for (int h = 0; h <= g; ++h) A[g * (g + 1) / 2 + h] += t2 * mrow[h];  // T^t N^-1 T
+        }
+        if (sample) {
+            if (a.fluct == DANGX_FLUCT_REFERENCE) {
+                // :1033-1040 '=' without component offset: only slot 0 receives the term,
+                // holding the LAST component's SED product
+                f0 += (eta * is) * mrow[NG - 1];
+            } else {
+                double u1, u2;
+                uniform2(a.seed, a.stream, gpix, (uint32_t)(k + 4 * (j + 1)), u1, u2);
+                const double ej = rand_normal(0.0, 1.0, u1, u2) * is;
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    const double t2 = mrow[g] * inv;
-                    bv[g] += d * t2;  // b = T^t N^-1 d, :489-508
-#pragma unroll
-                    for (int h = 0; h <= g; ++h) A[g * (g + 1) / 2 + h] += t2 * mrow[h];  // T^t N^-1 T
-                }
-                if (sample) {
-                    if (a.fluct == DANGX_FLUCT_REFERENCE) {
-                        // :1033-1040 '=' without component offset: only slot 0 receives the term,
-                        // holding the LAST component's SED product
-                        f0 += (eta * is) * mrow[NG - 1];
-                    } else {
-                        double u1, u2;
-                        uniform2(a.seed, a.stream, gpix, (uint32_t)(k + 4 * (j + 1)), u1, u2);
-                        const double ej = rand_normal(0.0, 1.0, u1, u2) * is;
-#pragma unroll
-                        for (int g = 0; g < NG; ++g) bv[g] += ej * mrow[g];
-                    }
-                }
+                for (int g = 0; g < NG; ++g) bv[g] += ej * mrow[g];
             }
         }
     }
@@ -434,7 +447,8 @@ struct ChainCtx {
     const Model& M;
     const Comp& c;
     const IndexArgs& a;
-    double* lds;
+    double* lds;        // per-thread columns
+    const double* tab;  // block-shared constant table (sed_table_build)
     int BS, tid, nb, Sp;
     double amp0, amp1, other;  // amplitudes on the planes; the index that is NOT sampled
     __device__ __forceinline__ double& D(int kk, int j) const { return lds[(kk * nb + j) * BS + tid]; }
@@ -509,7 +523,7 @@ __device__ __forceinline__ double chain_lnl_tiled(const ChainCtx& C, double th, 
 #pragma unroll
         for (int t = 0; t < TB; ++t) {
             const int j = j0 + t;
-            x[t] = (MODE == CH_MBB_T) ? s0 * M.band[j].nu_c : s0 * c.lnr[j];
+            x[t] = (MODE == CH_MBB_T) ? s0 * C.tab[(3 * M.ncomp) * C.nb + j] : s0 * C.tab[(3 * C.a.comp) * C.nb + j];
             f[t] = (MODE == CH_POW) ? 1.0 : C.F(j);
             d0[t] = C.D(0, j); i0[t] = C.IS(0, j);
             if (SP == 2) { d1[t] = C.D(1, j); i1[t] = C.IS(1, j); }
@@ -534,6 +548,7 @@ __device__ __forceinline__ double chain_lnl_tiled(const ChainCtx& C, double th, 
     return acc0 + acc1;
 }
 
+template <bool FAST>
 __device__ __forceinline__ double index_prior(const ChainCtx& C, double val) {
     const Comp& c = C.c;
     const int q = C.a.nind;
@@ -553,7 +568,8 @@ __device__ __forceinline__ double index_prior(const ChainCtx& C, double val) {
             for (int kk = 0; kk < C.Sp; ++kk)
                 for (int j = 0; j < C.nb; ++j) {
                     const double amp = kk ? C.amp1 : C.amp0;
-                    const double ss = amp * sed_eval(C.M, c, j, pr);
+                    const double ss = amp * (FAST ? sed_eval_tab(c.type, C.tab, C.nb, C.M.ncomp, C.a.comp, j, pr)
+                                                   : sed_eval(C.M, c, j, pr));
                     const double rr = C.IS(kk, j);  // 1/rms
                     const double tt = (rr * rr) * (ss / amp) * c.lnr[j];
                     sum = sum + tt * tt;
@@ -569,8 +585,8 @@ __device__ __forceinline__ double index_prior(const ChainCtx& C, double val) {
 // MODE == CH_GENERIC: everything decided at run time (a.mode, lnl type, plane count, any nb);
 // otherwise the chisq fast path above with compile-time MODE / SP / TB.
 template <int MODE, int SP, int TB>
-__device__ __forceinline__ unsigned long long index_chain(const Model& M, const IndexArgs& a, double* lds, int BS, int tid,
-                                                          int i, double chi[4]) {
+__device__ __forceinline__ unsigned long long index_chain(const Model& M, const IndexArgs& a, double* lds, const double* tab,
+                                                          int BS, int tid, int i, double chi[4]) {
     const int npix = M.npix, nb = M.nbands;
     const Comp& c = M.comp[a.comp];
     const int Sp = a.s2 - a.s1 + 1;
@@ -583,7 +599,7 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
     double sample0, sample1;
     load_theta(M, c, i, a.s1, sample0, sample1);
     const bool first = (a.nind == 0);
-    ChainCtx C{M, c, a, lds, BS, tid, nb, Sp, 0.0, 0.0, first ? sample1 : sample0};
+    ChainCtx C{M, c, a, lds, tab, BS, tid, nb, Sp, 0.0, 0.0, first ? sample1 : sample0};
     // --- stage data_raw (:173-177) and 1/rms: loads of ST bands are issued together
     constexpr int ST = (MODE == CH_GENERIC) ? 4 : TB;
     for (int kk = 0; kk < Sp; ++kk) {
@@ -606,7 +622,7 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
             for (int t = 0; t < ST; ++t) {
                 const int j = j0 + t;
                 if (j < nb) {
-                    C.D(kk, j) = (k == 1) ? (dv[t] - M.offset[j]) / M.gain[j] : dv[t];
+                    C.D(kk, j) = (k == 1) ? (dv[t] - tab[(3 * M.ncomp + 2) * nb + j]) / tab[(3 * M.ncomp + 1) * nb + j] : dv[t];
                     C.IS(kk, j) = 1.0 / rv[t];
                 }
             }
@@ -639,7 +655,11 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
             for (int kk = 0; kk < 2; ++kk)
                 if (kk < Sp) {
                     const Prep pr = sed_prep(c2, ct0[kk], ct1[kk]);
-                    for (int j = 0; j < nb; ++j) C.D(kk, j) -= ca[kk] * sed_eval(M, c2, j, pr);
+                    const int ty2 = c2.type;
+#pragma unroll 1
+                    for (int j = 0; j < nb; ++j)
+                        C.D(kk, j) -= ca[kk] * ((MODE != CH_GENERIC) ? sed_eval_tab(ty2, tab, nb, M.ncomp, l, j, pr)
+                                                                     : sed_eval(M, c2, j, pr));
                 }
             l = ln;
         }
@@ -648,9 +668,9 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
     if (a.mode == CH_MBB_BETA) {
         const double z = H_PLANCK / (K_B * sample1);
         const double A = exp(z * c.nu_ref) - 1.0;
-        for (int j = 0; j < nb; ++j) C.F(j) = A / (exp(z * M.band[j].nu_c) - 1.0);
+        for (int j = 0; j < nb; ++j) C.F(j) = A / (exp(z * tab[(3 * M.ncomp) * nb + j]) - 1.0);
     } else if (a.mode == CH_MBB_T) {
-        for (int j = 0; j < nb; ++j) C.F(j) = exp((sample0 + 1.0) * c.lnr[j]);
+        for (int j = 0; j < nb; ++j) C.F(j) = exp((sample0 + 1.0) * tab[(3 * a.comp) * nb + j]);
     } else if (a.mode == CH_LOGN_W) {
         for (int j = 0; j < nb; ++j) C.F(j) = log_pos(M.band[j].nu_c / (sample0 * 1e9));
     }
@@ -678,7 +698,7 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
         uniform2(a.seed, a.stream, gpix, 0u, u1, u2);
         cur = rand_normal(c.gauss[a.nind][0], c.gauss[a.nind][1], u1, u2);
     }
-    double lnl_old = lnl + index_prior(C, cur);
+    double lnl_old = lnl + index_prior<MODE != CH_GENERIC>(C, cur);
     if (sample_it) {
         const double step = c.step[a.nind];
         const double lo = c.uni[a.nind][0], hi = c.uni[a.nind][1];
@@ -688,7 +708,7 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
             const double prop = cur + rand_normal(0.0, step, u1, u2);  // :414
             if (prop < lo || prop > hi) continue;  // :415 (the accept draw is not used)
             lnl = lnl_of(prop, c0, c1);
-            const double lnl_new = lnl + index_prior(C, prop);
+            const double lnl_new = lnl + index_prior<MODE != CH_GENERIC>(C, prop);
             const double diff = lnl_new - lnl_old;
             bool acc;
             if (a.ml_mode == DANGX_ML_OPTIMIZE) {
@@ -716,12 +736,14 @@ template <int MODE, int SP, int TB>
 __global__ __launch_bounds__(BLOCK) void k_index_mh(const Model* __restrict__ Mp, IndexArgs a,
                                                     unsigned long long* __restrict__ accepted,
                                                     double* __restrict__ chi_partial) {
-    extern __shared__ double lds[];
+    extern __shared__ double lds[];  // [constant table | per-thread columns]
     const Model& M = *Mp;
     const int BS = blockDim.x, tid = threadIdx.x;
     const int i = blockIdx.x * BS + tid;
+    sed_table_build(M, lds, tid, BS);
+    __syncthreads();
     double chi[4] = {0.0, 0.0, 0.0, 0.0};
-    unsigned long long nacc = (i < M.npix) ? index_chain<MODE, SP, TB>(M, a, lds, BS, tid, i, chi) : 0ull;
+    unsigned long long nacc = (i < M.npix) ? index_chain<MODE, SP, TB>(M, a, lds + sed_table_size(M), lds, BS, tid, i, chi) : 0ull;
     if (accepted) {  // every lane takes part in the wave reduction
         for (int o = 32; o > 0; o >>= 1) nacc += __shfl_down(nacc, o, 64);
         if ((tid & 63) == 0 && nacc) atomicAdd(accepted, nacc);
@@ -966,6 +988,8 @@ int sync_model(dangx_ctx* ctx) {
         if (!ctx->comp_set[l]) return fail(ctx, "component " + std::to_string(l) + " not set");
     if (!ctx->sig || !ctx->rms || !ctx->mask) return fail(ctx, "map data not uploaded");
     M.sig = ctx->sig; M.rms = ctx->rms; M.mask = ctx->mask;
+    M.all_delta = 1;
+    for (int j = 0; j < M.nbands; ++j) if (M.band[j].n != 0) M.all_delta = 0;
     if (!ctx->bp_nu0.empty()) {
         if (ctx->d_bp_nu0) { (void)hipFree(ctx->d_bp_nu0); (void)hipFree(ctx->d_bp_tau0); }
         const size_t nbytes = ctx->bp_nu0.size() * sizeof(double);
@@ -1102,7 +1126,15 @@ template <int NG>
 struct LaunchAmp {
     static int run(dangx_ctx* ctx, const GroupArgs& a, long long SN) {
         Timed t(ctx, DANGX_K_AMP_DIRECT);
-        hipLaunchKernelGGL(k_amp_direct<NG>, dim3(nblocks(SN)), dim3(BLOCK), 0, ctx->stream, ctx->dm, a, ctx->counters);
+        const int nb = ctx->hm.nbands;
+        const size_t tabsz = (size_t)(3 * ctx->hm.ncomp + 3) * nb * sizeof(double);
+        int bs = BLOCK;
+        while (bs > 64 && tabsz + (size_t)2 * nb * bs * sizeof(double) > 40 * 1024) bs >>= 1;
+        const size_t ldsz = tabsz + (size_t)2 * nb * bs * sizeof(double);
+        if (ctx->hm.all_delta && a.no == 0)
+            hipLaunchKernelGGL((k_amp_direct<NG, true>), dim3(nblocks(SN, bs)), dim3(bs), ldsz, ctx->stream, ctx->dm, a, ctx->counters);
+        else
+            hipLaunchKernelGGL((k_amp_direct<NG, false>), dim3(nblocks(SN, bs)), dim3(bs), ldsz, ctx->stream, ctx->dm, a, ctx->counters);
         return 0;
     }
 };
@@ -1475,9 +1507,10 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
     }
     // LDS columns: (2*Sp+1)*nb doubles per thread; pick the block so that >= 2 blocks fit in 160 KiB
     const size_t per_thread = (size_t)(2 * Sp + 1) * ctx->hm.nbands * sizeof(double);
+    const size_t tabsz = (size_t)(3 * ctx->hm.ncomp + 3) * ctx->hm.nbands * sizeof(double);
     int bs = 256;
-    while (bs > 64 && per_thread * bs > 72 * 1024) bs >>= 1;
-    const size_t lds = per_thread * bs;
+    while (bs > 64 && tabsz + per_thread * bs > 76 * 1024) bs >>= 1;
+    const size_t lds = tabsz + per_thread * bs;
     const unsigned nblk = nblocks(ctx->hm.npix, bs);
     constexpr int RSTAGE = 128;  // blocks of the first reduction stage
     if (ensure_partial(ctx, 4ll * nblk + 4ll * RSTAGE)) return 1;

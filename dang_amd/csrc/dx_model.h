@@ -47,6 +47,7 @@ struct Comp {
 
 struct Model {
     int npix, nmaps, nbands, ncomp;
+    int all_delta, pad0;  // every band is a 'delta' bandpass (fast SED path)
     long long pix0;
     const double* sig;   // [nbands][nmaps][npix]
     const double* rms;   // [nbands][nmaps][npix]
