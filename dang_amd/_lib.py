@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdangx.so")
+# DANGX_LIB selects another build of the same library (A/B timing of kernel variants on one GPU)
+LIB_PATH = os.environ.get("DANGX_LIB") or os.path.join(_HERE, "lib", "libdangx.so")
 
 MAX_BANDS, MAX_COMPS, MAX_IND, MAX_GROUP = 32, 16, 2, 8
 

@@ -97,12 +97,19 @@ __global__ __launch_bounds__(BLOCK) void k_amp_direct(const Model* __restrict__ 
     // the group's spectral indices), results parked in LDS columns
     Prep pr[NG];
     int ty[NG], gl[NG];
+    bool cs[NG];  // SED is a per-band constant on this plane (spatially constant indices)
 #pragma unroll
-    for (int g = 0; g < NG; ++g) { gl[g] = a.gc[g]; ty[g] = M.comp[gl[g]].type; }
+    for (int g = 0; g < NG; ++g) {
+        gl[g] = a.gc[g]; ty[g] = M.comp[gl[g]].type;
+        cs[g] = FAST && ((M.comp[gl[g]].const_planes >> (k - 1)) & 1);
+    }
     if (live) {
         double th0[NG], th1[NG];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) load_theta(M, M.comp[gl[g]], i, k, th0[g], th1[g]);
+        for (int g = 0; g < NG; ++g) {
+            th0[g] = th1[g] = 0.0;
+            if (!cs[g]) load_theta(M, M.comp[gl[g]], i, k, th0[g], th1[g]);
+        }
         const long long bstride = (long long)M.nmaps * npix;
         const double* sigp = M.sig + (long long)(k - 1) * npix + i;
         const double* rmsp = M.rms + (long long)(k - 1) * npix + i;
@@ -123,7 +130,10 @@ __global__ __launch_bounds__(BLOCK) void k_amp_direct(const Model* __restrict__ 
                 }
         }
 #pragma unroll
-        for (int g = 0; g < NG; ++g) pr[g] = sed_prep(M.comp[gl[g]], th0[g], th1[g]);
+        for (int g = 0; g < NG; ++g) {
+            pr[g] = Prep{0.0, 0.0, 0.0};
+            if (!cs[g]) pr[g] = sed_prep(M.comp[gl[g]], th0[g], th1[g]);
+        }
     }
     __syncthreads();  // constant table complete
     if (!live) return;
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(BLOCK) void k_amp_direct(const Model* __restrict__ 
         eta = rand_normal(0.0, 1.0, u1, u2);  // eta(i), :258-260: ONE draw per unit, reused per band
     }
     // ---- phase 2: rolled band loop (one copy of the SED code per group component)
-    const double* gain = tab + (3 * M.ncomp + 1) * nb;
+    const double* gain = tab + (TROWS * M.ncomp + 1) * nb;
 #pragma unroll 1
     for (int j = 0; j < nb; ++j) {
         double d = col[j * BS + tid];
@@ -152,7 +162,8 @@ __global__ __launch_bounds__(BLOCK) void k_amp_direct(const Model* __restrict__ 
         const double inv = is * is;
 #pragma unroll
         for (int g = 0; g < NG; ++g)
-            mrow[g] = FAST ? sed_eval_tab(ty[g], tab, nb, M.ncomp, gl[g], j, pr[g]) : sed_eval(M, M.comp[gl[g]], j, pr[g]);
+            mrow[g] = !FAST ? sed_eval(M, M.comp[gl[g]], j, pr[g])
+                      : cs[g] ? sed_const_tab(tab, nb, gl[g], k, j) : sed_eval_tab(ty[g], tab, nb, M.ncomp, gl[g], j, pr[g]);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const double t2 = mrow[g] * inv;
@@ -523,7 +534,7 @@ __device__ __forceinline__ double chain_lnl_tiled(const ChainCtx& C, double th, 
 #pragma unroll
         for (int t = 0; t < TB; ++t) {
             const int j = j0 + t;
-            x[t] = (MODE == CH_MBB_T) ? s0 * C.tab[(3 * M.ncomp) * C.nb + j] : s0 * C.tab[(3 * C.a.comp) * C.nb + j];
+            x[t] = (MODE == CH_MBB_T) ? s0 * C.tab[(TROWS * M.ncomp) * C.nb + j] : s0 * C.tab[(TROWS * C.a.comp) * C.nb + j];
             f[t] = (MODE == CH_POW) ? 1.0 : C.F(j);
             d0[t] = C.D(0, j); i0[t] = C.IS(0, j);
             if (SP == 2) { d1[t] = C.D(1, j); i1[t] = C.IS(1, j); }
@@ -622,7 +633,7 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
             for (int t = 0; t < ST; ++t) {
                 const int j = j0 + t;
                 if (j < nb) {
-                    C.D(kk, j) = (k == 1) ? (dv[t] - tab[(3 * M.ncomp + 2) * nb + j]) / tab[(3 * M.ncomp + 1) * nb + j] : dv[t];
+                    C.D(kk, j) = (k == 1) ? (dv[t] - tab[(TROWS * M.ncomp + 2) * nb + j]) / tab[(TROWS * M.ncomp + 1) * nb + j] : dv[t];
                     C.IS(kk, j) = 1.0 / rv[t];
                 }
             }
@@ -640,7 +651,8 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
             for (int kk = 0; kk < 2; ++kk)
                 if (kk < Sp) {
                     na[kk] = c2.amp[(long long)(a.s1 + kk - 1) * npix + i];
-                    load_theta(M, c2, i, a.s1 + kk, nt0[kk], nt1[kk]);
+                    if (MODE == CH_GENERIC || !((c2.const_planes >> (a.s1 + kk - 1)) & 1))
+                        load_theta(M, c2, i, a.s1 + kk, nt0[kk], nt1[kk]);
                 }
         };
         int l = om ? __builtin_ctz(om) : -1;
@@ -654,12 +666,16 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
                 if (kk < Sp) {
-                    const Prep pr = sed_prep(c2, ct0[kk], ct1[kk]);
-                    const int ty2 = c2.type;
+                    if (MODE != CH_GENERIC && ((c2.const_planes >> (a.s1 + kk - 1)) & 1)) {
+                        for (int j = 0; j < nb; ++j) C.D(kk, j) -= ca[kk] * sed_const_tab(tab, nb, l, a.s1 + kk, j);
+                    } else {
+                        const Prep pr = sed_prep(c2, ct0[kk], ct1[kk]);
+                        const int ty2 = c2.type;
 #pragma unroll 1
-                    for (int j = 0; j < nb; ++j)
-                        C.D(kk, j) -= ca[kk] * ((MODE != CH_GENERIC) ? sed_eval_tab(ty2, tab, nb, M.ncomp, l, j, pr)
-                                                                     : sed_eval(M, c2, j, pr));
+                        for (int j = 0; j < nb; ++j)
+                            C.D(kk, j) -= ca[kk] * ((MODE != CH_GENERIC) ? sed_eval_tab(ty2, tab, nb, M.ncomp, l, j, pr)
+                                                                         : sed_eval(M, c2, j, pr));
+                    }
                 }
             l = ln;
         }
@@ -668,9 +684,9 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
     if (a.mode == CH_MBB_BETA) {
         const double z = H_PLANCK / (K_B * sample1);
         const double A = exp(z * c.nu_ref) - 1.0;
-        for (int j = 0; j < nb; ++j) C.F(j) = A / (exp(z * tab[(3 * M.ncomp) * nb + j]) - 1.0);
+        for (int j = 0; j < nb; ++j) C.F(j) = A / (exp(z * tab[(TROWS * M.ncomp) * nb + j]) - 1.0);
     } else if (a.mode == CH_MBB_T) {
-        for (int j = 0; j < nb; ++j) C.F(j) = exp((sample0 + 1.0) * tab[(3 * a.comp) * nb + j]);
+        for (int j = 0; j < nb; ++j) C.F(j) = exp((sample0 + 1.0) * tab[(TROWS * a.comp) * nb + j]);
     } else if (a.mode == CH_LOGN_W) {
         for (int j = 0; j < nb; ++j) C.F(j) = log_pos(M.band[j].nu_c / (sample0 * 1e9));
     }
@@ -729,6 +745,221 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
     if (lnl_type != DANGX_LNL_CHISQ) chain_lnl(C, cur, DANGX_LNL_CHISQ, a0, a1);
     chi[2] = -2.0 * a0; chi[3] = -2.0 * a1;
     return nacc;
+}
+
+// ---------------------------------------------------------------------------
+// Register-resident form of the same chain (chisq likelihood, delta bandpasses, CH_POW / CH_MBB_BETA /
+// CH_MBB_T) for compile-time band count NB and plane count SP: the cleaned data, 1/rms and the chain-
+// invariant SED factor live in VGPRs (statically indexed, fully unrolled), per-band constants in SGPRs,
+// and the kernel uses no LDS and no barrier.  The CU's vector register file (512 KB) is three times its
+// LDS, so this form runs at 2-3 waves/SIMD where the LDS-column form is capped at 1-2.
+// Arithmetic and operation order are identical to index_chain<MODE, SP, TB>.
+template <int MODE, int SP, int NB>
+struct RegChain {
+    double D[SP][NB], IS[SP][NB], F[NB];
+    double amp[SP];
+
+    __device__ __forceinline__ double lnl(const Model& M, const Comp& c, double th, double& acc0, double& acc1) const {
+        double s0 = 0.0, s1 = 0.0;
+        if (MODE == CH_POW) s0 = th;
+        else if (MODE == CH_MBB_BETA) s0 = th + 1.0;
+        else { s0 = H_PLANCK / (K_B * th); s1 = exp(s0 * c.nu_ref) - 1.0; }
+        acc0 = 0.0; acc1 = 0.0;
+        double s[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const double e = exp((MODE == CH_MBB_T) ? s0 * M.band[j].nu_c : s0 * c.lnr[j]);
+            if (MODE == CH_POW) s[j] = e;
+            else if (MODE == CH_MBB_BETA) s[j] = F[j] * e;
+            else s[j] = s1 / (e - 1.0) * F[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const double r0 = (D[0][j] - amp[0] * s[j]) * IS[0][j];
+            acc0 = acc0 - 0.5 * (r0 * r0);
+            if (SP == 2) {
+                const double r1 = (D[SP - 1][j] - amp[SP - 1] * s[j]) * IS[SP - 1][j];
+                acc1 = acc1 - 0.5 * (r1 * r1);
+            }
+        }
+        return acc0 + acc1;
+    }
+};
+
+// eval_sed of an "other" component for all NB bands of one plane, subtracted from D (static band index)
+template <int NB>
+__device__ __forceinline__ void subtract_other(const Model& M, const Comp& c2, int k, double amp2, double t0, double t1,
+                                               double (&Dk)[NB]) {
+    if ((c2.const_planes >> (k - 1)) & 1) {  // spatially constant indices: host-evaluated SED
+#pragma unroll
+        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * c2.csed[k - 1][j];
+        return;
+    }
+    const Prep pr = sed_prep(c2, t0, t1);
+    switch (c2.type) {
+    case DANGX_POWERLAW:
+#pragma unroll
+        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * exp(pr.p0 * c2.lnr[j]);
+        break;
+    case DANGX_MBB:
+#pragma unroll
+        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * (pr.p2 / (exp(pr.p1 * M.band[j].nu_c) - 1.0) * exp(pr.p0 * c2.lnr[j]));
+        break;
+    case DANGX_FREEFREE:
+#pragma unroll
+        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * (ff_gaunt(c2.lnu9[j], pr.p0) / pr.p1 * c2.cst[j]);
+        break;
+    case DANGX_LOGNORMAL:
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const double l2 = log_pos(M.band[j].nu_c / pr.p0) / pr.p1;
+            Dk[j] -= amp2 * (exp(-0.5 * (l2 * l2)) * c2.cst[j]);
+        }
+        break;
+    default:  // cmb
+#pragma unroll
+        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * c2.cst[j];
+        break;
+    }
+}
+
+template <int MODE, int SP, int NB>
+__device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, const IndexArgs& a, int i, double chi[4]) {
+    const int npix = M.npix;
+    const Comp& c = M.comp[a.comp];
+    double* out = c.idx + ((long long)a.nind * M.nmaps) * npix + i;
+    if (is_masked(M.mask[i])) {  // :362 cycle; index_map stays 0 (:223) and is copied back (:480-483)
+#pragma unroll
+        for (int kk = 0; kk < SP; ++kk) out[(long long)(a.s1 + kk - 1) * npix] = 0.0;
+        return 0ull;
+    }
+    RegChain<MODE, SP, NB> R;
+    double sample0, sample1;
+    load_theta(M, c, i, a.s1, sample0, sample1);  // sample(l) = c%indices(i, map_inds(1), l), :372-377
+    const bool first = (a.nind == 0);
+    // --- stage data_raw (:173-177) and rms: every load issued before the first use
+    const long long bstride = (long long)M.nmaps * npix;
+#pragma unroll
+    for (int kk = 0; kk < SP; ++kk) {
+        const int k = a.s1 + kk;
+        R.amp[kk] = c.amp[(long long)(k - 1) * npix + i];
+        const double* sigp = M.sig + (long long)(k - 1) * npix + i;
+        const double* rmsp = M.rms + (long long)(k - 1) * npix + i;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            R.D[kk][j] = sigp[j * bstride];
+            R.IS[kk][j] = rmsp[j * bstride];
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < SP; ++kk) {
+        const int k = a.s1 + kk;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (k == 1) R.D[kk][j] = (R.D[kk][j] - M.offset[j]) / M.gain[j];
+            R.IS[kk][j] = 1.0 / R.IS[kk][j];
+        }
+    }
+    // --- remove every OTHER component (:180-196) in component_list order, next one prefetched
+    {
+        unsigned om = a.others;
+        double na[SP], nt0[SP], nt1[SP];
+        auto fetch = [&](int l) {
+            const Comp& c2 = M.comp[l];
+#pragma unroll
+            for (int kk = 0; kk < SP; ++kk) {
+                na[kk] = c2.amp[(long long)(a.s1 + kk - 1) * npix + i];
+                nt0[kk] = nt1[kk] = 0.0;
+                if (!((c2.const_planes >> (a.s1 + kk - 1)) & 1)) load_theta(M, c2, i, a.s1 + kk, nt0[kk], nt1[kk]);
+            }
+        };
+        int l = om ? __builtin_ctz(om) : -1;
+        if (l >= 0) fetch(l);
+        while (l >= 0) {
+            const Comp& c2 = M.comp[l];
+            double ca[SP], ct0[SP], ct1[SP];
+#pragma unroll
+            for (int kk = 0; kk < SP; ++kk) { ca[kk] = na[kk]; ct0[kk] = nt0[kk]; ct1[kk] = nt1[kk]; }
+            om &= om - 1;
+            const int ln = om ? __builtin_ctz(om) : -1;
+            if (ln >= 0) fetch(ln);
+#pragma unroll
+            for (int kk = 0; kk < SP; ++kk) subtract_other<NB>(M, c2, a.s1 + kk, ca[kk], ct0[kk], ct1[kk], R.D[kk]);
+            l = ln;
+        }
+    }
+    // --- chain-invariant SED factor
+    if (MODE == CH_MBB_BETA) {
+        const double z = H_PLANCK / (K_B * sample1);
+        const double A = exp(z * c.nu_ref) - 1.0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) R.F[j] = A / (exp(z * M.band[j].nu_c) - 1.0);
+    } else if (MODE == CH_MBB_T) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) R.F[j] = exp((sample0 + 1.0) * c.lnr[j]);
+    }
+    // --- chain (gaussian / uniform prior inline; jeffreys falls back to the LDS form on the host side)
+    const unsigned long long gpix = (unsigned long long)(M.pix0 + i);
+    const int q = a.nind;
+    const bool gauss = c.prior_type[q] == DANGX_PRIOR_GAUSSIAN;
+    const double pmean = c.gauss[q][0], pstd = c.gauss[q][1], lgden = c.lgden[q];
+    auto prior = [&](double v) -> double {
+        if (!gauss) return 0.0;
+        const double arg = ((v - pmean) * (v - pmean)) / (2 * (pstd * pstd));
+        return (arg > 745.0) ? -INFINITY : -arg - lgden;
+    };
+    unsigned long long nacc = 0;
+    double cur = first ? sample0 : sample1;
+    double a0, a1, c0, c1;
+    double lnl = R.lnl(M, c, cur, a0, a1);
+    chi[0] = -2.0 * a0; chi[1] = -2.0 * a1;
+    double lnl_old = lnl + prior(cur);
+    const double step = c.step[q], lo = c.uni[q][0], hi = c.uni[q][1];
+    for (int l = 1; l <= a.nsample; ++l) {
+        double u1, u2, u3;
+        uniform3(a.seed, a.stream, gpix, (uint32_t)l, u1, u2, u3);
+        const double prop = cur + rand_normal(0.0, step, u1, u2);  // :414
+        if (prop < lo || prop > hi) continue;                      // :415
+        lnl = R.lnl(M, c, prop, c0, c1);
+        const double lnl_new = lnl + prior(prop);
+        const double diff = lnl_new - lnl_old;
+        const bool acc = (a.ml_mode == DANGX_ML_OPTIMIZE) ? (diff > 0.0) : ((diff >= 0.0) || (exp(diff) > u3));  // :443-454
+        if (acc) { cur = prop; lnl_old = lnl_new; a0 = c0; a1 = c1; ++nacc; }
+    }
+#pragma unroll
+    for (int kk = 0; kk < SP; ++kk) out[(long long)(a.s1 + kk - 1) * npix] = cur;  // :465, :483
+    chi[2] = -2.0 * a0; chi[3] = -2.0 * a1;
+    return nacc;
+}
+
+template <int MODE, int SP, int NB>
+__global__ __launch_bounds__(BLOCK) void k_index_mh_reg(const Model* __restrict__ Mp, IndexArgs a,
+                                                        unsigned long long* __restrict__ accepted,
+                                                        double* __restrict__ chi_partial) {
+    const Model& M = *Mp;
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * BLOCK + tid;
+    double chi[4] = {0.0, 0.0, 0.0, 0.0};
+    unsigned long long nacc = (i < M.npix) ? index_chain_reg<MODE, SP, NB>(M, a, i, chi) : 0ull;
+    if (accepted) {
+        for (int o = 32; o > 0; o >>= 1) nacc += __shfl_down(nacc, o, 64);
+        if ((tid & 63) == 0 && nacc) atomicAdd(accepted, nacc);
+    }
+    if (chi_partial) {
+        __shared__ double sh[4][BLOCK / 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double v = chi[q];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            if ((tid & 63) == 0) sh[q][tid >> 6] = v;
+        }
+        __syncthreads();
+        if (tid < 4) {
+            double s = 0.0;
+            for (int w = 0; w < BLOCK / 64; ++w) s += sh[tid][w];
+            chi_partial[(long long)tid * gridDim.x + blockIdx.x] = s;
+        }
+    }
 }
 
 // chi_partial (nullable): [4][gridDim.x] block sums of chi[0..3]
@@ -888,6 +1119,22 @@ __global__ __launch_bounds__(BLOCK) void k_any_nonzero(const double* __restrict_
     }
 }
 
+// flags bit (q*3 + k) is set when index map q, plane k+1 of an [nind][nmaps][npix] array is NOT spatially
+// constant; first[q*3 + k] receives its first element
+__global__ __launch_bounds__(BLOCK) void k_not_constant(const double* __restrict__ idx, long long npix, int nmaps, int nind,
+                                                        unsigned* __restrict__ flags, double* __restrict__ first) {
+    for (int q = 0; q < nind; ++q)
+        for (int k = 0; k < nmaps; ++k) {
+            const double* m = idx + ((long long)q * nmaps + k) * npix;
+            const double m0 = m[0];
+            bool diff = false;
+            for (long long t = (long long)blockIdx.x * BLOCK + threadIdx.x; t < npix; t += (long long)gridDim.x * BLOCK)
+                diff = diff || (m[t] != m0);
+            if (__ballot(diff) && (threadIdx.x & 63) == 0) atomicOr(flags, 1u << (q * 3 + k));
+            if (blockIdx.x == 0 && threadIdx.x == 0) first[q * 3 + k] = m0;
+        }
+}
+
 // eval_sed(band, pix, map_n) over the shard (src/dang_component_mod.f90:778-813)
 __global__ __launch_bounds__(BLOCK) void k_eval_sed(const Model* __restrict__ Mp, int comp, int band, int map_n,
                                                     double* __restrict__ out) {
@@ -924,6 +1171,8 @@ struct dangx_ctx {
     bool own_amp[MAXC] = {};
     bool own_idx[MAXC] = {};
     unsigned plane_nz[MAXC] = {};  // bit k-1: amplitude plane k of the component may be non-zero
+    unsigned idx_const[MAXC] = {}; // bit k-1: every index of the component is spatially constant on plane k
+    double idx_val[MAXC][3][MAXI] = {};
     std::vector<double> bp_nu0, bp_tau0;
     double *d_bp_nu0 = nullptr, *d_bp_tau0 = nullptr;
     // scratch
@@ -979,6 +1228,32 @@ double host_a2t(const dangx_ctx* ctx, int j) {
     return sum;
 }
 
+// eval_sed for a delta bandpass on the host (src/dang_component_mod.f90:886-1040), used for components whose
+// indices are spatially constant on a plane
+double host_sed(const Comp& c, double nu, double cmb_cst, double th0, double th1) {
+    switch (c.type) {
+    case DANGX_POWERLAW: return std::pow(nu / c.nu_ref, th0);
+    case DANGX_MBB: {
+        const double z = H_PLANCK / (K_B * th1);
+        return (std::exp(z * c.nu_ref) - 1.0) / (std::exp(z * nu) - 1.0) * std::pow(nu / c.nu_ref, th0 + 1.0);
+    }
+    case DANGX_FREEFREE: {
+        auto g = [&](double v) {
+            return std::log(std::exp(5.960 - std::sqrt(3.0) / PI * std::log(1.0 * v / 1.0e9 * std::pow(th0 / 1.0e4, -1.5))) + 2.71828);
+        };
+        const double r = nu / c.nu_ref;
+        return g(nu) / g(c.nu_ref) * (1.0 / (r * r));
+    }
+    case DANGX_LOGNORMAL: {
+        const double l = std::log(nu / (th0 * 1e9)) / th1;
+        const double q = c.nu_ref / nu;
+        return std::exp(-0.5 * (l * l)) * (q * q);
+    }
+    case DANGX_CMB: return cmb_cst;
+    default: return 0.0;
+    }
+}
+
 int sync_model(dangx_ctx* ctx) {
     if (!ctx->dirty) return 0;
     Model& M = ctx->hm;
@@ -1022,6 +1297,16 @@ int sync_model(dangx_ctx* ctx) {
             if (c.type == DANGX_CMB) c.cst[j] = 1.0 / host_a2t(ctx, j);
             else if (c.type == DANGX_FREEFREE) c.cst[j] = 1.0 / (r * r);
             else if (c.type == DANGX_LOGNORMAL) { const double q = c.nu_ref / nu; c.cst[j] = q * q; }
+        }
+        c.const_planes = 0;
+        if (M.all_delta) {
+            const unsigned cp = (c.nind == 0) ? 7u : ctx->idx_const[l];
+            for (int k = 0; k < M.nmaps; ++k)
+                if ((cp >> k) & 1) {
+                    c.const_planes |= 1 << k;
+                    for (int j = 0; j < M.nbands; ++j)
+                        c.csed[k][j] = host_sed(c, M.band[j].nu_c, c.cst[j], ctx->idx_val[l][k][0], ctx->idx_val[l][k][1]);
+                }
         }
     }
     HIPCHK(ctx, hipMemcpyAsync(ctx->dm, &ctx->hm, sizeof(Model), hipMemcpyHostToDevice, ctx->stream));
@@ -1127,7 +1412,7 @@ struct LaunchAmp {
     static int run(dangx_ctx* ctx, const GroupArgs& a, long long SN) {
         Timed t(ctx, DANGX_K_AMP_DIRECT);
         const int nb = ctx->hm.nbands;
-        const size_t tabsz = (size_t)(3 * ctx->hm.ncomp + 3) * nb * sizeof(double);
+        const size_t tabsz = (size_t)(TROWS * ctx->hm.ncomp + 3) * nb * sizeof(double);
         int bs = BLOCK;
         while (bs > 64 && tabsz + (size_t)2 * nb * bs * sizeof(double) > 40 * 1024) bs >>= 1;
         const size_t ldsz = tabsz + (size_t)2 * nb * bs * sizeof(double);
@@ -1404,6 +1689,20 @@ int dangx_get_amplitude(dangx_ctx* ctx, int comp, double* amp) {
 int dangx_put_indices(dangx_ctx* ctx, int comp, const double* ind) {
     if (!ctx || !ind || check_comp(ctx, comp)) return 1;
     if (!ctx->idx[comp]) return fail(ctx, "component has no indices");
+    {   // planes on which every index map is spatially constant
+        const long long np = ctx->dims.npix;
+        ctx->idx_const[comp] = 0;
+        for (int k = 0; k < ctx->dims.nmaps; ++k) {
+            bool cst = true;
+            for (int q = 0; q < ctx->desc[comp].nindices && cst; ++q) {
+                const double* m = ind + ((long long)q * ctx->dims.nmaps + k) * np;
+                for (long long t = 1; t < np; ++t) if (m[t] != m[0]) { cst = false; break; }
+                ctx->idx_val[comp][k][q] = m[0];
+            }
+            if (cst) ctx->idx_const[comp] |= 1u << k;
+        }
+        ctx->dirty = true;
+    }
     HIPCHK(ctx, hipMemcpyAsync(ctx->idx[comp], ind, (size_t)ctx->dims.npix * ctx->dims.nmaps * ctx->desc[comp].nindices * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
@@ -1432,6 +1731,26 @@ int dangx_adopt_device_state(dangx_ctx* ctx, int comp, double* amp_dev, double* 
         ctx->plane_nz[comp] = f;
     }
     ctx->idx[comp] = (ctx->desc[comp].nindices > 0) ? idx_dev : nullptr; ctx->own_idx[comp] = false;
+    ctx->idx_const[comp] = 0;
+    if (ctx->idx[comp]) {   // planes on which every index map is spatially constant (one small kernel, once)
+        const int nind = ctx->desc[comp].nindices, nmaps = ctx->dims.nmaps;
+        unsigned f = 0;
+        double first[6] = {};
+        unsigned* df = reinterpret_cast<unsigned*>(ctx->counters + 2);
+        HIPCHK(ctx, hipMemsetAsync(df, 0, sizeof(unsigned), ctx->stream));
+        hipLaunchKernelGGL(k_not_constant, dim3(1024), dim3(BLOCK), 0, ctx->stream, idx_dev, (long long)ctx->dims.npix, nmaps, nind, df, ctx->scalars + 2);
+        HIPCHK(ctx, hipMemcpyAsync(&f, df, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(first, ctx->scalars + 2, sizeof(first), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < nmaps; ++k) {
+            bool cst = true;
+            for (int q = 0; q < nind; ++q) {
+                if ((f >> (q * 3 + k)) & 1) cst = false;
+                ctx->idx_val[comp][k][q] = first[q * 3 + k];
+            }
+            if (cst) ctx->idx_const[comp] |= 1u << k;
+        }
+    }
     ctx->dirty = true;
     return 0;
 }
@@ -1481,6 +1800,11 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
                        uint64_t stream, int64_t* accepted) {
     if (!ctx || check_comp(ctx, comp)) return 1;
     (void)hipSetDevice(ctx->device);
+    {   // this sweep makes the component's index map pixel dependent on the touched planes
+        unsigned touched = 0;
+        if (map_n == -1) touched = 6u; else if (map_n >= 1 && map_n <= 3) touched = 1u << (map_n - 1);
+        if (ctx->idx_const[comp] & touched) { ctx->idx_const[comp] &= ~touched; ctx->dirty = true; }
+    }
     if (sync_model(ctx)) return 1;
     const dangx_comp_desc& d = ctx->desc[comp];
     if (nind < 0 || nind >= d.nindices) return fail(ctx, "index number out of range");
@@ -1507,10 +1831,14 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
     }
     // LDS columns: (2*Sp+1)*nb doubles per thread; pick the block so that >= 2 blocks fit in 160 KiB
     const size_t per_thread = (size_t)(2 * Sp + 1) * ctx->hm.nbands * sizeof(double);
-    const size_t tabsz = (size_t)(3 * ctx->hm.ncomp + 3) * ctx->hm.nbands * sizeof(double);
+    const size_t tabsz = (size_t)(TROWS * ctx->hm.ncomp + 3) * ctx->hm.nbands * sizeof(double);
     int bs = 256;
     while (bs > 64 && tabsz + per_thread * bs > 76 * 1024) bs >>= 1;
     const size_t lds = tabsz + per_thread * bs;
+    const bool reg_ok = d.lnl_type[nind] == DANGX_LNL_CHISQ && d.prior_type[nind] != DANGX_PRIOR_JEFFREYS &&
+                        (a.mode == CH_POW || a.mode == CH_MBB_BETA || a.mode == CH_MBB_T) &&
+                        (ctx->hm.nbands == 3 || ctx->hm.nbands == 5 || ctx->hm.nbands == 6 || ctx->hm.nbands == 8 || ctx->hm.nbands == 10);
+    if (reg_ok) bs = BLOCK;  // register-resident form: no LDS columns
     const unsigned nblk = nblocks(ctx->hm.npix, bs);
     constexpr int RSTAGE = 128;  // blocks of the first reduction stage
     if (ensure_partial(ctx, 4ll * nblk + 4ll * RSTAGE)) return 1;
@@ -1528,10 +1856,25 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
         do { if (tb == 5) DX_LAUNCH_MH(MODE_, SP_, 5); else if (tb == 4) DX_LAUNCH_MH(MODE_, SP_, 4);            \
              else if (tb == 3) DX_LAUNCH_MH(MODE_, SP_, 3); else DX_LAUNCH_MH(MODE_, SP_, 1); } while (0)
 #define DX_MH_SP(MODE_) do { if (Sp == 2) DX_MH_TB(MODE_, 2); else DX_MH_TB(MODE_, 1); } while (0)
+        const bool regform = fast && d.prior_type[nind] != DANGX_PRIOR_JEFFREYS &&
+                             (nb == 3 || nb == 5 || nb == 6 || nb == 8 || nb == 10);
+#define DX_LAUNCH_REG(MODE_, SP_, NB_)                                                                           \
+        hipLaunchKernelGGL((k_index_mh_reg<MODE_, SP_, NB_>), dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->dm, a, accp, ctx->partial)
+#define DX_REG_NB(MODE_, SP_)                                                                                    \
+        do { if (nb == 10) DX_LAUNCH_REG(MODE_, SP_, 10); else if (nb == 5) DX_LAUNCH_REG(MODE_, SP_, 5);        \
+             else if (nb == 3) DX_LAUNCH_REG(MODE_, SP_, 3); else if (nb == 6) DX_LAUNCH_REG(MODE_, SP_, 6);     \
+             else DX_LAUNCH_REG(MODE_, SP_, 8); } while (0)
+#define DX_REG_SP(MODE_) do { if (Sp == 2) DX_REG_NB(MODE_, 2); else DX_REG_NB(MODE_, 1); } while (0)
         if (!fast) DX_LAUNCH_MH(CH_GENERIC, 1, 1);
+        else if (regform && a.mode == CH_POW) DX_REG_SP(CH_POW);
+        else if (regform && a.mode == CH_MBB_BETA) DX_REG_SP(CH_MBB_BETA);
+        else if (regform) DX_REG_SP(CH_MBB_T);
         else if (a.mode == CH_POW) DX_MH_SP(CH_POW);
         else if (a.mode == CH_MBB_BETA) DX_MH_SP(CH_MBB_BETA);
         else DX_MH_SP(CH_MBB_T);
+#undef DX_REG_SP
+#undef DX_REG_NB
+#undef DX_LAUNCH_REG
 #undef DX_MH_SP
 #undef DX_MH_TB
 #undef DX_LAUNCH_MH

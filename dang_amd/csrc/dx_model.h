@@ -43,6 +43,10 @@ struct Comp {
     double cst[MAXB];   // cmb: 1/a2t(bp) ; freefree: 1/(r*r) ; lognormal: (nu_ref/nu_c)^2
     double lnu9[MAXB];  // freefree: log(1.0*nu_c/1e9)
     double lnuref9;     // freefree: log(1.0*nu_ref/1e9)
+    // planes (bit k-1) on which every spectral index of the component is spatially constant: the SED
+    // is then pixel independent and csed[k-1][j] holds it (evaluated once on the host)
+    int const_planes, pad1;
+    double csed[3][MAXB];
 };
 
 struct Model {

@@ -112,20 +112,21 @@ __device__ __forceinline__ double sed_eval(const Model& M, const Comp& c, int j,
 
 // Block-shared LDS table of the per-(component, band) constants, so that the band loops read them with
 // broadcast ds_read instead of scattered scalar loads:
-//   tab[(3*l + q)*nb + j], q = 0: lnr, 1: cst, 2: lnu9   (component l, band j)
-//   tab[(3*ncomp + q)*nb + j], q = 0: nu_c, 1: gain, 2: offset
-__device__ __forceinline__ int sed_table_size(const Model& M) { return (3 * M.ncomp + 3) * M.nbands; }
+//   tab[(6*l + q)*nb + j], q = 0: lnr, 1: cst, 2: lnu9, 3..5: csed of planes 1..3   (component l, band j)
+//   tab[(6*ncomp + q)*nb + j], q = 0: nu_c, 1: gain, 2: offset
+constexpr int TROWS = 6;
+__device__ __forceinline__ int sed_table_size(const Model& M) { return (TROWS * M.ncomp + 3) * M.nbands; }
 __device__ __forceinline__ void sed_table_build(const Model& M, double* tab, int tid, int nthreads) {
     const int nb = M.nbands, n = sed_table_size(M);
     for (int t = tid; t < n; t += nthreads) {
         const int row = t / nb, j = t - row * nb;
         double v;
-        if (row < 3 * M.ncomp) {
-            const Comp& c = M.comp[row / 3];
-            const int q = row - 3 * (row / 3);
-            v = (q == 0) ? c.lnr[j] : (q == 1) ? c.cst[j] : c.lnu9[j];
+        if (row < TROWS * M.ncomp) {
+            const Comp& c = M.comp[row / TROWS];
+            const int q = row - TROWS * (row / TROWS);
+            v = (q == 0) ? c.lnr[j] : (q == 1) ? c.cst[j] : (q == 2) ? c.lnu9[j] : c.csed[q - 3][j];
         } else {
-            const int q = row - 3 * M.ncomp;
+            const int q = row - TROWS * M.ncomp;
             v = (q == 0) ? M.band[j].nu_c : (q == 1) ? M.gain[j] : M.offset[j];
         }
         tab[t] = v;
@@ -133,18 +134,23 @@ __device__ __forceinline__ void sed_table_build(const Model& M, double* tab, int
 }
 // eval_sed for a delta bandpass from the table (same expressions as sed_eval)
 __device__ __forceinline__ double sed_eval_tab(int type, const double* tab, int nb, int ncomp, int l, int j, const Prep& p) {
-    const double* tc = tab + (3 * l) * nb + j;
+    const double* tc = tab + (TROWS * l) * nb + j;
     switch (type) {
     case DANGX_POWERLAW: return exp(p.p0 * tc[0]);
-    case DANGX_MBB: return p.p2 / (exp(p.p1 * tab[(3 * ncomp) * nb + j]) - 1.0) * exp(p.p0 * tc[0]);
+    case DANGX_MBB: return p.p2 / (exp(p.p1 * tab[(TROWS * ncomp) * nb + j]) - 1.0) * exp(p.p0 * tc[0]);
     case DANGX_FREEFREE: return ff_gaunt(tc[2 * nb], p.p0) / p.p1 * tc[nb];
     case DANGX_LOGNORMAL: {
-        const double l2 = log_pos(tab[(3 * ncomp) * nb + j] / p.p0) / p.p1;
+        const double l2 = log_pos(tab[(TROWS * ncomp) * nb + j] / p.p0) / p.p1;
         return exp(-0.5 * (l2 * l2)) * tc[nb];
     }
     case DANGX_CMB: return tc[nb];
     default: return 0.0;
     }
+}
+
+// SED of component l on plane k when its indices are spatially constant there (host-evaluated)
+__device__ __forceinline__ double sed_const_tab(const double* tab, int nb, int l, int k, int j) {
+    return tab[(TROWS * l + 2 + k) * nb + j];
 }
 
 // spectral indices of component c at (pixel i, map k): c%indices(i,k,:)
