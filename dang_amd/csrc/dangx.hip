@@ -78,7 +78,7 @@ __device__ __forceinline__ double rhs_data(const Model& M, const GroupArgs& a, i
 // FAST: every band is a delta bandpass and nothing has to be removed from the data (the common case);
 // the generic instantiation carries the bandpass-integrated SEDs and the other-component removal.
 template <int NG, bool FAST>
-__global__ __launch_bounds__(BLOCK) void k_amp_direct(const Model* __restrict__ Mp, GroupArgs a,
+__global__ __launch_bounds__(BLOCK, (FAST && NG <= 4) ? 3 : 1) void k_amp_direct(const Model* __restrict__ Mp, GroupArgs a,
                                                       unsigned long long* __restrict__ not_spd) {
     extern __shared__ double lds[];  // [table | D(j) and IS(j) columns: (2*nb) x blockDim]
     const Model& M = *Mp;
@@ -933,7 +933,7 @@ __device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, co
 }
 
 template <int MODE, int SP, int NB>
-__global__ __launch_bounds__(BLOCK) void k_index_mh_reg(const Model* __restrict__ Mp, IndexArgs a,
+__global__ __launch_bounds__(BLOCK, (SP == 1 && NB <= 10) ? 3 : 2) void k_index_mh_reg(const Model* __restrict__ Mp, IndexArgs a,
                                                         unsigned long long* __restrict__ accepted,
                                                         double* __restrict__ chi_partial) {
     const Model& M = *Mp;
