@@ -94,6 +94,26 @@ class DangData:
     engine: object = None
 
 
+def return_poltype_flag(string):
+    """return_poltype_flag, src/dang_util_mod.f90:228-292: 'T', 'Q', 'U', 'Q+U' -> bit flags 1, 2, 4, 8, one list
+    entry per flag.  As in the reference 'T+Q+U' sets local_flag = 0, which no `iand(flag, 0)` test can ever
+    match, so it yields no usable flag."""
+    local_flag, nflag = 0, 0
+    for tok in string.split(","):
+        tok = tok.strip()
+        if tok == "T":
+            local_flag += 1; nflag += 1
+        elif tok == "Q":
+            local_flag += 2; nflag += 1
+        elif tok == "U":
+            local_flag += 4; nflag += 1
+        elif tok == "Q+U":
+            local_flag += 8; nflag += 1
+        elif tok == "T+Q+U":
+            local_flag = 0; nflag += 1
+    return [1 << j for j in range(4) if local_flag & (1 << j)]
+
+
 def stream_id(it, phase, a=0, b=0, c=0):
     """64-bit random-stream label: Gibbs iteration, phase (0 amp / 1 index), and up to three small ids."""
     return ((int(it) & 0xFFFFFFFF) << 32) | ((phase & 0xF) << 28) | ((a & 0xFFF) << 16) | ((b & 0xFF) << 8) | (c & 0xFF)

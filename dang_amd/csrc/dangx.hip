@@ -58,7 +58,7 @@ __device__ __forceinline__ double remove_others(const Model& M, const GroupArgs&
         const double amp = c.amp[(long long)(k - 1) * M.npix + i];
         double t0, t1;
         load_theta(M, c, i, k, t0, t1);
-        d = d - amp * sed_eval(M, c, j, sed_prep(c, t0, t1));
+        d = d - signal_of(c, amp, sed_eval(M, c, j, sed_prep(c, t0, t1)));
     }
     return d;
 }
@@ -673,8 +673,8 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
                         const int ty2 = c2.type;
 #pragma unroll 1
                         for (int j = 0; j < nb; ++j)
-                            C.D(kk, j) -= ca[kk] * ((MODE != CH_GENERIC) ? sed_eval_tab(ty2, tab, nb, M.ncomp, l, j, pr)
-                                                                         : sed_eval(M, c2, j, pr));
+                            C.D(kk, j) -= (MODE != CH_GENERIC) ? ca[kk] * sed_eval_tab(ty2, tab, nb, M.ncomp, l, j, pr)
+                                                               : signal_of(c2, ca[kk], sed_eval(M, c2, j, pr));
                     }
                 }
             l = ln;
@@ -1072,11 +1072,11 @@ __global__ __launch_bounds__(BLOCK) void k_sky_chisq(const Model* __restrict__ M
                 for (int l = 0; l < M.ncomp; ++l) {
                     const Comp& c = M.comp[l];
                     const double amp = c.amp[(long long)(k - 1) * npix + i];
-                    if (amp == 0.0 && !want_maps) continue;
+                    if (amp == 0.0 && !want_maps && c.type != DANGX_TCMB) continue;
                     double t0, t1;
                     load_theta(M, c, i, k, t0, t1);
                     const Prep pr = sed_prep(c, t0, t1);
-                    for (int j = 0; j < nb; ++j) lds[j * BS + tid] = lds[j * BS + tid] + amp * sed_eval(M, c, j, pr);
+                    for (int j = 0; j < nb; ++j) lds[j * BS + tid] = lds[j * BS + tid] + signal_of(c, amp, sed_eval(M, c, j, pr));
                 }
                 double chi = 0.0;
                 for (int j = 0; j < nb; ++j) {
@@ -1265,6 +1265,7 @@ int sync_model(dangx_ctx* ctx) {
     M.sig = ctx->sig; M.rms = ctx->rms; M.mask = ctx->mask;
     M.all_delta = 1;
     for (int j = 0; j < M.nbands; ++j) if (M.band[j].n != 0) M.all_delta = 0;
+    for (int l = 0; l < M.ncomp; ++l) if (ctx->desc[l].type == DANGX_TCMB) M.all_delta = 0;  // bare-sed signal: generic paths only
     if (!ctx->bp_nu0.empty()) {
         if (ctx->d_bp_nu0) { (void)hipFree(ctx->d_bp_nu0); (void)hipFree(ctx->d_bp_tau0); }
         const size_t nbytes = ctx->bp_nu0.size() * sizeof(double);
@@ -1383,7 +1384,7 @@ int make_group(dangx_ctx* ctx, int group, int flag, GroupArgs& a) {
             unsigned planes = 0;  // planes this (group, flag) works on
             for (int pl = 0; pl < flag_planes_h(flag); ++pl)
                 planes |= 1u << (((flag & DANGX_FLAG_QU) ? 2 + pl : (flag & DANGX_FLAG_T) ? 1 : (flag & DANGX_FLAG_Q) ? 2 : 3) - 1);
-            if (ctx->plane_nz[l] & planes) a.oc[a.no++] = l;  // an all-zero plane contributes 0*sed: skipped
+            if ((ctx->plane_nz[l] & planes) || ctx->desc[l].type == DANGX_TCMB) a.oc[a.no++] = l;  // all-zero plane: 0*sed, skipped
         }
     }
     if (a.ng == 0) return fail(ctx, "Woah there, number of CG components = 0 for CG group " + std::to_string(group));
@@ -1599,9 +1600,11 @@ int dangx_set_band(dangx_ctx* ctx, int band, double nu_c, int n, const double* n
 int dangx_set_component(dangx_ctx* ctx, int comp, const dangx_comp_desc* d) {
     if (!ctx || !d) return 1;
     if (check_comp(ctx, comp)) return 1;
-    if (d->type < DANGX_POWERLAW || d->type > DANGX_CMB)
+    if (d->type < DANGX_POWERLAW || d->type > DANGX_TCMB)
         return fail(ctx, "Error - unrecognized component type (only diffuse types are built)");
     const int want = (d->type == DANGX_MBB || d->type == DANGX_LOGNORMAL) ? 2 : (d->type == DANGX_CMB ? 0 : 1);
+    if (d->type == DANGX_TCMB && d->sample_amplitude)
+        return fail(ctx, "T_cmb cannot be amplitude-sampled on the device yet (SURVEY 8f rank 1)");
     if (d->nindices != want) return fail(ctx, "nindices does not match the component type");
     (void)hipSetDevice(ctx->device);
     const size_t plane = (size_t)ctx->dims.npix * ctx->dims.nmaps * sizeof(double);
@@ -1815,14 +1818,15 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
     else return fail(ctx, "There is something wrong with the poltype flag (map_n must be 1,2,3 or -1)");
     if (a.s2 > ctx->dims.nmaps) return fail(ctx, "map_n exceeds nmaps");
     if (d.lnl_type[nind] < DANGX_LNL_CHISQ || d.lnl_type[nind] > DANGX_LNL_PRIOR) return fail(ctx, "bad lnl_type");
+    if (d.type == DANGX_TCMB) return fail(ctx, "T_cmb is sampled full-sky (index_mode 1) in the reference: not built (SURVEY 8f rank 2)");
     if (ml_mode != DANGX_ML_SAMPLE && ml_mode != DANGX_ML_OPTIMIZE) return fail(ctx, "bad ml_mode");
     const int Sp = a.s2 - a.s1 + 1;
     a.others = 0;
     for (int l = 0; l < ctx->hm.ncomp; ++l)
-        if (l != comp && (ctx->plane_nz[l] & ((1u << (a.s1 - 1)) | (1u << (a.s2 - 1))))) a.others |= 1u << l;
+        if (l != comp && ((ctx->plane_nz[l] & ((1u << (a.s1 - 1)) | (1u << (a.s2 - 1)))) || ctx->desc[l].type == DANGX_TCMB))
+            a.others |= 1u << l;
     // chain mode: factorised SED when every band is a delta bandpass
-    bool all_delta = true;
-    for (int j = 0; j < ctx->hm.nbands; ++j) all_delta = all_delta && ctx->hm.band[j].n == 0;
+    const bool all_delta = ctx->hm.all_delta != 0;
     a.mode = CH_GENERIC;
     if (all_delta) {
         if (d.type == DANGX_POWERLAW) a.mode = CH_POW;

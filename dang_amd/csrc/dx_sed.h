@@ -28,6 +28,16 @@ __device__ __forceinline__ double ff_gaunt(double lnu9, double lt15) {
     return log_pos(exp(5.960 - S3PI * (lnu9 + lt15)) + 2.71828);
 }
 
+// B_nu(nu,T)/compute_bnu_prime_RJ(nu)*1e6: evaluate_T_cmb / evaluate_hi_fit (src/dang_component_mod.f90:815-884,
+// B_nu :745-752, compute_bnu_prime_RJ src/dang_bp_mod.f90:160-168)
+__device__ __forceinline__ double planck_rj(double nu, double T) {
+    const double bnu = ((2.0 * H_PLANCK * (nu * nu * nu)) / (C_LIGHT * C_LIGHT)) * (1.0 / (exp((H_PLANCK * nu) / (K_B * T)) - 1));
+    const double rj = 2.0 * K_B * (nu * nu) / (C_LIGHT * C_LIGHT);
+    return bnu / rj;
+}
+// eval_signal (src/dang_component_mod.f90:754-776): amplitude*sed, except 'T_cmb' whose signal is the bare sed
+__device__ __forceinline__ double signal_of(const Comp& c, double amp, double sed) { return (c.type == DANGX_TCMB) ? sed : amp * sed; }
+
 __device__ __forceinline__ Prep sed_prep(const Comp& c, double th0, double th1) {
     Prep p = {0.0, 0.0, 0.0};
     switch (c.type) {
@@ -50,6 +60,9 @@ __device__ __forceinline__ Prep sed_prep(const Comp& c, double th0, double th1) 
     case DANGX_LOGNORMAL:  // :978-984
         p.p0 = th0 * 1e9;
         p.p1 = th1;
+        break;
+    case DANGX_TCMB:  // :830-834
+        p.p0 = th0;
         break;
     default:
         break;
@@ -83,11 +96,14 @@ __device__ inline double sed_bandpass(const Model& M, const Comp& c, int j, cons
             s = s + tau * exp(-0.5 * (l * l)) * (q * q);
             break;
         }
+        case DANGX_TCMB:
+            s = s + tau * planck_rj(nu, p.p0);
+            break;
         default:
             break;
         }
     }
-    return s;
+    return (c.type == DANGX_TCMB) ? s * 1e6f : s;
 }
 
 // eval_sed for band j given the prepared pixel state (src/dang_component_mod.f90:778-813)
@@ -105,6 +121,8 @@ __device__ __forceinline__ double sed_eval(const Model& M, const Comp& c, int j,
         const double l = log_pos(M.band[j].nu_c / p.p0) / p.p1;
         return exp(-0.5 * (l * l)) * c.cst[j];
     }
+    case DANGX_TCMB:  // :836-846
+        return planck_rj(M.band[j].nu_c, p.p0) * 1e6f;
     default:
         return 0.0;
     }

@@ -40,7 +40,10 @@ extern "C" {
 #define DANGX_MAX_GROUP 8
 
 /* component type == c%type string, src/dang_component_mod.f90:791-809 */
-enum { DANGX_POWERLAW = 1, DANGX_MBB = 2, DANGX_FREEFREE = 3, DANGX_LOGNORMAL = 4, DANGX_CMB = 5 };
+/* DANGX_TCMB: 'T_cmb' -- evaluate_T_cmb (:815-848); its eval_signal is the bare sed (:770-771).  Supported by
+ * dangx_eval_sed and wherever a component is REMOVED from the data / summed into the sky model; it cannot be a
+ * member of a sampled CG group or be index-sampled on the device yet. */
+enum { DANGX_POWERLAW = 1, DANGX_MBB = 2, DANGX_FREEFREE = 3, DANGX_LOGNORMAL = 4, DANGX_CMB = 5, DANGX_TCMB = 6 };
 /* c%lnl_type / c%prior_type strings, src/dang_sample_mod.f90:383-400 */
 enum { DANGX_LNL_CHISQ = 1, DANGX_LNL_MARGINAL = 2, DANGX_LNL_PRIOR = 3 };
 enum { DANGX_PRIOR_GAUSSIAN = 1, DANGX_PRIOR_UNIFORM = 2, DANGX_PRIOR_JEFFREYS = 3 };

@@ -194,6 +194,25 @@ static double sed_freefree(const dgo_band *b, double nu_ref, double T_e) {
     return s;
 }
 
+/* src/dang_component_mod.f90:745-752 */
+double dgo_B_nu(double nu, double T) {
+    const double h = planck_h();
+    return ((2.0 * h * pow(nu, 3.0)) / pow(C_LIGHT, 2.0)) * (1.0 / (exp((h * nu) / (K_B * T)) - 1));
+}
+/* src/dang_bp_mod.f90:160-168 */
+double dgo_bnu_prime_RJ(double nu) { return 2.0 * K_B * pow(nu, 2.0) / pow(C_LIGHT, 2.0); }
+/* evaluate_T_cmb / evaluate_hi_fit, src/dang_component_mod.f90:815-884 (same expression; hi_fit multiplies by its template) */
+static double sed_planck_rj(const dgo_band *b, double T) {
+    double s = 0.0;
+    if (b->n == 0) s = dgo_B_nu(b->nu_c, T) / dgo_bnu_prime_RJ(b->nu_c);
+    else
+        for (int i = 0; i < b->n; ++i) {
+            if (b->nu0[i] == 0.0) continue;
+            s = s + b->tau0[i] * dgo_B_nu(b->nu0[i], T) / dgo_bnu_prime_RJ(b->nu0[i]);
+        }
+    return s * 1e6f;
+}
+
 /* src/dang_component_mod.f90:778-813 */
 double dgo_eval_sed(const dgo_ctx *ctx, int comp, int band, int pix, int map_n, const double *theta) {
     const dgo_comp *c = &ctx->comps[comp];
@@ -206,6 +225,7 @@ double dgo_eval_sed(const dgo_ctx *ctx, int comp, int band, int pix, int map_n, 
     case DGO_FREEFREE: return sed_freefree(b, c->nu_ref, th[0]);
     case DGO_LOGNORMAL: return sed_lognormal(b, c->nu_ref, th[0], th[1]);
     case DGO_CMB: return 1.0 / dgo_a2t(ctx, band);
+    case DGO_TCMB: return sed_planck_rj(b, th[0]);
     default: return NAN;
     }
 }
@@ -213,6 +233,7 @@ double dgo_eval_sed(const dgo_ctx *ctx, int comp, int band, int pix, int map_n, 
 /* src/dang_component_mod.f90:754-776 (diffuse branch, :773) */
 double dgo_eval_signal(const dgo_ctx *ctx, int comp, int band, int pix, int map_n, const double *theta) {
     const dgo_comp *c = &ctx->comps[comp];
+    if (c->type == DGO_TCMB) return dgo_eval_sed(ctx, comp, band, pix, map_n, theta); /* :770-771 */
     return c->amplitude[IDX2(ctx, map_n, pix)] * dgo_eval_sed(ctx, comp, band, pix, map_n, theta);
 }
 

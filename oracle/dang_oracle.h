@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 /* component types: src/dang_component_mod.f90:791-809 (diffuse ones) */
-enum { DGO_POWERLAW = 1, DGO_MBB = 2, DGO_FREEFREE = 3, DGO_LOGNORMAL = 4, DGO_CMB = 5 };
+enum { DGO_POWERLAW = 1, DGO_MBB = 2, DGO_FREEFREE = 3, DGO_LOGNORMAL = 4, DGO_CMB = 5, DGO_TCMB = 6 };
 /* lnl_type / prior_type: src/dang_sample_mod.f90:383-400 */
 enum { DGO_LNL_CHISQ = 1, DGO_LNL_MARGINAL = 2, DGO_LNL_PRIOR = 3 };
 enum { DGO_PRIOR_GAUSSIAN = 1, DGO_PRIOR_UNIFORM = 2, DGO_PRIOR_JEFFREYS = 3 };
@@ -103,6 +103,9 @@ double dgo_eval_normal_prior(double prop, double mean, double std);
 
 /* ---- sky model (src/dang_component_mod.f90:754-813, src/dang_bp_mod.f90:211-243) ---- */
 double dgo_a2t(const dgo_ctx *ctx, int band);
+/* B_nu (src/dang_component_mod.f90:745-752) and compute_bnu_prime_RJ (src/dang_bp_mod.f90:160-168) */
+double dgo_B_nu(double nu, double T);
+double dgo_bnu_prime_RJ(double nu);
 double dgo_eval_sed(const dgo_ctx *ctx, int comp, int band /*0-based*/, int pix, int map_n /*1-based*/,
                     const double *theta /* NULL or [nindices] */);
 double dgo_eval_signal(const dgo_ctx *ctx, int comp, int band, int pix, int map_n, const double *theta);

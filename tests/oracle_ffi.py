@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "libdang_oracle.so")
 
-TYPE_CODES = {"power-law": 1, "mbb": 2, "freefree": 3, "lognormal": 4, "cmb": 5}
+TYPE_CODES = {"power-law": 1, "mbb": 2, "freefree": 3, "lognormal": 4, "cmb": 5, "T_cmb": 6}
 LNL_CODES = {"chisq": 1, "marginal": 2, "prior": 3}
 PRIOR_CODES = {"gaussian": 1, "uniform": 2, "jeffreys": 3}
 ML_CODES = {"sample": 1, "optimize": 2}
@@ -57,6 +57,10 @@ def lib():
         l.dgo_eval_normal_prior.restype = C.c_double
         l.dgo_eval_normal_prior.argtypes = [C.c_double] * 3
         l.dgo_uniform2.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _D]
+        l.dgo_B_nu.restype = C.c_double
+        l.dgo_B_nu.argtypes = [C.c_double, C.c_double]
+        l.dgo_bnu_prime_RJ.restype = C.c_double
+        l.dgo_bnu_prime_RJ.argtypes = [C.c_double]
         l.dgo_a2t.restype = C.c_double
         l.dgo_a2t.argtypes = [C.POINTER(Ctx), C.c_int]
         l.dgo_eval_sed.restype = C.c_double

@@ -298,3 +298,33 @@ def test_fused_chisq_matches_explicit_pass(built):
     da.sample_spectral_parameters(dpar, ddata, it=5)
     assert abs(ddata.chisq_after_amp - eager) <= 1e-11 * eager
     assert abs(ddata.chisq - eng.sky_model_chisq(1, 3) / meta["nbands"] / ddata.nump) <= 1e-11 * ddata.chisq
+
+
+def test_T_cmb_component_as_fixed_sky_signal(built):
+    """'T_cmb' (evaluate_T_cmb, B_nu/compute_bnu_prime_RJ): eval_sed parity, and its bare-sed signal is removed
+    from the data in the amplitude phase / the index sweeps and summed into the sky model (generic paths)."""
+    from dang_amd.api import DangComps
+    def tweak(dpar, ddata, bands, comps):
+        npix = ddata.sig_map.shape[-1]
+        comps.append(DangComps(label="tcmb", type="T_cmb", nu_ref=100.0, cg_group=9, sample_amplitude=False, nindices=1,
+                               ind_label=["T"], sample_index=[False], index_mode=[1], lnl_type=["chisq"],
+                               prior_type=["uniform"], gauss_prior=[[2.7255, 1.0]], uni_prior=[[0.0, 10.0]],
+                               step_size=[0.0], pol_flag=[[L.FLAG_T]], amplitude=np.zeros((1, npix)),
+                               indices=np.full((1, 1, npix), 0.5)))   # a cold blackbody: finite, band-dependent signal
+    case = make_case("C1", nside=8, start="truth", tweak=tweak)
+    eng, orc = pair(case)
+    comps, meta = case[3], case[4]
+    for j in range(meta["nbands"]):
+        g, o = eng.eval_sed(2, j, 1), orc.eval_sed_map(2, j, 1)
+        assert np.all(np.abs(g - o) <= TOL_SED * np.abs(o))      # (exp overflow at 857 GHz gives exactly 0 in both)
+    assert orc.eval_sed_map(2, 0, 1)[0] > 1e4
+    eng.amp_sample(1, L.FLAG_T, "sample", 3, 4)
+    orc.amp_sample_direct(1, L.FLAG_T, "sample", 3, 4, "reference")
+    assert_amps_close(eng, orc, 2, TOL_AMP_TIGHT)
+    ag = eng.index_sample(1, 0, 1, 10, "sample", 5, 6)
+    ao = orc.sample_index_mh(1, 0, 1, 10, "sample", 5, 6)
+    assert ag == ao
+    assert_indices_close(eng, orc, comps[:2], TOL_INDEX)
+    s, sky, res, chi = eng.sky_model_chisq(1, 1, want_maps=True)
+    osky, ores = orc.sky_model()
+    assert relmax(sky, osky) <= 1e-13 and relmax(res, ores) <= 1e-11

@@ -283,3 +283,35 @@ def test_index_posterior_tracks_truth():
     ok = ddata.masks[0] != 0
     err = o.indices(0)[0, 0][ok] - truth[ok]
     assert np.abs(err).mean() < 0.02 and abs(err.mean()) < 0.005
+
+
+def test_planck_and_T_cmb_closed_forms():
+    """B_nu (src/dang_component_mod.f90:745-752), compute_bnu_prime_RJ (src/dang_bp_mod.f90:160-168) and
+    evaluate_T_cmb (:815-848): B_nu(T)/(2 k nu^2/c^2) * 1e6 -> x/(e^x - 1) * T * 1e6, x = h nu / k T."""
+    lib = O.lib()
+    c_light = 2.99792458e8
+    for nu, T in [(30e9, 2.7255), (143e9, 2.7255), (857e9, 19.6)]:
+        x = H * nu / (K_B * T)
+        b = 2 * H * nu ** 3 / c_light ** 2 / (math.exp(x) - 1)
+        assert abs(lib.dgo_B_nu(nu, T) / b - 1) <= 1e-14
+        assert abs(lib.dgo_bnu_prime_RJ(nu) / (2 * K_B * nu ** 2 / c_light ** 2) - 1) <= 1e-15
+    from dang_amd.api import BandInfo, DangComps, DangData
+    bands = [BandInfo("b1", 30.0), BandInfo("b2", 143.0)]
+    comp = DangComps(label="tcmb", type="T_cmb", nu_ref=100.0, nindices=1, sample_amplitude=False,
+                     indices=np.full((1, 1, 4), 2.7255), amplitude=np.zeros((1, 4)))
+    dd = DangData(sig_map=np.zeros((2, 1, 4)), rms_map=np.ones((2, 1, 4)), masks=np.ones((1, 4)))
+    o = O.Oracle(bands, [comp], dd)
+    for j, nu in enumerate((30e9, 143e9)):
+        x = H * nu / (K_B * 2.7255)
+        ref = x / (math.exp(x) - 1) * 2.7255 * 1e6
+        assert abs(o.eval_sed_map(0, j, 1)[0] / ref - 1) <= 1e-14
+        assert o.L.dgo_eval_signal(o.c, 0, j, 0, 1, None) == o.eval_sed_map(0, j, 1)[0]   # bare sed (:770-771)
+
+
+def test_return_poltype_flag():
+    import dang_amd as da
+    assert da.return_poltype_flag("T") == [1]
+    assert da.return_poltype_flag("Q+U") == [8]
+    assert da.return_poltype_flag("T,Q+U") == [1, 8]
+    assert da.return_poltype_flag("T,Q,U") == [1, 2, 4]
+    assert da.return_poltype_flag("T+Q+U") == []      # quirk 1: flag 0 can never be matched
