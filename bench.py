@@ -28,6 +28,20 @@ import torch  # noqa: E402
 import torch.distributed as td  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic_r01.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary
+
+
+def measured_traffic(config, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC profile of the same command (FETCH_SIZE and
+    WRITE_SIZE collected in separate passes, FETCH corrected by the factor calibrated on kernels of known byte
+    count: profiles/r01_z_final.md).  None when no profile of this configuration is committed."""
+    try:
+        t = json.load(open(TRAFFIC_JSON))
+        if t.get("config") != config:
+            return None
+        return float(t["kernels"][kernel]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
 
 
 def algorithmic_bytes(meta, comps, kernel, units):
@@ -198,8 +212,11 @@ def main():
                                       "IQU" if nmaps == 3 else "I", args.nsample, world),
                        "npix": meta["npix_global"], "chisq_after_amp": chisq[0], "chisq_after_index": chisq[1]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "avg_launch_ms": prof[dom]["avg_ms"], "bytes_per_launch": bytes_per_launch},
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(args.config, dom) if (world == 1 and args.nside is None) else None,
+                         "avg_launch_ms": prof[dom]["avg_ms"], "bytes_per_launch": bytes_per_launch,
+                         "note": "the kernel is fp64-VALU bound (VALU issue ~92-98% busy, profiles/r01_z_final.md); "
+                                 "HBM traffic <= algorithmic bytes, so the HBM fraction is what the arithmetic leaves"},
             "kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"],
                             "ms_per_step": round(v["total_ms"] / args.steps, 4)} for k, v in prof.items()},
         }
