@@ -74,6 +74,11 @@ SYMBOLS = {
     "dangx_sky_model_chisq_dev": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "dangx_chisq_cached": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _D]),
     "dangx_chisq_cached_dev": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
+    "dangx_fullsky_prepare": (C.c_int, [_P, C.c_int, C.c_int]),
+    "dangx_fullsky_sums": (C.c_int, [_P, C.c_int, _P, _P, C.c_int]),
+    "dangx_fill_index": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_double]),
+    "dangx_gain_sums": (C.c_int, [_P, C.c_int, _P]),
+    "dangx_peek_indices": (C.c_int, [_P, C.c_int, C.c_int, C.c_longlong, _P]),
     "dangx_group_size": (C.c_int64, [_P, C.c_int, C.c_int]),
     "dangx_compute_rhs": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "dangx_compute_Ax": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),

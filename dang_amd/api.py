@@ -17,8 +17,11 @@ from typing import List, Optional
 
 import numpy as np
 
+import math
+
 from . import _lib as L
 from . import dist as _dist
+from . import rng as _rng
 
 MISSVAL = -1.6375e30  # src/dang_util_mod.f90:19
 
@@ -53,6 +56,7 @@ class DangComps:
     uni_prior: List[List[float]] = field(default_factory=list)    # [low, high]
     step_size: List[float] = field(default_factory=list)
     pol_flag: List[List[int]] = field(default_factory=list)  # per index: list of poltype bit flags
+    tuned: List[bool] = field(default_factory=list)          # c%tuned (empty = all tuned)
     amplitude: Optional[np.ndarray] = None                   # [nmaps][npix]
     indices: Optional[np.ndarray] = None                     # [nindices][nmaps][npix]
 
@@ -91,6 +95,7 @@ class DangData:
     nump: float = 0.0                 # number of unmasked (pixel, map) entries; an INPUT
     chisq: float = 0.0
     chisq_after_amp: float = 0.0      # chi^2 of the state the amplitude phase left (when deferred)
+    fit_gain: List[bool] = field(default_factory=list)   # ddata%fit_gain(:)
     engine: object = None
 
 
@@ -297,6 +302,35 @@ class Engine:
         """Asynchronous local chi^2 sum into a 1-element cuda fp64 tensor (for the RCCL all-reduce)."""
         self._chk(self.lib.dangx_sky_model_chisq_dev(self.h, pol_lo, pol_hi, out_tensor.data_ptr()))
 
+    # -- full-sky index mode / gain fit primitives (local sums; the caller all-reduces)
+    def fullsky_prepare(self, comp, map_n):
+        self._chk(self.lib.dangx_fullsky_prepare(self.h, comp, map_n))
+
+    def fullsky_sums(self, what, theta, nrows):
+        th = (C.c_double * 2)(float(theta[0]), float(theta[1]) if len(theta) > 1 else 0.0)
+        out = (C.c_double * nrows)()
+        self._chk(self.lib.dangx_fullsky_sums(self.h, what, th, out, nrows))
+        return np.array(out[:nrows])
+
+    def fill_index(self, comp, nind, map_n, value):
+        self._chk(self.lib.dangx_fill_index(self.h, comp, nind, map_n, float(value)))
+
+    def peek_indices(self, comp, map_n, pix=0):
+        n = self.component_list[comp].nindices
+        out = (C.c_double * max(n, 1))()
+        self._chk(self.lib.dangx_peek_indices(self.h, comp, map_n, pix, out))
+        return [out[q] for q in range(n)]
+
+    def gain_sums(self, band):
+        out = (C.c_double * 2)()
+        self._chk(self.lib.dangx_gain_sums(self.h, band, out))
+        return out[0], out[1]
+
+    def set_calibration(self, gain, offset):
+        g = np.ascontiguousarray(gain, dtype=np.float64)
+        o = np.ascontiguousarray(offset, dtype=np.float64)
+        self._chk(self.lib.dangx_set_calibration(self.h, g.ctypes.data, o.ctypes.data))
+
     # -- secondary seams
     def group_size(self, group, flag):
         n = self.lib.dangx_group_size(self.h, group, flag)
@@ -418,13 +452,14 @@ def sample_spectral_parameters(dpar: DangParams, ddata: DangData, it=2, verbose=
         for j in range(c.nindices):
             if not c.sample_index[j]:
                 continue
-            if c.index_mode and c.index_mode[j] != 2:
-                raise DangxError("index_mode 1 (full-sky) is not built yet (SURVEY 8f rank 2)")
             for f in c.pol_flag[j]:
                 if f not in _MAPN:
                     raise DangxError("There is something wrong with the poltype flag for component " + c.label)
-                acc = eng.index_sample(l, j, _MAPN[f], dpar.nsample, dpar.ml_mode, dpar.seed,
-                                       stream_id(it, 1, l, j, f))
+                if c.index_mode and c.index_mode[j] == 1:
+                    acc = sample_index_mh_fullsky(dpar, ddata, l, j, _MAPN[f], stream_id(it, 1, l, j, f))
+                else:
+                    acc = eng.index_sample(l, j, _MAPN[f], dpar.nsample, dpar.ml_mode, dpar.seed,
+                                           stream_id(it, 1, l, j, f))
                 info.append((l, j, f, acc))
     if sampled:
         lo, hi = ddata.pol_type[0], ddata.pol_type[-1]
@@ -438,3 +473,176 @@ def sample_spectral_parameters(dpar: DangParams, ddata: DangData, it=2, verbose=
         if verbose:
             print("%6d - Chisq: %16.5E" % (it, ddata.chisq))
     return info
+
+
+# --------------------------------------------------------------------------- full-sky mode, tuner, calibrators
+
+def _fullsky_lnl(eng, c, nind, theta, nb, Sp):
+    """evaluate_lnL / evaluate_marginal_lnL over the whole sky (src/dang_lnl_mod.f90:126-182, 47-124); the device
+    returns this shard's sums, the all-reduce makes them global."""
+    lt = c.lnl_type[nind]
+    if lt == "chisq":
+        return _dist.allreduce_sum_float(eng.fullsky_sums(0, theta, 1)[0])
+    if lt == "marginal":
+        rows = eng.fullsky_sums(1, theta, 2 * nb * Sp)
+        rows = np.array([_dist.allreduce_sum_float(v) for v in rows])
+        lnl = 0.0
+        for q in range(nb * Sp):  # j outer, k inner (:113-122)
+            TNd, TNT = rows[2 * q], rows[2 * q + 1]
+            lnl = lnl - 0.5 * TNd * (1.0 / TNT) * TNd
+        return lnl
+    return 0.0
+
+
+def _exp(x):
+    """exp with IEEE semantics (NaN stays NaN, overflow gives +inf) like the reference's `ratio = exp(diff)`."""
+    if x != x:
+        return x
+    return math.exp(x) if x < 709.0 else math.inf
+
+
+def _log_normal_prior(val, mean, std):
+    p = _rng.eval_normal_prior(val, mean, std)
+    return math.log(p) if p > 0.0 else -math.inf
+
+
+def _fullsky_prior(eng, c, nind, theta, val):
+    pt = c.prior_type[nind]
+    if pt == "gaussian":
+        return _log_normal_prior(val, c.gauss_prior[nind][0], c.gauss_prior[nind][1])
+    if pt == "jeffreys":
+        s = _dist.allreduce_sum_float(eng.fullsky_sums(2, [val, 0.0], 1)[0])
+        return math.log(math.sqrt(s)) if s > 0.0 else -math.inf
+    return 0.0
+
+
+def tune_spectral_parameter_length(dpar, eng, c, nind, theta_init, seed, stream, draw0=1, max_rounds=64):
+    """tune_spectral_parameter_length, src/dang_sample_mod.f90:623-717 (on data prepared by fullsky_prepare).
+    Adjusts c.step_size[nind] by +-50% until the acceptance over NUMSAMPLE steps is within [0.4, 0.6]; sets
+    c.tuned = True for ALL indices (:712).  Returns the next free draw counter."""
+    nb = eng.nbands
+    Sp = eng._fs_Sp
+    sample, theta = list(theta_init) + [0.0], list(theta_init) + [0.0]
+    sample, theta = sample[:2], theta[:2]
+    draw = draw0
+    lnl = lnl_new = lnl_old = 0.0
+    lt, pt = c.lnl_type[nind], c.prior_type[nind]
+    if lt in ("chisq", "marginal"):
+        lnl = _fullsky_lnl(eng, c, nind, sample, nb, Sp)
+    elif lt == "prior":
+        u1, u2 = _rng.uniform2(seed, stream, _rng.GLOBAL_PIX, draw)
+        draw += 1
+        sample[nind] = _rng.rand_normal(c.gauss_prior[nind][0], c.gauss_prior[nind][1], u1, u2)
+    if pt == "gaussian":
+        lnl_old = lnl + _log_normal_prior(sample[nind], c.gauss_prior[nind][0], c.gauss_prior[nind][1])
+    elif pt == "uniform":
+        lnl_old = lnl
+    rounds = 0
+    while not all(c.tuned) and rounds < max_rounds:
+        rounds += 1
+        accept = 0.0
+        for _ in range(dpar.nsample):
+            u1, u2, u3 = _rng.uniform3(seed, stream, _rng.GLOBAL_PIX, draw)
+            draw += 1
+            theta[nind] = sample[nind] + _rng.rand_normal(0.0, c.step_size[nind], u1, u2)
+            if theta[nind] < c.uni_prior[nind][0] or theta[nind] > c.uni_prior[nind][1]:
+                continue
+            if lt in ("chisq", "marginal"):
+                lnl = _fullsky_lnl(eng, c, nind, theta, nb, Sp)
+            if pt == "gaussian":
+                lnl_new = lnl + _log_normal_prior(theta[nind], c.gauss_prior[nind][0], c.gauss_prior[nind][1])
+            elif pt == "uniform":
+                lnl_new = lnl
+            diff = lnl_new - lnl_old
+            ratio = _exp(diff)
+            if (dpar.ml_mode == "optimize" and ratio > 1.0) or (dpar.ml_mode == "sample" and ratio > u3):
+                sample[nind] = theta[nind]
+                lnl_old = lnl_new
+                accept += 1
+            lnl = 0.0
+        l_after = dpar.nsample + 1                       # Fortran loop variable after the loop (:707)
+        if accept / l_after < float(np.float32(0.4)):
+            c.step_size[nind] = c.step_size[nind] - 0.5 * c.step_size[nind]
+        elif accept / l_after > float(np.float32(0.6)):
+            c.step_size[nind] = c.step_size[nind] + 0.5 * c.step_size[nind]
+        else:
+            c.tuned = [True] * max(c.nindices, 1)
+    return draw
+
+
+def sample_index_mh_fullsky(dpar, ddata, l, nind, map_n, stream):
+    """sample_index_mh, index_mode == 1 (src/dang_sample_mod.f90:229-329): one spectral index for the whole sky."""
+    eng = ddata.engine
+    c = eng.component_list[l]
+    s1 = 2 if map_n == -1 else map_n
+    Sp = 2 if map_n == -1 else 1
+    eng._fs_Sp = Sp
+    nb = eng.nbands
+    if not c.tuned:
+        c.tuned = [True] * max(c.nindices, 1)
+    eng.fullsky_prepare(l, map_n)                         # :173-196
+    first = _dist.bcast_from_rank0(eng.peek_indices(l, s1, 0))  # c%indices(0, map_inds(1), l), :240-242
+    sample = list(first) + [0.0] * (2 - c.nindices)
+    theta = list(sample)
+    lt = c.lnl_type[nind]
+    lnl, sample_it = 0.0, True
+    if lt in ("chisq", "marginal"):
+        lnl = _fullsky_lnl(eng, c, nind, sample, nb, Sp)
+    elif lt == "prior":                                   # :255-257
+        sample_it = False
+        u1, u2 = _rng.uniform2(dpar.seed, stream, _rng.GLOBAL_PIX, 0)
+        sample[nind] = _rng.rand_normal(c.gauss_prior[nind][0], c.gauss_prior[nind][1], u1, u2)
+    lnl_old = lnl + _fullsky_prior(eng, c, nind, sample, sample[nind])
+    accepted = 0
+    if sample_it:
+        if not c.tuned[nind]:                             # :272-275
+            tune_spectral_parameter_length(dpar, eng, c, nind, sample, dpar.seed, stream ^ 0x5555555555555555)
+            eng._chk(eng.lib.dangx_set_component(eng.h, l, C.byref(comp_desc(c))))   # the new step size
+        sample = list(first) + [0.0] * (2 - c.nindices)
+        theta = list(sample)
+        for step in range(1, dpar.nsample + 1):           # :282-324
+            u1, u2, u3 = _rng.uniform3(dpar.seed, stream, _rng.GLOBAL_PIX, step)
+            theta[nind] = sample[nind] + _rng.rand_normal(0.0, c.step_size[nind], u1, u2)
+            if theta[nind] < c.uni_prior[nind][0] or theta[nind] > c.uni_prior[nind][1]:
+                continue
+            lnl = _fullsky_lnl(eng, c, nind, theta, nb, Sp)
+            lnl_new = lnl + _fullsky_prior(eng, c, nind, theta, theta[nind])
+            diff = lnl_new - lnl_old
+            ratio = _exp(diff)
+            if (dpar.ml_mode == "optimize" and ratio > 1.0) or (dpar.ml_mode == "sample" and ratio > u3):
+                sample[nind] = theta[nind]
+                lnl_old = lnl_new
+                accepted += 1
+    eng.fill_index(l, nind, map_n, sample[nind])          # :329, :483
+    return accepted
+
+
+def fit_band_gain(dpar, ddata, band, it=1):
+    """fit_band_gain(ddata, 1, band), src/dang_sample_mod.f90:570-621 (band 0-based here)."""
+    eng = ddata.engine
+    mu, sigma = eng.gain_sums(band)
+    mu, sigma = _dist.allreduce_sum_float(mu), _dist.allreduce_sum_float(sigma)
+    mu = mu / sigma
+    sigma = math.sqrt(1.0 / sigma)
+    if dpar.ml_mode == "optimize":
+        gain = mu
+    else:
+        u1, u2 = _rng.uniform2(dpar.seed, stream_id(it, 2, 0, 0, 0), _rng.GLOBAL_PIX, band)
+        gain = mu + sigma * _rng.rand_normal(0.0, 1.0, u1, u2)
+    ddata.gain[band] = gain
+    eng.set_calibration(ddata.gain, ddata.offset)
+    return gain
+
+
+def sample_calibrators(dpar, ddata, it=2, verbose=False):
+    """sample_calibrators(ddata), src/dang_sample_mod.f90:487-518."""
+    sampled = False
+    for j, fit in enumerate(ddata.fit_gain or []):
+        if fit:
+            sampled = True
+            fit_band_gain(dpar, ddata, j, it=it)
+    if sampled:
+        compute_chisq(ddata)
+        if verbose:
+            print("%6d - Chisq: %16.5E" % (it, ddata.chisq))
+    return sampled

@@ -1108,6 +1108,147 @@ __global__ __launch_bounds__(BLOCK) void k_sky_chisq(const Model* __restrict__ M
     }
 }
 
+// ---------------------------------------------------------------------------
+// Full-sky index mode (index_mode == 1, src/dang_sample_mod.f90:229-329), the tuner (:623-717) and the
+// band-gain fit (:570-621).  With one spectral index for the whole sky the model's SED is pixel
+// independent, so each Metropolis step is ONE memory-bound pass that produces a few global sums; the
+// chain itself (proposal, prior, accept) runs on the host between the all-reduces (dang_amd/api.py).
+
+// data_raw minus every other component for planes s1..s2 (:173-196, all pixels) -> out[(kk*nb + j)*npix + i]
+__global__ __launch_bounds__(BLOCK) void k_fullsky_prepare(const Model* __restrict__ Mp, int comp, int s1, int s2,
+                                                           unsigned others, double* __restrict__ out) {
+    const Model& M = *Mp;
+    const int npix = M.npix, nb = M.nbands;
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= npix) return;
+    for (int k = s1; k <= s2; ++k)
+        for (int j = 0; j < nb; ++j) {
+            double d = M.sig[((long long)j * M.nmaps + (k - 1)) * npix + i];
+            if (k == 1) d = (d - M.offset[j]) / M.gain[j];
+            for (unsigned om = others; om; om &= om - 1) {
+                const Comp& c2 = M.comp[__builtin_ctz(om)];
+                double t0, t1;
+                load_theta(M, c2, i, k, t0, t1);
+                d = d - signal_of(c2, c2.amp[(long long)(k - 1) * npix + i], sed_eval(M, c2, j, sed_prep(c2, t0, t1)));
+            }
+            out[((long long)(k - s1) * nb + j) * npix + i] = d;
+        }
+}
+
+// row sums for one evaluation at theta: what = 0: evaluate_lnL (1 row: -1/2 sum ((d-m)/rms)^2, unmasked);
+// what = 1: evaluate_marginal_lnL (2*nb*Sp rows: TNd(j,k), TNT(j,k), all pixels); what = 2: jeffreys (1 row).
+// partial[row][gridDim.x]
+__global__ __launch_bounds__(BLOCK) void k_fullsky_rows(const Model* __restrict__ Mp, int comp, int s1, int s2, int what,
+                                                        double th0, double th1, const double* __restrict__ data,
+                                                        double* __restrict__ partial) {
+    __shared__ double sh[BLOCK / 64];
+    const Model& M = *Mp;
+    const Comp& c = M.comp[comp];
+    const int npix = M.npix, nb = M.nbands, Sp = s2 - s1 + 1;
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    const bool in = i < npix;
+    const bool msk = in ? is_masked(M.mask[i]) : true;
+    const Prep pr = sed_prep(c, th0, th1);
+    const int nrows = (what == 1) ? 2 * nb * Sp : 1;
+    double amp[2] = {0.0, 0.0};
+    if (in) for (int kk = 0; kk < Sp; ++kk) amp[kk] = c.amp[(long long)(s1 + kk - 1) * npix + i];
+    for (int row = 0; row < nrows; ++row) {
+        double v = 0.0;
+        if (in) {
+            if (what == 0 && !msk) {
+                for (int kk = 0; kk < Sp; ++kk)
+                    for (int j = 0; j < nb; ++j) {
+                        const double m = signal_of(c, amp[kk], sed_eval(M, c, j, pr));
+                        const double t = (data[((long long)kk * nb + j) * npix + i] - m) / M.rms[((long long)j * M.nmaps + (s1 + kk - 1)) * npix + i];
+                        v = v - 0.5 * (t * t);
+                    }
+            } else if (what == 1) {
+                const int q = row >> 1, j = q / Sp, kk = q - j * Sp;  // (j outer, k inner) as the reference sums
+                const double m = signal_of(c, amp[kk], sed_eval(M, c, j, pr));
+                const double rms = M.rms[((long long)j * M.nmaps + (s1 + kk - 1)) * npix + i];
+                const double TN = m / (rms * rms);
+                v = (row & 1) ? TN * m : TN * data[((long long)kk * nb + j) * npix + i];
+            } else if (what == 2 && !msk && c.is_synch) {
+                for (int kk = 0; kk < Sp; ++kk)
+                    for (int j = 0; j < nb; ++j) {
+                        const double ss = signal_of(c, amp[kk], sed_eval(M, c, j, pr));
+                        const double rr = 1.0 / M.rms[((long long)j * M.nmaps + (s1 + kk - 1)) * npix + i];
+                        const double t = (rr * rr) * (ss / amp[kk]) * c.lnr[j];
+                        v = v + t * t;
+                    }
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < BLOCK / 64; ++w) t += sh[w];
+            partial[(long long)row * gridDim.x + blockIdx.x] = t;
+        }
+        __syncthreads();
+    }
+}
+
+// fit_band_gain sums (src/dang_sample_mod.f90:590-607): rows 0: sum map2*N_inv*map1, 1: sum map1*N_inv*map1
+__global__ __launch_bounds__(BLOCK) void k_gain_rows(const Model* __restrict__ Mp, int band, double* __restrict__ partial) {
+    __shared__ double sh[2][BLOCK / 64];
+    const Model& M = *Mp;
+    const int npix = M.npix;
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    double v0 = 0.0, v1 = 0.0;
+    if (i < npix && !is_masked(M.mask[i])) {
+        double sky = 0.0;  // sky_model(i,1,band), update_sky_model order (:355-373)
+        for (int l = 0; l < M.ncomp; ++l) {
+            const Comp& c = M.comp[l];
+            double t0, t1;
+            load_theta(M, c, i, 1, t0, t1);
+            sky = sky + signal_of(c, c.amp[i], sed_eval(M, c, band, sed_prep(c, t0, t1)));
+        }
+        const long long q = ((long long)band * M.nmaps) * npix + i;
+        const double res = (M.sig[q] - M.offset[band]) / M.gain[band] - sky;  // res_map(i,1,band), :384
+        const double noise = M.rms[q];
+        const double N_inv = 1.0 / (noise * noise);
+        const double map2 = res + sky;
+        v0 = map2 * N_inv * sky;
+        v1 = sky * N_inv * sky;
+    }
+    for (int o = 32; o > 0; o >>= 1) { v0 += __shfl_down(v0, o, 64); v1 += __shfl_down(v1, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = v0; sh[1][threadIdx.x >> 6] = v1; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double t = 0.0;
+        for (int w = 0; w < BLOCK / 64; ++w) t += sh[threadIdx.x][w];
+        partial[(long long)threadIdx.x * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+// second stage: out[row] = sum(partial[row][0..n))
+__global__ __launch_bounds__(BLOCK) void k_reduce_rows_final(const double* __restrict__ partial, long long n, int rows,
+                                                             double* __restrict__ out) {
+    __shared__ double sh[BLOCK];
+    for (int q = 0; q < rows; ++q) {
+        double s = 0.0;
+        for (long long t = threadIdx.x; t < n; t += BLOCK) s += partial[(long long)q * n + t];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = BLOCK / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[q] = sh[0];
+        __syncthreads();
+    }
+}
+
+// c%indices(:, s1:s2, nind) = value (src/dang_sample_mod.f90:329, 483: every pixel, masked ones too)
+__global__ __launch_bounds__(BLOCK) void k_fill_index(const Model* __restrict__ Mp, int comp, int nind, int s1, int s2, double value) {
+    const Model& M = *Mp;
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= M.npix) return;
+    for (int k = s1; k <= s2; ++k) M.comp[comp].idx[((long long)nind * M.nmaps + (k - 1)) * M.npix + i] = value;
+}
+
 // bit k of flags[0] is set when plane k+1 of a [nmaps][npix] amplitude map holds a non-zero value
 __global__ __launch_bounds__(BLOCK) void k_any_nonzero(const double* __restrict__ amp, long long npix, int nmaps,
                                                        unsigned* __restrict__ flags) {
@@ -1183,6 +1324,10 @@ struct dangx_ctx {
     bool chi_before_valid[3] = {}, chi_after_valid[3] = {}, touched_since_amp[3] = {};
     unsigned long long* counters = nullptr; // device counters [4]
     double* work[6] = {};                   // CG vectors
+    double* fs_data = nullptr;              // full-sky mode: cleaned data [Sp][nb][npix]
+    long long fs_cap = 0;
+    int fs_comp = -1, fs_s1 = 0, fs_s2 = 0;
+    double* rows_out = nullptr;             // device [2*MAXB*2 + 8] row sums
     long long work_cap = 0;
     // profiling
     bool prof = false;
@@ -1543,6 +1688,7 @@ int dangx_create(dangx_ctx** out, const dangx_dims* dims) {
     for (int j = 0; j < MAXB; ++j) { M.gain[j] = 1.0; M.offset[j] = 0.0; }  // src/dang_data_mod.f90:127-128
     if (hipMalloc(&ctx->dm, sizeof(Model)) != hipSuccess || hipMalloc(&ctx->scalars, 8 * sizeof(double)) != hipSuccess ||
         hipMalloc(&ctx->chi_cache, 6 * sizeof(double)) != hipSuccess ||
+        hipMalloc(&ctx->rows_out, (4 * MAXB + 8) * sizeof(double)) != hipSuccess ||
         hipMalloc(&ctx->counters, 4 * sizeof(unsigned long long)) != hipSuccess) {
         delete ctx;
         return 5;
@@ -1563,6 +1709,8 @@ int dangx_destroy(dangx_ctx* ctx) {
     for (auto& w : ctx->work) if (w) (void)hipFree(w);
     if (ctx->partial) (void)hipFree(ctx->partial);
     if (ctx->d_bp_nu0) { (void)hipFree(ctx->d_bp_nu0); (void)hipFree(ctx->d_bp_tau0); }
+    if (ctx->fs_data) (void)hipFree(ctx->fs_data);
+    (void)hipFree(ctx->rows_out);
     (void)hipFree(ctx->dm); (void)hipFree(ctx->scalars); (void)hipFree(ctx->counters); (void)hipFree(ctx->chi_cache);
     for (auto& e : ctx->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     delete ctx;
@@ -1986,6 +2134,108 @@ int dangx_sky_model_chisq(dangx_ctx* ctx, int pol_lo, int pol_hi, double* chisq_
     if (res_d) (void)hipFree(res_d);
     if (chi_d) (void)hipFree(chi_d);
     return rc;
+}
+
+
+// ---- full-sky index mode / tuner / gain fit primitives ---------------------------------------------
+
+static int map_planes(dangx_ctx* ctx, int map_n, int& s1, int& s2) {
+    if (map_n == -1) { s1 = 2; s2 = 3; }
+    else if (map_n >= 1 && map_n <= 3) { s1 = s2 = map_n; }
+    else return fail(ctx, "There is something wrong with the poltype flag (map_n must be 1,2,3 or -1)");
+    if (s2 > ctx->dims.nmaps) return fail(ctx, "map_n exceeds nmaps");
+    return 0;
+}
+
+int dangx_fullsky_prepare(dangx_ctx* ctx, int comp, int map_n) {
+    if (!ctx || check_comp(ctx, comp)) return 1;
+    (void)hipSetDevice(ctx->device);
+    int s1, s2;
+    if (map_planes(ctx, map_n, s1, s2) || sync_model(ctx)) return 1;
+    const long long need = (long long)(s2 - s1 + 1) * ctx->hm.nbands * ctx->hm.npix;
+    if (need > ctx->fs_cap) {
+        if (ctx->fs_data) (void)hipFree(ctx->fs_data);
+        ctx->fs_data = nullptr;
+        HIPCHK(ctx, hipMalloc(&ctx->fs_data, sizeof(double) * (size_t)need));
+        ctx->fs_cap = need;
+    }
+    unsigned others = 0;
+    for (int l = 0; l < ctx->hm.ncomp; ++l)
+        if (l != comp && ((ctx->plane_nz[l] & ((1u << (s1 - 1)) | (1u << (s2 - 1)))) || ctx->desc[l].type == DANGX_TCMB)) others |= 1u << l;
+    hipLaunchKernelGGL(k_fullsky_prepare, dim3(nblocks(ctx->hm.npix)), dim3(BLOCK), 0, ctx->stream, ctx->dm, comp, s1, s2, others, ctx->fs_data);
+    HIPCHK(ctx, hipGetLastError());
+    ctx->fs_comp = comp; ctx->fs_s1 = s1; ctx->fs_s2 = s2;
+    return 0;
+}
+
+// what = 0 chisq lnL (1 value), 1 marginal (2*nb*Sp values: TNd(j,k), TNT(j,k) interleaved, j outer / k inner),
+// 2 jeffreys sum (1 value).  Local (this shard's) sums; the caller all-reduces and combines.
+int dangx_fullsky_sums(dangx_ctx* ctx, int what, const double* theta, double* out, int nout) {
+    if (!ctx || !theta || !out) return 1;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->fs_comp < 0) return fail(ctx, "dangx_fullsky_prepare has not been called");
+    if (what < 0 || what > 2) return fail(ctx, "bad sum selector");
+    if (sync_model(ctx)) return 1;
+    const int Sp = ctx->fs_s2 - ctx->fs_s1 + 1;
+    const int rows = (what == 1) ? 2 * ctx->hm.nbands * Sp : 1;
+    if (nout < rows) return fail(ctx, "output buffer too small");
+    const unsigned nblk = nblocks(ctx->hm.npix);
+    if (ensure_partial(ctx, (long long)rows * nblk)) return 1;
+    hipLaunchKernelGGL(k_fullsky_rows, dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->dm, ctx->fs_comp, ctx->fs_s1, ctx->fs_s2, what,
+                       theta[0], theta[1], ctx->fs_data, ctx->partial);
+    hipLaunchKernelGGL(k_reduce_rows_final, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->partial, (long long)nblk, rows, ctx->rows_out);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->rows_out, sizeof(double) * rows, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int dangx_fill_index(dangx_ctx* ctx, int comp, int nind, int map_n, double value) {
+    if (!ctx || check_comp(ctx, comp)) return 1;
+    (void)hipSetDevice(ctx->device);
+    int s1, s2;
+    if (map_planes(ctx, map_n, s1, s2)) return 1;
+    if (nind < 0 || nind >= ctx->desc[comp].nindices) return fail(ctx, "index number out of range");
+    if (sync_model(ctx)) return 1;
+    hipLaunchKernelGGL(k_fill_index, dim3(nblocks(ctx->hm.npix)), dim3(BLOCK), 0, ctx->stream, ctx->dm, comp, nind, s1, s2, value);
+    HIPCHK(ctx, hipGetLastError());
+    // the map is spatially constant on those planes now iff the component's other indices are; re-derive lazily:
+    // simply mark the planes non-constant unless the component has a single index
+    for (int k = s1; k <= s2; ++k) {
+        if (ctx->desc[comp].nindices == 1) { ctx->idx_const[comp] |= 1u << (k - 1); ctx->idx_val[comp][k - 1][0] = value; }
+        else if (ctx->idx_const[comp] & (1u << (k - 1))) ctx->idx_val[comp][k - 1][nind] = value;
+        ctx->chi_before_valid[k - 1] = ctx->chi_after_valid[k - 1] = false;
+    }
+    ctx->dirty = true;
+    return 0;
+}
+
+// c%indices(pix, map_n, 0:nindices-1) of one (local) pixel -> out[nindices]
+int dangx_peek_indices(dangx_ctx* ctx, int comp, int map_n, long long pix, double* out) {
+    if (!ctx || !out || check_comp(ctx, comp)) return 1;
+    if (!ctx->idx[comp]) return fail(ctx, "component has no indices");
+    if (map_n < 1 || map_n > ctx->dims.nmaps || pix < 0 || pix >= ctx->dims.npix) return fail(ctx, "bad map/pixel");
+    for (int q = 0; q < ctx->desc[comp].nindices; ++q)
+        HIPCHK(ctx, hipMemcpyAsync(out + q, ctx->idx[comp] + ((long long)q * ctx->dims.nmaps + (map_n - 1)) * ctx->dims.npix + pix,
+                                   sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// fit_band_gain sums for band (0-based), map_n = 1: out[0] = sum map2*N_inv*map1, out[1] = sum map1*N_inv*map1
+int dangx_gain_sums(dangx_ctx* ctx, int band, double* out) {
+    if (!ctx || !out) return 1;
+    (void)hipSetDevice(ctx->device);
+    if (band < 0 || band >= ctx->dims.nbands) return fail(ctx, "band index out of range");
+    if (sync_model(ctx)) return 1;
+    const unsigned nblk = nblocks(ctx->hm.npix);
+    if (ensure_partial(ctx, 2ll * nblk)) return 1;
+    hipLaunchKernelGGL(k_gain_rows, dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->dm, band, ctx->partial);
+    hipLaunchKernelGGL(k_reduce_rows_final, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->partial, (long long)nblk, 2, ctx->rows_out);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->rows_out, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
 }
 
 // ---- secondary seams, host vectors ------------------------------------------------

@@ -34,6 +34,16 @@ def allreduce_sum_float(x, device=None):
     return float(t.item())
 
 
+def bcast_from_rank0(values):
+    """Broadcast a short list of floats from rank 0 (e.g. c%indices(0, k, :), which lives on the first shard)."""
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return list(values)
+    device = torch.device("cuda", torch.cuda.current_device()) if td.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    td.broadcast(t, src=0)
+    return [float(v) for v in t.tolist()]
+
+
 def allreduce_sum_(t):
     """In-place sum of a tensor over all ranks (device tensors go through RCCL)."""
     if td.is_available() and td.is_initialized() and td.get_world_size() > 1:

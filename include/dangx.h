@@ -164,6 +164,24 @@ int dangx_sky_model_chisq_dev(dangx_ctx *ctx, int pol_lo, int pol_hi, double *ch
 int dangx_chisq_cached(dangx_ctx *ctx, int which, int pol_lo, int pol_hi, double *chisq_sum);
 int dangx_chisq_cached_dev(dangx_ctx *ctx, int which, int pol_lo, int pol_hi, double *chisq_sum_dev);
 
+/* ---- full-sky index mode (index_mode == 1, src/dang_sample_mod.f90:229-329), tune_spectral_parameter_length
+ * (:623-717) and fit_band_gain (:570-621).  With one index for the whole sky every Metropolis step is one pass
+ * that yields a few global sums; the chain (proposal, prior, accept, step-size tuning) stays with the caller,
+ * between its all-reduces (dang_amd/api.py: sample_index_mh_fullsky, tune_spectral_parameter_length,
+ * fit_band_gain).
+ *   dangx_fullsky_prepare: data_raw minus every other component for the planes of map_n (:173-196), kept in HBM.
+ *   dangx_fullsky_sums   : LOCAL sums at theta[2]: what = 0 evaluate_lnL (1 value); 1 evaluate_marginal_lnL
+ *                          (2*nbands*Sp values: TNd(j,k), TNT(j,k) interleaved, j outer / k inner; the caller forms
+ *                          sum -1/2 TNd^2/TNT after the all-reduce); 2 the jeffreys-prior sum (1 value).
+ *   dangx_fill_index     : c%indices(:, s1:s2, nind) = value for every pixel (:329, :483).
+ *   dangx_gain_sums      : out[0] = sum map2*N_inv*map1, out[1] = sum map1*N_inv*map1 of fit_band_gain (:606-607). */
+int dangx_fullsky_prepare(dangx_ctx *ctx, int comp, int map_n);
+int dangx_fullsky_sums(dangx_ctx *ctx, int what, const double *theta, double *out, int nout);
+int dangx_fill_index(dangx_ctx *ctx, int comp, int nind, int map_n, double value);
+int dangx_gain_sums(dangx_ctx *ctx, int band, double *out);
+/* c%indices(pix, map_n, :) of one local pixel (the full-sky chain starts from pixel 0, :240-242) */
+int dangx_peek_indices(dangx_ctx *ctx, int comp, int map_n, long long pix, double *out);
+
 /* ---- secondary seams (type-bound procedures of dang_cg_group), host vectors in the
  * reference's packing [c1: plane1(npix), plane2(npix) | c2: ... ] -------------------- */
 int64_t dangx_group_size(dangx_ctx *ctx, int group, int flag);

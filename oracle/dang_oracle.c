@@ -757,3 +757,196 @@ int64_t dgo_sample_index_mh(dgo_ctx *ctx, int comp, int nind, int map_n, int nsa
     (void)ms; (void)bs;
     return accepted;
 }
+
+/* ------------------------------------------------------------------ full-sky index mode, tuner, gain fit */
+
+#define DGO_GLOBAL_PIX ((uint64_t)0xFFFFFFFFFFull)
+
+typedef struct {
+    const dgo_ctx *ctx;
+    int comp, nind, s1, s2;
+    double *data; /* [nb][nmaps][npix] data_raw minus every other component (:173-196) */
+} fs_state;
+
+/* update_sample_model without pixel (:555-563) + evaluate_lnL / evaluate_marginal_lnL over the sky */
+static double fs_lnl(const fs_state *S, const double *theta) {
+    const dgo_ctx *ctx = S->ctx;
+    const dgo_comp *c = &ctx->comps[S->comp];
+    const int npix = ctx->npix, nb = ctx->nbands;
+    if (c->lnl_type[S->nind] == DGO_LNL_CHISQ) { /* src/dang_lnl_mod.f90:168-180: i outer, k, j inner */
+        double lnL = 0.0;
+        for (int i = 0; i < npix; ++i) {
+            if (masked(ctx->mask[i])) continue;
+            for (int k = S->s1; k <= S->s2; ++k)
+                for (int j = 0; j < nb; ++j) {
+                    double m = dgo_eval_signal(ctx, S->comp, j, i, k, theta);
+                    double t = (S->data[IDX3(ctx, j, k, i)] - m) / ctx->rms[IDX3(ctx, j, k, i)];
+                    lnL = lnL - 0.5 * (t * t);
+                }
+        }
+        return lnL;
+    }
+    if (c->lnl_type[S->nind] == DGO_LNL_MARGINAL) { /* src/dang_lnl_mod.f90:113-122: no mask test */
+        double lnL = 0.0;
+        for (int j = 0; j < nb; ++j)
+            for (int k = S->s1; k <= S->s2; ++k) {
+                double TNd = 0.0, TNT = 0.0;
+                for (int i = 0; i < npix; ++i) {
+                    double m = dgo_eval_signal(ctx, S->comp, j, i, k, theta);
+                    double rms = ctx->rms[IDX3(ctx, j, k, i)];
+                    double TN = m / (rms * rms);
+                    TNd += TN * S->data[IDX3(ctx, j, k, i)];
+                    TNT += TN * m;
+                }
+                lnL = lnL - 0.5 * TNd * (1.0 / TNT) * TNd;
+            }
+        return lnL;
+    }
+    return 0.0;
+}
+
+/* eval_jeffreys_prior over the sky (src/dang_lnl_mod.f90:289-302) */
+static double fs_jeffreys(const fs_state *S, double val) {
+    const dgo_ctx *ctx = S->ctx;
+    const dgo_comp *c = &ctx->comps[S->comp];
+    double sum = 0.0, theta[DGO_MAX_IND] = {val, 0.0};
+    if (c->is_synch)
+        for (int i = 0; i < ctx->npix; ++i) {
+            if (masked(ctx->mask[i])) continue;
+            for (int k = S->s1; k <= S->s2; ++k)
+                for (int j = 0; j < ctx->nbands; ++j) {
+                    double ss = dgo_eval_signal(ctx, S->comp, j, i, k, theta);
+                    double rr = 1.0 / ctx->rms[IDX3(ctx, j, k, i)];
+                    double t = ((rr * rr) * (ss / c->amplitude[IDX2(ctx, k, i)]) * log(ctx->bands[j].nu_c / c->nu_ref));
+                    sum = sum + t * t;
+                }
+        }
+    return sqrt(sum);
+}
+
+static double fs_prior(const fs_state *S, double val) {
+    const dgo_comp *c = &S->ctx->comps[S->comp];
+    switch (c->prior_type[S->nind]) {
+    case DGO_PRIOR_GAUSSIAN: return log(dgo_eval_normal_prior(val, c->gauss_prior[S->nind][0], c->gauss_prior[S->nind][1]));
+    case DGO_PRIOR_JEFFREYS: return log(fs_jeffreys(S, val));
+    default: return 0.0;
+    }
+}
+
+/* tune_spectral_parameter_length, src/dang_sample_mod.f90:623-717.  theta_init has 2 entries (quirk 10). */
+static void fs_tune(fs_state *S, dgo_comp *c, const double *theta_init, int nsample, int ml_mode, uint64_t seed,
+                    uint64_t stream, uint32_t *draw, int *tuned) {
+    double sample[2] = {theta_init[0], theta_init[1]}, theta[2] = {theta_init[0], theta_init[1]};
+    const int nind = S->nind;
+    double lnl = 0.0, lnl_new = 0.0, lnl_old = 0.0;
+    if (c->lnl_type[nind] == DGO_LNL_CHISQ || c->lnl_type[nind] == DGO_LNL_MARGINAL) lnl = fs_lnl(S, sample);
+    else if (c->lnl_type[nind] == DGO_LNL_PRIOR) {
+        double u[2];
+        dgo_uniform2(seed, stream, DGO_GLOBAL_PIX, (*draw)++, u);
+        sample[nind] = dgo_rand_normal(c->gauss_prior[nind][0], c->gauss_prior[nind][1], u[0], u[1]);
+    }
+    if (c->prior_type[nind] == DGO_PRIOR_GAUSSIAN) lnl_old = lnl + log(dgo_eval_normal_prior(sample[nind], c->gauss_prior[nind][0], c->gauss_prior[nind][1]));
+    else if (c->prior_type[nind] == DGO_PRIOR_UNIFORM) lnl_old = lnl;
+    int guard = 0;
+    while (!*tuned && guard++ < 64) { /* :663 do while (.not. c%tuned(nind)); guard: the reference can loop forever */
+        double accept = 0.0;
+        int l;
+        for (l = 1; l <= nsample; ++l) {
+            double u[3];
+            dgo_uniform3(seed, stream, DGO_GLOBAL_PIX, (*draw)++, u);
+            theta[nind] = sample[nind] + dgo_rand_normal(0.0, c->step_size[nind], u[0], u[1]);
+            if (theta[nind] < c->uni_prior[nind][0] || theta[nind] > c->uni_prior[nind][1]) continue;
+            if (c->lnl_type[nind] == DGO_LNL_CHISQ || c->lnl_type[nind] == DGO_LNL_MARGINAL) lnl = fs_lnl(S, theta);
+            if (c->prior_type[nind] == DGO_PRIOR_GAUSSIAN) lnl_new = lnl + log(dgo_eval_normal_prior(theta[nind], c->gauss_prior[nind][0], c->gauss_prior[nind][1]));
+            else if (c->prior_type[nind] == DGO_PRIOR_UNIFORM) lnl_new = lnl;
+            double diff = lnl_new - lnl_old, ratio = exp(diff);
+            if (ml_mode == DGO_ML_OPTIMIZE) {
+                if (ratio > 1.0) { sample[nind] = theta[nind]; lnl_old = lnl_new; accept = accept + 1; }
+            } else {
+                if (ratio > u[2]) { sample[nind] = theta[nind]; lnl_old = lnl_new; accept = accept + 1; }
+            }
+            lnl = 0.0; /* :705 */
+        }
+        /* :707-713  after the loop l == nsample+1 */
+        if (accept / l < 0.4f) c->step_size[nind] = c->step_size[nind] - 0.5f * c->step_size[nind];
+        else if (accept / l > 0.6f) c->step_size[nind] = c->step_size[nind] + 0.5f * c->step_size[nind];
+        else *tuned = 1;
+    }
+}
+
+int64_t dgo_sample_index_fullsky(dgo_ctx *ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed,
+                                 uint64_t stream, int *tuned) {
+    dgo_comp *c = &ctx->comps[comp];
+    const int npix = ctx->npix, nb = ctx->nbands, nmaps = ctx->nmaps;
+    fs_state S = {ctx, comp, nind, (map_n == -1) ? 2 : map_n, (map_n == -1) ? 3 : map_n, NULL};
+    uint32_t draw = 1;
+    int64_t accepted = 0;
+    S.data = (double *)malloc(sizeof(double) * (size_t)nb * nmaps * npix);
+    /* :173-196 (all pixels, no mask test) */
+    for (int i = 0; i < npix; ++i)
+        for (int k = 1; k <= nmaps; ++k)
+            for (int j = 0; j < nb; ++j) {
+                double d = (k == 1) ? (ctx->sig[IDX3(ctx, j, 1, i)] - ctx->offset[j]) / ctx->gain[j] : ctx->sig[IDX3(ctx, j, k, i)];
+                for (int l = 0; l < ctx->ncomp; ++l)
+                    if (l != comp) d = d - dgo_eval_signal(ctx, l, j, i, k, NULL);
+                S.data[IDX3(ctx, j, k, i)] = d;
+            }
+    double sample[DGO_MAX_IND] = {0, 0}, theta[DGO_MAX_IND] = {0, 0};
+    for (int l = 0; l < c->nindices; ++l) sample[l] = c->indices[((int64_t)l * nmaps + (S.s1 - 1)) * (int64_t)npix + 0]; /* :240-242 */
+    for (int l = 0; l < DGO_MAX_IND; ++l) theta[l] = sample[l];
+    double lnl = 0.0;
+    int sample_it = 1;
+    if (c->lnl_type[nind] == DGO_LNL_CHISQ || c->lnl_type[nind] == DGO_LNL_MARGINAL) lnl = fs_lnl(&S, sample);
+    else if (c->lnl_type[nind] == DGO_LNL_PRIOR) { /* :255-257 */
+        double u[2];
+        sample_it = 0;
+        dgo_uniform2(seed, stream, DGO_GLOBAL_PIX, 0u, u);
+        sample[nind] = dgo_rand_normal(c->gauss_prior[nind][0], c->gauss_prior[nind][1], u[0], u[1]);
+    }
+    double lnl_old = lnl + fs_prior(&S, sample[nind]); /* :260-268 */
+    if (sample_it) {
+        if (!*tuned) fs_tune(&S, c, sample, nsample, ml_mode, seed, stream ^ 0x5555555555555555ull, &draw, tuned); /* :272-275 */
+        for (int l = 0; l < c->nindices; ++l) sample[l] = c->indices[((int64_t)l * nmaps + (S.s1 - 1)) * (int64_t)npix + 0];
+        for (int l = 0; l < DGO_MAX_IND; ++l) theta[l] = sample[l];
+        for (int l = 1; l <= nsample; ++l) { /* :282-324 */
+            double u[3];
+            dgo_uniform3(seed, stream, DGO_GLOBAL_PIX, (uint32_t)l, u);
+            theta[nind] = sample[nind] + dgo_rand_normal(0.0, c->step_size[nind], u[0], u[1]);
+            if (theta[nind] < c->uni_prior[nind][0] || theta[nind] > c->uni_prior[nind][1]) continue;
+            lnl = fs_lnl(&S, theta);
+            double lnl_new = lnl + fs_prior(&S, theta[nind]);
+            double diff = lnl_new - lnl_old, ratio = exp(diff);
+            if (ml_mode == DGO_ML_OPTIMIZE) {
+                if (ratio > 1.0) { sample[nind] = theta[nind]; lnl_old = lnl_new; accepted += 1; }
+            } else {
+                if (ratio > u[2]) { sample[nind] = theta[nind]; lnl_old = lnl_new; accepted += 1; }
+            }
+        }
+    }
+    /* :329, :483  every pixel (masked ones too) receives the sampled value */
+    for (int k = S.s1; k <= S.s2; ++k)
+        for (int i = 0; i < npix; ++i) c->indices[((int64_t)nind * nmaps + (k - 1)) * (int64_t)npix + i] = sample[nind];
+    free(S.data);
+    return accepted;
+}
+
+/* fit_band_gain, src/dang_sample_mod.f90:570-621 (map_n = 1) */
+double dgo_fit_band_gain(const dgo_ctx *ctx, const double *sky, const double *res, int band, int ml_mode, uint64_t seed,
+                         uint64_t stream) {
+    double mu = 0.0, sigma = 0.0;
+    for (int i = 0; i < ctx->npix; ++i) {
+        if (masked(ctx->mask[i])) continue; /* :597-604 */
+        double noise = ctx->rms[IDX3(ctx, band, 1, i)];
+        double N_inv = 1.0 / (noise * noise);
+        double map1 = sky[IDX3(ctx, band, 1, i)];
+        double map2 = res[IDX3(ctx, band, 1, i)] + sky[IDX3(ctx, band, 1, i)];
+        mu += map2 * N_inv * map1;
+        sigma += map1 * N_inv * map1;
+    }
+    mu = mu / sigma;
+    sigma = sqrt(1.0 / sigma);
+    if (ml_mode == DGO_ML_OPTIMIZE) return mu;
+    double u[2];
+    dgo_uniform2(seed, stream, DGO_GLOBAL_PIX, (uint32_t)band, u);
+    return mu + sigma * dgo_rand_normal(0.0, 1.0, u[0], u[1]);
+}

@@ -146,6 +146,20 @@ double dgo_evaluate_marginal_lnL(int nbands, int s1, int s2, const double *data,
 int64_t dgo_sample_index_mh(dgo_ctx *ctx, int comp, int nind, int map_n, int nsample, int ml_mode,
                             uint64_t seed, uint64_t stream);
 
+/* ---- "next" rows: full-sky index mode, step-size tuner, band-gain fit ------------- */
+/* Full-sky Metropolis for index `nind` of component `comp` (index_mode==1, src/dang_sample_mod.f90:229-329),
+ * including the tuner call when *tuned == 0 (:272-275).  step_size / *tuned are updated like c%step_size /
+ * c%tuned.  Draw slots of the keyed stream: pixel = 2^40-1 (a label no real pixel uses), draw = running
+ * counter.  Returns accepted proposals of the sampling block. */
+int64_t dgo_sample_index_fullsky(dgo_ctx *ctx, int comp, int nind, int map_n, int nsample, int ml_mode,
+                                 uint64_t seed, uint64_t stream, int *tuned);
+/* tune_spectral_parameter_length (src/dang_sample_mod.f90:623-717) on prepared full-sky data;
+ * exposed through dgo_sample_index_fullsky. */
+/* fit_band_gain(ddata, map_n=1, band) (src/dang_sample_mod.f90:570-621): returns the new gain; sky/res are
+ * the arrays update_sky_model left (dgo_update_sky_model). */
+double dgo_fit_band_gain(const dgo_ctx *ctx, const double *sky, const double *res, int band, int ml_mode,
+                         uint64_t seed, uint64_t stream);
+
 #ifdef __cplusplus
 }
 #endif

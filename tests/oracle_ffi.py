@@ -94,6 +94,11 @@ def lib():
         l.dgo_sample_index_mh.restype = C.c_int64
         l.dgo_sample_index_mh.argtypes = [C.POINTER(Ctx), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
                                           C.c_uint64]
+        l.dgo_sample_index_fullsky.restype = C.c_int64
+        l.dgo_sample_index_fullsky.argtypes = [C.POINTER(Ctx), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
+                                               C.c_uint64, C.POINTER(C.c_int)]
+        l.dgo_fit_band_gain.restype = C.c_double
+        l.dgo_fit_band_gain.argtypes = [C.POINTER(Ctx), _D, _D, C.c_int, C.c_int, C.c_uint64, C.c_uint64]
         _lib = l
     return _lib
 
@@ -236,6 +241,15 @@ class Oracle:
         chi = np.empty((self.nmaps, self.npix))
         v = self.L.dgo_compute_chisq(self.c, _p(np.ascontiguousarray(sky)), pol_lo, pol_hi, nump, _p(chi))
         return v, chi
+
+    def sample_index_fullsky(self, comp, nind, map_n, nsample, ml_mode, seed, stream, tuned=True):
+        t = C.c_int(1 if tuned else 0)
+        acc = self.L.dgo_sample_index_fullsky(self.c, comp, nind, map_n, nsample, ML_CODES[ml_mode], seed, stream, C.byref(t))
+        return acc, bool(t.value), self._comps[comp].step_size[nind]
+
+    def fit_band_gain(self, band, ml_mode, seed, stream):
+        sky, res = self.sky_model()
+        return self.L.dgo_fit_band_gain(self.c, _p(sky), _p(res), band, ML_CODES[ml_mode], seed, stream)
 
     def sample_index_mh(self, comp, nind, map_n, nsample, ml_mode, seed, stream):
         return self.L.dgo_sample_index_mh(self.c, comp, nind, map_n, nsample, ML_CODES[ml_mode], seed, stream)
