@@ -754,32 +754,56 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
 // and the kernel uses no LDS and no barrier.  The CU's vector register file (512 KB) is three times its
 // LDS, so this form runs at 2-3 waves/SIMD where the LDS-column form is capped at 1-2.
 // Arithmetic and operation order are identical to index_chain<MODE, SP, TB>.
-template <int MODE, int SP, int NB>
+template <int MODE, int SP, int NB, bool ISLDS>
 struct RegChain {
-    double D[SP][NB], IS[SP][NB], F[NB];
+    double D[SP][NB], F[NB];
+    double ISr[ISLDS ? 1 : SP][ISLDS ? 1 : NB];  // 1/rms in registers ...
+    double* isl;                                  // ... or in LDS columns [slot][thread] when registers run out
     double amp[SP];
 
-    __device__ __forceinline__ double lnl(const Model& M, const Comp& c, double th, double& acc0, double& acc1) const {
+    __device__ __forceinline__ double is(int kk, int j) const { return ISLDS ? isl[(kk * NB + j) * BLOCK] : ISr[ISLDS ? 0 : kk][ISLDS ? 0 : j]; }
+    __device__ __forceinline__ void set_is(int kk, int j, double v) {
+        if (ISLDS) isl[(kk * NB + j) * BLOCK] = v; else ISr[ISLDS ? 0 : kk][ISLDS ? 0 : j] = v;
+    }
+
+    __device__ __forceinline__ double lnl(const Model& M, const Comp& c, double th, double other, double& acc0, double& acc1) const {
         double s0 = 0.0, s1 = 0.0;
         if (MODE == CH_POW) s0 = th;
         else if (MODE == CH_MBB_BETA) s0 = th + 1.0;
-        else { s0 = H_PLANCK / (K_B * th); s1 = exp(s0 * c.nu_ref) - 1.0; }
+        else if (MODE == CH_MBB_T) { s0 = H_PLANCK / (K_B * th); s1 = exp(s0 * c.nu_ref) - 1.0; }
+        else if (MODE == CH_LOGN_NUP) { s0 = th * 1e9; s1 = other; }
+        else s1 = th;  // CH_LOGN_W
         acc0 = 0.0; acc1 = 0.0;
-        double s[NB];
+        // bands in tiles of TT: TT independent exp chains interleave, then accumulate in band order
+        constexpr int TT = (NB % 5 == 0) ? 5 : (NB % 4 == 0) ? 4 : (NB % 3 == 0) ? 3 : 1;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const double e = exp((MODE == CH_MBB_T) ? s0 * M.band[j].nu_c : s0 * c.lnr[j]);
-            if (MODE == CH_POW) s[j] = e;
-            else if (MODE == CH_MBB_BETA) s[j] = F[j] * e;
-            else s[j] = s1 / (e - 1.0) * F[j];
-        }
+        for (int j0 = 0; j0 < NB; j0 += TT) {
+            double s[TT];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const double r0 = (D[0][j] - amp[0] * s[j]) * IS[0][j];
-            acc0 = acc0 - 0.5 * (r0 * r0);
-            if (SP == 2) {
-                const double r1 = (D[SP - 1][j] - amp[SP - 1] * s[j]) * IS[SP - 1][j];
-                acc1 = acc1 - 0.5 * (r1 * r1);
+            for (int t = 0; t < TT; ++t) {
+                const int j = j0 + t;
+                if (MODE == CH_LOGN_NUP) {
+                    const double l = log_pos(M.band[j].nu_c / s0) / s1;
+                    s[t] = exp(-0.5 * (l * l)) * c.cst[j];
+                } else if (MODE == CH_LOGN_W) {
+                    const double l = F[j] / s1;
+                    s[t] = exp(-0.5 * (l * l)) * c.cst[j];
+                } else {
+                    const double e = exp((MODE == CH_MBB_T) ? s0 * M.band[j].nu_c : s0 * c.lnr[j]);
+                    if (MODE == CH_POW) s[t] = e;
+                    else if (MODE == CH_MBB_BETA) s[t] = F[j] * e;
+                    else s[t] = s1 / (e - 1.0) * F[j];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const int j = j0 + t;
+                const double r0 = (D[0][j] - amp[0] * s[t]) * is(0, j);
+                acc0 = acc0 - 0.5 * (r0 * r0);
+                if (SP == 2) {
+                    const double r1 = (D[SP - 1][j] - amp[SP - 1] * s[t]) * is(SP - 1, j);
+                    acc1 = acc1 - 0.5 * (r1 * r1);
+                }
             }
         }
         return acc0 + acc1;
@@ -823,8 +847,8 @@ __device__ __forceinline__ void subtract_other(const Model& M, const Comp& c2, i
     }
 }
 
-template <int MODE, int SP, int NB>
-__device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, const IndexArgs& a, int i, double chi[4]) {
+template <int MODE, int SP, int NB, bool ISLDS>
+__device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, const IndexArgs& a, int i, double chi[4], double* isl) {
     const int npix = M.npix;
     const Comp& c = M.comp[a.comp];
     double* out = c.idx + ((long long)a.nind * M.nmaps) * npix + i;
@@ -833,7 +857,8 @@ __device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, co
         for (int kk = 0; kk < SP; ++kk) out[(long long)(a.s1 + kk - 1) * npix] = 0.0;
         return 0ull;
     }
-    RegChain<MODE, SP, NB> R;
+    RegChain<MODE, SP, NB, ISLDS> R;
+    R.isl = isl;
     double sample0, sample1;
     load_theta(M, c, i, a.s1, sample0, sample1);  // sample(l) = c%indices(i, map_inds(1), l), :372-377
     const bool first = (a.nind == 0);
@@ -845,19 +870,16 @@ __device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, co
         R.amp[kk] = c.amp[(long long)(k - 1) * npix + i];
         const double* sigp = M.sig + (long long)(k - 1) * npix + i;
         const double* rmsp = M.rms + (long long)(k - 1) * npix + i;
+        double rv[NB];
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             R.D[kk][j] = sigp[j * bstride];
-            R.IS[kk][j] = rmsp[j * bstride];
+            rv[j] = rmsp[j * bstride];
         }
-    }
-#pragma unroll
-    for (int kk = 0; kk < SP; ++kk) {
-        const int k = a.s1 + kk;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if (k == 1) R.D[kk][j] = (R.D[kk][j] - M.offset[j]) / M.gain[j];
-            R.IS[kk][j] = 1.0 / R.IS[kk][j];
+            R.set_is(kk, j, 1.0 / rv[j]);
         }
     }
     // --- remove every OTHER component (:180-196) in component_list order, next one prefetched
@@ -897,7 +919,11 @@ __device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, co
     } else if (MODE == CH_MBB_T) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) R.F[j] = exp((sample0 + 1.0) * c.lnr[j]);
+    } else if (MODE == CH_LOGN_W) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) R.F[j] = log_pos(M.band[j].nu_c / (sample0 * 1e9));
     }
+    const double other = first ? sample1 : sample0;  // the index that is not sampled
     // --- chain (gaussian / uniform prior inline; jeffreys falls back to the LDS form on the host side)
     const unsigned long long gpix = (unsigned long long)(M.pix0 + i);
     const int q = a.nind;
@@ -911,7 +937,7 @@ __device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, co
     unsigned long long nacc = 0;
     double cur = first ? sample0 : sample1;
     double a0, a1, c0, c1;
-    double lnl = R.lnl(M, c, cur, a0, a1);
+    double lnl = R.lnl(M, c, cur, other, a0, a1);
     chi[0] = -2.0 * a0; chi[1] = -2.0 * a1;
     double lnl_old = lnl + prior(cur);
     const double step = c.step[q], lo = c.uni[q][0], hi = c.uni[q][1];
@@ -920,7 +946,7 @@ __device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, co
         uniform3(a.seed, a.stream, gpix, (uint32_t)l, u1, u2, u3);
         const double prop = cur + rand_normal(0.0, step, u1, u2);  // :414
         if (prop < lo || prop > hi) continue;                      // :415
-        lnl = R.lnl(M, c, prop, c0, c1);
+        lnl = R.lnl(M, c, prop, other, c0, c1);
         const double lnl_new = lnl + prior(prop);
         const double diff = lnl_new - lnl_old;
         const bool acc = (a.ml_mode == DANGX_ML_OPTIMIZE) ? (diff > 0.0) : ((diff >= 0.0) || (exp(diff) > u3));  // :443-454
@@ -932,15 +958,16 @@ __device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, co
     return nacc;
 }
 
-template <int MODE, int SP, int NB>
+template <int MODE, int SP, int NB, bool ISLDS>
 __global__ __launch_bounds__(BLOCK, (SP == 1 && NB <= 10) ? 3 : 2) void k_index_mh_reg(const Model* __restrict__ Mp, IndexArgs a,
                                                         unsigned long long* __restrict__ accepted,
                                                         double* __restrict__ chi_partial) {
+    extern __shared__ double lds[];  // ISLDS: 1/rms columns [SP*NB][BLOCK]
     const Model& M = *Mp;
     const int tid = threadIdx.x;
     const int i = blockIdx.x * BLOCK + tid;
     double chi[4] = {0.0, 0.0, 0.0, 0.0};
-    unsigned long long nacc = (i < M.npix) ? index_chain_reg<MODE, SP, NB>(M, a, i, chi) : 0ull;
+    unsigned long long nacc = (i < M.npix) ? index_chain_reg<MODE, SP, NB, ISLDS>(M, a, i, chi, lds + tid) : 0ull;
     if (accepted) {
         for (int o = 32; o > 0; o >>= 1) nacc += __shfl_down(nacc, o, 64);
         if ((tid & 63) == 0 && nacc) atomicAdd(accepted, nacc);
@@ -1987,9 +2014,9 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
     int bs = 256;
     while (bs > 64 && tabsz + per_thread * bs > 76 * 1024) bs >>= 1;
     const size_t lds = tabsz + per_thread * bs;
-    const bool reg_ok = d.lnl_type[nind] == DANGX_LNL_CHISQ && d.prior_type[nind] != DANGX_PRIOR_JEFFREYS &&
-                        (a.mode == CH_POW || a.mode == CH_MBB_BETA || a.mode == CH_MBB_T) &&
-                        (ctx->hm.nbands == 3 || ctx->hm.nbands == 5 || ctx->hm.nbands == 6 || ctx->hm.nbands == 8 || ctx->hm.nbands == 10);
+    const bool reg_ok = d.lnl_type[nind] == DANGX_LNL_CHISQ && d.prior_type[nind] != DANGX_PRIOR_JEFFREYS && a.mode != CH_GENERIC &&
+                        (ctx->hm.nbands == 3 || ctx->hm.nbands == 5 || ctx->hm.nbands == 6 || ctx->hm.nbands == 8 ||
+                         ctx->hm.nbands == 10 || ctx->hm.nbands == 20);
     if (reg_ok) bs = BLOCK;  // register-resident form: no LDS columns
     const unsigned nblk = nblocks(ctx->hm.npix, bs);
     constexpr int RSTAGE = 128;  // blocks of the first reduction stage
@@ -2008,19 +2035,23 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
         do { if (tb == 5) DX_LAUNCH_MH(MODE_, SP_, 5); else if (tb == 4) DX_LAUNCH_MH(MODE_, SP_, 4);            \
              else if (tb == 3) DX_LAUNCH_MH(MODE_, SP_, 3); else DX_LAUNCH_MH(MODE_, SP_, 1); } while (0)
 #define DX_MH_SP(MODE_) do { if (Sp == 2) DX_MH_TB(MODE_, 2); else DX_MH_TB(MODE_, 1); } while (0)
-        const bool regform = fast && d.prior_type[nind] != DANGX_PRIOR_JEFFREYS &&
-                             (nb == 3 || nb == 5 || nb == 6 || nb == 8 || nb == 10);
-#define DX_LAUNCH_REG(MODE_, SP_, NB_)                                                                           \
-        hipLaunchKernelGGL((k_index_mh_reg<MODE_, SP_, NB_>), dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->dm, a, accp, ctx->partial)
+        const bool regmode = a.mode != CH_GENERIC && d.lnl_type[nind] == DANGX_LNL_CHISQ && d.prior_type[nind] != DANGX_PRIOR_JEFFREYS;
+        const bool regform = regmode && (nb == 3 || nb == 5 || nb == 6 || nb == 8 || nb == 10 || nb == 20);
+#define DX_LAUNCH_REG(MODE_, SP_, NB_, L_)                                                                       \
+        hipLaunchKernelGGL((k_index_mh_reg<MODE_, SP_, NB_, L_>), dim3(nblk), dim3(BLOCK),                       \
+                           (L_) ? (size_t)(SP_) * (NB_) * BLOCK * sizeof(double) : 0, ctx->stream, ctx->dm, a, accp, ctx->partial)
 #define DX_REG_NB(MODE_, SP_)                                                                                    \
-        do { if (nb == 10) DX_LAUNCH_REG(MODE_, SP_, 10); else if (nb == 5) DX_LAUNCH_REG(MODE_, SP_, 5);        \
-             else if (nb == 3) DX_LAUNCH_REG(MODE_, SP_, 3); else if (nb == 6) DX_LAUNCH_REG(MODE_, SP_, 6);     \
-             else DX_LAUNCH_REG(MODE_, SP_, 8); } while (0)
+        do { if (nb == 10) DX_LAUNCH_REG(MODE_, SP_, 10, false); else if (nb == 5) DX_LAUNCH_REG(MODE_, SP_, 5, false);     \
+             else if (nb == 3) DX_LAUNCH_REG(MODE_, SP_, 3, false); else if (nb == 6) DX_LAUNCH_REG(MODE_, SP_, 6, false);  \
+             else if (nb == 8) DX_LAUNCH_REG(MODE_, SP_, 8, false);                                                         \
+             else DX_LAUNCH_REG(MODE_, SP_, 20, ((SP_) == 2)); } while (0)
 #define DX_REG_SP(MODE_) do { if (Sp == 2) DX_REG_NB(MODE_, 2); else DX_REG_NB(MODE_, 1); } while (0)
-        if (!fast) DX_LAUNCH_MH(CH_GENERIC, 1, 1);
-        else if (regform && a.mode == CH_POW) DX_REG_SP(CH_POW);
+        if (regform && a.mode == CH_POW) DX_REG_SP(CH_POW);
         else if (regform && a.mode == CH_MBB_BETA) DX_REG_SP(CH_MBB_BETA);
-        else if (regform) DX_REG_SP(CH_MBB_T);
+        else if (regform && a.mode == CH_MBB_T) DX_REG_SP(CH_MBB_T);
+        else if (regform && a.mode == CH_LOGN_NUP) DX_REG_SP(CH_LOGN_NUP);
+        else if (regform && a.mode == CH_LOGN_W) DX_REG_SP(CH_LOGN_W);
+        else if (!fast) DX_LAUNCH_MH(CH_GENERIC, 1, 1);
         else if (a.mode == CH_POW) DX_MH_SP(CH_POW);
         else if (a.mode == CH_MBB_BETA) DX_MH_SP(CH_MBB_BETA);
         else DX_MH_SP(CH_MBB_T);
