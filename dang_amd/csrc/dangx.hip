@@ -9,6 +9,7 @@
 // consecutive doubles (512 B) per load.  Everything is fp64.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -83,9 +84,9 @@ __global__ __launch_bounds__(BLOCK, (FAST && NG <= 4) ? 3 : 1) void k_amp_direct
     extern __shared__ double lds[];  // [table | D(j) and IS(j) columns: (2*nb) x blockDim]
     const Model& M = *Mp;
     const int npix = M.npix, nb = M.nbands, BS = blockDim.x, tid = threadIdx.x;
-    double* tab = lds;
-    double* col = lds + sed_table_size(M);
-    sed_table_build(M, tab, tid, BS);
+    double* tab = lds;  // rows of the group's NG components only
+    double* col = lds + (TROWS * NG + 3) * nb;
+    sed_table_build(M, tab, tid, BS, a.gc, NG);
     const long long u = (long long)blockIdx.x * BS + tid;
     const bool in_range = u < (long long)flag_nplanes(a.flag) * npix;
     const int p = in_range ? (int)(u / npix) : 0;
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(BLOCK, (FAST && NG <= 4) ? 3 : 1) void k_amp_direct
         eta = rand_normal(0.0, 1.0, u1, u2);  // eta(i), :258-260: ONE draw per unit, reused per band
     }
     // ---- phase 2: rolled band loop (one copy of the SED code per group component)
-    const double* gain = tab + (TROWS * M.ncomp + 1) * nb;
+    const double* gain = tab + (TROWS * NG + 1) * nb;
 #pragma unroll 1
     for (int j = 0; j < nb; ++j) {
         double d = col[j * BS + tid];
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(BLOCK, (FAST && NG <= 4) ? 3 : 1) void k_amp_direct
 #pragma unroll
         for (int g = 0; g < NG; ++g)
             mrow[g] = !FAST ? sed_eval(M, M.comp[gl[g]], j, pr[g])
-                      : cs[g] ? sed_const_tab(tab, nb, gl[g], k, j) : sed_eval_tab(ty[g], tab, nb, M.ncomp, gl[g], j, pr[g]);
+                      : cs[g] ? sed_const_tab(tab, nb, g, k, j) : sed_eval_tab(ty[g], tab, nb, NG, g, j, pr[g]);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const double t2 = mrow[g] * inv;
@@ -1585,9 +1586,14 @@ struct LaunchAmp {
     static int run(dangx_ctx* ctx, const GroupArgs& a, long long SN) {
         Timed t(ctx, DANGX_K_AMP_DIRECT);
         const int nb = ctx->hm.nbands;
-        const size_t tabsz = (size_t)(TROWS * ctx->hm.ncomp + 3) * nb * sizeof(double);
-        int bs = BLOCK;
-        while (bs > 64 && tabsz + (size_t)2 * nb * bs * sizeof(double) > 40 * 1024) bs >>= 1;
+        const size_t tabsz = (size_t)(TROWS * NG + 3) * nb * sizeof(double);
+        int bs = 64, best = 0;  // block size that keeps the most waves resident in 160 KiB of LDS (ties: larger block)
+        for (int cand : {256, 128, 64}) {
+            const size_t need = tabsz + (size_t)2 * nb * cand * sizeof(double);
+            if (need > 160 * 1024) continue;
+            const int waves = std::min<int>((int)((160 * 1024) / need) * (cand / 64), 32);
+            if (waves > best) { best = waves; bs = cand; }
+        }
         const size_t ldsz = tabsz + (size_t)2 * nb * bs * sizeof(double);
         if (ctx->hm.all_delta && a.no == 0)
             hipLaunchKernelGGL((k_amp_direct<NG, true>), dim3(nblocks(SN, bs)), dim3(bs), ldsz, ctx->stream, ctx->dm, a, ctx->counters);

@@ -134,17 +134,21 @@ __device__ __forceinline__ double sed_eval(const Model& M, const Comp& c, int j,
 //   tab[(6*ncomp + q)*nb + j], q = 0: nu_c, 1: gain, 2: offset
 constexpr int TROWS = 6;
 __device__ __forceinline__ int sed_table_size(const Model& M) { return (TROWS * M.ncomp + 3) * M.nbands; }
-__device__ __forceinline__ void sed_table_build(const Model& M, double* tab, int tid, int nthreads) {
-    const int nb = M.nbands, n = sed_table_size(M);
+// list == nullptr: one row block per component of the model (nc = M.ncomp); otherwise row block g holds
+// component list[g] (nc entries) -- the amplitude kernel only needs its group's components
+__device__ __forceinline__ void sed_table_build(const Model& M, double* tab, int tid, int nthreads,
+                                                const int* list = nullptr, int nc = -1) {
+    if (nc < 0) nc = M.ncomp;
+    const int nb = M.nbands, n = (TROWS * nc + 3) * nb;
     for (int t = tid; t < n; t += nthreads) {
         const int row = t / nb, j = t - row * nb;
         double v;
-        if (row < TROWS * M.ncomp) {
-            const Comp& c = M.comp[row / TROWS];
+        if (row < TROWS * nc) {
+            const Comp& c = M.comp[list ? list[row / TROWS] : row / TROWS];
             const int q = row - TROWS * (row / TROWS);
             v = (q == 0) ? c.lnr[j] : (q == 1) ? c.cst[j] : (q == 2) ? c.lnu9[j] : c.csed[q - 3][j];
         } else {
-            const int q = row - TROWS * M.ncomp;
+            const int q = row - TROWS * nc;
             v = (q == 0) ? M.band[j].nu_c : (q == 1) ? M.gain[j] : M.offset[j];
         }
         tab[t] = v;
