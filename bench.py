@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--nside", type=int, default=None)
     ap.add_argument("--nsample", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for rehearsing "
+                                                      "the N>1 path with several ranks on ONE GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -124,11 +126,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if local_rank >= ndev and args.backend == "nccl":
+        raise SystemExit("LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, ndev))
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            td.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            td.init_process_group(args.backend, rank=rank, world_size=world)
 
     import dang_amd as da
     from dang_amd import synth
@@ -137,7 +148,7 @@ def main():
     dpar, ddata, bands, comps, meta = synth.make_sky(args.config, nside=args.nside, device=dev, rank=rank, nranks=world,
                                                      nsample=args.nsample, as_numpy=False)
     stream = torch.cuda.current_stream().cuda_stream
-    eng = da.initialize(bands, comps, ddata, npix_global=meta["npix_global"], pix0=meta["pix0"], device=local_rank,
+    eng = da.initialize(bands, comps, ddata, npix_global=meta["npix_global"], pix0=meta["pix0"], device=dev_index,
                         stream=stream if stream else None)
     nmaps, nb = meta["nmaps"], meta["nbands"]
     chisq_buf = torch.zeros(2, dtype=torch.float64, device=dev)
