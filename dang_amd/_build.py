@@ -37,16 +37,33 @@ def hip_sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(ROOT, "include", "dangx.h")]
 
 
+UNITS = [("dangx_core", "dangx_core.hip", []), ("dangx_amp", "dangx_amp.hip", []), ("dangx_mh", "dangx_mh.hip", []),
+         ("dangx_mhreg", "dangx_mhreg.hip", [])] + \
+        [("dangx_mhreg_m%d" % m, "dangx_mhreg.hip", ["-DDX_REG_MODE=%d" % m]) for m in (1, 2, 3, 4, 5)]
+
+
 def build_hip(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> dang_amd/lib/libdangx.so (+ kernel resource report)."""
+    """hipcc --offload-arch=gfx950 -> dang_amd/lib/libdangx.so (+ kernel resource report).
+    The translation units are compiled in parallel (objects under dang_amd/lib/obj/) and linked."""
     os.makedirs(LIBDIR, exist_ok=True)
     if not force and not _newer(LIB, hip_sources()):
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
-           "-I" + os.path.join(ROOT, "include"), "-Rpass-analysis=kernel-resource-usage",
-           "-o", LIB, os.path.join(CSRC, "dangx.hip")]
-    out = _run(cmd)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    common = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+              "-Rpass-analysis=kernel-resource-usage"]
+
+    def one(unit):
+        name, srcfile, defs = unit
+        obj = os.path.join(objdir, name + ".o")
+        return obj, _run(common + defs + ["-c", "-o", obj, os.path.join(CSRC, srcfile)])
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        results = list(ex.map(one, UNITS))
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [o for o, _ in results])
+    out = "".join(t for _, t in results)
     with open(os.path.join(LIBDIR, "kernel_resource_usage.txt"), "w") as f:
         f.write(out)
     if verbose:

@@ -1,0 +1,289 @@
+// dangx_mhreg.hip -- Metropolis index kernels, register-resident form.  Compiled once per chain mode
+// (-DDX_REG_MODE=1..5) so the instantiations build in parallel, and once without it for the dispatcher.
+#include "dx_host.h"
+
+#ifdef DX_REG_MODE
+namespace {
+
+// ---------------------------------------------------------------------------
+// Register-resident form of the same chain (chisq likelihood, delta bandpasses, CH_POW / CH_MBB_BETA /
+// CH_MBB_T) for compile-time band count NB and plane count SP: the cleaned data, 1/rms and the chain-
+// invariant SED factor live in VGPRs (statically indexed, fully unrolled), per-band constants in SGPRs,
+// and the kernel uses no LDS and no barrier.  The CU's vector register file (512 KB) is three times its
+// LDS, so this form runs at 2-3 waves/SIMD where the LDS-column form is capped at 1-2.
+// Arithmetic and operation order are identical to index_chain<MODE, SP, TB>.
+template <int MODE, int SP, int NB, bool ISLDS>
+struct RegChain {
+    double D[SP][NB], F[NB];
+    double ISr[ISLDS ? 1 : SP][ISLDS ? 1 : NB];  // 1/rms in registers ...
+    double* isl;                                  // ... or in LDS columns [slot][thread] when registers run out
+    double amp[SP];
+
+    __device__ __forceinline__ double is(int kk, int j) const { return ISLDS ? isl[(kk * NB + j) * BLOCK] : ISr[ISLDS ? 0 : kk][ISLDS ? 0 : j]; }
+    __device__ __forceinline__ void set_is(int kk, int j, double v) {
+        if (ISLDS) isl[(kk * NB + j) * BLOCK] = v; else ISr[ISLDS ? 0 : kk][ISLDS ? 0 : j] = v;
+    }
+
+    __device__ __forceinline__ double lnl(const Model& M, const Comp& c, double th, double other, double& acc0, double& acc1) const {
+        double s0 = 0.0, s1 = 0.0;
+        if (MODE == CH_POW) s0 = th;
+        else if (MODE == CH_MBB_BETA) s0 = th + 1.0;
+        else if (MODE == CH_MBB_T) { s0 = H_PLANCK / (K_B * th); s1 = exp(s0 * c.nu_ref) - 1.0; }
+        else if (MODE == CH_LOGN_NUP) { s0 = th * 1e9; s1 = other; }
+        else s1 = th;  // CH_LOGN_W
+        acc0 = 0.0; acc1 = 0.0;
+        // bands in tiles of TT: TT independent exp chains interleave, then accumulate in band order
+        constexpr int TT = (NB % 5 == 0) ? 5 : (NB % 4 == 0) ? 4 : (NB % 3 == 0) ? 3 : 1;
+#pragma unroll
+        for (int j0 = 0; j0 < NB; j0 += TT) {
+            double s[TT];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const int j = j0 + t;
+                if (MODE == CH_LOGN_NUP) {
+                    const double l = log_pos(M.band[j].nu_c / s0) / s1;
+                    s[t] = exp(-0.5 * (l * l)) * c.cst[j];
+                } else if (MODE == CH_LOGN_W) {
+                    const double l = F[j] / s1;
+                    s[t] = exp(-0.5 * (l * l)) * c.cst[j];
+                } else {
+                    const double e = exp((MODE == CH_MBB_T) ? s0 * M.band[j].nu_c : s0 * c.lnr[j]);
+                    if (MODE == CH_POW) s[t] = e;
+                    else if (MODE == CH_MBB_BETA) s[t] = F[j] * e;
+                    else s[t] = s1 / (e - 1.0) * F[j];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const int j = j0 + t;
+                const double r0 = (D[0][j] - amp[0] * s[t]) * is(0, j);
+                acc0 = acc0 - 0.5 * (r0 * r0);
+                if (SP == 2) {
+                    const double r1 = (D[SP - 1][j] - amp[SP - 1] * s[t]) * is(SP - 1, j);
+                    acc1 = acc1 - 0.5 * (r1 * r1);
+                }
+            }
+        }
+        return acc0 + acc1;
+    }
+};
+
+// eval_sed of an "other" component for all NB bands of one plane, subtracted from D (static band index)
+template <int NB>
+__device__ __forceinline__ void subtract_other(const Model& M, const Comp& c2, int k, double amp2, double t0, double t1,
+                                               double (&Dk)[NB]) {
+    if ((c2.const_planes >> (k - 1)) & 1) {  // spatially constant indices: host-evaluated SED
+#pragma unroll
+        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * c2.csed[k - 1][j];
+        return;
+    }
+    const Prep pr = sed_prep(c2, t0, t1);
+    switch (c2.type) {
+    case DANGX_POWERLAW:
+#pragma unroll
+        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * exp(pr.p0 * c2.lnr[j]);
+        break;
+    case DANGX_MBB:
+#pragma unroll
+        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * (pr.p2 / (exp(pr.p1 * M.band[j].nu_c) - 1.0) * exp(pr.p0 * c2.lnr[j]));
+        break;
+    case DANGX_FREEFREE:
+#pragma unroll
+        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * (ff_gaunt(c2.lnu9[j], pr.p0) / pr.p1 * c2.cst[j]);
+        break;
+    case DANGX_LOGNORMAL:
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const double l2 = log_pos(M.band[j].nu_c / pr.p0) / pr.p1;
+            Dk[j] -= amp2 * (exp(-0.5 * (l2 * l2)) * c2.cst[j]);
+        }
+        break;
+    default:  // cmb
+#pragma unroll
+        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * c2.cst[j];
+        break;
+    }
+}
+
+template <int MODE, int SP, int NB, bool ISLDS>
+__device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, const IndexArgs& a, int i, double chi[4], double* isl) {
+    const int npix = M.npix;
+    const Comp& c = M.comp[a.comp];
+    double* out = c.idx + ((long long)a.nind * M.nmaps) * npix + i;
+    if (is_masked(M.mask[i])) {  // :362 cycle; index_map stays 0 (:223) and is copied back (:480-483)
+#pragma unroll
+        for (int kk = 0; kk < SP; ++kk) out[(long long)(a.s1 + kk - 1) * npix] = 0.0;
+        return 0ull;
+    }
+    RegChain<MODE, SP, NB, ISLDS> R;
+    R.isl = isl;
+    double sample0, sample1;
+    load_theta(M, c, i, a.s1, sample0, sample1);  // sample(l) = c%indices(i, map_inds(1), l), :372-377
+    const bool first = (a.nind == 0);
+    // --- stage data_raw (:173-177) and rms: every load issued before the first use
+    const long long bstride = (long long)M.nmaps * npix;
+#pragma unroll
+    for (int kk = 0; kk < SP; ++kk) {
+        const int k = a.s1 + kk;
+        R.amp[kk] = c.amp[(long long)(k - 1) * npix + i];
+        const double* sigp = M.sig + (long long)(k - 1) * npix + i;
+        const double* rmsp = M.rms + (long long)(k - 1) * npix + i;
+        double rv[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            R.D[kk][j] = sigp[j * bstride];
+            rv[j] = rmsp[j * bstride];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (k == 1) R.D[kk][j] = (R.D[kk][j] - M.offset[j]) / M.gain[j];
+            R.set_is(kk, j, 1.0 / rv[j]);
+        }
+    }
+    // --- remove every OTHER component (:180-196) in component_list order, next one prefetched
+    {
+        unsigned om = a.others;
+        double na[SP], nt0[SP], nt1[SP];
+        auto fetch = [&](int l) {
+            const Comp& c2 = M.comp[l];
+#pragma unroll
+            for (int kk = 0; kk < SP; ++kk) {
+                na[kk] = c2.amp[(long long)(a.s1 + kk - 1) * npix + i];
+                nt0[kk] = nt1[kk] = 0.0;
+                if (!((c2.const_planes >> (a.s1 + kk - 1)) & 1)) load_theta(M, c2, i, a.s1 + kk, nt0[kk], nt1[kk]);
+            }
+        };
+        int l = om ? __builtin_ctz(om) : -1;
+        if (l >= 0) fetch(l);
+        while (l >= 0) {
+            const Comp& c2 = M.comp[l];
+            double ca[SP], ct0[SP], ct1[SP];
+#pragma unroll
+            for (int kk = 0; kk < SP; ++kk) { ca[kk] = na[kk]; ct0[kk] = nt0[kk]; ct1[kk] = nt1[kk]; }
+            om &= om - 1;
+            const int ln = om ? __builtin_ctz(om) : -1;
+            if (ln >= 0) fetch(ln);
+#pragma unroll
+            for (int kk = 0; kk < SP; ++kk) subtract_other<NB>(M, c2, a.s1 + kk, ca[kk], ct0[kk], ct1[kk], R.D[kk]);
+            l = ln;
+        }
+    }
+    // --- chain-invariant SED factor
+    if (MODE == CH_MBB_BETA) {
+        const double z = H_PLANCK / (K_B * sample1);
+        const double A = exp(z * c.nu_ref) - 1.0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) R.F[j] = A / (exp(z * M.band[j].nu_c) - 1.0);
+    } else if (MODE == CH_MBB_T) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) R.F[j] = exp((sample0 + 1.0) * c.lnr[j]);
+    } else if (MODE == CH_LOGN_W) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) R.F[j] = log_pos(M.band[j].nu_c / (sample0 * 1e9));
+    }
+    const double other = first ? sample1 : sample0;  // the index that is not sampled
+    // --- chain (gaussian / uniform prior inline; jeffreys falls back to the LDS form on the host side)
+    const unsigned long long gpix = (unsigned long long)(M.pix0 + i);
+    const int q = a.nind;
+    const bool gauss = c.prior_type[q] == DANGX_PRIOR_GAUSSIAN;
+    const double pmean = c.gauss[q][0], pstd = c.gauss[q][1], lgden = c.lgden[q];
+    auto prior = [&](double v) -> double {
+        if (!gauss) return 0.0;
+        const double arg = ((v - pmean) * (v - pmean)) / (2 * (pstd * pstd));
+        return (arg > 745.0) ? -INFINITY : -arg - lgden;
+    };
+    unsigned long long nacc = 0;
+    double cur = first ? sample0 : sample1;
+    double a0, a1, c0, c1;
+    double lnl = R.lnl(M, c, cur, other, a0, a1);
+    chi[0] = -2.0 * a0; chi[1] = -2.0 * a1;
+    double lnl_old = lnl + prior(cur);
+    const double step = c.step[q], lo = c.uni[q][0], hi = c.uni[q][1];
+    for (int l = 1; l <= a.nsample; ++l) {
+        double u1, u2, u3;
+        uniform3(a.seed, a.stream, gpix, (uint32_t)l, u1, u2, u3);
+        const double prop = cur + rand_normal(0.0, step, u1, u2);  // :414
+        if (prop < lo || prop > hi) continue;                      // :415
+        lnl = R.lnl(M, c, prop, other, c0, c1);
+        const double lnl_new = lnl + prior(prop);
+        const double diff = lnl_new - lnl_old;
+        const bool acc = (a.ml_mode == DANGX_ML_OPTIMIZE) ? (diff > 0.0) : ((diff >= 0.0) || (exp(diff) > u3));  // :443-454
+        if (acc) { cur = prop; lnl_old = lnl_new; a0 = c0; a1 = c1; ++nacc; }
+    }
+#pragma unroll
+    for (int kk = 0; kk < SP; ++kk) out[(long long)(a.s1 + kk - 1) * npix] = cur;  // :465, :483
+    chi[2] = -2.0 * a0; chi[3] = -2.0 * a1;
+    return nacc;
+}
+
+template <int MODE, int SP, int NB, bool ISLDS>
+__global__ __launch_bounds__(BLOCK, (SP == 1 && NB <= 10) ? 3 : 2) void k_index_mh_reg(const Model* __restrict__ Mp, IndexArgs a,
+                                                        unsigned long long* __restrict__ accepted,
+                                                        double* __restrict__ chi_partial) {
+    extern __shared__ double lds[];  // ISLDS: 1/rms columns [SP*NB][BLOCK]
+    const Model& M = *Mp;
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * BLOCK + tid;
+    double chi[4] = {0.0, 0.0, 0.0, 0.0};
+    unsigned long long nacc = (i < M.npix) ? index_chain_reg<MODE, SP, NB, ISLDS>(M, a, i, chi, lds + tid) : 0ull;
+    if (accepted) {
+        for (int o = 32; o > 0; o >>= 1) nacc += __shfl_down(nacc, o, 64);
+        if ((tid & 63) == 0 && nacc) atomicAdd(accepted, nacc);
+    }
+    if (chi_partial) {
+        __shared__ double sh[4][BLOCK / 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double v = chi[q];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            if ((tid & 63) == 0) sh[q][tid >> 6] = v;
+        }
+        __syncthreads();
+        if (tid < 4) {
+            double s = 0.0;
+            for (int w = 0; w < BLOCK / 64; ++w) s += sh[tid][w];
+            chi_partial[(long long)tid * gridDim.x + blockIdx.x] = s;
+        }
+    }
+}
+
+}  // namespace
+
+#define DX_CAT2(a, b) a##b
+#define DX_CAT(a, b) DX_CAT2(a, b)
+bool DX_CAT(dx_launch_mh_reg_mode, DX_REG_MODE)(dangx_ctx* ctx, const IndexArgs& a, int Sp, unsigned nblk, unsigned long long* accp) {
+    const int nb = ctx->hm.nbands;
+#define DX_LAUNCH_REG(SP_, NB_, L_)                                                                              \
+    hipLaunchKernelGGL((k_index_mh_reg<DX_REG_MODE, SP_, NB_, L_>), dim3(nblk), dim3(BLOCK),                     \
+                       (L_) ? (size_t)(SP_) * (NB_) * BLOCK * sizeof(double) : 0, ctx->stream, ctx->dm, a, accp, ctx->partial)
+#define DX_REG_NB(SP_)                                                                                           \
+    do { if (nb == 10) DX_LAUNCH_REG(SP_, 10, false); else if (nb == 5) DX_LAUNCH_REG(SP_, 5, false);            \
+         else if (nb == 3) DX_LAUNCH_REG(SP_, 3, false); else if (nb == 6) DX_LAUNCH_REG(SP_, 6, false);         \
+         else if (nb == 8) DX_LAUNCH_REG(SP_, 8, false); else if (nb == 20) DX_LAUNCH_REG(SP_, 20, ((SP_) == 2)); \
+         else return false; } while (0)
+    if (Sp == 2) DX_REG_NB(2); else DX_REG_NB(1);
+#undef DX_REG_NB
+#undef DX_LAUNCH_REG
+    return true;
+}
+#else
+bool dx_launch_mh_reg_mode1(dangx_ctx*, const IndexArgs&, int, unsigned, unsigned long long*);
+bool dx_launch_mh_reg_mode2(dangx_ctx*, const IndexArgs&, int, unsigned, unsigned long long*);
+bool dx_launch_mh_reg_mode3(dangx_ctx*, const IndexArgs&, int, unsigned, unsigned long long*);
+bool dx_launch_mh_reg_mode4(dangx_ctx*, const IndexArgs&, int, unsigned, unsigned long long*);
+bool dx_launch_mh_reg_mode5(dangx_ctx*, const IndexArgs&, int, unsigned, unsigned long long*);
+
+bool dx_mh_reg_supported(int mode, int nb) {
+    return mode >= CH_POW && mode <= CH_LOGN_W && (nb == 3 || nb == 5 || nb == 6 || nb == 8 || nb == 10 || nb == 20);
+}
+bool dx_launch_mh_reg(dangx_ctx* ctx, const IndexArgs& a, int Sp, unsigned nblk, unsigned long long* accp) {
+    switch (a.mode) {
+    case CH_POW: return dx_launch_mh_reg_mode1(ctx, a, Sp, nblk, accp);
+    case CH_MBB_BETA: return dx_launch_mh_reg_mode2(ctx, a, Sp, nblk, accp);
+    case CH_MBB_T: return dx_launch_mh_reg_mode3(ctx, a, Sp, nblk, accp);
+    case CH_LOGN_NUP: return dx_launch_mh_reg_mode4(ctx, a, Sp, nblk, accp);
+    case CH_LOGN_W: return dx_launch_mh_reg_mode5(ctx, a, Sp, nblk, accp);
+    default: return false;
+    }
+}
+#endif

@@ -1,0 +1,151 @@
+// dx_host.h -- host-side context and launch-argument structs shared by the translation units of libdangx.so
+// (dangx_core.hip: context, C ABI, small kernels; dangx_amp.hip: amplitude kernels; dangx_mh.hip: LDS-form
+// Metropolis kernels; dangx_mhreg.hip: register-resident Metropolis kernels, compiled once per chain mode).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dangx.h"
+#include "dx_model.h"
+#include "dx_rng.h"
+#include "dx_sed.h"
+
+using namespace dx;
+
+constexpr int BLOCK = 256;
+
+struct GroupArgs {
+    int ng;          // sampled diffuse components of the group
+    int gc[MAXG];    // their component indices, in component_list order
+    int no;          // components NOT solved for (removed from the data)
+    int oc[MAXC];
+    int flag;        // one poltype bit
+    int ml_mode, fluct;
+    unsigned long long seed, stream;
+};
+
+__device__ __forceinline__ int flag_nplanes(int flag) { return (flag & DANGX_FLAG_QU) ? 2 : 1; }
+// src/dang_cg_mod.f90:357-363 and the flag-8 branches (:488-494): plane p -> map number
+__device__ __forceinline__ int flag_map(int flag, int p) {
+    if (flag & DANGX_FLAG_QU) return 2 + p;
+    if (flag & DANGX_FLAG_T) return 1;
+    if (flag & DANGX_FLAG_Q) return 2;
+    return 3;
+}
+
+// chain modes of the Metropolis kernels (see dangx_mh.hip)
+enum { CH_GENERIC = 0, CH_POW = 1, CH_MBB_BETA = 2, CH_MBB_T = 3, CH_LOGN_NUP = 4, CH_LOGN_W = 5 };
+
+struct IndexArgs {
+    int comp, nind, s1, s2, nsample, ml_mode, mode;
+    unsigned others;  // bit l: component l (/= comp) may have a non-zero amplitude on planes s1..s2
+    unsigned long long seed, stream;
+};
+
+struct dangx_ctx {
+    dangx_dims dims{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // host mirror of the model + device copy
+    Model hm{};
+    Model* dm = nullptr;
+    bool dirty = true;
+    bool comp_set[MAXC] = {};
+    bool band_set[MAXB] = {};
+    dangx_comp_desc desc[MAXC] = {};
+    // owned device buffers
+    double *sig = nullptr, *rms = nullptr, *mask = nullptr;
+    bool own_data = false;
+    double* amp[MAXC] = {};
+    double* idx[MAXC] = {};
+    bool own_amp[MAXC] = {};
+    bool own_idx[MAXC] = {};
+    unsigned plane_nz[MAXC] = {};  // bit k-1: amplitude plane k of the component may be non-zero
+    unsigned idx_const[MAXC] = {}; // bit k-1: every index of the component is spatially constant on plane k
+    double idx_val[MAXC][3][MAXI] = {};
+    std::vector<double> bp_nu0, bp_tau0;
+    double *d_bp_nu0 = nullptr, *d_bp_tau0 = nullptr;
+    // scratch
+    double* partial = nullptr;
+    long long partial_cap = 0;
+    double* scalars = nullptr;              // device scalars [8]
+    double* chi_cache = nullptr;            // device [6]: chi^2 before/after of planes 1..3 (fused in k_index_mh)
+    bool chi_before_valid[3] = {}, chi_after_valid[3] = {}, touched_since_amp[3] = {};
+    unsigned long long* counters = nullptr; // device counters [4]
+    double* work[6] = {};                   // CG vectors
+    double* fs_data = nullptr;              // full-sky mode: cleaned data [Sp][nb][npix]
+    long long fs_cap = 0;
+    int fs_comp = -1, fs_s1 = 0, fs_s2 = 0;
+    double* rows_out = nullptr;             // device [2*MAXB*2 + 8] row sums
+    long long work_cap = 0;
+    // profiling
+    bool prof = false;
+    struct Ev { hipEvent_t a, b; int kid; };
+    std::vector<Ev> events;
+    double prof_ms[DANGX_K_COUNT] = {};
+    long long prof_n[DANGX_K_COUNT] = {};
+};
+
+#define HIPCHK(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
+            return 1;                                                                             \
+        }                                                                                         \
+    } while (0)
+
+inline int fail(dangx_ctx* ctx, const std::string& msg) {
+    ctx->err = msg;
+    return 1;
+}
+
+struct Timed {
+    dangx_ctx* ctx;
+    dangx_ctx::Ev ev{};
+    bool on;
+    Timed(dangx_ctx* c, int kid) : ctx(c), on(c->prof) {
+        if (!on) return;
+        ev.kid = kid;
+        (void)hipEventCreate(&ev.a);
+        (void)hipEventCreate(&ev.b);
+        (void)hipEventRecord(ev.a, ctx->stream);
+    }
+    ~Timed() {
+        if (!on) return;
+        (void)hipEventRecord(ev.b, ctx->stream);
+        ctx->events.push_back(ev);
+    }
+};
+
+
+inline int ensure_partial(dangx_ctx* ctx, long long n) {
+    if (n <= ctx->partial_cap) return 0;
+    if (ctx->partial) (void)hipFree(ctx->partial);
+    HIPCHK(ctx, hipMalloc(&ctx->partial, sizeof(double) * (size_t)n));
+    ctx->partial_cap = n;
+    return 0;
+}
+
+inline int flag_planes_h(int flag) { return (flag & DANGX_FLAG_QU) ? 2 : 1; }
+
+inline unsigned nblocks(long long n, int bs = BLOCK) { return (unsigned)((n + bs - 1) / bs); }
+
+// launchers defined next to their kernels
+int dx_launch_amp(dangx_ctx* ctx, const GroupArgs& a, long long SN);
+int dx_launch_rhs(dangx_ctx* ctx, const GroupArgs& a, long long SN, double* b);
+int dx_launch_Ax(dangx_ctx* ctx, const GroupArgs& a, long long SN, const double* x, double* res, double* part);
+int dx_launch_sample_vector(dangx_ctx* ctx, const GroupArgs& a, long long SN, const double* eta, double* res);
+// LDS-form Metropolis kernel (fast = chisq likelihood with CH_POW / CH_MBB_*; otherwise the generic chain)
+void dx_launch_mh_lds(dangx_ctx* ctx, const IndexArgs& a, bool fast, int Sp, unsigned nblk, int bs, size_t lds, unsigned long long* accp);
+// register-resident Metropolis kernels; return false when (mode, nb) is not instantiated
+bool dx_mh_reg_supported(int mode, int nb);
+bool dx_launch_mh_reg(dangx_ctx* ctx, const IndexArgs& a, int Sp, unsigned nblk, unsigned long long* accp);
