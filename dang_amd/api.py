@@ -57,6 +57,11 @@ class DangComps:
     step_size: List[float] = field(default_factory=list)
     pol_flag: List[List[int]] = field(default_factory=list)  # per index: list of poltype bit flags
     tuned: List[bool] = field(default_factory=list)          # c%tuned (empty = all tuned)
+    # global-amplitude types ('template', 'monopole', 'hi_fit'), src/dang_component_mod.f90:17-33
+    nfit: int = 0
+    corr: List[bool] = field(default_factory=list)           # c%corr(j): is band j fitted?
+    template: Optional[np.ndarray] = None                    # c%template, [nmaps][npix]
+    template_amplitudes: Optional[np.ndarray] = None         # c%template_amplitudes(band,map) stored [map][band]
     amplitude: Optional[np.ndarray] = None                   # [nmaps][npix]
     indices: Optional[np.ndarray] = None                     # [nindices][nmaps][npix]
 

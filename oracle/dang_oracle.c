@@ -226,6 +226,9 @@ double dgo_eval_sed(const dgo_ctx *ctx, int comp, int band, int pix, int map_n, 
     case DGO_LOGNORMAL: return sed_lognormal(b, c->nu_ref, th[0], th[1]);
     case DGO_CMB: return 1.0 / dgo_a2t(ctx, band);
     case DGO_TCMB: return sed_planck_rj(b, th[0]);
+    case DGO_TEMPLATE: /* :803-806 */
+    case DGO_MONOPOLE: return c->tmpl[IDX2(ctx, map_n, pix)];
+    case DGO_HIFIT: return c->tmpl[IDX2(ctx, map_n, pix)] * sed_planck_rj(b, th[0]); /* :807-808 */
     default: return NAN;
     }
 }
@@ -234,6 +237,10 @@ double dgo_eval_sed(const dgo_ctx *ctx, int comp, int band, int pix, int map_n, 
 double dgo_eval_signal(const dgo_ctx *ctx, int comp, int band, int pix, int map_n, const double *theta) {
     const dgo_comp *c = &ctx->comps[comp];
     if (c->type == DGO_TCMB) return dgo_eval_sed(ctx, comp, band, pix, map_n, theta); /* :770-771 */
+    if (c->type == DGO_HIFIT) /* :764-765 */
+        return c->template_amplitudes[(map_n - 1) * ctx->nbands + band] * dgo_eval_sed(ctx, comp, band, pix, map_n, theta);
+    if (c->type == DGO_TEMPLATE || c->type == DGO_MONOPOLE) /* :766-769 */
+        return c->template_amplitudes[(map_n - 1) * ctx->nbands + band] * c->tmpl[IDX2(ctx, map_n, pix)];
     return c->amplitude[IDX2(ctx, map_n, pix)] * dgo_eval_sed(ctx, comp, band, pix, map_n, theta);
 }
 
@@ -248,13 +255,28 @@ static int flag_map(int flag, int p) {
     return 3;
 }
 static int in_group(const dgo_comp *c, int group) { return c->cg_group == group && c->sample_amplitude; }
+static int is_global(const dgo_comp *c) { return c->type == DGO_TEMPLATE || c->type == DGO_MONOPOLE || c->type == DGO_HIFIT; }
+/* plane(s) a global component's row sums run over: hi_fit and monopole use plane 1 only (:531, :550, :840, :857);
+ * a template uses both planes under Q+U (:571-572) or map_n */
+static int glob_nplanes(const dgo_comp *c, int flag) { return (c->type == DGO_TEMPLATE && (flag & DGO_FLAG_QU)) ? 2 : 1; }
+static int glob_map(const dgo_comp *c, int flag, int p) { return (c->type == DGO_TEMPLATE) ? flag_map(flag, p) : 1; }
+/* slot of the noise vector temp1 that plane p of a global component reads/writes (:723, :737, :752-759) */
+static int64_t glob_slot(const dgo_ctx *ctx, const dgo_comp *c, int flag, int p, int i) {
+    (void)c; (void)flag;
+    return (int64_t)p * ctx->npix + i;
+}
 
 int64_t dgo_group_size(const dgo_ctx *ctx, int group, int flag, int *ncg) {
     int n = 0;
+    int64_t nglob = 0;
     for (int l = 0; l < ctx->ncomp; ++l)
-        if (in_group(&ctx->comps[l], group)) ++n;
+        if (in_group(&ctx->comps[l], group)) {
+            if (is_global(&ctx->comps[l])) nglob += ctx->comps[l].nfit; /* :401-410 (the reference omits a template's
+                                                                           nfit for single-plane flags: out of bounds there) */
+            else ++n;
+        }
     if (ncg) *ncg = n;
-    return (int64_t)n * flag_nplanes(flag) * ctx->npix;
+    return (int64_t)n * flag_nplanes(flag) * ctx->npix + nglob;
 }
 
 /* src/dang_cg_mod.f90:326-596 */
@@ -268,39 +290,72 @@ void dgo_compute_rhs(const dgo_ctx *ctx, int group, int flag, double *b) {
         for (int j = 0; j < nb; ++j)
             for (int i = 0; i < npix; ++i)
                 data[IDX3(ctx, j, k, i)] = (k == 1) ? ctx->sig[IDX3(ctx, j, k, i)] / ctx->gain[j] : ctx->sig[IDX3(ctx, j, k, i)];
-    /* :427-443 remove components that are not solved for in this group */
     for (int l = 0; l < ctx->ncomp; ++l) {
-        if (in_group(&ctx->comps[l], group)) continue;
+        const dgo_comp *c = &ctx->comps[l];
+        /* :427-443 remove components that are not solved for in this group */
+        if (!in_group(c, group)) {
 #pragma omp parallel for schedule(static)
-        for (int i = 0; i < npix; ++i) {
-            if (masked(ctx->mask[i])) continue;
-            for (int k = 1; k <= nmaps; ++k)
-                for (int j = 0; j < nb; ++j)
-                    data[IDX3(ctx, j, k, i)] = data[IDX3(ctx, j, k, i)] - dgo_eval_signal(ctx, l, j, i, k, NULL);
+            for (int i = 0; i < npix; ++i) {
+                if (masked(ctx->mask[i])) continue;
+                for (int k = 1; k <= nmaps; ++k)
+                    for (int j = 0; j < nb; ++j)
+                        data[IDX3(ctx, j, k, i)] = data[IDX3(ctx, j, k, i)] - dgo_eval_signal(ctx, l, j, i, k, NULL);
+            }
         }
+        /* :445-460 "still subtract templates which exist but may not be fit here": every template / monopole
+         * (whatever its group -- a non-member is thereby removed TWICE on these bands), bands with corr == false */
+        if (c->type == DGO_TEMPLATE || c->type == DGO_MONOPOLE)
+            for (int j = 0; j < nb; ++j) {
+                if (c->corr[j]) continue;
+                for (int i = 0; i < npix; ++i) {
+                    if (masked(ctx->mask[i])) continue;
+                    for (int k = 1; k <= nmaps; ++k)
+                        data[IDX3(ctx, j, k, i)] = data[IDX3(ctx, j, k, i)] - dgo_eval_signal(ctx, l, j, i, k, NULL);
+                }
+            }
     }
     int64_t n = dgo_group_size(ctx, group, flag, NULL);
     for (int64_t q = 0; q < n; ++q) b[q] = 0.0;
-    /* :464-521 */
+    /* :464-587 */
     int64_t offset = 0;
     for (int l = 0; l < ctx->ncomp; ++l) {
-        if (!in_group(&ctx->comps[l], group)) continue;
+        const dgo_comp *c = &ctx->comps[l];
+        if (!in_group(c, group)) continue;
+        if (!is_global(c)) {
 #pragma omp parallel for schedule(static)
-        for (int i = 0; i < npix; ++i) {
-            for (int j = 0; j < nb; ++j) {
-                if (ctx->mask[i] == 0.0) { /* :474 -- only the ==0 test here */
-                    for (int p = 0; p < S; ++p) b[(int64_t)p * npix + i] = 0.0;
-                    continue;
-                }
-                for (int p = 0; p < S; ++p) {
-                    int k = flag_map(flag, p);
-                    double rms = ctx->rms[IDX3(ctx, j, k, i)];
-                    b[offset + (int64_t)p * npix + i] = b[offset + (int64_t)p * npix + i] +
-                        (data[IDX3(ctx, j, k, i)] * dgo_eval_sed(ctx, l, j, i, k, NULL)) / (rms * rms);
+            for (int i = 0; i < npix; ++i) {
+                for (int j = 0; j < nb; ++j) {
+                    if (ctx->mask[i] == 0.0) { /* :474 -- only the ==0 test here */
+                        for (int p = 0; p < S; ++p) b[(int64_t)p * npix + i] = 0.0;
+                        continue;
+                    }
+                    for (int p = 0; p < S; ++p) {
+                        int k = flag_map(flag, p);
+                        double rms = ctx->rms[IDX3(ctx, j, k, i)];
+                        b[offset + (int64_t)p * npix + i] = b[offset + (int64_t)p * npix + i] +
+                            (data[IDX3(ctx, j, k, i)] * dgo_eval_sed(ctx, l, j, i, k, NULL)) / (rms * rms);
+                    }
                 }
             }
+            offset += (int64_t)S * npix;
+        } else { /* :522-587: one entry per fitted band, b(offset+l) += sum(val_array) */
+            int lfit = 0;
+            for (int j = 0; j < nb; ++j) {
+                if (!c->corr[j]) continue;
+                double sum = 0.0;
+                for (int p = 0; p < glob_nplanes(c, flag); ++p) {
+                    const int k = glob_map(c, flag, p);
+                    for (int i = 0; i < npix; ++i) {
+                        if (masked(ctx->mask[i])) continue;
+                        double rms = ctx->rms[IDX3(ctx, j, k, i)];
+                        sum += data[IDX3(ctx, j, k, i)] / (rms * rms) * dgo_eval_sed(ctx, l, j, i, k, NULL);
+                    }
+                }
+                b[offset + lfit] = b[offset + lfit] + sum;
+                lfit++;
+            }
+            offset += c->nfit;
         }
-        offset += (int64_t)S * npix;
     }
     free(data);
 }
@@ -314,22 +369,38 @@ void dgo_compute_Ax(const dgo_ctx *ctx, int group, int flag, const double *x, do
     set_threads(ctx);
     double *temp1 = (double *)malloc(sizeof(double) * (size_t)m);
     double *temp3 = (double *)malloc(sizeof(double) * (size_t)n);
+    int lcount[64]; /* l(:) = 1, one counter per template-like component (:654) */
+    for (int t = 0; t < 64; ++t) lcount[t] = 0;
     for (int64_t q = 0; q < n; ++q) res[q] = 0.0;
     for (int j = 0; j < nb; ++j) {
         for (int64_t q = 0; q < m; ++q) temp1[q] = 0.0;
         for (int64_t q = 0; q < n; ++q) temp3[q] = 0.0;
         int64_t offset = 0;
+        int l_ind = 0;
         /* :685-769 temp1 = T_nu x */
         for (int l = 0; l < ctx->ncomp; ++l) {
-            if (!in_group(&ctx->comps[l], group)) continue;
+            const dgo_comp *c = &ctx->comps[l];
+            if (!in_group(c, group)) continue;
+            if (!is_global(c)) {
 #pragma omp parallel for schedule(static)
-            for (int i = 0; i < npix; ++i) {
-                if (masked(ctx->mask[i])) continue;
-                for (int p = 0; p < S; ++p)
-                    temp1[(int64_t)p * npix + i] = temp1[(int64_t)p * npix + i] +
-                        x[offset + (int64_t)p * npix + i] * dgo_eval_sed(ctx, l, j, i, flag_map(flag, p), NULL);
+                for (int i = 0; i < npix; ++i) {
+                    if (masked(ctx->mask[i])) continue;
+                    for (int p = 0; p < S; ++p)
+                        temp1[(int64_t)p * npix + i] = temp1[(int64_t)p * npix + i] +
+                            x[offset + (int64_t)p * npix + i] * dgo_eval_sed(ctx, l, j, i, flag_map(flag, p), NULL);
+                }
+                offset += m;
+            } else {
+                if (c->corr[j])
+                    for (int p = 0; p < glob_nplanes(c, flag); ++p)
+                        for (int i = 0; i < npix; ++i) {
+                            if (masked(ctx->mask[i])) continue;
+                            temp1[glob_slot(ctx, c, flag, p, i)] = temp1[glob_slot(ctx, c, flag, p, i)] +
+                                x[offset + lcount[l_ind]] * dgo_eval_sed(ctx, l, j, i, glob_map(c, flag, p), NULL);
+                        }
+                l_ind++;
+                offset += c->nfit;
             }
-            offset += m;
         }
         /* :775-791 temp1 = N^-1 temp1 */
 #pragma omp parallel for schedule(static)
@@ -342,16 +413,35 @@ void dgo_compute_Ax(const dgo_ctx *ctx, int group, int flag, const double *x, do
         }
         /* :801-894 temp3 = T_nu^t temp1 */
         offset = 0;
+        l_ind = 0;
         for (int l = 0; l < ctx->ncomp; ++l) {
-            if (!in_group(&ctx->comps[l], group)) continue;
+            const dgo_comp *c = &ctx->comps[l];
+            if (!in_group(c, group)) continue;
+            if (!is_global(c)) {
 #pragma omp parallel for schedule(static)
-            for (int i = 0; i < npix; ++i) {
-                if (masked(ctx->mask[i])) continue;
-                for (int p = 0; p < S; ++p)
-                    temp3[offset + (int64_t)p * npix + i] =
-                        temp1[(int64_t)p * npix + i] * dgo_eval_sed(ctx, l, j, i, flag_map(flag, p), NULL);
+                for (int i = 0; i < npix; ++i) {
+                    if (masked(ctx->mask[i])) continue;
+                    for (int p = 0; p < S; ++p)
+                        temp3[offset + (int64_t)p * npix + i] =
+                            temp1[(int64_t)p * npix + i] * dgo_eval_sed(ctx, l, j, i, flag_map(flag, p), NULL);
+                }
+                offset += m;
+            } else {
+                if (c->corr[j]) {
+                    double sum = 0.0;
+                    for (int p = 0; p < glob_nplanes(c, flag); ++p)
+                        for (int i = 0; i < npix; ++i) {
+                            if (masked(ctx->mask[i])) continue;
+                            /* :857 the monopole row sums temp1(i) WITHOUT its template factor */
+                            const double w = (c->type == DGO_MONOPOLE) ? 1.0 : dgo_eval_sed(ctx, l, j, i, glob_map(c, flag, p), NULL);
+                            sum += temp1[glob_slot(ctx, c, flag, p, i)] * w;
+                        }
+                    temp3[offset + lcount[l_ind]] = temp3[offset + lcount[l_ind]] + sum;
+                    lcount[l_ind] = lcount[l_ind] + 1;
+                }
+                l_ind++;
+                offset += c->nfit;
             }
-            offset += m;
         }
         for (int64_t q = 0; q < n; ++q) res[q] = res[q] + temp3[q]; /* :904 */
     }
@@ -361,7 +451,8 @@ void dgo_compute_Ax(const dgo_ctx *ctx, int group, int flag, const double *x, do
 
 /* src/dang_cg_mod.f90:913-1100.  NOTE (quirks 2,3): the diffuse branch writes
  * temp2(i)/temp2(npix+i) WITHOUT the component offset and with '=' (:1033-1040),
- * and the same eta is used for every band (:1008-1015). */
+ * and the same eta is used for every band (:1008-1015).  The global rows use ONE offset (the total diffuse
+ * length, :975-990) and ONE running counter l over bands and components (:970, :1057, :1071, :1094). */
 void dgo_compute_sample_vector(const dgo_ctx *ctx, int group, int flag, const double *eta, double *res) {
     const int npix = ctx->npix, nb = ctx->nbands;
     const int S = flag_nplanes(flag);
@@ -370,6 +461,10 @@ void dgo_compute_sample_vector(const dgo_ctx *ctx, int group, int flag, const do
     set_threads(ctx);
     double *temp1 = (double *)malloc(sizeof(double) * (size_t)m);
     double *temp2 = (double *)malloc(sizeof(double) * (size_t)n);
+    int64_t offset = 0;
+    for (int l = 0; l < ctx->ncomp; ++l)
+        if (in_group(&ctx->comps[l], group) && !is_global(&ctx->comps[l])) offset += m;
+    int lrun = 0;
     for (int64_t q = 0; q < n; ++q) res[q] = 0.0;
     for (int j = 0; j < nb; ++j) {
         for (int64_t q = 0; q < m; ++q) temp1[q] = 0.0;
@@ -381,13 +476,26 @@ void dgo_compute_sample_vector(const dgo_ctx *ctx, int group, int flag, const do
                 temp1[(int64_t)p * npix + i] = eta[(int64_t)p * npix + i] / ctx->rms[IDX3(ctx, j, flag_map(flag, p), i)];
         }
         for (int l = 0; l < ctx->ncomp; ++l) {
-            if (!in_group(&ctx->comps[l], group)) continue;
+            const dgo_comp *c = &ctx->comps[l];
+            if (!in_group(c, group)) continue;
+            if (!is_global(c)) {
 #pragma omp parallel for schedule(static)
-            for (int i = 0; i < npix; ++i) {
-                if (masked(ctx->mask[i])) continue;
-                for (int p = 0; p < S; ++p)
-                    temp2[(int64_t)p * npix + i] =
-                        temp1[(int64_t)p * npix + i] * dgo_eval_sed(ctx, l, j, i, flag_map(flag, p), NULL);
+                for (int i = 0; i < npix; ++i) {
+                    if (masked(ctx->mask[i])) continue;
+                    for (int p = 0; p < S; ++p)
+                        temp2[(int64_t)p * npix + i] =
+                            temp1[(int64_t)p * npix + i] * dgo_eval_sed(ctx, l, j, i, flag_map(flag, p), NULL);
+                }
+            } else if (c->corr[j]) {
+                double sum = 0.0;
+                for (int p = 0; p < glob_nplanes(c, flag); ++p)
+                    for (int i = 0; i < npix; ++i) {
+                        if (masked(ctx->mask[i])) continue;
+                        const double w = (c->type == DGO_MONOPOLE) ? 1.0 : dgo_eval_sed(ctx, l, j, i, glob_map(c, flag, p), NULL);
+                        sum += temp1[glob_slot(ctx, c, flag, p, i)] * w;
+                    }
+                if (offset + lrun < n) temp2[offset + lrun] = temp2[offset + lrun] + sum; /* (the reference would run out of bounds) */
+                lrun++;
             }
         }
         for (int64_t q = 0; q < n; ++q) res[q] = res[q] + temp2[q];
@@ -396,28 +504,54 @@ void dgo_compute_sample_vector(const dgo_ctx *ctx, int group, int flag, const do
     free(temp2);
 }
 
-/* src/dang_cg_mod.f90:1173-1282 (diffuse branch) */
+/* src/dang_cg_mod.f90:1173-1282 */
 void dgo_initialize_x(const dgo_ctx *ctx, int group, int flag, double *x) {
     const int S = flag_nplanes(flag);
     int64_t offset = 0;
     for (int l = 0; l < ctx->ncomp; ++l) {
-        if (!in_group(&ctx->comps[l], group)) continue;
-        for (int p = 0; p < S; ++p) {
-            for (int i = 0; i < ctx->npix; ++i) x[offset + i] = ctx->comps[l].amplitude[IDX2(ctx, flag_map(flag, p), i)];
-            offset += ctx->npix;
+        const dgo_comp *c = &ctx->comps[l];
+        if (!in_group(c, group)) continue;
+        if (!is_global(c)) {
+            for (int p = 0; p < S; ++p) {
+                for (int i = 0; i < ctx->npix; ++i) x[offset + i] = c->amplitude[IDX2(ctx, flag_map(flag, p), i)];
+                offset += ctx->npix;
+            }
+        } else { /* :1244-1279: template_amplitudes(j, map_n); a template under Q+U reads plane 2 (:1270) */
+            const int k = (c->type == DGO_TEMPLATE) ? flag_map(flag, 0) : flag_map(flag, 0);
+            int lfit = 0;
+            for (int j = 0; j < ctx->nbands && lfit < c->nfit; ++j)
+                if (c->corr[j]) x[offset + lfit++] = c->template_amplitudes[(k - 1) * ctx->nbands + j];
+            offset += lfit;
         }
     }
 }
 
-/* src/dang_cg_mod.f90:1284-1396 (diffuse branch) */
+/* src/dang_cg_mod.f90:1284-1396 */
 void dgo_unpack_amplitudes(dgo_ctx *ctx, int group, int flag, const double *x) {
     const int S = flag_nplanes(flag);
     int64_t offset = 0;
     for (int l = 0; l < ctx->ncomp; ++l) {
-        if (!in_group(&ctx->comps[l], group)) continue;
-        for (int p = 0; p < S; ++p) {
-            for (int i = 0; i < ctx->npix; ++i) ctx->comps[l].amplitude[IDX2(ctx, flag_map(flag, p), i)] = x[offset + i];
-            offset += ctx->npix;
+        dgo_comp *c = &ctx->comps[l];
+        if (!in_group(c, group)) continue;
+        if (!is_global(c)) {
+            for (int p = 0; p < S; ++p) {
+                for (int i = 0; i < ctx->npix; ++i) c->amplitude[IDX2(ctx, flag_map(flag, p), i)] = x[offset + i];
+                offset += ctx->npix;
+            }
+        } else {
+            int lfit = 0;
+            for (int j = 0; j < ctx->nbands && lfit < c->nfit; ++j)
+                if (c->corr[j]) {
+                    /* :1380-1382 a template under Q+U shares ONE amplitude between Q and U */
+                    if (c->type == DGO_TEMPLATE && (flag & DGO_FLAG_QU)) {
+                        c->template_amplitudes[1 * ctx->nbands + j] = x[offset + lfit];
+                        c->template_amplitudes[2 * ctx->nbands + j] = x[offset + lfit];
+                    } else {
+                        c->template_amplitudes[(flag_map(flag, 0) - 1) * ctx->nbands + j] = x[offset + lfit];
+                    }
+                    lfit++;
+                }
+            offset += lfit;
         }
     }
 }
@@ -504,6 +638,7 @@ int dgo_amp_sample_direct(dgo_ctx *ctx, int group, int flag, int ml_mode, int fl
     const int npix = ctx->npix, nb = ctx->nbands, S = flag_nplanes(flag);
     int gc[DGO_MAX_NC], oc[64], ng = 0, no = 0;
     for (int l = 0; l < ctx->ncomp; ++l) {
+        if (in_group(&ctx->comps[l], group) && is_global(&ctx->comps[l])) return -2; /* coupled system: CG only */
         if (in_group(&ctx->comps[l], group)) { if (ng >= DGO_MAX_NC) return -1; gc[ng++] = l; }
         else { if (no >= 64) return -1; oc[no++] = l; }
     }
@@ -586,6 +721,10 @@ void dgo_update_sky_model(const dgo_ctx *ctx, double *sky, double *res) {
     set_threads(ctx);
     for (int64_t q = 0; q < (int64_t)nb * nmaps * npix; ++q) sky[q] = 0.0;
     for (int l = 0; l < ctx->ncomp; ++l) {
+        if (ctx->comps[l].type == DGO_MONOPOLE) { /* :357-361: sets the band offsets, not part of the sky model */
+            for (int j = 0; j < nb; ++j) ctx->offset[j] = ctx->comps[l].template_amplitudes[j];
+            continue;
+        }
 #pragma omp parallel for schedule(static)
         for (int i = 0; i < npix; ++i)
             for (int k = 1; k <= nmaps; ++k)

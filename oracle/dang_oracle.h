@@ -32,7 +32,8 @@ extern "C" {
 #endif
 
 /* component types: src/dang_component_mod.f90:791-809 (diffuse ones) */
-enum { DGO_POWERLAW = 1, DGO_MBB = 2, DGO_FREEFREE = 3, DGO_LOGNORMAL = 4, DGO_CMB = 5, DGO_TCMB = 6 };
+enum { DGO_POWERLAW = 1, DGO_MBB = 2, DGO_FREEFREE = 3, DGO_LOGNORMAL = 4, DGO_CMB = 5, DGO_TCMB = 6,
+       DGO_TEMPLATE = 7, DGO_MONOPOLE = 8, DGO_HIFIT = 9 }; /* 7-9: global-amplitude types */
 /* lnl_type / prior_type: src/dang_sample_mod.f90:383-400 */
 enum { DGO_LNL_CHISQ = 1, DGO_LNL_MARGINAL = 2, DGO_LNL_PRIOR = 3 };
 enum { DGO_PRIOR_GAUSSIAN = 1, DGO_PRIOR_UNIFORM = 2, DGO_PRIOR_JEFFREYS = 3 };
@@ -67,6 +68,11 @@ typedef struct {
     double gauss_prior[DGO_MAX_IND][2];
     double uni_prior[DGO_MAX_IND][2];
     double step_size[DGO_MAX_IND];
+    /* global-amplitude types only (src/dang_component_mod.f90:17,22,31,33) */
+    int nfit;                     /* number of fitted (corr) bands */
+    const int *corr;              /* [nbands] c%corr(j) */
+    const double *tmpl;           /* c%template, [nmaps][npix] */
+    double *template_amplitudes;  /* c%template_amplitudes(band,map) stored [map][band] */
 } dgo_comp;
 
 typedef struct {
@@ -76,7 +82,7 @@ typedef struct {
     const double *rms;    /* [nbands][nmaps][npix] */
     const double *mask;   /* [nmaps][npix] */
     const double *gain;   /* [nbands] */
-    const double *offset; /* [nbands] */
+    double *offset;       /* [nbands]; update_sky_model overwrites it from a monopole component (:357-361) */
     const dgo_band *bands;
     dgo_comp *comps;
     double T_CMB;         /* src/dang_util_mod.f90:15 (global, mutable in the reference) */

@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "libdang_oracle.so")
 
-TYPE_CODES = {"power-law": 1, "mbb": 2, "freefree": 3, "lognormal": 4, "cmb": 5, "T_cmb": 6}
+TYPE_CODES = {"power-law": 1, "mbb": 2, "freefree": 3, "lognormal": 4, "cmb": 5, "T_cmb": 6, "template": 7, "monopole": 8,
+              "hi_fit": 9}
 LNL_CODES = {"chisq": 1, "marginal": 2, "prior": 3}
 PRIOR_CODES = {"gaussian": 1, "uniform": 2, "jeffreys": 3}
 ML_CODES = {"sample": 1, "optimize": 2}
@@ -30,7 +31,8 @@ class Comp(C.Structure):
     _fields_ = [("type", C.c_int), ("is_synch", C.c_int), ("nu_ref", C.c_double), ("nindices", C.c_int),
                 ("cg_group", C.c_int), ("sample_amplitude", C.c_int), ("amplitude", _D), ("indices", _D),
                 ("lnl_type", C.c_int * 2), ("prior_type", C.c_int * 2), ("gauss_prior", (C.c_double * 2) * 2),
-                ("uni_prior", (C.c_double * 2) * 2), ("step_size", C.c_double * 2)]
+                ("uni_prior", (C.c_double * 2) * 2), ("step_size", C.c_double * 2),
+                ("nfit", C.c_int), ("corr", C.POINTER(C.c_int)), ("tmpl", _D), ("template_amplitudes", _D)]
 
 
 class Ctx(C.Structure):
@@ -138,6 +140,7 @@ class Oracle:
                 self._bands[j].tau0 = _p(tau0)
         self._comps = (Comp * self.ncomp)()
         self.amp, self.idx = [], []
+        self._glob = {}
         for l, c in enumerate(component_list):
             cc = self._comps[l]
             cc.type = TYPE_CODES[c.type]
@@ -153,6 +156,16 @@ class Oracle:
             self.idx.append(np.ascontiguousarray(x))
             cc.amplitude = _p(self.amp[l])
             cc.indices = _p(self.idx[l])
+            if c.type in ("template", "monopole", "hi_fit"):
+                corr = np.ascontiguousarray(np.asarray(c.corr, dtype=bool).astype(np.int32))
+                tm = np.ascontiguousarray(c.template, dtype=np.float64)
+                ta = np.zeros((nmaps, nb)) if c.template_amplitudes is None else np.array(c.template_amplitudes, dtype=np.float64, copy=True)
+                ta = np.ascontiguousarray(ta)
+                self._glob[l] = (corr, tm, ta)
+                cc.nfit = int(c.nfit)
+                cc.corr = corr.ctypes.data_as(C.POINTER(C.c_int))
+                cc.tmpl = _p(tm)
+                cc.template_amplitudes = _p(ta)
             for q in range(c.nindices):
                 cc.lnl_type[q] = LNL_CODES[c.lnl_type[q]] if q < len(c.lnl_type) else 1
                 cc.prior_type[q] = PRIOR_CODES[c.prior_type[q]] if q < len(c.prior_type) else 2
@@ -170,6 +183,9 @@ class Oracle:
 
     def amplitude(self, l):
         return self.amp[l]
+
+    def template_amplitudes(self, l):
+        return self._glob[l][2]
 
     def indices(self, l):
         return self.idx[l]
