@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("DANGX_LIB") or os.path.join(_HERE, "lib", "libdangx.s
 MAX_BANDS, MAX_COMPS, MAX_IND, MAX_GROUP = 32, 16, 2, 8
 
 # enums (include/dangx.h)
-POWERLAW, MBB, FREEFREE, LOGNORMAL, CMB, TCMB = 1, 2, 3, 4, 5, 6
+POWERLAW, MBB, FREEFREE, LOGNORMAL, CMB, TCMB, TEMPLATE, MONOPOLE, HIFIT = 1, 2, 3, 4, 5, 6, 7, 8, 9
 LNL_CHISQ, LNL_MARGINAL, LNL_PRIOR = 1, 2, 3
 PRIOR_GAUSSIAN, PRIOR_UNIFORM, PRIOR_JEFFREYS = 1, 2, 3
 ML_SAMPLE, ML_OPTIMIZE = 1, 2
@@ -24,7 +24,8 @@ K_AMP_DIRECT, K_INDEX_MH, K_SKY_CHISQ, K_REDUCE, K_CG_AX, K_CG_VEC, K_GIBBS_FUSE
 KERNEL_NAMES = {K_AMP_DIRECT: "k_amp_direct", K_INDEX_MH: "k_index_mh", K_SKY_CHISQ: "k_sky_chisq",
                 K_REDUCE: "k_reduce", K_CG_AX: "k_Ax", K_CG_VEC: "k_cg_vec", K_GIBBS_FUSED: "k_gibbs_fused"}
 
-TYPE_CODES = {"power-law": POWERLAW, "mbb": MBB, "freefree": FREEFREE, "lognormal": LOGNORMAL, "cmb": CMB, "T_cmb": TCMB}
+TYPE_CODES = {"power-law": POWERLAW, "mbb": MBB, "freefree": FREEFREE, "lognormal": LOGNORMAL, "cmb": CMB, "T_cmb": TCMB,
+              "template": TEMPLATE, "monopole": MONOPOLE, "hi_fit": HIFIT}
 LNL_CODES = {"chisq": LNL_CHISQ, "marginal": LNL_MARGINAL, "prior": LNL_PRIOR}
 PRIOR_CODES = {"gaussian": PRIOR_GAUSSIAN, "uniform": PRIOR_UNIFORM, "jeffreys": PRIOR_JEFFREYS}
 ML_CODES = {"sample": ML_SAMPLE, "optimize": ML_OPTIMIZE}
@@ -63,6 +64,9 @@ SYMBOLS = {
     "dangx_get_amplitude": (C.c_int, [_P, C.c_int, _P]),
     "dangx_put_indices": (C.c_int, [_P, C.c_int, _P]),
     "dangx_get_indices": (C.c_int, [_P, C.c_int, _P]),
+    "dangx_set_template": (C.c_int, [_P, C.c_int, _P, _P, C.c_int]),
+    "dangx_put_template_amplitudes": (C.c_int, [_P, C.c_int, _P]),
+    "dangx_get_template_amplitudes": (C.c_int, [_P, C.c_int, _P]),
     "dangx_adopt_device_state": (C.c_int, [_P, C.c_int, _P, _P]),
     "dangx_amplitude_devptr": (_P, [_P, C.c_int]),
     "dangx_indices_devptr": (_P, [_P, C.c_int]),

@@ -184,6 +184,14 @@ class Engine:
         else:
             s, r, m = (np.ascontiguousarray(a, dtype=np.float64) for a in (ddata.sig_map, ddata.rms_map, ddata.masks))
             self._chk(self.lib.dangx_upload_data(self.h, s.ctypes.data, r.ctypes.data, m.ctypes.data))
+        for l, c in enumerate(component_list):
+            if c.type in ("template", "monopole", "hi_fit"):
+                tm = np.ascontiguousarray(c.template, dtype=np.float64)
+                corr = np.ascontiguousarray(np.asarray(c.corr, dtype=bool).astype(np.int32))
+                assert tm.shape == (nmaps, npix) and corr.size == nb
+                self._chk(self.lib.dangx_set_template(self.h, l, tm.ctypes.data, corr.ctypes.data, int(c.nfit)))
+                if c.template_amplitudes is not None:
+                    self.put_template_amplitudes(l, c.template_amplitudes)
         self._adopted = {}
         for l, c in enumerate(component_list):
             if c.amplitude is not None and _is_torch(c.amplitude) and c.amplitude.is_cuda:
@@ -251,12 +259,24 @@ class Engine:
         self._chk(self.lib.dangx_get_indices(self.h, l, x.ctypes.data))
         return x
 
+    def put_template_amplitudes(self, l, ta):
+        ta = np.ascontiguousarray(ta, dtype=np.float64)
+        assert ta.shape == (self.nmaps, self.nbands)
+        self._chk(self.lib.dangx_put_template_amplitudes(self.h, l, ta.ctypes.data))
+
+    def get_template_amplitudes(self, l):
+        ta = np.empty((self.nmaps, self.nbands))
+        self._chk(self.lib.dangx_get_template_amplitudes(self.h, l, ta.ctypes.data))
+        return ta
+
     def pull_state(self):
         """Copy the resident amplitude / index maps back into component_list (before output)."""
         for l, c in enumerate(self.component_list):
             c.amplitude = self.get_amplitude(l)
             if c.nindices > 0:
                 c.indices = self.get_indices(l)
+            if c.type in ("template", "monopole", "hi_fit"):
+                c.template_amplitudes = self.get_template_amplitudes(l)
 
     # -- hot path
     def amp_sample(self, group, flag, ml_mode, seed, stream, solver="direct", fluct_mode="reference",
@@ -385,7 +405,7 @@ class Engine:
 def comp_desc(c: DangComps):
     d = L.CompDesc()
     if c.type not in L.TYPE_CODES:
-        raise DangxError("Error - unrecognized component type '%s' (template/monopole/hi_fit/T_cmb: not built)" % c.type)
+        raise DangxError("Error - unrecognized component type '%s'" % c.type)
     d.type = L.TYPE_CODES[c.type]
     d.is_synch = 1 if c.label.strip() == "synch" else 0
     d.nindices = c.nindices
@@ -430,11 +450,16 @@ def sample_cg_groups(dpar: DangParams, ddata: DangData, it=1, verbose=False, def
     for g in dpar.cg_groups:
         if not g.sample:
             continue
+        has_global = any(c.cg_group == g.cg_group and c.type in ("template", "monopole", "hi_fit") for c in eng.component_list)
         for f in g.pol_flag:
             cg_it, bad = eng.amp_sample(g.cg_group, f, dpar.ml_mode, dpar.seed, stream_id(it, 0, g.cg_group, 0, f),
-                                        solver=dpar.solver, fluct_mode=dpar.fluct_mode, i_max=g.i_max,
-                                        converge=g.converge)
+                                        solver="cg" if has_global else dpar.solver, fluct_mode=dpar.fluct_mode,
+                                        i_max=g.i_max, converge=g.converge)
             info.append((g.cg_group, f, cg_it, bad))
+        if has_global:  # update_sky_model: self%offset = c%template_amplitudes(:,1) of a monopole (src/dang_data_mod.f90:357-361)
+            for l, c in enumerate(eng.component_list):
+                if c.type == "monopole" and c.cg_group == g.cg_group:
+                    ddata.offset = eng.get_template_amplitudes(l)[0].copy()
         if not defer_chisq:
             compute_chisq(ddata)  # update_sky_model + write_stats_to_term, :172-173
             if verbose:

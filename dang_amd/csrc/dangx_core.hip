@@ -77,6 +77,22 @@ __global__ __launch_bounds__(BLOCK) void k_cg_vec(int mode, long long n, double 
     }
 }
 
+// block partials of sum(u*v)
+__global__ __launch_bounds__(BLOCK) void k_dot(const double* __restrict__ u, const double* __restrict__ v, long long n,
+                                               double* __restrict__ partial) {
+    __shared__ double sh[BLOCK / 64];
+    const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    double s = (t < n) ? u[t] * v[t] : 0.0;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double w = 0.0;
+        for (int q = 0; q < BLOCK / 64; ++q) w += sh[q];
+        partial[blockIdx.x] = w;
+    }
+}
+
 // deterministic second stage: out[0] = sum(partial[0..n)) in a fixed order
 __global__ __launch_bounds__(BLOCK) void k_reduce(const double* __restrict__ partial, long long n, double* __restrict__ out) {
     __shared__ double sh[BLOCK];
@@ -167,11 +183,12 @@ __global__ __launch_bounds__(BLOCK) void k_sky_chisq(const Model* __restrict__ M
                 for (int l = 0; l < M.ncomp; ++l) {
                     const Comp& c = M.comp[l];
                     const double amp = c.amp[(long long)(k - 1) * npix + i];
-                    if (amp == 0.0 && !want_maps && c.type != DANGX_TCMB) continue;
+                    if (c.type == DANGX_MONOPOLE) continue;  // sets the band offsets instead (src/dang_data_mod.f90:357-361)
+                    if (amp == 0.0 && !want_maps && c.type != DANGX_TCMB && !is_global_type(c.type)) continue;
                     double t0, t1;
                     load_theta(M, c, i, k, t0, t1);
                     const Prep pr = sed_prep(c, t0, t1);
-                    for (int j = 0; j < nb; ++j) lds[j * BS + tid] = lds[j * BS + tid] + signal_of(c, amp, sed_eval(M, c, j, pr));
+                    for (int j = 0; j < nb; ++j) lds[j * BS + tid] = lds[j * BS + tid] + comp_signal(M, c, i, k, j, amp, pr);
                 }
                 double chi = 0.0;
                 for (int j = 0; j < nb; ++j) {
@@ -224,7 +241,7 @@ __global__ __launch_bounds__(BLOCK) void k_fullsky_prepare(const Model* __restri
                 const Comp& c2 = M.comp[__builtin_ctz(om)];
                 double t0, t1;
                 load_theta(M, c2, i, k, t0, t1);
-                d = d - signal_of(c2, c2.amp[(long long)(k - 1) * npix + i], sed_eval(M, c2, j, sed_prep(c2, t0, t1)));
+                d = d - comp_signal(M, c2, i, k, j, c2.amp[(long long)(k - 1) * npix + i], sed_prep(c2, t0, t1));
             }
             out[((long long)(k - s1) * nb + j) * npix + i] = d;
         }
@@ -298,7 +315,8 @@ __global__ __launch_bounds__(BLOCK) void k_gain_rows(const Model* __restrict__ M
             const Comp& c = M.comp[l];
             double t0, t1;
             load_theta(M, c, i, 1, t0, t1);
-            sky = sky + signal_of(c, c.amp[i], sed_eval(M, c, band, sed_prep(c, t0, t1)));
+            if (c.type == DANGX_MONOPOLE) continue;
+            sky = sky + comp_signal(M, c, i, 1, band, c.amp[i], sed_prep(c, t0, t1));
         }
         const long long q = ((long long)band * M.nmaps) * npix + i;
         const double res = (M.sig[q] - M.offset[band]) / M.gain[band] - sky;  // res_map(i,1,band), :384
@@ -380,12 +398,17 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sed(const Model* __restrict__ Mp
     const Comp& c = M.comp[comp];
     double t0, t1;
     load_theta(M, c, i, map_n, t0, t1);
-    out[i] = sed_eval(M, c, band, sed_prep(c, t0, t1));
+    out[i] = comp_sed(M, c, i, map_n, band, sed_prep(c, t0, t1));
 }
 
 }  // namespace
 
 // ======================================================================= host side
+
+void dx_reduce_rows_to(dangx_ctx* ctx, const double* partial, unsigned nblk, int rows, double* out_dev) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(k_reduce_rows_final, dim3(1), dim3(BLOCK), 0, ctx->stream, partial, (long long)nblk, rows, out_dev);
+}
 
 namespace {
 
@@ -447,7 +470,8 @@ int sync_model(dangx_ctx* ctx) {
     M.sig = ctx->sig; M.rms = ctx->rms; M.mask = ctx->mask;
     M.all_delta = 1;
     for (int j = 0; j < M.nbands; ++j) if (M.band[j].n != 0) M.all_delta = 0;
-    for (int l = 0; l < M.ncomp; ++l) if (ctx->desc[l].type == DANGX_TCMB) M.all_delta = 0;  // bare-sed signal: generic paths only
+    for (int l = 0; l < M.ncomp; ++l)
+        if (ctx->desc[l].type == DANGX_TCMB || is_global_type(ctx->desc[l].type)) M.all_delta = 0;  // generic paths only
     if (!ctx->bp_nu0.empty()) {
         if (ctx->d_bp_nu0) { (void)hipFree(ctx->d_bp_nu0); (void)hipFree(ctx->d_bp_tau0); }
         const size_t nbytes = ctx->bp_nu0.size() * sizeof(double);
@@ -463,6 +487,10 @@ int sync_model(dangx_ctx* ctx) {
         c.type = d.type; c.nind = d.nindices; c.group = d.cg_group; c.sample_amp = d.sample_amplitude;
         c.is_synch = d.is_synch; c.nu_ref = d.nu_ref;
         c.amp = ctx->amp[l]; c.idx = ctx->idx[l];
+        c.tmpl = ctx->tmpl[l]; c.corr_mask = ctx->corr_mask[l]; c.nfit = ctx->nfit[l];
+        for (int k = 0; k < 3; ++k)
+            for (int j = 0; j < MAXB; ++j) c.tamp[k][j] = ctx->tamp[l][k][j];
+        if (is_global_type(c.type) && !c.tmpl) return fail(ctx, "global-amplitude component without a template map (dangx_set_template)");
         for (int q = 0; q < MAXI; ++q) {
             c.lnl_type[q] = d.lnl_type[q]; c.prior_type[q] = d.prior_type[q];
             c.gauss[q][0] = d.gauss_prior[q][0]; c.gauss[q][1] = d.gauss_prior[q][1];
@@ -533,17 +561,24 @@ int make_group(dangx_ctx* ctx, int group, int flag, GroupArgs& a) {
     a.flag = flag;
     for (int l = 0; l < ctx->hm.ncomp; ++l) {
         const dangx_comp_desc& d = ctx->desc[l];
-        if (d.cg_group == group && d.sample_amplitude) {
+        if (d.type == DANGX_TEMPLATE || d.type == DANGX_MONOPOLE) a.uc[a.nuc++] = l;
+        if (d.cg_group == group && d.sample_amplitude && is_global_type(d.type)) {
+            if (a.nt >= MAXT) return fail(ctx, "too many global-amplitude components in CG group");
+            if (d.type != DANGX_TEMPLATE && flag != DANGX_FLAG_T)
+                return fail(ctx, "hi_fit / monopole components are fitted on plane 1: use CG_POLTYPE T for their group");
+            a.tc[a.nt] = l; a.trow[a.nt] = a.nglob; a.nglob += ctx->nfit[l]; ++a.nt;
+        } else if (d.cg_group == group && d.sample_amplitude) {
+            if (a.nt > 0) return fail(ctx, "diffuse components must precede the global-amplitude ones in a CG group");
             if (a.ng >= MAXG) return fail(ctx, "too many components in CG group");
             a.gc[a.ng++] = l;
         } else {
             unsigned planes = 0;  // planes this (group, flag) works on
             for (int pl = 0; pl < flag_planes_h(flag); ++pl)
                 planes |= 1u << (((flag & DANGX_FLAG_QU) ? 2 + pl : (flag & DANGX_FLAG_T) ? 1 : (flag & DANGX_FLAG_Q) ? 2 : 3) - 1);
-            if ((ctx->plane_nz[l] & planes) || ctx->desc[l].type == DANGX_TCMB) a.oc[a.no++] = l;  // all-zero plane: 0*sed, skipped
+            if ((ctx->plane_nz[l] & planes) || ctx->desc[l].type == DANGX_TCMB || is_global_type(ctx->desc[l].type)) a.oc[a.no++] = l;  // all-zero plane: 0*sed, skipped
         }
     }
-    if (a.ng == 0) return fail(ctx, "Woah there, number of CG components = 0 for CG group " + std::to_string(group));
+    if (a.ng + a.nt == 0) return fail(ctx, "Woah there, number of CG components = 0 for CG group " + std::to_string(group));
     return 0;
 }
 
@@ -558,35 +593,85 @@ int reduce_to_host(dangx_ctx* ctx, long long nblk, double* out) {
     return 0;
 }
 
-// cg_search on the device, src/dang_cg_mod.f90:179-324.  work[0]=x, [1]=r, [2]=d, [3]=q, [4]=b2, [5]=eta/b
+// global rows of x <-> c%template_amplitudes (initialize_x :1244-1279, unpack_amplitudes :1355-1393)
+void globals_to_x(dangx_ctx* ctx, const GroupArgs& a, std::vector<double>& xg) {
+    xg.assign(std::max(a.nglob, 1), 0.0);
+    const int k = (a.flag & DANGX_FLAG_QU) ? 2 : (a.flag & DANGX_FLAG_T) ? 1 : (a.flag & DANGX_FLAG_Q) ? 2 : 3;
+    for (int t = 0; t < a.nt; ++t) {
+        const int l = a.tc[t];
+        int lf = 0;
+        for (int j = 0; j < ctx->hm.nbands && lf < ctx->nfit[l]; ++j)
+            if ((ctx->corr_mask[l] >> j) & 1) xg[a.trow[t] + lf++] = ctx->tamp[l][k - 1][j];
+    }
+}
+void x_to_globals(dangx_ctx* ctx, const GroupArgs& a, const std::vector<double>& xg) {
+    const int k = (a.flag & DANGX_FLAG_QU) ? 2 : (a.flag & DANGX_FLAG_T) ? 1 : (a.flag & DANGX_FLAG_Q) ? 2 : 3;
+    for (int t = 0; t < a.nt; ++t) {
+        const int l = a.tc[t];
+        int lf = 0;
+        for (int j = 0; j < ctx->hm.nbands && lf < ctx->nfit[l]; ++j)
+            if ((ctx->corr_mask[l] >> j) & 1) {
+                const double v = xg[a.trow[t] + lf++];
+                if (ctx->desc[l].type == DANGX_TEMPLATE && (a.flag & DANGX_FLAG_QU)) {  // :1380-1382 one amplitude for Q and U
+                    ctx->tamp[l][1][j] = v; ctx->tamp[l][2][j] = v;
+                } else {
+                    ctx->tamp[l][k - 1][j] = v;
+                }
+            }
+        if (ctx->desc[l].type == DANGX_MONOPOLE)  // update_sky_model: self%offset = c%template_amplitudes(:,1), src/dang_data_mod.f90:357-361
+            for (int j = 0; j < ctx->hm.nbands; ++j) ctx->hm.offset[j] = ctx->tamp[l][0][j];
+    }
+    ctx->dirty = true;
+}
+
+// sum(a*b) over n entries -> host (deterministic two-stage reduction)
+int device_dot(dangx_ctx* ctx, const double* u, const double* v, long long n, double* out) {
+    const unsigned nblk = nblocks(n);
+    if (ensure_partial(ctx, nblk)) return 1;
+    hipLaunchKernelGGL(k_dot, dim3(nblk), dim3(BLOCK), 0, ctx->stream, u, v, n, ctx->partial);
+    return reduce_to_host(ctx, nblk, out);
+}
+
+// cg_search on the device, src/dang_cg_mod.f90:179-324.  work[0]=x, [1]=r, [2]=d, [3]=q, [4]=b2, [5]=eta/b.
+// Groups with global-amplitude members use the mixed kernels; their vectors are [diffuse | global rows].
 int device_cg(dangx_ctx* ctx, const GroupArgs& a, int i_max, double converge, int* iters) {
     const long long SN = (long long)flag_planes_h(a.flag) * ctx->hm.npix;
-    const long long n = SN * a.ng;
+    const long long n = SN * a.ng + a.nglob;
+    const bool mixed = a.nt > 0;
     if (ensure_work(ctx, n)) return 1;
     if (ensure_partial(ctx, nblocks(n))) return 1;
     double *x = ctx->work[0], *r = ctx->work[1], *d = ctx->work[2], *q = ctx->work[3], *b2 = ctx->work[4], *tmp = ctx->work[5];
     hipStream_t st = ctx->stream;
+    auto Ax = [&](const double* in, double* out) -> int {
+        return mixed ? dx_launch_Ax_mixed(ctx, a, SN, in, out) : dx_launch_Ax(ctx, a, SN, in, out, nullptr);
+    };
     // b = compute_rhs
-    if (dx_launch_rhs(ctx, a, SN, tmp)) return 1;
+    if (mixed ? dx_launch_rhs_mixed(ctx, a, SN, tmp) : dx_launch_rhs(ctx, a, SN, tmp)) return 1;
     if (a.ml_mode == DANGX_ML_SAMPLE) {  // b2 = b + compute_sample_vector(eta)
         hipLaunchKernelGGL(k_draw_eta, dim3(nblocks(SN)), dim3(BLOCK), 0, st, ctx->dm, a, r);
-        if (dx_launch_sample_vector(ctx, a, SN, r, q)) return 1;
+        if (mixed ? dx_launch_sv_mixed(ctx, a, SN, r, q) : dx_launch_sample_vector(ctx, a, SN, r, q)) return 1;
         hipLaunchKernelGGL(k_cg_vec, dim3(nblocks(n)), dim3(BLOCK), 0, st, 3, n, 0.0, b2, nullptr, nullptr, q, tmp, nullptr);
     } else {
         HIPCHK(ctx, hipMemcpyAsync(b2, tmp, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
     }
     // x0 = current amplitudes (the reference keeps self%x; identical as amplitudes only change via unpack)
-    hipLaunchKernelGGL(k_pack, dim3(nblocks(SN)), dim3(BLOCK), 0, st, ctx->dm, a, x, 0);
-    if (dx_launch_Ax(ctx, a, SN, x, q, nullptr)) return 1;
+    if (a.ng) hipLaunchKernelGGL(k_pack, dim3(nblocks(SN)), dim3(BLOCK), 0, st, ctx->dm, a, x, 0);
+    std::vector<double> xg;
+    if (mixed) {
+        globals_to_x(ctx, a, xg);
+        HIPCHK(ctx, hipMemcpyAsync(x + SN * a.ng, xg.data(), sizeof(double) * a.nglob, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+    }
+    if (Ax(x, q)) return 1;
     hipLaunchKernelGGL(k_cg_vec, dim3(nblocks(n)), dim3(BLOCK), 0, st, 0, n, 0.0, x, r, d, q, b2, ctx->partial);
     double delta_new = 0.0, delta_old, dq = 0.0;
     if (reduce_to_host(ctx, nblocks(n), &delta_new)) return 1;
     int i = 1;
     while (i < i_max && delta_new > converge) {
-        if (ensure_partial(ctx, nblocks(SN))) return 1;
-        if (dx_launch_Ax(ctx, a, SN, d, q, ctx->partial)) return 1;
-        if (reduce_to_host(ctx, nblocks(SN), &dq)) return 1;
+        if (Ax(d, q)) return 1;
+        if (device_dot(ctx, d, q, n, &dq)) return 1;
         const double alpha = delta_new / dq;
+        if (ensure_partial(ctx, nblocks(n))) return 1;
         {
             Timed t(ctx, DANGX_K_CG_VEC);
             hipLaunchKernelGGL(k_cg_vec, dim3(nblocks(n)), dim3(BLOCK), 0, st, 1, n, alpha, x, r, d, q, b2, ctx->partial);
@@ -600,7 +685,12 @@ int device_cg(dangx_ctx* ctx, const GroupArgs& a, int i_max, double converge, in
         }
         i = i + 1;
     }
-    hipLaunchKernelGGL(k_pack, dim3(nblocks(SN)), dim3(BLOCK), 0, st, ctx->dm, a, x, 1);
+    if (a.ng) hipLaunchKernelGGL(k_pack, dim3(nblocks(SN)), dim3(BLOCK), 0, st, ctx->dm, a, x, 1);
+    if (mixed) {
+        HIPCHK(ctx, hipMemcpyAsync(xg.data(), x + SN * a.ng, sizeof(double) * a.nglob, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        x_to_globals(ctx, a, xg);
+    }
     if (iters) *iters = i;
     return 0;
 }
@@ -661,6 +751,7 @@ int dangx_destroy(dangx_ctx* ctx) {
     }
     for (auto& w : ctx->work) if (w) (void)hipFree(w);
     if (ctx->partial) (void)hipFree(ctx->partial);
+    for (int l = 0; l < MAXC; ++l) if (ctx->tmpl[l]) (void)hipFree(ctx->tmpl[l]);
     if (ctx->d_bp_nu0) { (void)hipFree(ctx->d_bp_nu0); (void)hipFree(ctx->d_bp_tau0); }
     if (ctx->fs_data) (void)hipFree(ctx->fs_data);
     (void)hipFree(ctx->rows_out);
@@ -701,9 +792,10 @@ int dangx_set_band(dangx_ctx* ctx, int band, double nu_c, int n, const double* n
 int dangx_set_component(dangx_ctx* ctx, int comp, const dangx_comp_desc* d) {
     if (!ctx || !d) return 1;
     if (check_comp(ctx, comp)) return 1;
-    if (d->type < DANGX_POWERLAW || d->type > DANGX_TCMB)
+    if (d->type < DANGX_POWERLAW || d->type > DANGX_HIFIT)
         return fail(ctx, "Error - unrecognized component type (only diffuse types are built)");
-    const int want = (d->type == DANGX_MBB || d->type == DANGX_LOGNORMAL) ? 2 : (d->type == DANGX_CMB ? 0 : 1);
+    const int want = (d->type == DANGX_MBB || d->type == DANGX_LOGNORMAL) ? 2
+                     : (d->type == DANGX_CMB || d->type == DANGX_TEMPLATE || d->type == DANGX_MONOPOLE) ? 0 : 1;
     if (d->type == DANGX_TCMB && d->sample_amplitude)
         return fail(ctx, "T_cmb cannot be amplitude-sampled on the device yet (SURVEY 8f rank 1)");
     if (d->nindices != want) return fail(ctx, "nindices does not match the component type");
@@ -818,6 +910,36 @@ int dangx_get_indices(dangx_ctx* ctx, int comp, double* ind) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
+int dangx_set_template(dangx_ctx* ctx, int comp, const double* tmpl, const int32_t* corr, int nfit) {
+    if (!ctx || !tmpl || !corr || check_comp(ctx, comp)) return 1;
+    if (!ctx->comp_set[comp] || !is_global_type(ctx->desc[comp].type)) return fail(ctx, "not a template / monopole / hi_fit component");
+    (void)hipSetDevice(ctx->device);
+    int mask = 0, cnt = 0;
+    for (int j = 0; j < ctx->dims.nbands; ++j) if (corr[j]) { mask |= 1 << j; ++cnt; }
+    if (cnt != nfit) return fail(ctx, "nfit does not match the number of fitted (corr) bands");
+    const size_t bytes = (size_t)ctx->dims.npix * ctx->dims.nmaps * sizeof(double);
+    if (!ctx->tmpl[comp]) HIPCHK(ctx, hipMalloc(&ctx->tmpl[comp], bytes));
+    HIPCHK(ctx, hipMemcpy(ctx->tmpl[comp], tmpl, bytes, hipMemcpyHostToDevice));
+    ctx->corr_mask[comp] = mask; ctx->nfit[comp] = nfit;
+    ctx->dirty = true;
+    return 0;
+}
+int dangx_put_template_amplitudes(dangx_ctx* ctx, int comp, const double* ta) {
+    if (!ctx || !ta || check_comp(ctx, comp)) return 1;
+    for (int k = 0; k < ctx->dims.nmaps; ++k)
+        for (int j = 0; j < ctx->dims.nbands; ++j) ctx->tamp[comp][k][j] = ta[k * ctx->dims.nbands + j];
+    if (ctx->desc[comp].type == DANGX_MONOPOLE)
+        for (int j = 0; j < ctx->dims.nbands; ++j) ctx->hm.offset[j] = ctx->tamp[comp][0][j];
+    ctx->dirty = true;
+    return 0;
+}
+int dangx_get_template_amplitudes(dangx_ctx* ctx, int comp, double* ta) {
+    if (!ctx || !ta || check_comp(ctx, comp)) return 1;
+    for (int k = 0; k < ctx->dims.nmaps; ++k)
+        for (int j = 0; j < ctx->dims.nbands; ++j) ta[k * ctx->dims.nbands + j] = ctx->tamp[comp][k][j];
+    return 0;
+}
+
 int dangx_adopt_device_state(dangx_ctx* ctx, int comp, double* amp_dev, double* idx_dev) {
     if (!ctx || !amp_dev || check_comp(ctx, comp)) return 1;
     if (!ctx->comp_set[comp]) return fail(ctx, "component not set");
@@ -864,7 +986,7 @@ void* dangx_indices_devptr(dangx_ctx* ctx, int comp) { return (ctx && comp >= 0 
 int64_t dangx_group_size(dangx_ctx* ctx, int group, int flag) {
     GroupArgs a;
     if (!ctx || make_group(ctx, group, flag, a)) return -1;
-    return (int64_t)a.ng * flag_planes_h(flag) * ctx->hm.npix;
+    return (int64_t)a.ng * flag_planes_h(flag) * ctx->hm.npix + a.nglob;
 }
 
 int dangx_amp_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed,
@@ -883,6 +1005,8 @@ int dangx_amp_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solve
     }
     if (cg_iters) *cg_iters = 0;
     if (n_not_spd) *n_not_spd = 0;
+    if (a.nt > 0 && solver != DANGX_SOLVER_CG)
+        return fail(ctx, "a CG group with template / monopole / hi_fit members is a coupled system: use DANGX_SOLVER_CG");
     if (solver == DANGX_SOLVER_CG) {
         if (fluct_mode != DANGX_FLUCT_REFERENCE && ml_mode == DANGX_ML_SAMPLE)
             return fail(ctx, "the CG solver reproduces the reference's fluctuation term only");
@@ -919,12 +1043,14 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
     else return fail(ctx, "There is something wrong with the poltype flag (map_n must be 1,2,3 or -1)");
     if (a.s2 > ctx->dims.nmaps) return fail(ctx, "map_n exceeds nmaps");
     if (d.lnl_type[nind] < DANGX_LNL_CHISQ || d.lnl_type[nind] > DANGX_LNL_PRIOR) return fail(ctx, "bad lnl_type");
+    if (d.type == DANGX_HIFIT) return fail(ctx, "hi_fit index sampling is not built (its model has one amplitude per band)");
     if (d.type == DANGX_TCMB) return fail(ctx, "T_cmb is sampled full-sky (index_mode 1) in the reference: not built (SURVEY 8f rank 2)");
     if (ml_mode != DANGX_ML_SAMPLE && ml_mode != DANGX_ML_OPTIMIZE) return fail(ctx, "bad ml_mode");
     const int Sp = a.s2 - a.s1 + 1;
     a.others = 0;
     for (int l = 0; l < ctx->hm.ncomp; ++l)
-        if (l != comp && ((ctx->plane_nz[l] & ((1u << (a.s1 - 1)) | (1u << (a.s2 - 1)))) || ctx->desc[l].type == DANGX_TCMB))
+        if (l != comp && ((ctx->plane_nz[l] & ((1u << (a.s1 - 1)) | (1u << (a.s2 - 1)))) || ctx->desc[l].type == DANGX_TCMB ||
+                          is_global_type(ctx->desc[l].type)))
             a.others |= 1u << l;
     // chain mode: factorised SED when every band is a delta bandpass
     const bool all_delta = ctx->hm.all_delta != 0;
@@ -1084,7 +1210,7 @@ int dangx_fullsky_prepare(dangx_ctx* ctx, int comp, int map_n) {
     }
     unsigned others = 0;
     for (int l = 0; l < ctx->hm.ncomp; ++l)
-        if (l != comp && ((ctx->plane_nz[l] & ((1u << (s1 - 1)) | (1u << (s2 - 1)))) || ctx->desc[l].type == DANGX_TCMB)) others |= 1u << l;
+        if (l != comp && ((ctx->plane_nz[l] & ((1u << (s1 - 1)) | (1u << (s2 - 1)))) || ctx->desc[l].type == DANGX_TCMB || is_global_type(ctx->desc[l].type))) others |= 1u << l;
     hipLaunchKernelGGL(k_fullsky_prepare, dim3(nblocks(ctx->hm.npix)), dim3(BLOCK), 0, ctx->stream, ctx->dm, comp, s1, s2, others, ctx->fs_data);
     HIPCHK(ctx, hipGetLastError());
     ctx->fs_comp = comp; ctx->fs_s1 = s1; ctx->fs_s2 = s2;
@@ -1167,7 +1293,7 @@ static int seam_common(dangx_ctx* ctx, int group, int flag, GroupArgs& a, long l
     (void)hipSetDevice(ctx->device);
     if (make_group(ctx, group, flag, a) || sync_model(ctx)) return 1;
     SN = (long long)flag_planes_h(flag) * ctx->hm.npix;
-    n = SN * a.ng;
+    n = SN * a.ng + a.nglob;
     if (ensure_work(ctx, n)) return 1;
     return 0;
 }
@@ -1176,7 +1302,7 @@ int dangx_compute_rhs(dangx_ctx* ctx, int group, int flag, double* b) {
     if (!ctx || !b) return 1;
     GroupArgs a; long long SN, n;
     if (seam_common(ctx, group, flag, a, SN, n)) return 1;
-    if (dx_launch_rhs(ctx, a, SN, ctx->work[0])) return 1;
+    if (a.nt ? dx_launch_rhs_mixed(ctx, a, SN, ctx->work[0]) : dx_launch_rhs(ctx, a, SN, ctx->work[0])) return 1;
     HIPCHK(ctx, hipMemcpyAsync(b, ctx->work[0], sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
@@ -1187,7 +1313,7 @@ int dangx_compute_Ax(dangx_ctx* ctx, int group, int flag, const double* x, doubl
     GroupArgs a; long long SN, n;
     if (seam_common(ctx, group, flag, a, SN, n)) return 1;
     HIPCHK(ctx, hipMemcpyAsync(ctx->work[0], x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    if (dx_launch_Ax(ctx, a, SN, ctx->work[0], ctx->work[1], nullptr)) return 1;
+    if (a.nt ? dx_launch_Ax_mixed(ctx, a, SN, ctx->work[0], ctx->work[1]) : dx_launch_Ax(ctx, a, SN, ctx->work[0], ctx->work[1], nullptr)) return 1;
     HIPCHK(ctx, hipMemcpyAsync(res, ctx->work[1], sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
@@ -1198,7 +1324,7 @@ int dangx_compute_sample_vector(dangx_ctx* ctx, int group, int flag, const doubl
     GroupArgs a; long long SN, n;
     if (seam_common(ctx, group, flag, a, SN, n)) return 1;
     HIPCHK(ctx, hipMemcpyAsync(ctx->work[0], eta, sizeof(double) * (size_t)SN, hipMemcpyHostToDevice, ctx->stream));
-    if (dx_launch_sample_vector(ctx, a, SN, ctx->work[0], ctx->work[1])) return 1;
+    if (a.nt ? dx_launch_sv_mixed(ctx, a, SN, ctx->work[0], ctx->work[1]) : dx_launch_sample_vector(ctx, a, SN, ctx->work[0], ctx->work[1])) return 1;
     HIPCHK(ctx, hipMemcpyAsync(res, ctx->work[1], sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;

@@ -240,7 +240,7 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
 #pragma unroll 1
                         for (int j = 0; j < nb; ++j)
                             C.D(kk, j) -= (MODE != CH_GENERIC) ? ca[kk] * sed_eval_tab(ty2, tab, nb, M.ncomp, l, j, pr)
-                                                               : signal_of(c2, ca[kk], sed_eval(M, c2, j, pr));
+                                                               : comp_signal(M, c2, i, a.s1 + kk, j, ca[kk], pr);
                     }
                 }
             l = ln;

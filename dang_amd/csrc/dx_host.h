@@ -29,6 +29,13 @@ struct GroupArgs {
     int flag;        // one poltype bit
     int ml_mode, fluct;
     unsigned long long seed, stream;
+    // global-amplitude members of the group (template / monopole / hi_fit), after the diffuse ones in x:
+    // x = [diffuse: ng blocks of S*npix | global: nglob entries], component t owns rows trow[t] .. trow[t]+nfit-1
+    int nt, nglob;
+    int tc[MAXT], trow[MAXT];
+    // every template / monopole of the model (any group): bands with corr == false are removed from the data
+    // in compute_rhs (src/dang_cg_mod.f90:445-460)
+    int nuc, uc[MAXC];
 };
 
 __device__ __forceinline__ int flag_nplanes(int flag) { return (flag & DANGX_FLAG_QU) ? 2 : 1; }
@@ -69,6 +76,9 @@ struct dangx_ctx {
     bool own_amp[MAXC] = {};
     bool own_idx[MAXC] = {};
     unsigned plane_nz[MAXC] = {};  // bit k-1: amplitude plane k of the component may be non-zero
+    double* tmpl[MAXC] = {};       // device c%template of global-amplitude components
+    int corr_mask[MAXC] = {}, nfit[MAXC] = {};
+    double tamp[MAXC][3][MAXB] = {};  // c%template_amplitudes, host mirror [map][band]
     unsigned idx_const[MAXC] = {}; // bit k-1: every index of the component is spatially constant on plane k
     double idx_val[MAXC][3][MAXI] = {};
     std::vector<double> bp_nu0, bp_tau0;
@@ -139,11 +149,18 @@ inline int flag_planes_h(int flag) { return (flag & DANGX_FLAG_QU) ? 2 : 1; }
 
 inline unsigned nblocks(long long n, int bs = BLOCK) { return (unsigned)((n + bs - 1) / bs); }
 
+// out[row] = sum(partial[row][0..nblk)) for rows 0..rows-1 (deterministic; defined in dangx_core.hip)
+void dx_reduce_rows_to(dangx_ctx* ctx, const double* partial, unsigned nblk, int rows, double* out_dev);
+
 // launchers defined next to their kernels
 int dx_launch_amp(dangx_ctx* ctx, const GroupArgs& a, long long SN);
 int dx_launch_rhs(dangx_ctx* ctx, const GroupArgs& a, long long SN, double* b);
 int dx_launch_Ax(dangx_ctx* ctx, const GroupArgs& a, long long SN, const double* x, double* res, double* part);
 int dx_launch_sample_vector(dangx_ctx* ctx, const GroupArgs& a, long long SN, const double* eta, double* res);
+// groups with global-amplitude members (a.nt > 0): vectors are [diffuse | global rows]
+int dx_launch_rhs_mixed(dangx_ctx* ctx, const GroupArgs& a, long long SN, double* b);
+int dx_launch_Ax_mixed(dangx_ctx* ctx, const GroupArgs& a, long long SN, const double* x, double* res);
+int dx_launch_sv_mixed(dangx_ctx* ctx, const GroupArgs& a, long long SN, const double* eta, double* res);
 // LDS-form Metropolis kernel (fast = chisq likelihood with CH_POW / CH_MBB_*; otherwise the generic chain)
 void dx_launch_mh_lds(dangx_ctx* ctx, const IndexArgs& a, bool fast, int Sp, unsigned nblk, int bs, size_t lds, unsigned long long* accp);
 // register-resident Metropolis kernels; return false when (mode, nb) is not instantiated

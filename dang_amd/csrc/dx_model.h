@@ -16,6 +16,7 @@ constexpr int MAXB = DANGX_MAX_BANDS;
 constexpr int MAXC = DANGX_MAX_COMPS;
 constexpr int MAXI = DANGX_MAX_IND;
 constexpr int MAXG = DANGX_MAX_GROUP;
+constexpr int MAXT = 4;  // global-amplitude components per CG group
 
 // constants, src/dang_util_mod.f90:12-15,19 (exact literals)
 constexpr double PI = 3.141592653589793238462643383279502884197;
@@ -47,6 +48,10 @@ struct Comp {
     // is then pixel independent and csed[k-1][j] holds it (evaluated once on the host)
     int const_planes, pad1;
     double csed[3][MAXB];
+    // global-amplitude types (template / monopole / hi_fit)
+    const double* tmpl;      // c%template [nmaps][npix]
+    int corr_mask, nfit;     // bit j: band j is fitted (c%corr), number of fitted bands
+    double tamp[3][MAXB];    // c%template_amplitudes(band, map) as [map][band]
 };
 
 struct Model {
@@ -65,5 +70,6 @@ struct Model {
 };
 
 __host__ __device__ inline bool is_masked(double m) { return m == 0.0 || m == MISSVAL; }
+__host__ __device__ inline bool is_global_type(int t) { return t >= DANGX_TEMPLATE && t <= DANGX_HIFIT; }
 
 }  // namespace dx

@@ -62,6 +62,7 @@ __device__ __forceinline__ Prep sed_prep(const Comp& c, double th0, double th1) 
         p.p1 = th1;
         break;
     case DANGX_TCMB:  // :830-834
+    case DANGX_HIFIT:  // :865-869
         p.p0 = th0;
         break;
     default:
@@ -173,6 +174,32 @@ __device__ __forceinline__ double sed_eval_tab(int type, const double* tab, int 
 // SED of component l on plane k when its indices are spatially constant there (host-evaluated)
 __device__ __forceinline__ double sed_const_tab(const double* tab, int nb, int l, int k, int j) {
     return tab[(TROWS * l + 2 + k) * nb + j];
+}
+
+// eval_sed / eval_signal for EVERY component type at (pixel i, map k, band j) -- the generic paths use these
+// (src/dang_component_mod.f90:754-813): template / monopole: sed = template(pix,map); hi_fit: template * evaluate_hi_fit;
+// signal = template_amplitudes(band,map) * sed for the three global types, the bare sed for T_cmb, amplitude * sed else.
+__device__ __forceinline__ double comp_sed(const Model& M, const Comp& c, int i, int k, int j, const Prep& p) {
+    if (c.type == DANGX_TEMPLATE || c.type == DANGX_MONOPOLE) return c.tmpl[(long long)(k - 1) * M.npix + i];
+    if (c.type == DANGX_HIFIT) {  // :850-884 (same expression as evaluate_T_cmb)
+        double s;
+        if (M.band[j].n == 0) s = planck_rj(M.band[j].nu_c, p.p0);
+        else {
+            s = 0.0;
+            for (int q = 0; q < M.band[j].n; ++q) {
+                const double nu = M.bp_nu0[M.band[j].off + q];
+                if (nu == 0.0) continue;
+                s = s + M.bp_tau0[M.band[j].off + q] * planck_rj(nu, p.p0);
+            }
+        }
+        return c.tmpl[(long long)(k - 1) * M.npix + i] * (s * 1e6f);
+    }
+    return sed_eval(M, c, j, p);
+}
+__device__ __forceinline__ double comp_signal(const Model& M, const Comp& c, int i, int k, int j, double amp, const Prep& p) {
+    const double s = comp_sed(M, c, i, k, j, p);
+    if (is_global_type(c.type)) return c.tamp[k - 1][j] * s;
+    return (c.type == DANGX_TCMB) ? s : amp * s;
 }
 
 // spectral indices of component c at (pixel i, map k): c%indices(i,k,:)

