@@ -15,7 +15,7 @@ module dangx_mod
   implicit none
 
   integer(c_int), parameter :: DANGX_POWERLAW = 1, DANGX_MBB = 2, DANGX_FREEFREE = 3, &
-       DANGX_LOGNORMAL = 4, DANGX_CMB = 5
+       DANGX_LOGNORMAL = 4, DANGX_CMB = 5, DANGX_TCMB = 6, DANGX_TEMPLATE = 7, DANGX_MONOPOLE = 8, DANGX_HIFIT = 9
   integer(c_int), parameter :: DANGX_LNL_CHISQ = 1, DANGX_LNL_MARGINAL = 2, DANGX_LNL_PRIOR = 3
   integer(c_int), parameter :: DANGX_PRIOR_GAUSSIAN = 1, DANGX_PRIOR_UNIFORM = 2, DANGX_PRIOR_JEFFREYS = 3
   integer(c_int), parameter :: DANGX_ML_SAMPLE = 1, DANGX_ML_OPTIMIZE = 2
@@ -114,6 +114,48 @@ module dangx_mod
        integer(c_int), value :: comp, nind, map_n, nsample, ml_mode
        integer(c_int64_t), value :: seed, stream
        integer(c_int64_t), intent(out) :: accepted
+     end function
+     integer(c_int) function dangx_set_template(ctx, comp, tmpl, corr, nfit) bind(C, name='dangx_set_template')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, tmpl, corr        ! corr: integer(c_int32_t)(nbands), 1 = fitted band
+       integer(c_int), value :: comp, nfit
+     end function
+     integer(c_int) function dangx_put_template_amplitudes(ctx, comp, ta) bind(C, name='dangx_put_template_amplitudes')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, ta                ! real(c_double)(nbands, nmaps) == C [map][band]
+       integer(c_int), value :: comp
+     end function
+     integer(c_int) function dangx_get_template_amplitudes(ctx, comp, ta) bind(C, name='dangx_get_template_amplitudes')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, ta
+       integer(c_int), value :: comp
+     end function
+     integer(c_int) function dangx_chisq_cached(ctx, which, pol_lo, pol_hi, chisq_sum) bind(C, name='dangx_chisq_cached')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: which, pol_lo, pol_hi
+       real(c_double), intent(out) :: chisq_sum
+     end function
+     integer(c_int) function dangx_fullsky_prepare(ctx, comp, map_n) bind(C, name='dangx_fullsky_prepare')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: comp, map_n
+     end function
+     integer(c_int) function dangx_fullsky_sums(ctx, what, theta, out, nout) bind(C, name='dangx_fullsky_sums')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, theta, out
+       integer(c_int), value :: what, nout
+     end function
+     integer(c_int) function dangx_fill_index(ctx, comp, nind, map_n, value) bind(C, name='dangx_fill_index')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: comp, nind, map_n
+       real(c_double), value :: value
+     end function
+     integer(c_int) function dangx_gain_sums(ctx, band, out) bind(C, name='dangx_gain_sums')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, out
+       integer(c_int), value :: band
      end function
      integer(c_int) function dangx_sky_model_chisq(ctx, pol_lo, pol_hi, chisq_sum, sky, res, chi_map) &
           bind(C, name='dangx_sky_model_chisq')

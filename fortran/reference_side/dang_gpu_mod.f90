@@ -36,6 +36,10 @@ contains
     case ('freefree');  type_code = DANGX_FREEFREE
     case ('lognormal'); type_code = DANGX_LOGNORMAL
     case ('cmb');       type_code = DANGX_CMB
+    case ('T_cmb');     type_code = DANGX_TCMB
+    case ('template');  type_code = DANGX_TEMPLATE
+    case ('monopole');  type_code = DANGX_MONOPOLE
+    case ('hi_fit');    type_code = DANGX_HIFIT
     case default
        write(*,*) 'dang_gpu_mod: component type not on the GPU path: ', trim(c%type)
        stop
@@ -49,6 +53,7 @@ contains
     type(dangx_dims)      :: dims
     type(dangx_comp_desc) :: d
     real(c_double), allocatable, target :: gain(:), offs(:)
+    integer(c_int32_t), allocatable, target :: icorr(:)
     integer :: i, j
 
     dims = dangx_dims(npix, nmaps, nbands, ncomp, 0_c_int64_t, int(npix, c_int64_t), -1, 0)
@@ -87,6 +92,13 @@ contains
           d%step_size(j)      = c%step_size(j)
        end do
        call dangx_check(gpu_ctx, dangx_set_component(gpu_ctx, i-1, d), 'set_component')
+       if (d%type >= DANGX_TEMPLATE) then     ! c%template(0:npix-1,nmaps), c%corr(nbands), c%nfit
+          allocate(icorr(nbands)); icorr = merge(1_c_int32_t, 0_c_int32_t, c%corr)
+          call dangx_check(gpu_ctx, dangx_set_template(gpu_ctx, i-1, c_loc(c%template), c_loc(icorr), c%nfit), 'set_template')
+          deallocate(icorr)
+          ! c%template_amplitudes(nbands,nmaps) is already [map][band] in memory
+          call dangx_check(gpu_ctx, dangx_put_template_amplitudes(gpu_ctx, i-1, c_loc(c%template_amplitudes)), 'put_tamp')
+       end if
     end do
     allocate(gain(nbands), offs(nbands)); gain = ddata%gain; offs = ddata%offset
     call dangx_check(gpu_ctx, dangx_set_calibration(gpu_ctx, c_loc(gain), c_loc(offs)), 'set_calibration')
@@ -112,6 +124,8 @@ contains
        c => component_list(i)%p
        call dangx_check(gpu_ctx, dangx_get_amplitude(gpu_ctx, i-1, c_loc(c%amplitude)), 'get_amplitude')
        if (c%nindices > 0) call dangx_check(gpu_ctx, dangx_get_indices(gpu_ctx, i-1, c_loc(c%indices)), 'get_indices')
+       if (trim(c%type) == 'template' .or. trim(c%type) == 'monopole' .or. trim(c%type) == 'hi_fit') &
+            call dangx_check(gpu_ctx, dangx_get_template_amplitudes(gpu_ctx, i-1, c_loc(c%template_amplitudes)), 'get_tamp')
     end do
   end subroutine dangx_pull_state
 
@@ -129,16 +143,25 @@ contains
     ! same signature and effect as sample_cg_groups, src/dang_cg_mod.f90:142-177
     type(dang_data)   :: ddata
     type(dang_params) :: dpar
-    integer(i4b) :: i, f, mode
-    integer(c_int) :: iters
+    integer(i4b) :: i, f, k, mode
+    integer(c_int) :: iters, solver
     integer(c_int64_t) :: nbad
     mode = merge(DANGX_ML_SAMPLE, DANGX_ML_OPTIMIZE, trim(dpar%ml_mode) == 'sample')
     do i = 1, ncg_groups
        if (cg_groups(i)%p%sample) then
           write(*,fmt='(a,i4)') "Computing a CG search of CG group ", i
+          ! a group with template / monopole / hi_fit members is a coupled system: the reference's CG on the device
+          solver = DANGX_SOLVER_DIRECT
+          if (cg_groups(i)%p%ntemp > 0) then
+             do k = 1, cg_groups(i)%p%ncg_components
+                select case (trim(cg_groups(i)%p%cg_component(k)%p%type))
+                case ('template', 'monopole', 'hi_fit'); solver = DANGX_SOLVER_CG
+                end select
+             end do
+          end if
           do f = 1, cg_groups(i)%p%nflag
              call dangx_check(gpu_ctx, dangx_amp_sample(gpu_ctx, i, cg_groups(i)%p%pol_flag(f), mode, &
-                  DANGX_SOLVER_DIRECT, DANGX_FLUCT_REFERENCE, gpu_seed, &
+                  solver, DANGX_FLUCT_REFERENCE, gpu_seed, &
                   dangx_stream_id(iter, 0, i, 0, cg_groups(i)%p%pol_flag(f)), cg_groups(i)%p%i_max, &
                   cg_groups(i)%p%converge, iters, nbad), 'amp_sample')
              if (nbad > 0) write(*,*) 'warning: ', nbad, ' non-SPD pixel blocks left unchanged'
