@@ -20,9 +20,9 @@ ML_SAMPLE, ML_OPTIMIZE = 1, 2
 FLAG_T, FLAG_Q, FLAG_U, FLAG_QU = 1, 2, 4, 8
 SOLVER_DIRECT, SOLVER_CG = 0, 1
 FLUCT_CORRECT, FLUCT_REFERENCE = 0, 1
-K_AMP_DIRECT, K_INDEX_MH, K_SKY_CHISQ, K_REDUCE, K_CG_AX, K_CG_VEC, K_GIBBS_FUSED = range(7)
+K_AMP_DIRECT, K_INDEX_MH, K_SKY_CHISQ, K_REDUCE, K_CG_AX, K_CG_VEC = range(6)
 KERNEL_NAMES = {K_AMP_DIRECT: "k_amp_direct", K_INDEX_MH: "k_index_mh", K_SKY_CHISQ: "k_sky_chisq",
-                K_REDUCE: "k_reduce", K_CG_AX: "k_Ax", K_CG_VEC: "k_cg_vec", K_GIBBS_FUSED: "k_gibbs_fused"}
+                K_REDUCE: "k_reduce", K_CG_AX: "k_Ax", K_CG_VEC: "k_cg_vec"}
 
 TYPE_CODES = {"power-law": POWERLAW, "mbb": MBB, "freefree": FREEFREE, "lognormal": LOGNORMAL, "cmb": CMB, "T_cmb": TCMB,
               "template": TEMPLATE, "monopole": MONOPOLE, "hi_fit": HIFIT}

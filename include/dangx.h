@@ -66,7 +66,7 @@ enum { DANGX_FLUCT_CORRECT = 0, DANGX_FLUCT_REFERENCE = 1 };
 /* kernel ids for dangx_profile_get */
 enum {
     DANGX_K_AMP_DIRECT = 0, DANGX_K_INDEX_MH = 1, DANGX_K_SKY_CHISQ = 2, DANGX_K_REDUCE = 3,
-    DANGX_K_CG_AX = 4, DANGX_K_CG_VEC = 5, DANGX_K_GIBBS_FUSED = 6, DANGX_K_COUNT = 8
+    DANGX_K_CG_AX = 4, DANGX_K_CG_VEC = 5, DANGX_K_COUNT = 8
 };
 
 typedef struct dangx_ctx dangx_ctx;
