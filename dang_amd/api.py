@@ -453,7 +453,7 @@ def sample_cg_groups(dpar: DangParams, ddata: DangData, it=1, verbose=False, def
         has_global = any(c.cg_group == g.cg_group and c.type in ("template", "monopole", "hi_fit") for c in eng.component_list)
         for f in g.pol_flag:
             cg_it, bad = eng.amp_sample(g.cg_group, f, dpar.ml_mode, dpar.seed, stream_id(it, 0, g.cg_group, 0, f),
-                                        solver="cg" if has_global else dpar.solver, fluct_mode=dpar.fluct_mode,
+                                        solver=dpar.solver, fluct_mode=dpar.fluct_mode,
                                         i_max=g.i_max, converge=g.converge)
             info.append((g.cg_group, f, cg_it, bad))
         if has_global:  # update_sky_model: self%offset = c%template_amplitudes(:,1) of a monopole (src/dang_data_mod.f90:357-361)

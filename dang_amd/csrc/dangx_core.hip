@@ -340,7 +340,7 @@ __global__ __launch_bounds__(BLOCK) void k_gain_rows(const Model* __restrict__ M
 __global__ __launch_bounds__(BLOCK) void k_reduce_rows_final(const double* __restrict__ partial, long long n, int rows,
                                                              double* __restrict__ out) {
     __shared__ double sh[BLOCK];
-    for (int q = 0; q < rows; ++q) {
+    for (int q = blockIdx.x; q < rows; q += gridDim.x) {  // a row is always summed by one block, in one order
         double s = 0.0;
         for (long long t = threadIdx.x; t < n; t += BLOCK) s += partial[(long long)q * n + t];
         sh[threadIdx.x] = s;
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sed(const Model* __restrict__ Mp
 
 void dx_reduce_rows_to(dangx_ctx* ctx, const double* partial, unsigned nblk, int rows, double* out_dev) {
     if (rows <= 0) return;
-    hipLaunchKernelGGL(k_reduce_rows_final, dim3(1), dim3(BLOCK), 0, ctx->stream, partial, (long long)nblk, rows, out_dev);
+    hipLaunchKernelGGL(k_reduce_rows_final, dim3(rows < 1024 ? rows : 1024), dim3(BLOCK), 0, ctx->stream, partial, (long long)nblk, rows, out_dev);
 }
 
 namespace {
@@ -693,6 +693,97 @@ int device_cg(dangx_ctx* ctx, const GroupArgs& a, int i_max, double converge, in
     }
     if (iters) *iters = i;
     return 0;
+}
+
+// Direct solve of a group with global-amplitude members: eliminate every (pixel, plane) block on the device
+// (pass 1), solve the nglob x nglob Schur system on the host, back-substitute per unit (pass 2).  The linear
+// system is the one cg_search iterates on (compute_rhs / compute_Ax / compute_sample_vector,
+// src/dang_cg_mod.f90:326-1096), quirks included; the answer is its exact solution instead of the iterate at i_max.
+int device_schur(dangx_ctx* ctx, const GroupArgs& a, long long SN, int64_t* n_not_spd) {
+    const int R = a.nglob, nb = ctx->hm.nbands;
+    if (R > DX_MAX_ROWS) return fail(ctx, "more than 32 global amplitudes in one CG group: use DANGX_SOLVER_CG");
+    SchurArgs sa;
+    std::memset(&sa, 0, sizeof(sa));
+    sa.nrows = R;
+    for (int j = 0; j < MAXB; ++j) sa.bslot[j] = -1;
+    for (int t = 0; t < a.nt; ++t) {
+        const int l = a.tc[t];
+        int lf = 0;
+        for (int j = 0; j < nb && lf < ctx->nfit[l]; ++j)
+            if ((ctx->corr_mask[l] >> j) & 1) {
+                const int r = a.trow[t] + lf++;
+                sa.rt[r] = (unsigned char)t; sa.rj[r] = (unsigned char)j; sa.ftarget[r] = -1;
+            }
+    }
+    for (int j = 0; j < nb; ++j)
+        for (int r = 0; r < R; ++r)
+            if (sa.rj[r] == j && sa.bslot[j] < 0) sa.bslot[j] = (signed char)sa.nslots++;
+    int lrun = 0;  // the running row counter of compute_sample_vector (:970, :1057, :1071, :1094)
+    for (int j = 0; j < nb; ++j)
+        for (int t = 0; t < a.nt; ++t) {
+            const unsigned m = ctx->corr_mask[a.tc[t]];
+            if ((m >> j) & 1) {
+                int lt = 0;
+                for (int jj = 0; jj < j; ++jj) lt += (m >> jj) & 1;
+                if (lt < ctx->nfit[a.tc[t]] && lrun < R) sa.ftarget[a.trow[t] + lt] = (signed char)lrun;
+                ++lrun;
+            }
+        }
+    const int nrows = R * R + 3 * R;
+    if (ensure_work(ctx, std::max<long long>(nrows, 1))) return 1;
+    if (dx_launch_schur_pass1(ctx, a, sa, SN, ctx->work[0])) return 1;
+    std::vector<double> rows(nrows);
+    unsigned long long bad = 0;
+    HIPCHK(ctx, hipMemcpyAsync(rows.data(), ctx->work[0], sizeof(double) * nrows, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&bad, ctx->counters, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_not_spd) *n_not_spd = (int64_t)bad;
+    // S g = t (+ fluctuation sums): Gaussian elimination with partial pivoting (S is not symmetric when a monopole is fitted)
+    std::vector<double> S(rows.begin(), rows.begin() + (size_t)R * R), g(rows.begin() + (size_t)R * R, rows.begin() + (size_t)R * R + R);
+    if (a.ml_mode == DANGX_ML_SAMPLE)
+        for (int r = 0; r < R; ++r)
+            if (sa.ftarget[r] >= 0) g[sa.ftarget[r]] += rows[(size_t)R * R + R + r];
+    // equilibrate (row amplitudes span ~1e-6 for hi_fit to ~1e2), then eliminate; a pivot that cancels to rounding
+    // level means the global rows are degenerate with the diffuse members (e.g. a template fitted at every band
+    // together with a pixel-independent SED such as the CMB): the reference's CG drifts along that valley, a
+    // direct solve has no answer to give.
+    std::vector<double> sc(R);
+    for (int r = 0; r < R; ++r) {
+        const double dg = std::fabs(rows[(size_t)R * R + 2 * R + r]);  // G[r][r] = sum_u w_r s_r / sigma^2, before elimination
+        if (!(dg > 0.0) || !std::isfinite(dg))
+            return fail(ctx, "global amplitude row " + std::to_string(r) + " of the CG group has no support (template zero or fully masked)");
+        sc[r] = 1.0 / std::sqrt(dg);
+    }
+    for (int r = 0; r < R; ++r) {
+        for (int k = 0; k < R; ++k) S[(size_t)r * R + k] *= sc[r] * sc[k];
+        g[r] *= sc[r];
+    }
+    for (int c = 0; c < R; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < R; ++r)
+            if (std::fabs(S[(size_t)r * R + c]) > std::fabs(S[(size_t)piv * R + c])) piv = r;
+        if (!(std::fabs(S[(size_t)piv * R + c]) > 1e-10))  // in units of G's diagonal: 1 = nothing absorbed by the diffuse members
+            return fail(ctx, "the global amplitudes of the CG group are degenerate with its diffuse members (pivot " +
+                             std::to_string(S[(size_t)piv * R + c]) + "): fit them on fewer bands or use DANGX_SOLVER_CG");
+        if (piv != c) {
+            for (int k = 0; k < R; ++k) std::swap(S[(size_t)piv * R + k], S[(size_t)c * R + k]);
+            std::swap(g[piv], g[c]);
+        }
+        for (int r = c + 1; r < R; ++r) {
+            const double f = S[(size_t)r * R + c] / S[(size_t)c * R + c];
+            for (int k = c; k < R; ++k) S[(size_t)r * R + k] -= f * S[(size_t)c * R + k];
+            g[r] -= f * g[c];
+        }
+    }
+    for (int r = R - 1; r >= 0; --r) {
+        double v = g[r];
+        for (int k = r + 1; k < R; ++k) v -= S[(size_t)r * R + k] * g[k];
+        g[r] = v / S[(size_t)r * R + r];
+    }
+    for (int r = 0; r < R; ++r) g[r] *= sc[r];
+    x_to_globals(ctx, a, g);
+    if (sync_model(ctx)) return 1;
+    return dx_launch_schur_pass2(ctx, a, SN);
 }
 
 int check_comp(dangx_ctx* ctx, int comp) {
@@ -1005,8 +1096,11 @@ int dangx_amp_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solve
     }
     if (cg_iters) *cg_iters = 0;
     if (n_not_spd) *n_not_spd = 0;
-    if (a.nt > 0 && solver != DANGX_SOLVER_CG)
-        return fail(ctx, "a CG group with template / monopole / hi_fit members is a coupled system: use DANGX_SOLVER_CG");
+    if (a.nt > 0 && solver != DANGX_SOLVER_CG) {
+        if (fluct_mode != DANGX_FLUCT_REFERENCE && ml_mode == DANGX_ML_SAMPLE)
+            return fail(ctx, "groups with template / monopole / hi_fit members reproduce the reference's fluctuation term only");
+        return device_schur(ctx, a, SN, n_not_spd);
+    }
     if (solver == DANGX_SOLVER_CG) {
         if (fluct_mode != DANGX_FLUCT_REFERENCE && ml_mode == DANGX_ML_SAMPLE)
             return fail(ctx, "the CG solver reproduces the reference's fluctuation term only");

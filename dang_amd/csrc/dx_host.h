@@ -157,6 +157,18 @@ int dx_launch_amp(dangx_ctx* ctx, const GroupArgs& a, long long SN);
 int dx_launch_rhs(dangx_ctx* ctx, const GroupArgs& a, long long SN, double* b);
 int dx_launch_Ax(dangx_ctx* ctx, const GroupArgs& a, long long SN, const double* x, double* res, double* part);
 int dx_launch_sample_vector(dangx_ctx* ctx, const GroupArgs& a, long long SN, const double* eta, double* res);
+// direct (Schur complement) solve of a group with global-amplitude members; rows <= DX_MAX_ROWS
+constexpr int DX_MAX_ROWS = 32;
+struct SchurArgs {
+    int nrows;
+    unsigned char rt[DX_MAX_ROWS], rj[DX_MAX_ROWS];  // row r <-> (global member rt[r], band rj[r])
+    signed char ftarget[DX_MAX_ROWS];                // row that receives row r's fluctuation sum (running counter of
+                                                     // compute_sample_vector, src/dang_cg_mod.f90:970-1094); -1 = dropped
+    signed char bslot[MAXB];                         // LDS slot of band j (-1: no global row at that band)
+    int nslots;
+};
+int dx_launch_schur_pass1(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
+int dx_launch_schur_pass2(dangx_ctx* ctx, const GroupArgs& a, long long SN);
 // groups with global-amplitude members (a.nt > 0): vectors are [diffuse | global rows]
 int dx_launch_rhs_mixed(dangx_ctx* ctx, const GroupArgs& a, long long SN, double* b);
 int dx_launch_Ax_mixed(dangx_ctx* ctx, const GroupArgs& a, long long SN, const double* x, double* res);

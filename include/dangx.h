@@ -46,7 +46,8 @@ extern "C" {
 enum { DANGX_POWERLAW = 1, DANGX_MBB = 2, DANGX_FREEFREE = 3, DANGX_LOGNORMAL = 4, DANGX_CMB = 5, DANGX_TCMB = 6,
        /* global-amplitude types: one amplitude per fitted band instead of one per pixel (c%template,
         * c%template_amplitudes, c%corr, c%nfit; src/dang_component_mod.f90:536-710).  A CG group that contains
-        * them is a coupled system and is solved with DANGX_SOLVER_CG (the reference's algorithm on the device). */
+        * them is a coupled system: DANGX_SOLVER_CG runs the reference's iteration on the device, DANGX_SOLVER_DIRECT
+        * eliminates the per-pixel blocks and solves the Schur system of the (<= 32) global rows exactly. */
        DANGX_TEMPLATE = 7, DANGX_MONOPOLE = 8, DANGX_HIFIT = 9 };
 /* c%lnl_type / c%prior_type strings, src/dang_sample_mod.f90:383-400 */
 enum { DANGX_LNL_CHISQ = 1, DANGX_LNL_MARGINAL = 2, DANGX_LNL_PRIOR = 3 };

@@ -1,5 +1,5 @@
 """GPU parity for SURVEY 8f rank 1: CG groups with global-amplitude components (template / monopole / hi_fit):
-the mixed CG building blocks and the device CG against the oracle's restatement of src/dang_cg_mod.f90."""
+the mixed CG building blocks, the device CG and the direct (Schur complement) solve against the oracle's restatement of src/dang_cg_mod.f90."""
 import numpy as np
 import pytest
 
@@ -15,9 +15,9 @@ pytestmark = pytest.mark.gpu
 CASES = [(("monopole", "hi_fit"), 1, L.FLAG_T), (("template",), 2, L.FLAG_QU), (("hi_fit",), 1, L.FLAG_T)]
 
 
-def _case(which, group, nside=4, start="truth"):
+def _case(which, group, nside=4, start="truth", skip_band0=False):
     def tweak(dpar, ddata, bands, comps):
-        add_globals(dpar, ddata, bands, comps, which, group)
+        add_globals(dpar, ddata, bands, comps, which, group, skip_band0=skip_band0)
     return make_case("C2", nside=nside, start=start, tweak=tweak)
 
 
@@ -55,8 +55,78 @@ def test_device_cg_with_global_components_matches_oracle(built, which, group, fl
             assert np.abs(a - b).max() <= tol * max(np.abs(b).max(), 1e-12)
         else:
             assert relmax(eng.get_amplitude(l), orc.amplitude(l)) <= tol
-    with pytest.raises(da.DangxError):
-        eng.amp_sample(group, flag, ml_mode, 8, 9, solver="direct")
+
+
+def _packed_x(eng, comps, which, group, flag, nbands):
+    """x in the layout of initialize_x (src/dang_cg_mod.f90:1173-1279): [diffuse members | global rows]."""
+    planes = {L.FLAG_T: [0], L.FLAG_Q: [1], L.FLAG_U: [2], L.FLAG_QU: [1, 2]}[flag]
+    parts, rows = [], []
+    for l, c in enumerate(comps):
+        if c.cg_group != group or not c.sample_amplitude:
+            continue
+        if c.type in ("template", "monopole", "hi_fit"):
+            ta = eng.get_template_amplitudes(l)
+            rows.extend(ta[planes[0], j] for j in range(nbands) if c.corr[j])
+        else:
+            parts.append(eng.get_amplitude(l)[planes].ravel())
+    return np.concatenate(parts + [np.asarray(rows, dtype=np.float64)])
+
+
+@pytest.mark.parametrize("ml_mode", ["optimize", "sample"])
+@pytest.mark.parametrize("which,group,flag", CASES)
+def test_direct_solve_with_global_components_solves_the_reference_system(built, which, group, flag, ml_mode):
+    """solver='direct' eliminates the per-pixel blocks and solves the Schur system of the global rows: its answer
+    must satisfy A x = b (+ sample vector) of the reference's operators (checked through the seams, which are
+    themselves checked against the oracle above), i.e. it is the point the reference's CG converges to."""
+    case = _case(which, group, start="truth", skip_band0=True)  # a regular system: see add_globals
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+    b = eng.compute_rhs(group, flag)
+    assert relmax(b, orc.compute_rhs(group, flag)) <= 1e-12
+    if ml_mode == "sample":
+        b = b + orc.compute_sample_vector(group, flag, orc.draw_eta(flag, 8, 9))
+    _, bad = eng.amp_sample(group, flag, ml_mode, 8, 9, solver="direct")
+    assert bad == 0
+    x = _packed_x(eng, comps, which, group, flag, meta["nbands"])
+    assert x.size == eng.group_size(group, flag)
+    Ax = orc.compute_Ax(group, flag, x)
+    # residual relative to the size of the terms that cancel in each row
+    scale = orc.compute_Ax(group, flag, np.abs(x)) + np.abs(b)
+    live = scale > 0
+    assert np.abs(Ax - b)[live].max() <= 1e-9 * scale[live].max()
+    assert (np.abs(Ax - b)[live] / scale[live]).max() <= 1e-7
+    # and the oracle's CG, left to converge, lands on the same point
+    it_o = orc.amp_sample_cg(group, flag, ml_mode, 8, 9, i_max=6000, converge=1e-16)
+    if it_o < 6000:
+        for l, c in enumerate(comps):
+            if c.cg_group == group and c.type not in which:
+                assert relmax(eng.get_amplitude(l), orc.amplitude(l)) <= 1e-4
+
+
+def test_direct_solve_rejects_a_degenerate_group(built):
+    """hi_fit fitted at every band next to the CMB (pixel-independent SED) is exactly degenerate: loud error."""
+    eng, orc = pair(_case(("hi_fit",), 1, start="truth"))
+    with pytest.raises(da.DangxError, match="degenerate"):
+        eng.amp_sample(1, L.FLAG_T, "optimize", 8, 9, solver="direct")
+    eng.amp_sample(1, L.FLAG_T, "optimize", 8, 9, solver="cg", i_max=20, converge=1e-10)  # the reference algorithm still runs
+
+
+def test_direct_solve_of_a_group_of_global_components_only(built):
+    """No diffuse member (a template-only group): the Schur system is the whole system."""
+    def tweak(dpar, ddata, bands, comps):
+        add_globals(dpar, ddata, bands, comps, ("template",), 7)
+    case = make_case("C2", nside=4, start="truth", tweak=tweak)
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+    b = orc.compute_rhs(7, L.FLAG_QU)
+    eng.amp_sample(7, L.FLAG_QU, "optimize", 8, 9, solver="direct")
+    x = _packed_x(eng, comps, ("template",), 7, L.FLAG_QU, meta["nbands"])
+    Ax = orc.compute_Ax(7, L.FLAG_QU, x)
+    assert np.abs(Ax - b).max() <= 1e-10 * np.abs(b).max()
+    it_o = orc.amp_sample_cg(7, L.FLAG_QU, "optimize", 8, 9, i_max=200, converge=1e-20)
+    l = len(comps) - 1
+    a, o = eng.get_template_amplitudes(l), orc.template_amplitudes(l)
+    assert np.abs(a - o).max() <= 1e-8 * np.abs(o).max()
 
 
 def test_global_components_elsewhere_in_the_path(built):

@@ -9,28 +9,36 @@ import oracle_ffi as O
 from util import make_case
 
 
-def add_globals(dpar, ddata, bands, comps, which=("monopole", "hi_fit"), group=1):
+def add_globals(dpar, ddata, bands, comps, which=("monopole", "hi_fit"), group=1, skip_band0=False):
+    """skip_band0: do not fit band 0 for any of them.  A global component fitted at EVERY band is exactly degenerate
+    with a diffuse component of pixel-independent SED in the same group (the CMB): g_j*s_j proportional to the CMB's
+    SED is absorbed by -tmpl(i)*const in the CMB amplitude.  CG returns some point of that valley; a direct solve
+    needs the system to be regular."""
     nb, nmaps, npix = ddata.sig_map.shape
     rng = np.random.default_rng(11)
     sky_add = np.zeros_like(ddata.sig_map)
     from dang_amd.synth import H, K_B
     for w in which:
         corr = [True] * nb
-        if w == "template":
+        if w == "template" or skip_band0:
             corr[0] = False
         tmpl = np.zeros((nmaps, npix))
         ta = np.zeros((nmaps, nb))
         if w == "monopole":
             tmpl[0] = 1.0                                   # src/dang_component_mod.f90:593-595
             truth = rng.normal(0.0, 5.0, nb)
+            if skip_band0:
+                truth[0] = 0.0
             ta_true = np.zeros((nmaps, nb)); ta_true[0] = truth
             sky_add[:, 0, :] += truth[:, None]
-            c = DangComps(label="mono", type="monopole", nu_ref=100.0, cg_group=group, nindices=0, nfit=nb, corr=corr,
+            c = DangComps(label="mono", type="monopole", nu_ref=100.0, cg_group=group, nindices=0, nfit=sum(corr), corr=corr,
                           template=tmpl, template_amplitudes=ta, amplitude=np.zeros((nmaps, npix)))
         elif w == "hi_fit":
             tmpl[0] = rng.uniform(0.2, 1.0, npix)
             T = np.full((1, nmaps, npix), 18.0)
             truth = rng.uniform(0.5, 2.0, nb) * 1e-6
+            if skip_band0:
+                truth[0] = 0.0
             ta_true = np.zeros((nmaps, nb)); ta_true[0] = truth
             for j, b in enumerate(bands):
                 nu = b.nu_c * 1e9
@@ -39,7 +47,7 @@ def add_globals(dpar, ddata, bands, comps, which=("monopole", "hi_fit"), group=1
             c = DangComps(label="hi", type="hi_fit", nu_ref=100.0, cg_group=group, nindices=1, ind_label=["T"],
                           sample_index=[False], index_mode=[2], lnl_type=["chisq"], prior_type=["uniform"],
                           gauss_prior=[[18.0, 1.0]], uni_prior=[[5.0, 40.0]], step_size=[0.1], pol_flag=[[L.FLAG_T]],
-                          nfit=nb, corr=corr, template=tmpl, template_amplitudes=ta, indices=T,
+                          nfit=sum(corr), corr=corr, template=tmpl, template_amplitudes=ta, indices=T,
                           amplitude=np.zeros((nmaps, npix)))
         else:  # polarisation template, fitted under Q+U with ONE amplitude per band for Q and U (:1380-1382)
             tmpl[1], tmpl[2] = rng.normal(0, 1, npix), rng.normal(0, 1, npix)
