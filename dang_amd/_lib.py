@@ -47,6 +47,8 @@ class CompDesc(C.Structure):
 # every symbol include/dangx.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 _D = C.POINTER(C.c_double)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)  # dangx_allreduce_fn
+
 SYMBOLS = {
     "dangx_create": (C.c_int, [C.POINTER(_P), C.POINTER(Dims)]),
     "dangx_destroy": (C.c_int, [_P]),
@@ -54,6 +56,7 @@ SYMBOLS = {
     "dangx_version": (C.c_char_p, []),
     "dangx_set_stream": (C.c_int, [_P, _P]),
     "dangx_synchronize": (C.c_int, [_P]),
+    "dangx_set_allreduce": (C.c_int, [_P, _P, _P, C.c_int]),
     "dangx_set_band": (C.c_int, [_P, C.c_int, C.c_double, C.c_int, _P, _P]),
     "dangx_set_component": (C.c_int, [_P, C.c_int, C.POINTER(CompDesc)]),
     "dangx_set_tcmb": (C.c_int, [_P, C.c_double]),

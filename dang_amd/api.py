@@ -209,6 +209,30 @@ class Engine:
                 self.put_amplitude(l, c.amplitude)
             if c.nindices > 0 and c.indices is not None:
                 self.put_indices(l, c.indices)
+        self._allreduce_cb = None
+        rank, nranks = _dist.world()
+        if nranks > 1:
+            self.set_allreduce(_dist.allreduce_sum_inplace_host, is_root=(rank == 0))
+
+    def set_allreduce(self, fn, is_root=True):
+        """Pixel-sharded runs: `fn(numpy float64 array)` sums the array over all ranks in place (see
+        dangx_set_allreduce in include/dangx.h).  Installed automatically when torch.distributed is initialised
+        with more than one rank; fn=None returns to single-rank behaviour."""
+        if fn is None:
+            self._allreduce_cb = None
+            self._chk(self.lib.dangx_set_allreduce(self.h, None, None, 1))
+            return
+
+        def cb(_user, buf, n):
+            try:
+                fn(np.ctypeslib.as_array(buf, shape=(int(n),)))
+                return 0
+            except Exception as e:  # an exception must not unwind through the C frames
+                import sys
+                print("dangx all-reduce callback failed: %r" % (e,), file=sys.stderr)
+                return 1
+        self._allreduce_cb = L.ALLREDUCE_FN(cb)   # keep the trampoline alive as long as the context
+        self._chk(self.lib.dangx_set_allreduce(self.h, C.cast(self._allreduce_cb, C.c_void_p), None, 1 if is_root else 0))
 
     # -- plumbing
     def _chk(self, rc):

@@ -44,7 +44,8 @@ __global__ __launch_bounds__(BLOCK) void k_pack(const Model* __restrict__ Mp, Gr
 //  mode 1: x += alpha*d ; r -= alpha*q               -> partial sum(r*r)
 //  mode 2: d = r + beta*d
 //  mode 3: b2 = b + f
-__global__ __launch_bounds__(BLOCK) void k_cg_vec(int mode, long long n, double alpha, double* __restrict__ x,
+// entries t >= ndot do not enter the partial sums (replicated global rows on the non-root ranks of a sharded run)
+__global__ __launch_bounds__(BLOCK) void k_cg_vec(int mode, long long n, long long ndot, double alpha, double* __restrict__ x,
                                                   double* __restrict__ r, double* __restrict__ d,
                                                   const double* __restrict__ q, const double* __restrict__ b2,
                                                   double* __restrict__ partial) {
@@ -53,11 +54,11 @@ __global__ __launch_bounds__(BLOCK) void k_cg_vec(int mode, long long n, double 
     if (t < n) {
         if (mode == 0) {
             const double rv = b2[t] - q[t];
-            r[t] = rv; d[t] = rv; rr = rv * rv;
+            r[t] = rv; d[t] = rv; rr = (t < ndot) ? rv * rv : 0.0;
         } else if (mode == 1) {
             x[t] = x[t] + alpha * d[t];
             const double rv = r[t] - alpha * q[t];
-            r[t] = rv; rr = rv * rv;
+            r[t] = rv; rr = (t < ndot) ? rv * rv : 0.0;
         } else if (mode == 2) {
             d[t] = r[t] + alpha * d[t];
         } else {
@@ -79,10 +80,10 @@ __global__ __launch_bounds__(BLOCK) void k_cg_vec(int mode, long long n, double 
 
 // block partials of sum(u*v)
 __global__ __launch_bounds__(BLOCK) void k_dot(const double* __restrict__ u, const double* __restrict__ v, long long n,
-                                               double* __restrict__ partial) {
+                                               long long ndot, double* __restrict__ partial) {
     __shared__ double sh[BLOCK / 64];
     const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    double s = (t < n) ? u[t] * v[t] : 0.0;
+    double s = (t < n && t < ndot) ? u[t] * v[t] : 0.0;
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -625,11 +626,29 @@ void x_to_globals(dangx_ctx* ctx, const GroupArgs& a, const std::vector<double>&
 }
 
 // sum(a*b) over n entries -> host (deterministic two-stage reduction)
-int device_dot(dangx_ctx* ctx, const double* u, const double* v, long long n, double* out) {
+int device_dot(dangx_ctx* ctx, const double* u, const double* v, long long n, long long ndot, double* out) {
     const unsigned nblk = nblocks(n);
     if (ensure_partial(ctx, nblk)) return 1;
-    hipLaunchKernelGGL(k_dot, dim3(nblk), dim3(BLOCK), 0, ctx->stream, u, v, n, ctx->partial);
+    hipLaunchKernelGGL(k_dot, dim3(nblk), dim3(BLOCK), 0, ctx->stream, u, v, n, ndot, ctx->partial);
     return reduce_to_host(ctx, nblk, out);
+}
+
+// sum of host doubles over the ranks of a pixel-sharded run (dangx_set_allreduce); identity on a single rank
+int rank_sum(dangx_ctx* ctx, double* buf, int64_t n) {
+    if (!ctx->allreduce || n <= 0) return 0;
+    if (ctx->allreduce(ctx->allreduce_user, buf, n)) return fail(ctx, "the all-reduce callback reported an error");
+    return 0;
+}
+// the global rows at the tail of a device vector hold this rank's sums: make them the sums over all ranks
+int rank_sum_rows(dangx_ctx* ctx, double* tail_dev, int rows) {
+    if (!ctx->allreduce || rows <= 0) return 0;
+    std::vector<double> h(rows);
+    HIPCHK(ctx, hipMemcpyAsync(h.data(), tail_dev, sizeof(double) * rows, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (rank_sum(ctx, h.data(), rows)) return 1;
+    HIPCHK(ctx, hipMemcpyAsync(tail_dev, h.data(), sizeof(double) * rows, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
 }
 
 // cg_search on the device, src/dang_cg_mod.f90:179-324.  work[0]=x, [1]=r, [2]=d, [3]=q, [4]=b2, [5]=eta/b.
@@ -638,19 +657,25 @@ int device_cg(dangx_ctx* ctx, const GroupArgs& a, int i_max, double converge, in
     const long long SN = (long long)flag_planes_h(a.flag) * ctx->hm.npix;
     const long long n = SN * a.ng + a.nglob;
     const bool mixed = a.nt > 0;
+    // pixel-sharded run: the diffuse entries are this rank's, the global rows are replicated (and summed over ranks
+    // wherever an operator produces them); dot products count the global rows on the root rank only
+    const long long ndot = ctx->is_root ? n : SN * a.ng;
     if (ensure_work(ctx, n)) return 1;
     if (ensure_partial(ctx, nblocks(n))) return 1;
     double *x = ctx->work[0], *r = ctx->work[1], *d = ctx->work[2], *q = ctx->work[3], *b2 = ctx->work[4], *tmp = ctx->work[5];
     hipStream_t st = ctx->stream;
     auto Ax = [&](const double* in, double* out) -> int {
-        return mixed ? dx_launch_Ax_mixed(ctx, a, SN, in, out) : dx_launch_Ax(ctx, a, SN, in, out, nullptr);
+        if (mixed ? dx_launch_Ax_mixed(ctx, a, SN, in, out) : dx_launch_Ax(ctx, a, SN, in, out, nullptr)) return 1;
+        return mixed ? rank_sum_rows(ctx, out + SN * a.ng, a.nglob) : 0;
     };
     // b = compute_rhs
     if (mixed ? dx_launch_rhs_mixed(ctx, a, SN, tmp) : dx_launch_rhs(ctx, a, SN, tmp)) return 1;
+    if (mixed && rank_sum_rows(ctx, tmp + SN * a.ng, a.nglob)) return 1;
     if (a.ml_mode == DANGX_ML_SAMPLE) {  // b2 = b + compute_sample_vector(eta)
         hipLaunchKernelGGL(k_draw_eta, dim3(nblocks(SN)), dim3(BLOCK), 0, st, ctx->dm, a, r);
         if (mixed ? dx_launch_sv_mixed(ctx, a, SN, r, q) : dx_launch_sample_vector(ctx, a, SN, r, q)) return 1;
-        hipLaunchKernelGGL(k_cg_vec, dim3(nblocks(n)), dim3(BLOCK), 0, st, 3, n, 0.0, b2, nullptr, nullptr, q, tmp, nullptr);
+        if (mixed && rank_sum_rows(ctx, q + SN * a.ng, a.nglob)) return 1;
+        hipLaunchKernelGGL(k_cg_vec, dim3(nblocks(n)), dim3(BLOCK), 0, st, 3, n, n, 0.0, b2, nullptr, nullptr, q, tmp, nullptr);
     } else {
         HIPCHK(ctx, hipMemcpyAsync(b2, tmp, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
     }
@@ -663,25 +688,25 @@ int device_cg(dangx_ctx* ctx, const GroupArgs& a, int i_max, double converge, in
         HIPCHK(ctx, hipStreamSynchronize(st));
     }
     if (Ax(x, q)) return 1;
-    hipLaunchKernelGGL(k_cg_vec, dim3(nblocks(n)), dim3(BLOCK), 0, st, 0, n, 0.0, x, r, d, q, b2, ctx->partial);
+    hipLaunchKernelGGL(k_cg_vec, dim3(nblocks(n)), dim3(BLOCK), 0, st, 0, n, ndot, 0.0, x, r, d, q, b2, ctx->partial);
     double delta_new = 0.0, delta_old, dq = 0.0;
-    if (reduce_to_host(ctx, nblocks(n), &delta_new)) return 1;
+    if (reduce_to_host(ctx, nblocks(n), &delta_new) || rank_sum(ctx, &delta_new, 1)) return 1;
     int i = 1;
     while (i < i_max && delta_new > converge) {
         if (Ax(d, q)) return 1;
-        if (device_dot(ctx, d, q, n, &dq)) return 1;
+        if (device_dot(ctx, d, q, n, ndot, &dq) || rank_sum(ctx, &dq, 1)) return 1;
         const double alpha = delta_new / dq;
         if (ensure_partial(ctx, nblocks(n))) return 1;
         {
             Timed t(ctx, DANGX_K_CG_VEC);
-            hipLaunchKernelGGL(k_cg_vec, dim3(nblocks(n)), dim3(BLOCK), 0, st, 1, n, alpha, x, r, d, q, b2, ctx->partial);
+            hipLaunchKernelGGL(k_cg_vec, dim3(nblocks(n)), dim3(BLOCK), 0, st, 1, n, ndot, alpha, x, r, d, q, b2, ctx->partial);
         }
         delta_old = delta_new;
-        if (reduce_to_host(ctx, nblocks(n), &delta_new)) return 1;
+        if (reduce_to_host(ctx, nblocks(n), &delta_new) || rank_sum(ctx, &delta_new, 1)) return 1;
         const double beta = delta_new / delta_old;
         {
             Timed t(ctx, DANGX_K_CG_VEC);
-            hipLaunchKernelGGL(k_cg_vec, dim3(nblocks(n)), dim3(BLOCK), 0, st, 2, n, beta, x, r, d, q, b2, nullptr);
+            hipLaunchKernelGGL(k_cg_vec, dim3(nblocks(n)), dim3(BLOCK), 0, st, 2, n, n, beta, x, r, d, q, b2, nullptr);
         }
         i = i + 1;
     }
@@ -738,6 +763,7 @@ int device_schur(dangx_ctx* ctx, const GroupArgs& a, long long SN, int64_t* n_no
     HIPCHK(ctx, hipMemcpyAsync(&bad, ctx->counters, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (n_not_spd) *n_not_spd = (int64_t)bad;
+    if (rank_sum(ctx, rows.data(), nrows)) return 1;  // pixel-sharded run: every rank then solves the same small system
     // S g = t (+ fluctuation sums): Gaussian elimination with partial pivoting (S is not symmetric when a monopole is fitted)
     std::vector<double> S(rows.begin(), rows.begin() + (size_t)R * R), g(rows.begin() + (size_t)R * R, rows.begin() + (size_t)R * R + R);
     if (a.ml_mode == DANGX_ML_SAMPLE)
@@ -857,6 +883,12 @@ const char* dangx_last_error(const dangx_ctx* ctx) { return ctx ? ctx->err.c_str
 int dangx_set_stream(dangx_ctx* ctx, void* s) {
     if (!ctx) return 1;
     ctx->stream = (hipStream_t)s;
+    return 0;
+}
+
+int dangx_set_allreduce(dangx_ctx* ctx, dangx_allreduce_fn fn, void* user, int is_root) {
+    if (!ctx) return 1;
+    ctx->allreduce = fn; ctx->allreduce_user = user; ctx->is_root = (fn == nullptr) || is_root != 0;
     return 0;
 }
 

@@ -34,6 +34,21 @@ def allreduce_sum_float(x, device=None):
     return float(t.item())
 
 
+def allreduce_sum_inplace_host(a):
+    """Sum a small host float64 array over all ranks in place: the callback behind dangx_set_allreduce (dot products
+    of the device CG, global-amplitude rows of template groups).  nccl process groups reduce on the device (RCCL)."""
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return a
+    if td.get_backend() == "nccl":
+        t = torch.from_numpy(a).to(torch.device("cuda", torch.cuda.current_device()))
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+        a[...] = t.cpu().numpy()
+    else:
+        t = torch.from_numpy(a)     # shares memory
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+    return a
+
+
 def bcast_from_rank0(values):
     """Broadcast a short list of floats from rank 0 (e.g. c%indices(0, k, :), which lives on the first shard)."""
     if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:

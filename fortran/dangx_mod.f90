@@ -157,6 +157,14 @@ module dangx_mod
        type(c_ptr), value :: ctx, out
        integer(c_int), value :: band
      end function
+     ! pixel-sharded (MPI) runs: fn = c_funloc of a bind(C) function that does
+     ! MPI_Allreduce(MPI_IN_PLACE, buf, n, MPI_DOUBLE_PRECISION, MPI_SUM, comm) and returns 0
+     integer(c_int) function dangx_set_allreduce(ctx, fn, user, is_root) bind(C, name='dangx_set_allreduce')
+       import :: c_int, c_ptr, c_funptr
+       type(c_ptr), value :: ctx, user
+       type(c_funptr), value :: fn
+       integer(c_int), value :: is_root
+     end function
      integer(c_int) function dangx_sky_model_chisq(ctx, pol_lo, pol_hi, chisq_sum, sky, res, chi_map) &
           bind(C, name='dangx_sky_model_chisq')
        import :: c_int, c_ptr, c_double

@@ -106,6 +106,15 @@ const char *dangx_last_error(const dangx_ctx *ctx);
 const char *dangx_version(void);
 /* run all work of this context on the given hipStream_t (NULL = default stream) */
 int dangx_set_stream(dangx_ctx *ctx, void *hip_stream);
+/* Pixel-sharded runs (one context per rank, dangx_dims.pix0/npix = the rank's RING range): the few places where the
+ * reference sums over the WHOLE sky inside a call -- the dot products of cg_search (src/dang_cg_mod.f90:279-312) and
+ * the global-amplitude rows of compute_rhs / compute_Ax / compute_sample_vector (:522-587, :833-893, :1045-1096) --
+ * hand their local sums (host doubles, n <= 32*32+96) to this callback, which must replace buf[0..n) by its sum over
+ * all ranks and return 0 (an MPI_Allreduce(MPI_IN_PLACE, buf, n, MPI_DOUBLE, MPI_SUM) or a torch.distributed
+ * all_reduce).  is_root != 0 on exactly one rank: the replicated global rows are counted there in dot products.
+ * fn == NULL (the default) = single rank.  Every rank must make the same sequence of calls. */
+typedef int (*dangx_allreduce_fn)(void *user, double *buf, int64_t n);
+int dangx_set_allreduce(dangx_ctx *ctx, dangx_allreduce_fn fn, void *user, int is_root);
 int dangx_synchronize(dangx_ctx *ctx);
 
 /* ---- static description (once, after src/dang.f90:73) ------------------------ */

@@ -1,0 +1,114 @@
+"""Two ranks (gloo, both on cuda:0) against one rank: the places where a pixel-sharded run needs a sum over the
+whole sky INSIDE an amplitude solve -- the dot products of the device CG and the global-amplitude rows of template
+groups (SURVEY 8e collectives (3)) -- go through the dangx_set_allreduce callback."""
+import copy
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as td
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+JOBS = [  # (global members, group, flag, solver, ml_mode)
+    (("template",), 2, 8, "direct", "sample"),
+    (("monopole", "hi_fit"), 1, 1, "direct", "optimize"),
+    (("template",), 2, 8, "cg", "sample"),
+    ((), 1, 1, "cg", "sample"),
+]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _full_case(which, group):
+    from test_oracle_templates_cpu import add_globals
+    from util import make_case
+
+    def tweak(dpar, ddata, bands, comps):
+        if which:
+            add_globals(dpar, ddata, bands, comps, which, group, skip_band0=True)
+    return make_case("C2", nside=4, start="truth", tweak=tweak)
+
+
+def _shard(case, rank, world):
+    from dang_amd import dist
+    dpar, ddata, bands, comps, meta = case
+    p0, n = dist.shard_range(meta["npix_global"], rank, world)
+    ddata = copy.copy(ddata)
+    ddata.sig_map = np.ascontiguousarray(ddata.sig_map[..., p0:p0 + n])
+    ddata.rms_map = np.ascontiguousarray(ddata.rms_map[..., p0:p0 + n])
+    ddata.masks = np.ascontiguousarray(ddata.masks[..., p0:p0 + n])
+    comps = copy.deepcopy(comps)
+    for c in comps:
+        c.amplitude = np.ascontiguousarray(c.amplitude[..., p0:p0 + n])
+        if c.nindices:
+            c.indices = np.ascontiguousarray(c.indices[..., p0:p0 + n])
+        if getattr(c, "template", None) is not None:
+            c.template = np.ascontiguousarray(c.template[..., p0:p0 + n])
+    return ddata, comps, p0, n
+
+
+def _run(case, which, group, flag, solver, ml_mode, rank=0, world=1):
+    import dang_amd as da
+    dpar, ddata, bands, comps, meta = case
+    ddata, comps, p0, n = _shard(case, rank, world)
+    eng = da.Engine(bands, comps, ddata, npix_global=meta["npix_global"], pix0=p0, device=0)
+    # few CG iterations: the check is on the mechanics (every sum over the sky complete), before the rounding-level
+    # differences of the summation order are amplified along an unconverged trajectory
+    it, _ = eng.amp_sample(group, flag, ml_mode, 8, 9, solver=solver, i_max=6, converge=1e-10)
+    amps = [eng.get_amplitude(l) for l in range(len(comps))]
+    tas = [eng.get_template_amplitudes(l) for l, c in enumerate(comps) if c.type in ("template", "monopole", "hi_fit")]
+    return it, amps, tas
+
+
+def _worker(rank, world, port, out):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), here]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from dang_amd import dist
+    import torch
+    res = {}
+    for n, (which, group, flag, solver, ml_mode) in enumerate(JOBS):
+        it, amps, tas = _run(_full_case(which, group), which, group, flag, solver, ml_mode, rank, world)
+        res["it%d" % n] = it
+        for l, a in enumerate(amps):
+            g = dist.gather_maps(torch.from_numpy(a), 192, dst=0)
+            if rank == 0:
+                res["amp%d_%d" % (n, l)] = g.numpy()
+        for l, t in enumerate(tas):
+            res["ta%d_%d_r%d" % (n, l, rank)] = t
+    gathered = [None] * world
+    td.all_gather_object(gathered, {k: v for k, v in res.items() if k.startswith("ta")})
+    if rank == 0:
+        for g in gathered:
+            res.update(g)
+        np.savez(out, **res)
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_two_ranks_solve_the_same_coupled_systems_as_one(built, tmp_path):
+    out = str(tmp_path / "r.npz")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    for n, (which, group, flag, solver, ml_mode) in enumerate(JOBS):
+        it, amps, tas = _run(_full_case(which, group), which, group, flag, solver, ml_mode)
+        assert int(got["it%d" % n]) == it, (n, int(got["it%d" % n]), it)
+        # sums over the sky are formed in a different order (per-rank partials, then the all-reduce)
+        tol = 1e-9
+        for l, a in enumerate(amps):
+            assert np.abs(got["amp%d_%d" % (n, l)] - a).max() <= tol * max(np.abs(a).max(), 1e-300), (n, l)
+        for l, t in enumerate(tas):
+            for r in range(2):  # replicated on every rank
+                assert np.abs(got["ta%d_%d_r%d" % (n, l, r)] - t).max() <= tol * max(np.abs(t).max(), 1e-300), (n, l, r)
+            assert np.array_equal(got["ta%d_%d_r0" % (n, l)], got["ta%d_%d_r1" % (n, l)])
