@@ -105,6 +105,43 @@ __device__ __forceinline__ void subtract_other(const Model& M, const Comp& c2, i
     }
 }
 
+// Q and U planes of one pixel whose "other" component has the same indices on both (always the case once a Q+U
+// sweep has written them, :465): one SED evaluation per band serves both planes -- same values, same operations.
+template <int NB>
+__device__ __forceinline__ void subtract_other_pair(const Model& M, const Comp& c2, double ampa, double ampb, double t0, double t1,
+                                                    double (&Da)[NB], double (&Db)[NB]) {
+    const Prep pr = sed_prep(c2, t0, t1);
+    switch (c2.type) {
+    case DANGX_POWERLAW:
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { const double s = exp(pr.p0 * c2.lnr[j]); Da[j] -= ampa * s; Db[j] -= ampb * s; }
+        break;
+    case DANGX_MBB:
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const double s = pr.p2 / (exp(pr.p1 * M.band[j].nu_c) - 1.0) * exp(pr.p0 * c2.lnr[j]);
+            Da[j] -= ampa * s; Db[j] -= ampb * s;
+        }
+        break;
+    case DANGX_FREEFREE:
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { const double s = ff_gaunt(c2.lnu9[j], pr.p0) / pr.p1 * c2.cst[j]; Da[j] -= ampa * s; Db[j] -= ampb * s; }
+        break;
+    case DANGX_LOGNORMAL:
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const double l2 = log_pos(M.band[j].nu_c / pr.p0) / pr.p1;
+            const double s = exp(-0.5 * (l2 * l2)) * c2.cst[j];
+            Da[j] -= ampa * s; Db[j] -= ampb * s;
+        }
+        break;
+    default:  // cmb
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { Da[j] -= ampa * c2.cst[j]; Db[j] -= ampb * c2.cst[j]; }
+        break;
+    }
+}
+
 template <int MODE, int SP, int NB, bool ISLDS>
 __device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, const IndexArgs& a, int i, double chi[4], double* isl) {
     const int npix = M.npix;
@@ -163,8 +200,13 @@ __device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, co
             om &= om - 1;
             const int ln = om ? __builtin_ctz(om) : -1;
             if (ln >= 0) fetch(ln);
+            const unsigned cp = (c2.const_planes >> (a.s1 - 1)) & 3u;
+            if (SP == 2 && cp == 0 && ct0[0] == ct0[SP - 1] && ct1[0] == ct1[SP - 1]) {
+                subtract_other_pair<NB>(M, c2, ca[0], ca[SP - 1], ct0[0], ct1[0], R.D[0], R.D[SP - 1]);
+            } else {
 #pragma unroll
-            for (int kk = 0; kk < SP; ++kk) subtract_other<NB>(M, c2, a.s1 + kk, ca[kk], ct0[kk], ct1[kk], R.D[kk]);
+                for (int kk = 0; kk < SP; ++kk) subtract_other<NB>(M, c2, a.s1 + kk, ca[kk], ct0[kk], ct1[kk], R.D[kk]);
+            }
             l = ln;
         }
     }
