@@ -375,6 +375,10 @@ class Engine:
         self._chk(self.lib.dangx_gain_sums(self.h, band, out))
         return out[0], out[1]
 
+    def set_tcmb(self, T):
+        """The global T_CMB (src/dang_util_mod.f90:15): enters a2t of the 'cmb' component."""
+        self._chk(self.lib.dangx_set_tcmb(self.h, float(T)))
+
     def set_calibration(self, gain, offset):
         g = np.ascontiguousarray(gain, dtype=np.float64)
         o = np.ascontiguousarray(offset, dtype=np.float64)
@@ -455,6 +459,19 @@ def initialize(bands, component_list, ddata, **kw):
     return ddata.engine
 
 
+def mask_hi_threshold(ddata, c, thresh):
+    """ddata%mask_hi_threshold(dpar), src/dang_data_mod.f90:398-427 -- what the driver does once BEFORE
+    `initialize` when a 'hi_fit' component is present (src/dang.f90:74): pixels whose HI template exceeds the
+    threshold are masked, missing / zero-rms pixels too, and the template is normalised by the threshold."""
+    m = np.asarray(ddata.masks)
+    t = np.asarray(c.template)
+    m0 = m[0]
+    bad = (t[0] > thresh) | (m0 == MISSVAL) | (m0 == 0.0) | (np.asarray(ddata.rms_map)[0, 0] == 0.0)
+    m[0] = np.where(bad, 0.0, 1.0)
+    c.template = t / thresh
+    return ddata.masks
+
+
 def compute_chisq(ddata):
     """update_sky_model + compute_chisq (src/dang_data_mod.f90:339-396, 494-526); all-reduced over shards."""
     eng = ddata.engine
@@ -515,6 +532,9 @@ def sample_spectral_parameters(dpar: DangParams, ddata: DangData, it=2, verbose=
                     acc = eng.index_sample(l, j, _MAPN[f], dpar.nsample, dpar.ml_mode, dpar.seed,
                                            stream_id(it, 1, l, j, f))
                 info.append((l, j, f, acc))
+        if c.type == "T_cmb":  # "Update the global variable T_CMB": T_CMB = c%indices(0,1,1), :75-78 (it enters a2t of 'cmb')
+            t = eng.peek_indices(l, 1, 0)[0] if eng.pix0 == 0 else 0.0
+            eng.set_tcmb(_dist.bcast_from_rank0([t])[0])
     if sampled:
         lo, hi = ddata.pol_type[0], ddata.pol_type[-1]
         before, after = eng.chisq_cached(0, lo, hi), eng.chisq_cached(1, lo, hi)

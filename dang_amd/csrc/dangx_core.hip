@@ -1169,8 +1169,6 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
     else return fail(ctx, "There is something wrong with the poltype flag (map_n must be 1,2,3 or -1)");
     if (a.s2 > ctx->dims.nmaps) return fail(ctx, "map_n exceeds nmaps");
     if (d.lnl_type[nind] < DANGX_LNL_CHISQ || d.lnl_type[nind] > DANGX_LNL_PRIOR) return fail(ctx, "bad lnl_type");
-    if (d.type == DANGX_HIFIT) return fail(ctx, "hi_fit index sampling is not built (its model has one amplitude per band)");
-    if (d.type == DANGX_TCMB) return fail(ctx, "T_cmb is sampled full-sky (index_mode 1) in the reference: not built (SURVEY 8f rank 2)");
     if (ml_mode != DANGX_ML_SAMPLE && ml_mode != DANGX_ML_OPTIMIZE) return fail(ctx, "bad ml_mode");
     const int Sp = a.s2 - a.s1 + 1;
     a.others = 0;

@@ -28,6 +28,7 @@ struct ChainCtx {
     const double* tab;  // block-shared constant table (sed_table_build)
     int BS, tid, nb, Sp;
     double amp0, amp1, other;  // amplitudes on the planes; the index that is NOT sampled
+    int i, k0;                 // pixel and first map (hi_fit: template(pix,map) * template_amplitudes(band,map))
     __device__ __forceinline__ double& D(int kk, int j) const { return lds[(kk * nb + j) * BS + tid]; }
     __device__ __forceinline__ double& IS(int kk, int j) const { return lds[((Sp + kk) * nb + j) * BS + tid]; }
     __device__ __forceinline__ double& F(int j) const { return lds[(2 * Sp * nb + j) * BS + tid]; }
@@ -59,18 +60,27 @@ __device__ __forceinline__ double chain_lnl(const ChainCtx& C, double th, int ln
         case CH_MBB_T: s = s1 / (exp(s0 * M.band[j].nu_c) - 1.0) * C.F(j); break;
         case CH_LOGN_NUP: { const double l = log_pos(M.band[j].nu_c / s0) / s1; s = exp(-0.5 * (l * l)) * c.cst[j]; break; }
         case CH_LOGN_W: { const double l = C.F(j) / s1; s = exp(-0.5 * (l * l)) * c.cst[j]; break; }
-        default: s = sed_eval(M, c, j, pr); break;
+        default: s = (c.type == DANGX_HIFIT) ? 0.0 : sed_eval(M, c, j, pr); break;
+        }
+        // eval_signal (src/dang_component_mod.f90:754-776): amplitude(pix,map) * sed; T_cmb: the sed itself;
+        // hi_fit: template_amplitudes(band,map) * (template(pix,map) * evaluate_hi_fit)
+        double m0 = C.amp0 * s, m1 = C.amp1 * s;
+        if (c.type == DANGX_TCMB) {  // the bare sed (:770-771)
+            m0 = s; m1 = s;
+        } else if (c.type == DANGX_HIFIT) {
+            m0 = c.tamp[C.k0 - 1][j] * comp_sed(M, c, C.i, C.k0, j, pr);
+            if (C.Sp == 2) m1 = c.tamp[C.k0][j] * comp_sed(M, c, C.i, C.k0 + 1, j, pr);
         }
         if (lnl_type == DANGX_LNL_CHISQ) {
-            const double t = (C.D(0, j) - C.amp0 * s) * C.IS(0, j);
+            const double t = (C.D(0, j) - m0) * C.IS(0, j);
             acc0 = acc0 - 0.5 * (t * t);
             if (C.Sp == 2) {
-                const double t2 = (C.D(1, j) - C.amp1 * s) * C.IS(1, j);
+                const double t2 = (C.D(1, j) - m1) * C.IS(1, j);
                 acc1 = acc1 - 0.5 * (t2 * t2);
             }
         } else {  // marginal: -0.5*TNd*invTNT*TNd per (band, plane), src/dang_lnl_mod.f90:113-122
             for (int kk = 0; kk < C.Sp; ++kk) {
-                const double m = (kk ? C.amp1 : C.amp0) * s;
+                const double m = kk ? m1 : m0;
                 const double is = C.IS(kk, j);
                 const double TN = m * (is * is);
                 const double TNd = TN * C.D(kk, j);
@@ -176,7 +186,7 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
     double sample0, sample1;
     load_theta(M, c, i, a.s1, sample0, sample1);
     const bool first = (a.nind == 0);
-    ChainCtx C{M, c, a, lds, tab, BS, tid, nb, Sp, 0.0, 0.0, first ? sample1 : sample0};
+    ChainCtx C{M, c, a, lds, tab, BS, tid, nb, Sp, 0.0, 0.0, first ? sample1 : sample0, i, a.s1};
     // --- stage data_raw (:173-177) and 1/rms: loads of ST bands are issued together
     constexpr int ST = (MODE == CH_GENERIC) ? 4 : TB;
     for (int kk = 0; kk < Sp; ++kk) {

@@ -155,3 +155,89 @@ def test_global_components_elsewhere_in_the_path(built):
         ao = orc.sample_index_mh(l, j, mapn, 10, "sample", 5, 60 + l)
         assert ag == ao
         assert np.abs(eng.get_indices(l) - orc.indices(l)).max() <= 1e-12
+
+
+# --------------------------------------------------------------------------- index sampling of hi_fit and T_cmb
+
+def _hi_case(nside=4):
+    """The HI fit (src/dang_component_mod.f90:597-640): s = A_nu * HI_p * B_nu(T_p) with a per-pixel temperature."""
+    def tweak(dpar, ddata, bands, comps):
+        add_globals(dpar, ddata, bands, comps, ("hi_fit",), 1)   # every band carries an amplitude (marginal form: m /= 0)
+        hi = comps[-1]
+        hi.template_amplitudes = hi.truth_ta.copy()
+        hi.sample_index = [True]
+        hi.step_size = [0.8]
+        rng = np.random.default_rng(5)
+        hi.indices = hi.indices + rng.normal(0.0, 1.0, hi.indices.shape)
+    return make_case("C2", nside=nside, start="truth", tweak=tweak)
+
+
+@pytest.mark.parametrize("lnl,ml_mode", [("chisq", "sample"), ("chisq", "optimize"), ("marginal", "sample")])
+def test_hi_fit_temperature_sampling_matches_oracle(built, lnl, ml_mode):
+    case = _hi_case()
+    dpar, ddata, bands, comps, meta = case
+    l = len(comps) - 1
+    comps[l].lnl_type = [lnl]
+    eng, orc = pair(case)
+    ag = eng.index_sample(l, 0, 1, 10, ml_mode, 5, 77)
+    ao = orc.sample_index_mh(l, 0, 1, 10, ml_mode, 5, 77)
+    assert ag == ao and ag > 0
+    assert np.abs(eng.get_indices(l) - orc.indices(l)).max() <= 1e-12
+    # the sweep's by-product chi^2 equals a fresh evaluation
+    s = eng.sky_model_chisq(1, 1)
+    assert abs(eng.chisq_cached(1, 1, 1) - s) <= 1e-10 * s
+
+
+def test_mask_hi_threshold_mirrors_the_reference():
+    from dang_amd.api import mask_hi_threshold
+    case = _hi_case()
+    dpar, ddata, bands, comps, meta = case
+    hi = comps[-1]
+    t0, m0 = hi.template.copy(), ddata.masks.copy()
+    mask_hi_threshold(ddata, hi, 0.6)
+    assert np.array_equal(ddata.masks[0] == 0.0, (t0[0] > 0.6) | (m0[0] == 0.0))
+    assert np.allclose(hi.template, t0 / 0.6, rtol=0, atol=0)
+
+
+def _tcmb_case(index_mode):
+    from dang_amd.api import DangComps
+
+    def tweak(dpar, ddata, bands, comps):
+        npix = ddata.sig_map.shape[-1]
+        comps.append(DangComps(label="tcmb", type="T_cmb", nu_ref=100.0, cg_group=9, sample_amplitude=False, nindices=1,
+                               ind_label=["T"], sample_index=[True], index_mode=[index_mode], lnl_type=["chisq"],
+                               prior_type=["gaussian"], gauss_prior=[[0.5, 0.05]], uni_prior=[[0.1, 2.0]],
+                               step_size=[1e-3], pol_flag=[[L.FLAG_T]], amplitude=np.zeros((3, npix)),
+                               indices=np.full((1, 3, npix), 0.5)))
+    return make_case("C2", nside=4, start="truth", tweak=tweak)
+
+
+def test_T_cmb_sampling_per_pixel_and_full_sky(built):
+    """'T_cmb' has no amplitude (eval_signal = the bare sed, src/dang_component_mod.f90:770-771); after its
+    indices are sampled the driver copies c%indices(0,1,1) into the global T_CMB (src/dang_sample_mod.f90:75-78)."""
+    case = _tcmb_case(2)
+    dpar, ddata, bands, comps, meta = case
+    l = len(comps) - 1
+    eng, orc = pair(case)
+    ag = eng.index_sample(l, 0, 1, 10, "sample", 5, 78)
+    ao = orc.sample_index_mh(l, 0, 1, 10, "sample", 5, 78)
+    assert ag == ao
+    assert np.abs(eng.get_indices(l) - orc.indices(l)).max() <= 1e-13
+    case = _tcmb_case(1)
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+    s = da.stream_id(2, 1, l, 0, 1)
+    ag = da.sample_index_mh_fullsky(dpar, ddata, l, 0, 1, s)
+    ao, _, _ = orc.sample_index_fullsky(l, 0, 1, dpar.nsample, dpar.ml_mode, dpar.seed, s)
+    assert ag == ao
+    assert np.abs(eng.get_indices(l) - orc.indices(l)).max() <= 1e-13
+    # through the orchestrator: the new temperature becomes the global T_CMB, i.e. the cmb SED 1/a2t moves with it
+    cmb_before = eng.eval_sed(0, 1, 1)[0]
+    for c in comps[:-1]:
+        c.sample_index = [False] * c.nindices
+    da.sample_spectral_parameters(dpar, ddata, it=3)
+    T = eng.get_indices(l)[0, 0, 0]
+    cmb_after = eng.eval_sed(0, 1, 1)[0]
+    assert cmb_after != cmb_before
+    want = O.Oracle(bands, comps, ddata, tcmb=T).eval_sed_map(0, 1, 1)[0]
+    assert abs(cmb_after - want) <= 1e-12 * abs(want)
