@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--nside", type=int, default=None)
     ap.add_argument("--nsample", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bandpass", type=int, default=0, help="diagnostic (not a BASELINE config): integrate every second "
+                    "band over an N-sample +-10%% top-hat bandpass instead of a delta (SURVEY 8f rank 3)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for rehearsing "
                                                       "the N>1 path with several ranks on ONE GPU)")
     args = ap.parse_args()
@@ -147,6 +149,12 @@ def main():
     log("building synthetic sky %s on %s" % (args.config, dev))
     dpar, ddata, bands, comps, meta = synth.make_sky(args.config, nside=args.nside, device=dev, rank=rank, nranks=world,
                                                      nsample=args.nsample, as_numpy=False)
+    if args.bandpass > 0:
+        import numpy as np
+        for b in bands[1::2]:
+            b.id = "tophat"
+            b.nu0 = b.nu_c * 1e9 * np.linspace(0.9, 1.1, args.bandpass)
+            b.tau0 = np.full(args.bandpass, 1.0 / args.bandpass)
     stream = torch.cuda.current_stream().cuda_stream
     eng = da.initialize(bands, comps, ddata, npix_global=meta["npix_global"], pix0=meta["pix0"], device=dev_index,
                         stream=stream if stream else None)
@@ -218,9 +226,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: Nside=%d, %d bands, %d components (%s), %s, NUMSAMPLE=%d, per-pixel indices, "
-                                   "direct block solve, reference fluctuation term; pixel-sharded over %d rank(s)"
+                                   "direct block solve, reference fluctuation term; pixel-sharded over %d rank(s)%s"
                                    % (args.config, meta["nside"], nb, len(meta["phys"]), "+".join(meta["phys"]),
-                                      "IQU" if nmaps == 3 else "I", args.nsample, world),
+                                      "IQU" if nmaps == 3 else "I", args.nsample, world,
+                                      "; DIAGNOSTIC: every second band integrated over a %d-sample bandpass" % args.bandpass
+                                      if args.bandpass else ""),
                        "npix": meta["npix_global"], "chisq_after_amp": chisq[0], "chisq_after_index": chisq[1]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(BLOCK, (FAST && NG <= 4) ? 3 : 1) void k_amp_direct
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         gl[g] = a.gc[g]; ty[g] = M.comp[gl[g]].type;
-        cs[g] = FAST && ((M.comp[gl[g]].const_planes >> (k - 1)) & 1);
+        cs[g] = (M.comp[gl[g]].const_planes >> (k - 1)) & 1;
     }
     if (live) {
         double th0[NG], th1[NG];
@@ -117,8 +117,8 @@ __global__ __launch_bounds__(BLOCK, (FAST && NG <= 4) ? 3 : 1) void k_amp_direct
         const double inv = is * is;
 #pragma unroll
         for (int g = 0; g < NG; ++g)
-            mrow[g] = !FAST ? sed_eval(M, M.comp[gl[g]], j, pr[g])
-                      : cs[g] ? sed_const_tab(tab, nb, g, k, j) : sed_eval_tab(ty[g], tab, nb, NG, g, j, pr[g]);
+            mrow[g] = cs[g] ? sed_const_tab(tab, nb, g, k, j)
+                      : !FAST ? sed_eval(M, M.comp[gl[g]], j, pr[g]) : sed_eval_tab(ty[g], tab, nb, NG, g, j, pr[g]);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const double t2 = mrow[g] * inv;

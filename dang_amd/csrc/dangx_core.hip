@@ -473,13 +473,25 @@ int sync_model(dangx_ctx* ctx) {
     for (int j = 0; j < M.nbands; ++j) if (M.band[j].n != 0) M.all_delta = 0;
     for (int l = 0; l < M.ncomp; ++l)
         if (ctx->desc[l].type == DANGX_TCMB || is_global_type(ctx->desc[l].type)) M.all_delta = 0;  // generic paths only
-    if (!ctx->bp_nu0.empty()) {
-        if (ctx->d_bp_nu0) { (void)hipFree(ctx->d_bp_nu0); (void)hipFree(ctx->d_bp_tau0); }
-        const size_t nbytes = ctx->bp_nu0.size() * sizeof(double);
+    const size_t nbp = ctx->bp_nu0.size();
+    if (nbp && ctx->bp_dirty) {
+        if (ctx->d_bp_nu0) { (void)hipFree(ctx->d_bp_nu0); (void)hipFree(ctx->d_bp_tau0); (void)hipFree(ctx->d_bp_lnr); }
+        const size_t nbytes = nbp * sizeof(double);
         HIPCHK(ctx, hipMalloc(&ctx->d_bp_nu0, nbytes));
         HIPCHK(ctx, hipMalloc(&ctx->d_bp_tau0, nbytes));
-        HIPCHK(ctx, hipMemcpy(ctx->d_bp_nu0, ctx->bp_nu0.data(), nbytes, hipMemcpyHostToDevice));
-        HIPCHK(ctx, hipMemcpy(ctx->d_bp_tau0, ctx->bp_tau0.data(), nbytes, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMalloc(&ctx->d_bp_lnr, nbytes * M.ncomp));
+        // samples with nu0 == 0 are skipped by the reference: on the device they carry tau = 0 and nu = 1 GHz
+        std::vector<double> nue(ctx->bp_nu0), taue(ctx->bp_tau0);
+        for (size_t q = 0; q < nbp; ++q)
+            if (nue[q] == 0.0) { nue[q] = 1.0e9; taue[q] = 0.0; }
+        HIPCHK(ctx, hipMemcpy(ctx->d_bp_nu0, nue.data(), nbytes, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(ctx->d_bp_tau0, taue.data(), nbytes, hipMemcpyHostToDevice));
+        std::vector<double> lnr(nbp * M.ncomp, 0.0);  // (nu/nu_ref)**beta = exp(beta*log(nu/nu_ref)): the log once, here
+        for (int l = 0; l < M.ncomp; ++l)
+            for (size_t q = 0; q < nbp; ++q)
+                if (ctx->bp_nu0[q] != 0.0) lnr[l * nbp + q] = std::log(ctx->bp_nu0[q] / ctx->desc[l].nu_ref);
+        HIPCHK(ctx, hipMemcpy(ctx->d_bp_lnr, lnr.data(), nbytes * M.ncomp, hipMemcpyHostToDevice));
+        ctx->bp_dirty = false;
     }
     M.bp_nu0 = ctx->d_bp_nu0; M.bp_tau0 = ctx->d_bp_tau0;
     for (int l = 0; l < M.ncomp; ++l) {
@@ -489,6 +501,7 @@ int sync_model(dangx_ctx* ctx) {
         c.is_synch = d.is_synch; c.nu_ref = d.nu_ref;
         c.amp = ctx->amp[l]; c.idx = ctx->idx[l];
         c.tmpl = ctx->tmpl[l]; c.corr_mask = ctx->corr_mask[l]; c.nfit = ctx->nfit[l];
+        c.bp_lnr = ctx->d_bp_lnr ? ctx->d_bp_lnr + (size_t)l * nbp : nullptr;
         for (int k = 0; k < 3; ++k)
             for (int j = 0; j < MAXB; ++j) c.tamp[k][j] = ctx->tamp[l][k][j];
         if (is_global_type(c.type) && !c.tmpl) return fail(ctx, "global-amplitude component without a template map (dangx_set_template)");
@@ -511,13 +524,20 @@ int sync_model(dangx_ctx* ctx) {
             else if (c.type == DANGX_LOGNORMAL) { const double q = c.nu_ref / nu; c.cst[j] = q * q; }
         }
         c.const_planes = 0;
-        if (M.all_delta) {
+        if (c.type >= DANGX_POWERLAW && c.type <= DANGX_CMB) {  // the diffuse types; bandpass bands: the tau0-weighted sum
             const unsigned cp = (c.nind == 0) ? 7u : ctx->idx_const[l];
             for (int k = 0; k < M.nmaps; ++k)
                 if ((cp >> k) & 1) {
                     c.const_planes |= 1 << k;
-                    for (int j = 0; j < M.nbands; ++j)
-                        c.csed[k][j] = host_sed(c, M.band[j].nu_c, c.cst[j], ctx->idx_val[l][k][0], ctx->idx_val[l][k][1]);
+                    const double t0 = ctx->idx_val[l][k][0], t1 = ctx->idx_val[l][k][1];
+                    for (int j = 0; j < M.nbands; ++j) {
+                        const Band& b = M.band[j];
+                        if (b.n == 0 || c.type == DANGX_CMB) { c.csed[k][j] = host_sed(c, b.nu_c, c.cst[j], t0, t1); continue; }
+                        double sum = 0.0;
+                        for (int q = 0; q < b.n; ++q)
+                            if (ctx->bp_nu0[b.off + q] != 0.0) sum = sum + ctx->bp_tau0[b.off + q] * host_sed(c, ctx->bp_nu0[b.off + q], 0.0, t0, t1);
+                        c.csed[k][j] = sum;
+                    }
                 }
         }
     }
@@ -869,7 +889,7 @@ int dangx_destroy(dangx_ctx* ctx) {
     for (auto& w : ctx->work) if (w) (void)hipFree(w);
     if (ctx->partial) (void)hipFree(ctx->partial);
     for (int l = 0; l < MAXC; ++l) if (ctx->tmpl[l]) (void)hipFree(ctx->tmpl[l]);
-    if (ctx->d_bp_nu0) { (void)hipFree(ctx->d_bp_nu0); (void)hipFree(ctx->d_bp_tau0); }
+    if (ctx->d_bp_nu0) { (void)hipFree(ctx->d_bp_nu0); (void)hipFree(ctx->d_bp_tau0); (void)hipFree(ctx->d_bp_lnr); }
     if (ctx->fs_data) (void)hipFree(ctx->fs_data);
     (void)hipFree(ctx->rows_out);
     (void)hipFree(ctx->dm); (void)hipFree(ctx->scalars); (void)hipFree(ctx->counters); (void)hipFree(ctx->chi_cache);
@@ -908,7 +928,7 @@ int dangx_set_band(dangx_ctx* ctx, int band, double nu_c, int n, const double* n
     b.off = (int)ctx->bp_nu0.size();
     for (int i = 0; i < n; ++i) { ctx->bp_nu0.push_back(nu0[i]); ctx->bp_tau0.push_back(tau0[i]); }
     ctx->band_set[band] = true;
-    ctx->dirty = true;
+    ctx->dirty = true; ctx->bp_dirty = true;
     return 0;
 }
 
@@ -937,7 +957,7 @@ int dangx_set_component(dangx_ctx* ctx, int comp, const dangx_comp_desc* d) {
     ctx->desc[comp] = *d;
     if (ctx->desc[comp].nu_ref < 1e7) ctx->desc[comp].nu_ref *= 1e9;  // src/dang_param_mod.f90:571-573
     ctx->comp_set[comp] = true;
-    ctx->dirty = true;
+    ctx->dirty = true; ctx->bp_dirty = true;
     return 0;
 }
 

@@ -82,7 +82,8 @@ struct dangx_ctx {
     unsigned idx_const[MAXC] = {}; // bit k-1: every index of the component is spatially constant on plane k
     double idx_val[MAXC][3][MAXI] = {};
     std::vector<double> bp_nu0, bp_tau0;
-    double *d_bp_nu0 = nullptr, *d_bp_tau0 = nullptr;
+    double *d_bp_nu0 = nullptr, *d_bp_tau0 = nullptr, *d_bp_lnr = nullptr;  // lnr: [ncomp][samples]
+    bool bp_dirty = true;  // bandpass samples or component reference frequencies changed since the last upload
     // scratch
     double* partial = nullptr;
     long long partial_cap = 0;

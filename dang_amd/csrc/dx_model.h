@@ -52,6 +52,8 @@ struct Comp {
     const double* tmpl;      // c%template [nmaps][npix]
     int corr_mask, nfit;     // bit j: band j is fitted (c%corr), number of fitted bands
     double tamp[3][MAXB];    // c%template_amplitudes(band, map) as [map][band]
+    // bandpass-integrated bands: log(nu0/nu_ref) of every bandpass sample (same indexing as Model::bp_nu0)
+    const double* bp_lnr;
 };
 
 struct Model {

@@ -71,38 +71,48 @@ __device__ __forceinline__ Prep sed_prep(const Comp& c, double th0, double th1) 
     return p;
 }
 
-// bandpass-integrated forms (bp%id /= 'delta'): tau0-weighted sums, e.g. :909-913
+// bandpass-integrated forms (bp%id /= 'delta'): tau0-weighted sums in sample order, e.g. :909-913.  The reference
+// skips samples with nu0 == 0; the device copies carry tau = 0 and a harmless nu for those (s + 0*finite == s), so
+// the loops are branch-free, one loop per component type, four independent transcendental chains in flight.
+// (nu/nu_ref)**beta is exp(beta*log(nu/nu_ref)) with the log tabulated per (component, sample) on the host: the
+// same identity the delta-bandpass path uses (20 fp64 ops instead of pow's ~150).
 __device__ inline double sed_bandpass(const Model& M, const Comp& c, int j, const Prep& p) {
     const Band& b = M.band[j];
+    const double* __restrict__ nu = M.bp_nu0 + b.off;
+    const double* __restrict__ tau = M.bp_tau0 + b.off;
+    const double* __restrict__ lnr = c.bp_lnr + b.off;
+    const int n = b.n;
     double s = 0.0;
-    for (int i = 0; i < b.n; ++i) {
-        const double nu = M.bp_nu0[b.off + i];
-        const double tau = M.bp_tau0[b.off + i];
-        if (nu == 0.0) continue;
-        switch (c.type) {
-        case DANGX_POWERLAW:
-            s = s + tau * pow(nu / c.nu_ref, p.p0);
-            break;
-        case DANGX_MBB:
-            s = s + tau * p.p2 / (exp(p.p1 * nu) - 1.0) * pow(nu / c.nu_ref, p.p0);
-            break;
-        case DANGX_FREEFREE: {
-            const double r = nu / c.nu_ref;
-            s = s + tau * ff_gaunt(log_pos(1.0 * nu / 1.0e9), p.p0) / p.p1 * (1.0 / (r * r));
-            break;
+    switch (c.type) {
+    case DANGX_POWERLAW:
+#pragma unroll 4
+        for (int i = 0; i < n; ++i) s = s + tau[i] * exp(p.p0 * lnr[i]);
+        break;
+    case DANGX_MBB:
+#pragma unroll 4
+        for (int i = 0; i < n; ++i) s = s + tau[i] * p.p2 / (exp(p.p1 * nu[i]) - 1.0) * exp(p.p0 * lnr[i]);
+        break;
+    case DANGX_FREEFREE:
+#pragma unroll 2
+        for (int i = 0; i < n; ++i) {
+            const double r = nu[i] / c.nu_ref;
+            s = s + tau[i] * ff_gaunt(log_pos(1.0 * nu[i] / 1.0e9), p.p0) / p.p1 * (1.0 / (r * r));
         }
-        case DANGX_LOGNORMAL: {
-            const double l = log_pos(nu / p.p0) / p.p1;
-            const double q = c.nu_ref / nu;
-            s = s + tau * exp(-0.5 * (l * l)) * (q * q);
-            break;
+        break;
+    case DANGX_LOGNORMAL:
+#pragma unroll 2
+        for (int i = 0; i < n; ++i) {
+            const double l = log_pos(nu[i] / p.p0) / p.p1;
+            const double q = c.nu_ref / nu[i];
+            s = s + tau[i] * exp(-0.5 * (l * l)) * (q * q);
         }
-        case DANGX_TCMB:
-            s = s + tau * planck_rj(nu, p.p0);
-            break;
-        default:
-            break;
-        }
+        break;
+    case DANGX_TCMB:
+#pragma unroll 2
+        for (int i = 0; i < n; ++i) s = s + tau[i] * planck_rj(nu[i], p.p0);
+        break;
+    default:
+        break;
     }
     return (c.type == DANGX_TCMB) ? s * 1e6f : s;
 }
@@ -180,17 +190,15 @@ __device__ __forceinline__ double sed_const_tab(const double* tab, int nb, int l
 // (src/dang_component_mod.f90:754-813): template / monopole: sed = template(pix,map); hi_fit: template * evaluate_hi_fit;
 // signal = template_amplitudes(band,map) * sed for the three global types, the bare sed for T_cmb, amplitude * sed else.
 __device__ __forceinline__ double comp_sed(const Model& M, const Comp& c, int i, int k, int j, const Prep& p) {
+    if ((c.const_planes >> (k - 1)) & 1) return c.csed[k - 1][j];  // spatially constant indices: evaluated once on the host
     if (c.type == DANGX_TEMPLATE || c.type == DANGX_MONOPOLE) return c.tmpl[(long long)(k - 1) * M.npix + i];
     if (c.type == DANGX_HIFIT) {  // :850-884 (same expression as evaluate_T_cmb)
         double s;
         if (M.band[j].n == 0) s = planck_rj(M.band[j].nu_c, p.p0);
         else {
             s = 0.0;
-            for (int q = 0; q < M.band[j].n; ++q) {
-                const double nu = M.bp_nu0[M.band[j].off + q];
-                if (nu == 0.0) continue;
-                s = s + M.bp_tau0[M.band[j].off + q] * planck_rj(nu, p.p0);
-            }
+            for (int q = 0; q < M.band[j].n; ++q)
+                s = s + M.bp_tau0[M.band[j].off + q] * planck_rj(M.bp_nu0[M.band[j].off + q], p.p0);
         }
         return c.tmpl[(long long)(k - 1) * M.npix + i] * (s * 1e6f);
     }

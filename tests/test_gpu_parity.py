@@ -56,6 +56,35 @@ def test_eval_sed_bandpass(built):
     assert worst <= TOL_SED, worst
 
 
+def test_gibbs_iteration_with_bandpass_integrated_bands(built):
+    """Amplitude solve, index sweeps and chi^2 when some bands are bandpass-integrated (generic kernels)."""
+    def tweak(dpar, ddata, bands, comps):
+        rng = np.random.default_rng(4)
+        for b in bands[1::2]:
+            nu = b.nu_c * 1e9 * np.linspace(0.9, 1.1, 9)
+            tau = rng.uniform(0.2, 1.0, nu.size)
+            nu[3] = 0.0                      # an empty bandpass row: skipped (src/dang_component_mod.f90:909-913)
+            b.id, b.nu0, b.tau0 = "bp", nu, tau / tau.sum()
+    case = make_case("C2", nside=4, tweak=tweak)
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+    for group, flag in ((1, L.FLAG_T), (2, L.FLAG_QU)):
+        eng.amp_sample(group, flag, "sample", 7, 70 + flag)
+        orc.amp_sample_direct(group, flag, "sample", 7, 70 + flag, "reference")
+    assert_amps_close(eng, orc, len(comps), TOL_AMP)
+    for l, c in enumerate(comps):
+        for j in range(c.nindices):
+            if c.sample_index[j]:
+                for f in c.pol_flag[j]:
+                    ag = eng.index_sample(l, j, MAPN[f], 10, "sample", 7, 900 + 10 * l + j + f)
+                    ao = orc.sample_index_mh(l, j, MAPN[f], 10, "sample", 7, 900 + 10 * l + j + f)
+                    assert ag == ao, (l, j, f)
+    assert_indices_close(eng, orc, comps)
+    s = eng.sky_model_chisq(1, 3)
+    ochisq, _ = orc.chisq(1, 3, ddata.nump)
+    assert abs(s / meta["nbands"] / ddata.nump - ochisq) <= TOL_CHISQ * ochisq
+
+
 # ------------------------------------------------------------------ amplitude phase
 
 FLAGS = {"T": (1, L.FLAG_T), "QU": (2, L.FLAG_QU)}
