@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 output directories into small text files for profiles/.
 
-usage: prof_summary.py --stats <dir with *_kernel_stats.csv> --pmc NAME=<dir with *_counter_collection.csv> ... -o out.md
+usage: prof_summary.py --stats <dir with *kernel_stats.csv> --pmc NAME=<dir with *counter_collection.csv> ... -o out.md
 FETCH_SIZE / WRITE_SIZE are reported in KB by rocprofv3; per MI355X_MICROARCH.md (HBM section) gfx950
 FETCH_SIZE counts 64 B per 128-B request for wide coalesced streams, i.e. HALF the bytes -- the
 corrected column doubles it; the calibration factor for this repo's 8-B-per-lane access pattern is
@@ -27,12 +27,16 @@ def main():
     ap.add_argument("--stats")
     ap.add_argument("--pmc", action="append", default=[])
     ap.add_argument("--only", default="k_", help="keep kernels whose short name starts with this")
+    ap.add_argument("--sq", help="dir with the SQ_* counter pass (VALU issue occupancy table)")
+    ap.add_argument("--traffic-json", help="write {kernel family: HBM bytes per launch} from the FETCH_SIZE/WRITE_SIZE passes")
+    ap.add_argument("--fetch-factor", type=float, default=2.0, help="FETCH_SIZE correction (tools/pmc_calib.py: 2.000 here)")
+    ap.add_argument("--config", default="C3")
     ap.add_argument("-o", "--out", required=True)
     ap.add_argument("--title", default="rocprofv3 summary")
     a = ap.parse_args()
     lines = ["# " + a.title, ""]
     if a.stats:
-        f = glob.glob(os.path.join(a.stats, "**", "*_kernel_stats.csv"), recursive=True)[0]
+        f = glob.glob(os.path.join(a.stats, "**", "*kernel_stats.csv"), recursive=True)[0]
         lines += ["## kernel-trace --stats (%s)" % os.path.relpath(f), "",
                   "| kernel | calls | avg ms | min ms | max ms | total ms | % |", "|---|---|---|---|---|---|---|"]
         for r in csv.DictReader(open(f)):
@@ -45,7 +49,7 @@ def main():
         lines.append("")
     for spec in a.pmc:
         cname, d = spec.split("=", 1)
-        f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
+        f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
         agg = collections.OrderedDict()
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != cname:
@@ -63,6 +67,61 @@ def main():
             lines.append("| %s | %s | %d | %.1f | %.4e | %s |" % (s, g, len(v), m, m * 1024,
                                                                   ("%.4e" % (2 * m * 1024)) if cname == "FETCH_SIZE" else "-"))
         lines.append("")
+    if a.sq:
+        f = glob.glob(os.path.join(a.sq, "**", "*counter_collection.csv"), recursive=True)[0]
+        agg = collections.OrderedDict()
+        for r in csv.DictReader(open(f)):
+            s = short(r["Kernel_Name"])
+            if not s.startswith(a.only):
+                continue
+            key = (s, r["Grid_Size"])
+            e = agg.setdefault(key, {"n": collections.Counter(), "v": collections.Counter(), "meta": r})
+            e["n"][r["Counter_Name"]] += 1
+            e["v"][r["Counter_Name"]] += float(r["Counter_Value"])
+        lines += ["## SQ counters (%s)" % os.path.relpath(f), "",
+                  "resident waves/SIMD from the dispatch's VGPR (arch+accum, 512 per lane) and LDS (160 KiB/CU) footprint; "
+                  "VALU issue busy = resident waves/SIMD x the share of a wave's cycles with a VALU instruction issuing.", "",
+                  "| kernel | grid | vgpr (arch+acc) | LDS B/block | VALU instr / wave | inst active % | VALU active % | wait_any % | wait_inst % | waves/SIMD | VALU issue busy |",
+                  "|---|---|---|---|---|---|---|---|---|---|---|"]
+        for (s, g), e in agg.items():
+            m = {k: e["v"][k] / e["n"][k] for k in e["v"]}
+            r = e["meta"]
+            vg = 2 * (int(r["VGPR_Count"]) + int(r["Accum_VGPR_Count"]))  # the CSV counts register PAIRS for wave64 dispatches
+            lds, wg = int(r["LDS_Block_Size"]), int(r["Workgroup_Size"])
+            w_v = min(8, 512 // max(8 * ((vg + 7) // 8), 8))
+            w_l = ((160 * 1024) // lds) * (wg // 64) // 4 if lds else 8
+            w = max(1, min(w_v, w_l))
+            wc = m.get("SQ_WAVE_CYCLES", 0.0) or 1.0
+            valu = 100.0 * m.get("SQ_ACTIVE_INST_VALU", 0.0) / wc
+            lines.append("| %s | %s | %d | %d | %.0f | %.1f | %.1f | %.1f | %.1f | %d | %.0f %% |" % (
+                s, g, vg, lds, m.get("SQ_INSTS_VALU", 0.0) / max(m.get("SQ_WAVES", 1.0), 1.0),
+                100.0 * m.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, valu, 100.0 * m.get("SQ_WAIT_ANY", 0.0) / wc,
+                100.0 * m.get("SQ_WAIT_INST_ANY", 0.0) / wc, w, min(100.0, w * valu)))
+        lines.append("")
+    if a.traffic_json:
+        import json
+        fam = collections.OrderedDict()
+        for spec in a.pmc:
+            cname, d = spec.split("=", 1)
+            if cname not in ("FETCH_SIZE", "WRITE_SIZE"):
+                continue
+            f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] != cname:
+                    continue
+                s = short(r["Kernel_Name"])
+                k = "k_amp_direct" if s.startswith("k_amp_direct") else "k_index_mh" if s.startswith("k_index_mh") else None
+                if k:
+                    fam.setdefault(k, {}).setdefault(cname, []).append(float(r["Counter_Value"]) * 1024.0)
+        out = {"source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH corrected by the measured "
+                         "k_cg_vec calibration factor %.3f)" % (a.out, a.fetch_factor),
+               "config": a.config, "fetch_correction": a.fetch_factor, "kernels": {}}
+        for k, v in fam.items():
+            fr = sum(v.get("FETCH_SIZE", [0.0])) / max(len(v.get("FETCH_SIZE", [0.0])), 1)
+            wr = sum(v.get("WRITE_SIZE", [0.0])) / max(len(v.get("WRITE_SIZE", [0.0])), 1)
+            out["kernels"][k] = {"fetch_raw_bytes": fr, "fetch_corrected_bytes": fr * a.fetch_factor, "write_bytes": wr,
+                                 "hbm_bytes_per_launch": fr * a.fetch_factor + wr}
+        json.dump(out, open(a.traffic_json, "w"), indent=1)
     open(a.out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
