@@ -1199,19 +1199,21 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
     // chain mode: factorised SED when every band is a delta bandpass
     const bool all_delta = ctx->hm.all_delta != 0;
     a.mode = CH_GENERIC;
-    if (all_delta) {
-        if (d.type == DANGX_POWERLAW) a.mode = CH_POW;
-        else if (d.type == DANGX_MBB) a.mode = nind == 0 ? CH_MBB_BETA : CH_MBB_T;
-        else if (d.type == DANGX_LOGNORMAL) a.mode = nind == 0 ? CH_LOGN_NUP : CH_LOGN_W;
-    }
+    a.bp = all_delta ? 0 : 1;
+    if (d.type == DANGX_POWERLAW) a.mode = CH_POW;
+    else if (d.type == DANGX_MBB) a.mode = nind == 0 ? CH_MBB_BETA : CH_MBB_T;
+    else if (d.type == DANGX_LOGNORMAL && all_delta) a.mode = nind == 0 ? CH_LOGN_NUP : CH_LOGN_W;
+    // with bandpass-integrated bands (or T_cmb / template-type components present) the compile-time modes exist for the
+    // chisq likelihood with a gaussian / uniform prior only; everything else takes the run-time generic chain
+    if (a.bp && (d.lnl_type[nind] != DANGX_LNL_CHISQ || d.prior_type[nind] == DANGX_PRIOR_JEFFREYS)) a.mode = CH_GENERIC;
     // LDS columns: (2*Sp+1)*nb doubles per thread; pick the block so that >= 2 blocks fit in 160 KiB
     const size_t per_thread = (size_t)(2 * Sp + 1) * ctx->hm.nbands * sizeof(double);
     const size_t tabsz = (size_t)(TROWS * ctx->hm.ncomp + 3) * ctx->hm.nbands * sizeof(double);
     int bs = 256;
     while (bs > 64 && tabsz + per_thread * bs > 76 * 1024) bs >>= 1;
     const size_t lds = tabsz + per_thread * bs;
-    const bool reg_ok = d.lnl_type[nind] == DANGX_LNL_CHISQ && d.prior_type[nind] != DANGX_PRIOR_JEFFREYS && a.mode != CH_GENERIC &&
-                        dx_mh_reg_supported(a.mode, ctx->hm.nbands);
+    const bool reg_ok = !a.bp && d.lnl_type[nind] == DANGX_LNL_CHISQ && d.prior_type[nind] != DANGX_PRIOR_JEFFREYS &&
+                        a.mode != CH_GENERIC && dx_mh_reg_supported(a.mode, ctx->hm.nbands);
     if (reg_ok) bs = BLOCK;  // register-resident form: no LDS columns
     const unsigned nblk = nblocks(ctx->hm.npix, bs);
     constexpr int RSTAGE = 128;  // blocks of the first reduction stage

@@ -96,7 +96,9 @@ __device__ __forceinline__ double chain_lnl(const ChainCtx& C, double th, int ln
 // (CH_POW / CH_MBB_BETA / CH_MBB_T), plane count SP and band tile TB (nb % TB == 0).  A tile first issues
 // every LDS / scalar load of its TB bands, then runs the TB independent exp chains interleaved, then
 // accumulates in band order (same summation order as the plain loop).
-template <int MODE, int SP, int TB>
+// BP: band j may be bandpass-integrated -- its SED is the tau-weighted sum over the samples, in the operation order of
+// sed_bandpass (the chain-invariant factor of the mbb modes is per SAMPLE there and is recomputed).
+template <int MODE, int SP, int TB, bool BP>
 __device__ __forceinline__ double chain_lnl_tiled(const ChainCtx& C, double th, double& acc0, double& acc1) {
     const Model& M = C.M;
     const Comp& c = C.c;
@@ -105,6 +107,39 @@ __device__ __forceinline__ double chain_lnl_tiled(const ChainCtx& C, double th, 
     else if (MODE == CH_MBB_BETA) s0 = th + 1.0;
     else { s0 = H_PLANCK / (K_B * th); s1 = exp(s0 * c.nu_ref) - 1.0; }
     acc0 = 0.0; acc1 = 0.0;
+    if (BP) {
+        // chain-invariant scalars of the per-sample factor: mbb beta chain: z, A from the fixed temperature;
+        // mbb T chain: the fixed beta + 1
+        double bz = 0.0, bA = 0.0, bb1 = 0.0;
+        if (MODE == CH_MBB_BETA) { bz = H_PLANCK / (K_B * C.other); bA = exp(bz * c.nu_ref) - 1.0; }
+        if (MODE == CH_MBB_T) bb1 = C.other + 1.0;
+        for (int j = 0; j < C.nb; ++j) {
+            const Band& b = M.band[j];
+            double s;
+            if (b.n == 0) {
+                const double e = exp((MODE == CH_MBB_T) ? s0 * b.nu_c : s0 * c.lnr[j]);
+                s = (MODE == CH_POW) ? e : (MODE == CH_MBB_BETA) ? C.F(j) * e : s1 / (e - 1.0) * C.F(j);
+            } else {
+                const kptr nu = as_const(M.bp_nu0 + b.off);
+                const kptr tau = as_const(M.bp_tau0 + b.off);
+                const kptr lnr = as_const(c.bp_lnr + b.off);
+                s = 0.0;
+#pragma unroll 4
+                for (int q = 0; q < b.n; ++q) {
+                    if (MODE == CH_POW) s = s + tau[q] * exp(s0 * lnr[q]);
+                    else if (MODE == CH_MBB_BETA) s = s + tau[q] * bA / (exp(bz * nu[q]) - 1.0) * exp(s0 * lnr[q]);
+                    else s = s + tau[q] * s1 / (exp(s0 * nu[q]) - 1.0) * exp(bb1 * lnr[q]);
+                }
+            }
+            const double r0 = (C.D(0, j) - C.amp0 * s) * C.IS(0, j);
+            acc0 = acc0 - 0.5 * (r0 * r0);
+            if (SP == 2) {
+                const double r1 = (C.D(1, j) - C.amp1 * s) * C.IS(1, j);
+                acc1 = acc1 - 0.5 * (r1 * r1);
+            }
+        }
+        return acc0 + acc1;
+    }
     for (int j0 = 0; j0 < C.nb; j0 += TB) {
         double f[TB], d0[TB], i0[TB], d1[TB], i1[TB], x[TB], s[TB];
 #pragma unroll
@@ -171,7 +206,7 @@ __device__ __forceinline__ double index_prior(const ChainCtx& C, double val) {
 // planes before (plane0, plane1) and after (plane0, plane1) the sweep
 // MODE == CH_GENERIC: everything decided at run time (a.mode, lnl type, plane count, any nb);
 // otherwise the chisq fast path above with compile-time MODE / SP / TB.
-template <int MODE, int SP, int TB>
+template <int MODE, int SP, int TB, bool BP>
 __device__ __forceinline__ unsigned long long index_chain(const Model& M, const IndexArgs& a, double* lds, const double* tab,
                                                           int BS, int tid, int i, double chi[4]) {
     const int npix = M.npix, nb = M.nbands;
@@ -227,7 +262,7 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
             for (int kk = 0; kk < 2; ++kk)
                 if (kk < Sp) {
                     na[kk] = c2.amp[(long long)(a.s1 + kk - 1) * npix + i];
-                    if (MODE == CH_GENERIC || !((c2.const_planes >> (a.s1 + kk - 1)) & 1))
+                    if (MODE == CH_GENERIC || BP || !((c2.const_planes >> (a.s1 + kk - 1)) & 1))
                         load_theta(M, c2, i, a.s1 + kk, nt0[kk], nt1[kk]);
                 }
         };
@@ -242,15 +277,15 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
                 if (kk < Sp) {
-                    if (MODE != CH_GENERIC && ((c2.const_planes >> (a.s1 + kk - 1)) & 1)) {
+                    if (MODE != CH_GENERIC && !BP && ((c2.const_planes >> (a.s1 + kk - 1)) & 1)) {
                         for (int j = 0; j < nb; ++j) C.D(kk, j) -= ca[kk] * sed_const_tab(tab, nb, l, a.s1 + kk, j);
                     } else {
                         const Prep pr = sed_prep(c2, ct0[kk], ct1[kk]);
                         const int ty2 = c2.type;
 #pragma unroll 1
                         for (int j = 0; j < nb; ++j)
-                            C.D(kk, j) -= (MODE != CH_GENERIC) ? ca[kk] * sed_eval_tab(ty2, tab, nb, M.ncomp, l, j, pr)
-                                                               : comp_signal(M, c2, i, a.s1 + kk, j, ca[kk], pr);
+                            C.D(kk, j) -= (MODE != CH_GENERIC && !BP) ? ca[kk] * sed_eval_tab(ty2, tab, nb, M.ncomp, l, j, pr)
+                                                                      : comp_signal(M, c2, i, a.s1 + kk, j, ca[kk], pr);
                     }
                 }
             l = ln;
@@ -273,7 +308,7 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
     double a0, a1, c0, c1;                   // per-plane likelihood parts: current / proposal
     auto lnl_of = [&](double th, double& p0, double& p1) -> double {
         if (MODE == CH_GENERIC) return chain_lnl(C, th, lnl_type, p0, p1);
-        return chain_lnl_tiled<MODE == CH_GENERIC ? CH_POW : MODE, SP, TB>(C, th, p0, p1);
+        return chain_lnl_tiled<MODE == CH_GENERIC ? CH_POW : MODE, SP, TB, BP>(C, th, p0, p1);
     };
     double lnl = lnl_of(cur, a0, a1);
     if (lnl_type != DANGX_LNL_CHISQ) {       // chi^2 bookkeeping needs the chisq form
@@ -324,7 +359,7 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
 }
 
 // chi_partial (nullable): [4][gridDim.x] block sums of chi[0..3]
-template <int MODE, int SP, int TB>
+template <int MODE, int SP, int TB, bool BP>
 __global__ __launch_bounds__(BLOCK) void k_index_mh(const Model* __restrict__ Mp, IndexArgs a,
                                                     unsigned long long* __restrict__ accepted,
                                                     double* __restrict__ chi_partial) {
@@ -335,7 +370,7 @@ __global__ __launch_bounds__(BLOCK) void k_index_mh(const Model* __restrict__ Mp
     sed_table_build(M, lds, tid, BS);
     __syncthreads();
     double chi[4] = {0.0, 0.0, 0.0, 0.0};
-    unsigned long long nacc = (i < M.npix) ? index_chain<MODE, SP, TB>(M, a, lds + sed_table_size(M), lds, BS, tid, i, chi) : 0ull;
+    unsigned long long nacc = (i < M.npix) ? index_chain<MODE, SP, TB, BP>(M, a, lds + sed_table_size(M), lds, BS, tid, i, chi) : 0ull;
     if (accepted) {  // every lane takes part in the wave reduction
         for (int o = 32; o > 0; o >>= 1) nacc += __shfl_down(nacc, o, 64);
         if ((tid & 63) == 0 && nacc) atomicAdd(accepted, nacc);
@@ -363,16 +398,23 @@ void dx_launch_mh_lds(dangx_ctx* ctx, const IndexArgs& a, bool fast, int Sp, uns
     const int nb = ctx->hm.nbands;
     const int tb = (nb % 5 == 0) ? 5 : (nb % 4 == 0) ? 4 : (nb % 3 == 0) ? 3 : 1;
 #define DX_LAUNCH_MH(MODE_, SP_, TB_)                                                                            \
-    hipLaunchKernelGGL((k_index_mh<MODE_, SP_, TB_>), dim3(nblk), dim3(bs), lds, ctx->stream, ctx->dm, a, accp, ctx->partial)
+    hipLaunchKernelGGL((k_index_mh<MODE_, SP_, TB_, false>), dim3(nblk), dim3(bs), lds, ctx->stream, ctx->dm, a, accp, ctx->partial)
+#define DX_LAUNCH_MH_BP(MODE_)                                                                                   \
+    do { if (Sp == 2) hipLaunchKernelGGL((k_index_mh<MODE_, 2, 1, true>), dim3(nblk), dim3(bs), lds, ctx->stream, ctx->dm, a, accp, ctx->partial); \
+         else hipLaunchKernelGGL((k_index_mh<MODE_, 1, 1, true>), dim3(nblk), dim3(bs), lds, ctx->stream, ctx->dm, a, accp, ctx->partial); } while (0)
 #define DX_MH_TB(MODE_, SP_)                                                                                     \
     do { if (tb == 5) DX_LAUNCH_MH(MODE_, SP_, 5); else if (tb == 4) DX_LAUNCH_MH(MODE_, SP_, 4);                \
          else if (tb == 3) DX_LAUNCH_MH(MODE_, SP_, 3); else DX_LAUNCH_MH(MODE_, SP_, 1); } while (0)
 #define DX_MH_SP(MODE_) do { if (Sp == 2) DX_MH_TB(MODE_, 2); else DX_MH_TB(MODE_, 1); } while (0)
     if (!fast) DX_LAUNCH_MH(CH_GENERIC, 1, 1);
+    else if (a.bp && a.mode == CH_POW) DX_LAUNCH_MH_BP(CH_POW);
+    else if (a.bp && a.mode == CH_MBB_BETA) DX_LAUNCH_MH_BP(CH_MBB_BETA);
+    else if (a.bp) DX_LAUNCH_MH_BP(CH_MBB_T);
     else if (a.mode == CH_POW) DX_MH_SP(CH_POW);
     else if (a.mode == CH_MBB_BETA) DX_MH_SP(CH_MBB_BETA);
     else DX_MH_SP(CH_MBB_T);
 #undef DX_MH_SP
 #undef DX_MH_TB
 #undef DX_LAUNCH_MH
+#undef DX_LAUNCH_MH_BP
 }

@@ -52,6 +52,8 @@ enum { CH_GENERIC = 0, CH_POW = 1, CH_MBB_BETA = 2, CH_MBB_T = 3, CH_LOGN_NUP = 
 
 struct IndexArgs {
     int comp, nind, s1, s2, nsample, ml_mode, mode;
+    int bp;           // some band is bandpass-integrated or a non-diffuse component is present: the compile-time chain
+                      // modes then sum over the bandpass samples and remove the other components through comp_signal
     unsigned others;  // bit l: component l (/= comp) may have a non-zero amplitude on planes s1..s2
     unsigned long long seed, stream;
 };

@@ -76,11 +76,16 @@ __device__ __forceinline__ Prep sed_prep(const Comp& c, double th0, double th1) 
 // the loops are branch-free, one loop per component type, four independent transcendental chains in flight.
 // (nu/nu_ref)**beta is exp(beta*log(nu/nu_ref)) with the log tabulated per (component, sample) on the host: the
 // same identity the delta-bandpass path uses (20 fp64 ops instead of pow's ~150).
+// The sample tables are read-only for the whole launch and indexed wave-uniformly: viewed through the constant
+// address space they are fetched with scalar loads (s_load, scalar cache) instead of per-lane flat loads.
+typedef const double __attribute__((address_space(4))) * kptr;
+__device__ __forceinline__ kptr as_const(const double* p) { return reinterpret_cast<kptr>(reinterpret_cast<uintptr_t>(p)); }
+
 __device__ inline double sed_bandpass(const Model& M, const Comp& c, int j, const Prep& p) {
     const Band& b = M.band[j];
-    const double* __restrict__ nu = M.bp_nu0 + b.off;
-    const double* __restrict__ tau = M.bp_tau0 + b.off;
-    const double* __restrict__ lnr = c.bp_lnr + b.off;
+    const kptr nu = as_const(M.bp_nu0 + b.off);
+    const kptr tau = as_const(M.bp_tau0 + b.off);
+    const kptr lnr = as_const(c.bp_lnr + b.off);
     const int n = b.n;
     double s = 0.0;
     switch (c.type) {
