@@ -12,17 +12,13 @@ namespace {
 // and the kernel uses no LDS and no barrier.  The CU's vector register file (512 KB) is three times its
 // LDS, so this form runs at 2-3 waves/SIMD where the LDS-column form is capped at 1-2.
 // Arithmetic and operation order are identical to index_chain<MODE, SP, TB>.
-template <int MODE, int SP, int NB, bool ISLDS>
+template <int MODE, int SP, int NB>
 struct RegChain {
-    double D[SP][NB], F[NB];
-    double ISr[ISLDS ? 1 : SP][ISLDS ? 1 : NB];  // 1/rms in registers ...
-    double* isl;                                  // ... or in LDS columns [slot][thread] when registers run out
+    double D[SP][NB], F[NB], ISr[SP][NB];  // cleaned data, chain-invariant SED factor, 1/rms
     double amp[SP];
 
-    __device__ __forceinline__ double is(int kk, int j) const { return ISLDS ? isl[(kk * NB + j) * BLOCK] : ISr[ISLDS ? 0 : kk][ISLDS ? 0 : j]; }
-    __device__ __forceinline__ void set_is(int kk, int j, double v) {
-        if (ISLDS) isl[(kk * NB + j) * BLOCK] = v; else ISr[ISLDS ? 0 : kk][ISLDS ? 0 : j] = v;
-    }
+    __device__ __forceinline__ double is(int kk, int j) const { return ISr[kk][j]; }
+    __device__ __forceinline__ void set_is(int kk, int j, double v) { ISr[kk][j] = v; }
 
     __device__ __forceinline__ double lnl(const Model& M, const Comp& c, double th, double other, double& acc0, double& acc1) const {
         double s0 = 0.0, s1 = 0.0;
@@ -142,8 +138,8 @@ __device__ __forceinline__ void subtract_other_pair(const Model& M, const Comp& 
     }
 }
 
-template <int MODE, int SP, int NB, bool ISLDS>
-__device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, const IndexArgs& a, int i, double chi[4], double* isl) {
+template <int MODE, int SP, int NB>
+__device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, const IndexArgs& a, int i, double chi[4]) {
     const int npix = M.npix;
     const Comp& c = M.comp[a.comp];
     double* out = c.idx + ((long long)a.nind * M.nmaps) * npix + i;
@@ -152,8 +148,7 @@ __device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, co
         for (int kk = 0; kk < SP; ++kk) out[(long long)(a.s1 + kk - 1) * npix] = 0.0;
         return 0ull;
     }
-    RegChain<MODE, SP, NB, ISLDS> R;
-    R.isl = isl;
+    RegChain<MODE, SP, NB> R;
     double sample0, sample1;
     load_theta(M, c, i, a.s1, sample0, sample1);  // sample(l) = c%indices(i, map_inds(1), l), :372-377
     const bool first = (a.nind == 0);
@@ -258,16 +253,18 @@ __device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, co
     return nacc;
 }
 
-template <int MODE, int SP, int NB, bool ISLDS>
-__global__ __launch_bounds__(BLOCK, (SP == 1 && NB <= 10) ? 3 : 2) void k_index_mh_reg(const Model* __restrict__ Mp, IndexArgs a,
+// Resident waves per SIMD follow the register need: 3 (<= 168 VGPRs) for one plane of <= 10 bands, 2 (<= 256) otherwise,
+// except two planes of 20 bands (C5), which need ~330 registers: one wave per SIMD with the overflow in AGPRs runs
+// 25 % faster than two waves spilling 70 registers to scratch (the chain has five independent exp chains in flight).
+template <int MODE, int SP, int NB>
+__global__ __launch_bounds__(BLOCK, (SP == 1 && NB <= 10) ? 3 : (SP == 2 && NB >= 20) ? 1 : 2) void k_index_mh_reg(const Model* __restrict__ Mp, IndexArgs a,
                                                         unsigned long long* __restrict__ accepted,
                                                         double* __restrict__ chi_partial) {
-    extern __shared__ double lds[];  // ISLDS: 1/rms columns [SP*NB][BLOCK]
     const Model& M = *Mp;
     const int tid = threadIdx.x;
     const int i = blockIdx.x * BLOCK + tid;
     double chi[4] = {0.0, 0.0, 0.0, 0.0};
-    unsigned long long nacc = (i < M.npix) ? index_chain_reg<MODE, SP, NB, ISLDS>(M, a, i, chi, lds + tid) : 0ull;
+    unsigned long long nacc = (i < M.npix) ? index_chain_reg<MODE, SP, NB>(M, a, i, chi) : 0ull;
     if (accepted) {
         for (int o = 32; o > 0; o >>= 1) nacc += __shfl_down(nacc, o, 64);
         if ((tid & 63) == 0 && nacc) atomicAdd(accepted, nacc);
@@ -295,13 +292,12 @@ __global__ __launch_bounds__(BLOCK, (SP == 1 && NB <= 10) ? 3 : 2) void k_index_
 #define DX_CAT(a, b) DX_CAT2(a, b)
 bool DX_CAT(dx_launch_mh_reg_mode, DX_REG_MODE)(dangx_ctx* ctx, const IndexArgs& a, int Sp, unsigned nblk, unsigned long long* accp) {
     const int nb = ctx->hm.nbands;
-#define DX_LAUNCH_REG(SP_, NB_, L_)                                                                              \
-    hipLaunchKernelGGL((k_index_mh_reg<DX_REG_MODE, SP_, NB_, L_>), dim3(nblk), dim3(BLOCK),                     \
-                       (L_) ? (size_t)(SP_) * (NB_) * BLOCK * sizeof(double) : 0, ctx->stream, ctx->dm, a, accp, ctx->partial)
+#define DX_LAUNCH_REG(SP_, NB_)                                                                                  \
+    hipLaunchKernelGGL((k_index_mh_reg<DX_REG_MODE, SP_, NB_>), dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->dm, a, accp, ctx->partial)
 #define DX_REG_NB(SP_)                                                                                           \
-    do { if (nb == 10) DX_LAUNCH_REG(SP_, 10, false); else if (nb == 5) DX_LAUNCH_REG(SP_, 5, false);            \
-         else if (nb == 3) DX_LAUNCH_REG(SP_, 3, false); else if (nb == 6) DX_LAUNCH_REG(SP_, 6, false);         \
-         else if (nb == 8) DX_LAUNCH_REG(SP_, 8, false); else if (nb == 20) DX_LAUNCH_REG(SP_, 20, ((SP_) == 2)); \
+    do { if (nb == 10) DX_LAUNCH_REG(SP_, 10); else if (nb == 5) DX_LAUNCH_REG(SP_, 5);                          \
+         else if (nb == 3) DX_LAUNCH_REG(SP_, 3); else if (nb == 6) DX_LAUNCH_REG(SP_, 6);                       \
+         else if (nb == 8) DX_LAUNCH_REG(SP_, 8); else if (nb == 20) DX_LAUNCH_REG(SP_, 20);                     \
          else return false; } while (0)
     if (Sp == 2) DX_REG_NB(2); else DX_REG_NB(1);
 #undef DX_REG_NB
