@@ -19,6 +19,7 @@ program dangx_fsmoke
   type(dangx_comp_desc) :: d
   character(len=512) :: fin, fout
   integer :: j, u
+  integer, save :: ncalls = 0
 
   call get_command_argument(1, fin)
   call get_command_argument(2, fout)
@@ -62,10 +63,33 @@ program dangx_fsmoke
   call dangx_check(ctx, dangx_get_amplitude(ctx, 1, c_loc(amp2)), 'get_amplitude')
   call dangx_check(ctx, dangx_get_indices(ctx, 0, c_loc(ind1)), 'get_indices')
   call dangx_check(ctx, dangx_get_indices(ctx, 1, c_loc(ind2)), 'get_indices')
+  ! the pixel-sharded hook: the device CG hands its dot products to a callback written in the driver's language
+  ! (an MPI_Allreduce in a real driver; one rank here, so the sum over ranks is the identity)
+  ncalls = 0
+  call dangx_check(ctx, dangx_set_allreduce(ctx, c_funloc(smoke_allreduce), c_null_ptr, 1), 'dangx_set_allreduce')
+  st = dangx_amp_sample(ctx, 1, DANGX_FLAG_T, DANGX_ML_OPTIMIZE, DANGX_SOLVER_CG, DANGX_FLUCT_REFERENCE, seed, &
+       dangx_stream_id(3, 0, 1, 0, DANGX_FLAG_T), 4, 0.d0, iters, nbad)
+  call dangx_check(ctx, st, 'dangx_amp_sample(cg)')
   call dangx_check(ctx, dangx_destroy(ctx), 'dangx_destroy')
 
   open(newunit=u, file=trim(fout), access='stream', form='unformatted', status='replace')
   write(u) chisq_sum, amp1, amp2, ind1, ind2
   close(u)
   write(*,'(a,es24.16,a,i0)') 'dangx_fsmoke ok: chisq_sum = ', chisq_sum, '  not_spd = ', nbad
+  write(*,'(a,i0,a,i0)') 'allreduce callback calls = ', ncalls, '  cg iterations = ', iters
+
+contains
+
+  integer(c_int) function smoke_allreduce(user, buf, n) bind(C)
+    type(c_ptr), value :: user
+    integer(c_int64_t), value :: n
+    real(c_double) :: buf(n)
+    ncalls = ncalls + 1
+    if (n < 1 .or. buf(1) /= buf(1)) then   ! touch the buffer: a NaN or an empty call is an error
+       smoke_allreduce = 1
+    else
+       smoke_allreduce = 0
+    end if
+  end function smoke_allreduce
+
 end program dangx_fsmoke

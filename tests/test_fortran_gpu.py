@@ -29,6 +29,8 @@ def test_fortran_driver_matches_python_host(built, tmp_path):
     r = subprocess.run([exe, fin, fout], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout
     assert "dangx_fsmoke ok" in r.stdout
+    # the Fortran all-reduce callback (c_funloc of a bind(C) function) served the device CG: 1 + 2 per iteration
+    assert "allreduce callback calls = 7  cg iterations = 4" in r.stdout, r.stdout
     out = np.fromfile(fout, dtype="<f8")
     chisq_f, rest = out[0], out[1:]
     amp1, amp2, ind1, ind2 = np.split(rest, np.cumsum([npix, npix, npix]))
