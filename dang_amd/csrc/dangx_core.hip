@@ -460,6 +460,8 @@ double host_sed(const Comp& c, double nu, double cmb_cst, double th0, double th1
     }
 }
 
+int ensure_state(dangx_ctx* ctx, int comp);
+
 int sync_model(dangx_ctx* ctx) {
     if (!ctx->dirty) return 0;
     Model& M = ctx->hm;
@@ -468,6 +470,8 @@ int sync_model(dangx_ctx* ctx) {
     for (int l = 0; l < M.ncomp; ++l)
         if (!ctx->comp_set[l]) return fail(ctx, "component " + std::to_string(l) + " not set");
     if (!ctx->sig || !ctx->rms || !ctx->mask) return fail(ctx, "map data not uploaded");
+    for (int l = 0; l < M.ncomp; ++l)
+        if (ensure_state(ctx, l)) return 1;
     M.sig = ctx->sig; M.rms = ctx->rms; M.mask = ctx->mask;
     M.all_delta = 1;
     for (int j = 0; j < M.nbands; ++j) if (M.band[j].n != 0) M.all_delta = 0;
@@ -837,6 +841,25 @@ int check_comp(dangx_ctx* ctx, int comp) {
     return 0;
 }
 
+// c%amplitude / c%indices of a component, zero-initialised, unless the caller's device buffers were adopted
+int ensure_state(dangx_ctx* ctx, int comp) {
+    if (!ctx->comp_set[comp]) return fail(ctx, "component not set");
+    (void)hipSetDevice(ctx->device);
+    const size_t plane = (size_t)ctx->dims.npix * ctx->dims.nmaps * sizeof(double);
+    if (!ctx->amp[comp]) {
+        HIPCHK(ctx, hipMalloc(&ctx->amp[comp], plane));
+        HIPCHK(ctx, hipMemset(ctx->amp[comp], 0, plane));
+        ctx->own_amp[comp] = true; ctx->dirty = true;
+    }
+    const int nind = ctx->desc[comp].nindices;
+    if (nind > 0 && !ctx->idx[comp]) {
+        HIPCHK(ctx, hipMalloc(&ctx->idx[comp], plane * nind));
+        HIPCHK(ctx, hipMemset(ctx->idx[comp], 0, plane * nind));
+        ctx->own_idx[comp] = true; ctx->dirty = true;
+    }
+    return 0;
+}
+
 }  // namespace
 
 // ======================================================================= C ABI
@@ -942,18 +965,8 @@ int dangx_set_component(dangx_ctx* ctx, int comp, const dangx_comp_desc* d) {
     if (d->type == DANGX_TCMB && d->sample_amplitude)
         return fail(ctx, "T_cmb cannot be amplitude-sampled on the device yet (SURVEY 8f rank 1)");
     if (d->nindices != want) return fail(ctx, "nindices does not match the component type");
-    (void)hipSetDevice(ctx->device);
-    const size_t plane = (size_t)ctx->dims.npix * ctx->dims.nmaps * sizeof(double);
-    if (!ctx->amp[comp]) {
-        HIPCHK(ctx, hipMalloc(&ctx->amp[comp], plane));
-        HIPCHK(ctx, hipMemset(ctx->amp[comp], 0, plane));
-        ctx->own_amp[comp] = true;
-    }
-    if (d->nindices > 0 && !ctx->idx[comp]) {
-        HIPCHK(ctx, hipMalloc(&ctx->idx[comp], plane * d->nindices));
-        HIPCHK(ctx, hipMemset(ctx->idx[comp], 0, plane * d->nindices));
-        ctx->own_idx[comp] = true;
-    }
+    // the amplitude / index maps are allocated on first use (ensure_state): a caller that adopts its own device
+    // buffers (dangx_adopt_device_state) never holds two copies
     ctx->desc[comp] = *d;
     if (ctx->desc[comp].nu_ref < 1e7) ctx->desc[comp].nu_ref *= 1e9;  // src/dang_param_mod.f90:571-573
     ctx->comp_set[comp] = true;
@@ -1008,8 +1021,7 @@ int dangx_adopt_device_data(dangx_ctx* ctx, const double* sig, const double* rms
 }
 
 int dangx_put_amplitude(dangx_ctx* ctx, int comp, const double* amp) {
-    if (!ctx || !amp || check_comp(ctx, comp)) return 1;
-    if (!ctx->amp[comp]) return fail(ctx, "component not set");
+    if (!ctx || !amp || check_comp(ctx, comp) || ensure_state(ctx, comp)) return 1;
     ctx->plane_nz[comp] = 0;
     for (int k = 0; k < ctx->dims.nmaps; ++k)
         for (long long t = 0; t < ctx->dims.npix; ++t)
@@ -1019,14 +1031,13 @@ int dangx_put_amplitude(dangx_ctx* ctx, int comp, const double* amp) {
     return 0;
 }
 int dangx_get_amplitude(dangx_ctx* ctx, int comp, double* amp) {
-    if (!ctx || !amp || check_comp(ctx, comp)) return 1;
-    if (!ctx->amp[comp]) return fail(ctx, "component not set");
+    if (!ctx || !amp || check_comp(ctx, comp) || ensure_state(ctx, comp)) return 1;
     HIPCHK(ctx, hipMemcpyAsync(amp, ctx->amp[comp], (size_t)ctx->dims.npix * ctx->dims.nmaps * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 int dangx_put_indices(dangx_ctx* ctx, int comp, const double* ind) {
-    if (!ctx || !ind || check_comp(ctx, comp)) return 1;
+    if (!ctx || !ind || check_comp(ctx, comp) || ensure_state(ctx, comp)) return 1;
     if (!ctx->idx[comp]) return fail(ctx, "component has no indices");
     {   // planes on which every index map is spatially constant
         const long long np = ctx->dims.npix;
@@ -1047,7 +1058,7 @@ int dangx_put_indices(dangx_ctx* ctx, int comp, const double* ind) {
     return 0;
 }
 int dangx_get_indices(dangx_ctx* ctx, int comp, double* ind) {
-    if (!ctx || !ind || check_comp(ctx, comp)) return 1;
+    if (!ctx || !ind || check_comp(ctx, comp) || ensure_state(ctx, comp)) return 1;
     if (!ctx->idx[comp]) return fail(ctx, "component has no indices");
     HIPCHK(ctx, hipMemcpyAsync(ind, ctx->idx[comp], (size_t)ctx->dims.npix * ctx->dims.nmaps * ctx->desc[comp].nindices * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1123,8 +1134,12 @@ int dangx_adopt_device_state(dangx_ctx* ctx, int comp, double* amp_dev, double* 
     ctx->dirty = true;
     return 0;
 }
-void* dangx_amplitude_devptr(dangx_ctx* ctx, int comp) { return (ctx && comp >= 0 && comp < MAXC) ? ctx->amp[comp] : nullptr; }
-void* dangx_indices_devptr(dangx_ctx* ctx, int comp) { return (ctx && comp >= 0 && comp < MAXC) ? ctx->idx[comp] : nullptr; }
+void* dangx_amplitude_devptr(dangx_ctx* ctx, int comp) {
+    return (ctx && comp >= 0 && comp < ctx->dims.ncomp && !ensure_state(ctx, comp)) ? ctx->amp[comp] : nullptr;
+}
+void* dangx_indices_devptr(dangx_ctx* ctx, int comp) {
+    return (ctx && comp >= 0 && comp < ctx->dims.ncomp && !ensure_state(ctx, comp)) ? ctx->idx[comp] : nullptr;
+}
 
 int64_t dangx_group_size(dangx_ctx* ctx, int group, int flag) {
     GroupArgs a;
