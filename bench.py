@@ -119,6 +119,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bandpass", type=int, default=0, help="diagnostic (not a BASELINE config): integrate every second "
                     "band over an N-sample +-10%% top-hat bandpass instead of a delta (SURVEY 8f rank 3)")
+    ap.add_argument("--streams", type=int, default=0, choices=[0, 1, 2], help="2: the temperature chain (group 1, T sweeps) and the "
+                    "polarisation chain (group 2, Q+U sweeps) of one Gibbs iteration are independent: run them on two HIP "
+                    "streams (two contexts over the same resident maps), which fills the launch tails of small shards "
+                    "(+5%% at the 8-rank shard size, +0.4%% on a whole C3 sky).  0 = auto: 1 on one rank, 2 on several")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for rehearsing "
                                                       "the N>1 path with several ranks on ONE GPU)")
     args = ap.parse_args()
@@ -161,24 +165,39 @@ def main():
     nmaps, nb = meta["nmaps"], meta["nbands"]
     chisq_buf = torch.zeros(2, dtype=torch.float64, device=dev)
     mapn = {1: 1, 2: 2, 4: 3, 8: -1}
+    two = (args.streams == 2 or (args.streams == 0 and world > 1)) and nmaps == 3
+    if two:
+        side = torch.cuda.Stream(device=dev)
+        engP = da.Engine(bands, comps, ddata, npix_global=meta["npix_global"], pix0=meta["pix0"], device=dev_index,
+                         stream=side.cuda_stream)
+        chisq_P = torch.zeros(2, dtype=torch.float64, device=dev)
+    eng_of = (lambda f: engP if (two and f != 1) else eng)
 
     def gibbs_iteration(it):
         # sample_cg_groups (src/dang_cg_mod.f90:142-177)
         for g in dpar.cg_groups:
             for f in g.pol_flag:
-                eng.amp_sample(g.cg_group, f, dpar.ml_mode, dpar.seed, da.stream_id(it, 0, g.cg_group, 0, f),
-                               solver="direct", fluct_mode=dpar.fluct_mode, want_counts=False)
+                eng_of(f).amp_sample(g.cg_group, f, dpar.ml_mode, dpar.seed, da.stream_id(it, 0, g.cg_group, 0, f),
+                                     solver="direct", fluct_mode=dpar.fluct_mode, want_counts=False)
         # the chi^2 after the amplitude phase is captured by the first index sweep on each plane (fused);
         # sample_spectral_parameters (src/dang_sample_mod.f90:21-86)
         for l, c in enumerate(comps):
             for j in range(c.nindices):
                 if c.sample_index[j]:
                     for f in c.pol_flag[j]:
-                        eng.index_sample(l, j, mapn[f], dpar.nsample, dpar.ml_mode, dpar.seed,
-                                         da.stream_id(it, 1, l, j, f), want_counts=False)
+                        eng_of(f).index_sample(l, j, mapn[f], dpar.nsample, dpar.ml_mode, dpar.seed,
+                                               da.stream_id(it, 1, l, j, f), want_counts=False)
         # update_sky_model + compute_chisq after each phase (src/dang_cg_mod.f90:172-173,
         # src/dang_sample_mod.f90:81-84): both values come out of the sweeps, no extra pass over the maps
-        if not (eng.chisq_cached_dev(0, 1, nmaps, chisq_buf[0:1]) and eng.chisq_cached_dev(1, 1, nmaps, chisq_buf[1:2])):
+        if two:  # T planes from the main context, Q/U planes from the side context; joined on the main stream
+            okT = eng.chisq_cached_dev(0, 1, 1, chisq_buf[0:1]) and eng.chisq_cached_dev(1, 1, 1, chisq_buf[1:2])
+            okP = engP.chisq_cached_dev(0, 2, 3, chisq_P[0:1]) and engP.chisq_cached_dev(1, 2, 3, chisq_P[1:2])
+            if not (okT and okP):
+                raise SystemExit("--streams 2 needs a sampled index on every plane")
+            torch.cuda.current_stream().wait_stream(side)
+            chisq_buf.add_(chisq_P)
+            side.wait_stream(torch.cuda.current_stream())
+        elif not (eng.chisq_cached_dev(0, 1, nmaps, chisq_buf[0:1]) and eng.chisq_cached_dev(1, 1, nmaps, chisq_buf[1:2])):
             eng.sky_model_chisq_dev(1, nmaps, chisq_buf[1:2])  # a plane without a sampled index: explicit pass
         if world > 1:
             td.all_reduce(chisq_buf)  # global chi^2 (RCCL over xGMI); 16-byte message
@@ -194,6 +213,8 @@ def main():
         gibbs_iteration(it)
         it += 1
     eng.profile(True)
+    if two:
+        engP.profile(True)
     fence()
     log("warmup done, timing %d steps" % args.steps)
     t0 = time.perf_counter()
@@ -205,6 +226,14 @@ def main():
     log("timed region: %.3f s" % elapsed)
     prof = eng.profile_get()
     eng.profile(False)
+    if two:
+        for k, v in engP.profile_get().items():
+            if k in prof:
+                t = prof[k]
+                t["total_ms"] += v["total_ms"]; t["launches"] += v["launches"]; t["avg_ms"] = t["total_ms"] / t["launches"]
+            else:
+                prof[k] = v
+        engP.profile(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
@@ -226,9 +255,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: Nside=%d, %d bands, %d components (%s), %s, NUMSAMPLE=%d, per-pixel indices, "
-                                   "direct block solve, reference fluctuation term; pixel-sharded over %d rank(s)%s"
+                                   "direct block solve, reference fluctuation term; pixel-sharded over %d rank(s), %d stream(s) per rank%s"
                                    % (args.config, meta["nside"], nb, len(meta["phys"]), "+".join(meta["phys"]),
-                                      "IQU" if nmaps == 3 else "I", args.nsample, world,
+                                      "IQU" if nmaps == 3 else "I", args.nsample, world, 2 if two else 1,
                                       "; DIAGNOSTIC: every second band integrated over a %d-sample bandpass" % args.bandpass
                                       if args.bandpass else ""),
                        "npix": meta["npix_global"], "chisq_after_amp": chisq[0], "chisq_after_index": chisq[1]},
