@@ -153,3 +153,17 @@ def test_fullsize_window_matches_oracle(built):
         assert np.abs(a - b).max() <= 1e-9 * max(np.abs(b).max(), 1.0), l
         if c.nindices:
             assert np.abs(c.indices[:, :, sl].cpu().numpy() - orc.indices(l)).max() <= 1e-12, l
+
+
+def test_fullsize_gibbs_chain_with_the_textbook_fluctuation_term(built):
+    """C3 at Nside 1024 as a sampler: 150 Gibbs iterations from the prior start with `fluct_mode='correct'` end at
+    chi^2 = 1 (a posterior draw has nb degrees of freedom per unit; see tests/test_gpu_gibbs.py)."""
+    dpar, ddata, bands, comps, meta, eng = _device_case("C3", fluct_mode="correct")
+    trace = []
+    for it in range(1, 151):
+        da.sample_cg_groups(dpar, ddata, it=it, defer_chisq=(it > 1))
+        if it > 1:
+            da.sample_spectral_parameters(dpar, ddata, it=it)
+        trace.append(ddata.chisq)
+    assert np.all(np.isfinite(trace))
+    assert trace[0] > 5.0 and abs(np.mean(trace[-20:]) - 1.0) < 0.03, (trace[0], trace[-1])
