@@ -748,7 +748,7 @@ int device_cg(dangx_ctx* ctx, const GroupArgs& a, int i_max, double converge, in
 // (pass 1), solve the nglob x nglob Schur system on the host, back-substitute per unit (pass 2).  The linear
 // system is the one cg_search iterates on (compute_rhs / compute_Ax / compute_sample_vector,
 // src/dang_cg_mod.f90:326-1096), quirks included; the answer is its exact solution instead of the iterate at i_max.
-int device_schur(dangx_ctx* ctx, const GroupArgs& a, long long SN, int64_t* n_not_spd) {
+int device_schur(dangx_ctx* ctx, const GroupArgs& a, long long SN, int64_t* n_not_spd, int* nullity) {
     const int R = a.nglob, nb = ctx->hm.nbands;
     if (R > DX_MAX_ROWS) return fail(ctx, "more than 32 global amplitudes in one CG group: use DANGX_SOLVER_CG");
     SchurArgs sa;
@@ -788,16 +788,21 @@ int device_schur(dangx_ctx* ctx, const GroupArgs& a, long long SN, int64_t* n_no
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (n_not_spd) *n_not_spd = (int64_t)bad;
     if (rank_sum(ctx, rows.data(), nrows)) return 1;  // pixel-sharded run: every rank then solves the same small system
-    // S g = t (+ fluctuation sums): Gaussian elimination with partial pivoting (S is not symmetric when a monopole is fitted)
-    std::vector<double> S(rows.begin(), rows.begin() + (size_t)R * R), g(rows.begin() + (size_t)R * R, rows.begin() + (size_t)R * R + R);
+    // S g = t (+ fluctuation sums).  S is not symmetric when a monopole is fitted (its row weight is 1, :857), so:
+    // Gaussian elimination, on the system equilibrated by G's diagonal (row amplitudes span ~1e-6 for hi_fit to ~1e2),
+    // for the CORRECTION to the current amplitudes, S d = t - S g0, with complete pivoting.  A remaining pivot at
+    // rounding level (1e-10 in units of G's diagonal, where 1 = nothing absorbed by the diffuse members) means the
+    // global rows are degenerate with the diffuse members -- a template fitted at every band beside a pixel-independent
+    // SED such as the CMB, or spatially constant index maps (the state a run starts from).  The normal equations stay
+    // consistent; the free directions keep their current value (d = 0 there), which is what the reference's CG does
+    // with them too (a Krylov iterate never moves along the null space).  nullity is reported through cg_iters.
+    std::vector<double> S(rows.begin(), rows.begin() + (size_t)R * R), t(rows.begin() + (size_t)R * R, rows.begin() + (size_t)R * R + R);
     if (a.ml_mode == DANGX_ML_SAMPLE)
         for (int r = 0; r < R; ++r)
-            if (sa.ftarget[r] >= 0) g[sa.ftarget[r]] += rows[(size_t)R * R + R + r];
-    // equilibrate (row amplitudes span ~1e-6 for hi_fit to ~1e2), then eliminate; a pivot that cancels to rounding
-    // level means the global rows are degenerate with the diffuse members (e.g. a template fitted at every band
-    // together with a pixel-independent SED such as the CMB): the reference's CG drifts along that valley, a
-    // direct solve has no answer to give.
-    std::vector<double> sc(R);
+            if (sa.ftarget[r] >= 0) t[sa.ftarget[r]] += rows[(size_t)R * R + R + r];
+    std::vector<double> g0;
+    globals_to_x(ctx, a, g0);
+    std::vector<double> sc(R), d(R, 0.0);
     for (int r = 0; r < R; ++r) {
         const double dg = std::fabs(rows[(size_t)R * R + 2 * R + r]);  // G[r][r] = sum_u w_r s_r / sigma^2, before elimination
         if (!(dg > 0.0) || !std::isfinite(dg))
@@ -805,32 +810,48 @@ int device_schur(dangx_ctx* ctx, const GroupArgs& a, long long SN, int64_t* n_no
         sc[r] = 1.0 / std::sqrt(dg);
     }
     for (int r = 0; r < R; ++r) {
-        for (int k = 0; k < R; ++k) S[(size_t)r * R + k] *= sc[r] * sc[k];
-        g[r] *= sc[r];
+        double v = t[r];
+        for (int k = 0; k < R; ++k) v -= S[(size_t)r * R + k] * g0[k];
+        t[r] = v * sc[r];  // scaled residual
     }
+    for (int r = 0; r < R; ++r)
+        for (int k = 0; k < R; ++k) S[(size_t)r * R + k] *= sc[r] * sc[k];
+    std::vector<int> perm(R);
+    for (int c = 0; c < R; ++c) perm[c] = c;
+    int rank = 0;
     for (int c = 0; c < R; ++c) {
-        int piv = c;
-        for (int r = c + 1; r < R; ++r)
-            if (std::fabs(S[(size_t)r * R + c]) > std::fabs(S[(size_t)piv * R + c])) piv = r;
-        if (!(std::fabs(S[(size_t)piv * R + c]) > 1e-10))  // in units of G's diagonal: 1 = nothing absorbed by the diffuse members
-            return fail(ctx, "the global amplitudes of the CG group are degenerate with its diffuse members (pivot " +
-                             std::to_string(S[(size_t)piv * R + c]) + "): fit them on fewer bands or use DANGX_SOLVER_CG");
-        if (piv != c) {
-            for (int k = 0; k < R; ++k) std::swap(S[(size_t)piv * R + k], S[(size_t)c * R + k]);
-            std::swap(g[piv], g[c]);
+        int pr = c, pc = c;
+        double best = -1.0;
+        for (int r = c; r < R; ++r)
+            for (int k = c; k < R; ++k) {
+                const double v = std::fabs(S[(size_t)r * R + k]);
+                if (!std::isfinite(v)) return fail(ctx, "non-finite entry in the system of the global amplitudes");
+                if (v > best) { best = v; pr = r; pc = k; }
+            }
+        if (!(best > 1e-10)) break;
+        if (pr != c) {
+            for (int k = 0; k < R; ++k) std::swap(S[(size_t)pr * R + k], S[(size_t)c * R + k]);
+            std::swap(t[pr], t[c]);
+        }
+        if (pc != c) {
+            for (int r = 0; r < R; ++r) std::swap(S[(size_t)r * R + pc], S[(size_t)r * R + c]);
+            std::swap(perm[pc], perm[c]);
         }
         for (int r = c + 1; r < R; ++r) {
             const double f = S[(size_t)r * R + c] / S[(size_t)c * R + c];
             for (int k = c; k < R; ++k) S[(size_t)r * R + k] -= f * S[(size_t)c * R + k];
-            g[r] -= f * g[c];
+            t[r] -= f * t[c];
         }
+        ++rank;
     }
-    for (int r = R - 1; r >= 0; --r) {
-        double v = g[r];
-        for (int k = r + 1; k < R; ++k) v -= S[(size_t)r * R + k] * g[k];
-        g[r] = v / S[(size_t)r * R + r];
+    for (int r = rank - 1; r >= 0; --r) {  // free unknowns (columns rank..R-1) keep d = 0
+        double v = t[r];
+        for (int k = r + 1; k < rank; ++k) v -= S[(size_t)r * R + k] * d[perm[k]];
+        d[perm[r]] = v / S[(size_t)r * R + r];
     }
-    for (int r = 0; r < R; ++r) g[r] *= sc[r];
+    std::vector<double> g(R);
+    for (int r = 0; r < R; ++r) g[r] = g0[r] + d[r] * sc[r];
+    if (nullity) *nullity = R - rank;
     x_to_globals(ctx, a, g);
     if (sync_model(ctx)) return 1;
     return dx_launch_schur_pass2(ctx, a, SN);
@@ -1166,7 +1187,10 @@ int dangx_amp_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solve
     if (a.nt > 0 && solver != DANGX_SOLVER_CG) {
         if (fluct_mode != DANGX_FLUCT_REFERENCE && ml_mode == DANGX_ML_SAMPLE)
             return fail(ctx, "groups with template / monopole / hi_fit members reproduce the reference's fluctuation term only");
-        return device_schur(ctx, a, SN, n_not_spd);
+        int nullity = 0;
+        if (device_schur(ctx, a, SN, n_not_spd, &nullity)) return 1;
+        if (cg_iters) *cg_iters = -nullity;  // 0: regular system; -k: k directions of the global amplitudes left at their current value
+        return 0;
     }
     if (solver == DANGX_SOLVER_CG) {
         if (fluct_mode != DANGX_FLUCT_REFERENCE && ml_mode == DANGX_ML_SAMPLE)

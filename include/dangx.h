@@ -153,8 +153,10 @@ void *dangx_indices_devptr(dangx_ctx *ctx, int comp);
  * replaces compute_rhs + cg_search + unpack_amplitudes (src/dang_cg_mod.f90:166-171).
  * flag is one poltype bit (T, Q, U or Q+U).  seed/stream select the keyed random
  * stream (the reference uses an unseeded RANDOM_NUMBER, src/dang.f90:67).
- * cg_iters (nullable): CG iteration counter as printed by the reference (CG solver),
- * 0 for DIRECT.  n_not_spd (nullable): units whose block was not SPD (left unchanged). */
+ * cg_iters (nullable): CG iteration counter as printed by the reference (CG solver); 0 for DIRECT, or -k when the
+ * DIRECT solve of a group with template / monopole / hi_fit members found k directions of the global amplitudes
+ * that the diffuse members absorb completely (those keep their current value, as they do under the reference's CG).
+ * n_not_spd (nullable): units whose block was not SPD (left unchanged). */
 int dangx_amp_sample(dangx_ctx *ctx, int group, int flag, int ml_mode, int solver, int fluct_mode,
                      uint64_t seed, uint64_t stream, int i_max, double converge,
                      int *cg_iters, int64_t *n_not_spd);

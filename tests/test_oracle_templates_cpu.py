@@ -9,7 +9,7 @@ import oracle_ffi as O
 from util import make_case
 
 
-def add_globals(dpar, ddata, bands, comps, which=("monopole", "hi_fit"), group=1, skip_band0=False):
+def add_globals(dpar, ddata, bands, comps, which=("monopole", "hi_fit"), group=1, skip_band0=False, fit_bands=None):
     """skip_band0: do not fit band 0 for any of them.  A global component fitted at EVERY band is exactly degenerate
     with a diffuse component of pixel-independent SED in the same group (the CMB): g_j*s_j proportional to the CMB's
     SED is absorbed by -tmpl(i)*const in the CMB amplitude.  CG returns some point of that valley; a direct solve
@@ -22,6 +22,8 @@ def add_globals(dpar, ddata, bands, comps, which=("monopole", "hi_fit"), group=1
         corr = [True] * nb
         if w == "template" or skip_band0:
             corr[0] = False
+        if fit_bands is not None:   # fit only these bands (a well-posed fit: few global amplitudes)
+            corr = [j in fit_bands for j in range(nb)]
         tmpl = np.zeros((nmaps, npix))
         ta = np.zeros((nmaps, nb))
         if w == "monopole":
@@ -52,11 +54,11 @@ def add_globals(dpar, ddata, bands, comps, which=("monopole", "hi_fit"), group=1
         else:  # polarisation template, fitted under Q+U with ONE amplitude per band for Q and U (:1380-1382)
             tmpl[1], tmpl[2] = rng.normal(0, 1, npix), rng.normal(0, 1, npix)
             truth = rng.normal(0.0, 3.0, nb)
-            truth[0] = 0.0                                   # band 0 is not fitted (corr false) and carries nothing
+            truth[~np.asarray(corr)] = 0.0                   # unfitted bands (corr false) carry nothing
             ta_true = np.zeros((nmaps, nb)); ta_true[1] = truth; ta_true[2] = truth
             for k in (1, 2):
                 sky_add[:, k, :] += truth[:, None] * tmpl[k][None, :]
-            c = DangComps(label="tmpl", type="template", nu_ref=100.0, cg_group=group, nindices=0, nfit=nb - 1, corr=corr,
+            c = DangComps(label="tmpl", type="template", nu_ref=100.0, cg_group=group, nindices=0, nfit=sum(corr), corr=corr,
                           template=tmpl, template_amplitudes=ta, amplitude=np.zeros((nmaps, npix)))
         c.truth_ta = ta_true
         comps.append(c)
