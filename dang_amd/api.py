@@ -57,6 +57,7 @@ class DangComps:
     step_size: List[float] = field(default_factory=list)
     pol_flag: List[List[int]] = field(default_factory=list)  # per index: list of poltype bit flags
     tuned: List[bool] = field(default_factory=list)          # c%tuned (empty = all tuned)
+    sample_nside: List[int] = field(default_factory=list)    # c%sample_nside(nind) (empty / 0 = nside)
     # global-amplitude types ('template', 'monopole', 'hi_fit'), src/dang_component_mod.f90:17-33
     nfit: int = 0
     corr: List[bool] = field(default_factory=list)           # c%corr(j): is band j fitted?
@@ -364,6 +365,27 @@ class Engine:
     def fill_index(self, comp, nind, map_n, value):
         self._chk(self.lib.dangx_fill_index(self.h, comp, nind, map_n, float(value)))
 
+    def index_sample_coarse(self, comp, nind, map_n, nsample, ml_mode, seed, stream, sample_nside, want_counts=True):
+        """sample_index_mh with sample_nside < nside (one whole-sky context); see dangx_index_sample_coarse."""
+        acc = C.c_int64(0)
+        self._chk(self.lib.dangx_index_sample_coarse(self.h, comp, nind, map_n, nsample, L.ML_CODES[ml_mode], seed, stream,
+                                                     self.nside, int(sample_nside), C.byref(acc) if want_counts else None))
+        return acc.value
+
+    def udgrade(self, mode, m, nside_in, nside_out):
+        """udgrade_ring (0) / udgrade_rms (1) / udgrade_mask (2) of one RING map on the device."""
+        m = np.ascontiguousarray(m, dtype=np.float64)
+        out = np.empty(12 * nside_out * nside_out)
+        self._chk(self.lib.dangx_udgrade(self.h, mode, m.ctypes.data, nside_in, out.ctypes.data, nside_out))
+        return out
+
+    @property
+    def nside(self):
+        n = int(round(math.sqrt(self.npix_global / 12.0)))
+        if 12 * n * n != self.npix_global:
+            raise DangxError("npix_global is not 12*nside^2")
+        return n
+
     def peek_indices(self, comp, map_n, pix=0):
         n = self.component_list[comp].nindices
         out = (C.c_double * max(n, 1))()
@@ -526,8 +548,14 @@ def sample_spectral_parameters(dpar: DangParams, ddata: DangData, it=2, verbose=
             for f in c.pol_flag[j]:
                 if f not in _MAPN:
                     raise DangxError("There is something wrong with the poltype flag for component " + c.label)
+                coarse = c.sample_nside[j] if c.sample_nside else 0
                 if c.index_mode and c.index_mode[j] == 1:
+                    if coarse and coarse != eng.nside:
+                        raise DangxError("full-sky index mode with sample_nside /= nside is not built")
                     acc = sample_index_mh_fullsky(dpar, ddata, l, j, _MAPN[f], stream_id(it, 1, l, j, f))
+                elif coarse and coarse != eng.nside:
+                    acc = eng.index_sample_coarse(l, j, _MAPN[f], dpar.nsample, dpar.ml_mode, dpar.seed,
+                                                  stream_id(it, 1, l, j, f), coarse)
                 else:
                     acc = eng.index_sample(l, j, _MAPN[f], dpar.nsample, dpar.ml_mode, dpar.seed,
                                            stream_id(it, 1, l, j, f))

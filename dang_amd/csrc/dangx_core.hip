@@ -355,6 +355,142 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_rows_final(const double* __res
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Coarse-Nside index sampling (src/dang_sample_mod.f90:199-217, 332-483).  HEALPix is an external library of the
+// reference (absent from its tree); nest2ring and udgrade_ring are restated from the published algorithm
+// (Gorski et al. 2005, ApJ 622, 759; HEALPix pix_tools::nest2ring, udgrade_nr::udgrade_ring -> sub_udgrade_nest).
+
+// udgrade of one RING map per blockIdx.y: out pixel o (RING) -> NEST -> children (degrade: mean of the good ones, in
+// NEST child order; upgrade: the parent's value) -> RING.  mode 0: udgrade_ring; 1: udgrade_rms (input squared,
+// sqrt(mean)*nside_out/nside_in, src/dang_util_mod.f90:341-356); 2: udgrade_mask (mean < 0.5 -> 0 else 1 when
+// degrading, :358-376).  layout 0: plane q at q*npix_in; layout 1: plane q = kk*nb + j of M.rms ((j*nmaps + s1+kk-1)*npix_in)
+__global__ __launch_bounds__(BLOCK) void k_udgrade(const double* __restrict__ in, double* __restrict__ out,
+                                                   const int* __restrict__ n2r_in, const int* __restrict__ r2n_out,
+                                                   long long npix_in, long long npix_out, int ratio, int degrade, int mode,
+                                                   double scale, int layout, int nb, int nmaps, int s1) {
+    const long long o = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (o >= npix_out) return;
+    const int q = blockIdx.y;
+    const double* src = in + (layout == 0 ? (long long)q * npix_in
+                                          : ((long long)(q % nb) * nmaps + (s1 + q / nb - 1)) * npix_in);
+    const long long nest = r2n_out[o];
+    double v;
+    if (degrade) {
+        double total = 0.0;
+        int nobs = 0;
+        for (int ip = 0; ip < ratio; ++ip) {
+            double x = src[n2r_in[nest * ratio + ip]];
+            if (mode == 1) x = x * x;
+            if (fabs(x - MISSVAL) > fabs(1e-5 * MISSVAL)) { total = total + x; ++nobs; }  // bad pixels do not enter the mean
+        }
+        v = nobs ? total / nobs : MISSVAL;
+    } else {
+        v = src[n2r_in[nest / ratio]];
+        if (mode == 1) v = v * v;
+    }
+    if (mode == 1) v = sqrt(v) * scale;
+    if (mode == 2 && degrade) v = (v < 0.5) ? 0.0 : 1.0;
+    out[(long long)q * npix_out + o] = v;
+}
+
+// One Metropolis chain per COARSE pixel i, literally as the reference runs it: ddata%masks(i,1), c%indices(i,..) and
+// eval_signal's c%amplitude(i,k) are the FULL-resolution arrays read at the coarse index (:362, :372-377, :548-553);
+// data / rms / mask(:,1) are the degraded maps.  evaluate_lnL sums k outer, j inner with ((d-m)/rms)**2 (:171-177),
+// evaluate_marginal_lnL j outer, k inner (:113-122).  index_map(i) -> idxmap[i] (0 where the chain is skipped, :223).
+__global__ __launch_bounds__(BLOCK) void k_index_mh_coarse(const Model* __restrict__ Mp, IndexArgs a, long long npix_c,
+                                                           const double* __restrict__ cdata, const double* __restrict__ crms,
+                                                           const double* __restrict__ cmask, double* __restrict__ idxmap,
+                                                           unsigned long long* __restrict__ accepted) {
+    const Model& M = *Mp;
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    unsigned long long nacc = 0;
+    if (i < npix_c) {
+        idxmap[i] = 0.0;
+        if (!is_masked(M.mask[i])) {
+            const Comp& c = M.comp[a.comp];
+            const int nb = M.nbands, Sp = a.s2 - a.s1 + 1, q = a.nind;
+            double sample0, sample1;
+            load_theta(M, c, (int)i, a.s1, sample0, sample1);
+            const bool first = (q == 0);
+            const double other = first ? sample1 : sample0;
+            double amp[2] = {0.0, 0.0};
+            for (int kk = 0; kk < Sp; ++kk) amp[kk] = c.amp[(long long)(a.s1 + kk - 1) * M.npix + i];
+            const int lnl_type = c.lnl_type[q];
+            const bool cmasked = is_masked(cmask[i]);
+            auto lnl_of = [&](double th) -> double {
+                if (lnl_type == DANGX_LNL_PRIOR) return 0.0;
+                const Prep pr = sed_prep(c, first ? th : other, first ? other : th);
+                double lnL = 0.0;
+                if (lnl_type == DANGX_LNL_CHISQ) {
+                    if (cmasked) return 0.0;  // evaluate_lnL cycles on the (degraded) mask, :169
+                    for (int kk = 0; kk < Sp; ++kk)
+                        for (int j = 0; j < nb; ++j) {
+                            const double m = signal_of(c, amp[kk], sed_eval(M, c, j, pr));
+                            const long long e = ((long long)kk * nb + j) * npix_c + i;
+                            const double t = (cdata[e] - m) / crms[e];
+                            lnL = lnL - 0.5 * (t * t);
+                        }
+                } else {
+                    for (int j = 0; j < nb; ++j)
+                        for (int kk = 0; kk < Sp; ++kk) {
+                            const double m = signal_of(c, amp[kk], sed_eval(M, c, j, pr));
+                            const long long e = ((long long)kk * nb + j) * npix_c + i;
+                            const double TN = m / (crms[e] * crms[e]);
+                            const double TNd = TN * cdata[e], TNT = TN * m;
+                            lnL = lnL - 0.5 * TNd * (1.0 / TNT) * TNd;
+                        }
+                }
+                return lnL;
+            };
+            auto prior = [&](double v) -> double {
+                if (c.prior_type[q] != DANGX_PRIOR_GAUSSIAN) return 0.0;
+                const double arg = ((v - c.gauss[q][0]) * (v - c.gauss[q][0])) / (2 * (c.gauss[q][1] * c.gauss[q][1]));
+                return (arg > 745.0) ? -INFINITY : -arg - c.lgden[q];
+            };
+            double cur = first ? sample0 : sample1;
+            double lnl = lnl_of(cur);
+            bool sample_it = true;
+            if (lnl_type == DANGX_LNL_PRIOR) {  // :389-392
+                double u1, u2;
+                sample_it = false;
+                uniform2(a.seed, a.stream, (unsigned long long)i, 0u, u1, u2);
+                cur = rand_normal(c.gauss[q][0], c.gauss[q][1], u1, u2);
+            }
+            double lnl_old = lnl + prior(cur);
+            if (sample_it) {
+                const double step = c.step[q], lo = c.uni[q][0], hi = c.uni[q][1];
+                for (int l = 1; l <= a.nsample; ++l) {
+                    double u1, u2, u3;
+                    uniform3(a.seed, a.stream, (unsigned long long)i, (uint32_t)l, u1, u2, u3);
+                    const double prop = cur + rand_normal(0.0, step, u1, u2);
+                    if (prop < lo || prop > hi) continue;
+                    const double lnl_new = lnl_of(prop) + prior(prop);
+                    const double diff = lnl_new - lnl_old;
+                    const bool acc = (a.ml_mode == DANGX_ML_OPTIMIZE) ? (diff > 0.0) : ((diff >= 0.0) || (exp(diff) > u3));
+                    if (acc) { cur = prop; lnl_old = lnl_new; ++nacc; }
+                }
+            }
+            idxmap[i] = cur;  // :465
+        }
+    }
+    if (accepted) {
+        for (int o = 32; o > 0; o >>= 1) nacc += __shfl_down(nacc, o, 64);
+        if ((threadIdx.x & 63) == 0 && nacc) atomicAdd(accepted, nacc);
+    }
+}
+
+// udgrade_ring(index_map, sample_nside -> nside) + c%indices(:, s1:s2, nind) = index_full_res(:, s1:s2) (:480-483)
+__global__ __launch_bounds__(BLOCK) void k_coarse_writeback(const Model* __restrict__ Mp, int comp, int nind, int s1, int s2,
+                                                            const double* __restrict__ idxmap, const int* __restrict__ r2n_f,
+                                                            const int* __restrict__ n2r_c, int ratio) {
+    const Model& M = *Mp;
+    const int p = blockIdx.x * BLOCK + threadIdx.x;
+    if (p >= M.npix) return;
+    const double v = idxmap[n2r_c[r2n_f[p] / ratio]];
+    for (int k = s1; k <= s2; ++k) M.comp[comp].idx[((long long)nind * M.nmaps + (k - 1)) * M.npix + p] = v;
+}
+
 // c%indices(:, s1:s2, nind) = value (src/dang_sample_mod.f90:329, 483: every pixel, masked ones too)
 __global__ __launch_bounds__(BLOCK) void k_fill_index(const Model* __restrict__ Mp, int comp, int nind, int s1, int s2, double value) {
     const Model& M = *Mp;
@@ -480,6 +616,8 @@ int sync_model(dangx_ctx* ctx) {
     const size_t nbp = ctx->bp_nu0.size();
     if (nbp && ctx->bp_dirty) {
         if (ctx->d_bp_nu0) { (void)hipFree(ctx->d_bp_nu0); (void)hipFree(ctx->d_bp_tau0); (void)hipFree(ctx->d_bp_lnr); }
+    for (int* b : {ctx->hp_n2r_f, ctx->hp_r2n_f, ctx->hp_n2r_c, ctx->hp_r2n_c}) if (b) (void)hipFree(b);
+    for (double* b : {ctx->cs_data, ctx->cs_rms, ctx->cs_mask, ctx->cs_index}) if (b) (void)hipFree(b);
         const size_t nbytes = nbp * sizeof(double);
         HIPCHK(ctx, hipMalloc(&ctx->d_bp_nu0, nbytes));
         HIPCHK(ctx, hipMalloc(&ctx->d_bp_tau0, nbytes));
@@ -1421,6 +1559,143 @@ int dangx_fullsky_sums(dangx_ctx* ctx, int what, const double* theta, double* ou
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(out, ctx->rows_out, sizeof(double) * rows, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+
+// ---- HEALPix index maps on the host (published algorithm; see k_udgrade) ------------------------------------------
+// nest2ring: face f = ipnest / nside^2, (ix, iy) = the even / odd bits of the in-face index, ring jr counted from the
+// north pole, position jp in the ring.
+static void hp_nest2ring_table(int nside, std::vector<int>& n2r) {
+    static const int jrll[12] = {2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4}, jpll[12] = {1, 3, 5, 7, 0, 2, 4, 6, 1, 3, 5, 7};
+    const long long ns2 = (long long)nside * nside, npix = 12 * ns2, ncap = 2LL * nside * (nside - 1);
+    n2r.resize((size_t)npix);
+    for (long long ip = 0; ip < npix; ++ip) {
+        const int face = (int)(ip / ns2);
+        const long long ipf = ip % ns2;
+        int ix = 0, iy = 0;
+        for (int b = 0; b < 16; ++b) { ix |= (int)((ipf >> (2 * b)) & 1) << b; iy |= (int)((ipf >> (2 * b + 1)) & 1) << b; }
+        const long long jr = (long long)jrll[face] * nside - ix - iy - 1;
+        long long nr, n_before;
+        int kshift;
+        if (jr < nside) { nr = jr; n_before = 2 * nr * (nr - 1); kshift = 0; }
+        else if (jr > 3LL * nside) { nr = 4LL * nside - jr; n_before = npix - 2 * (nr + 1) * nr; kshift = 0; }
+        else { nr = nside; n_before = ncap + (jr - nside) * 4LL * nside; kshift = (int)((jr - nside) & 1); }
+        long long jp = ((long long)jpll[face] * nr + ix - iy + 1 + kshift) / 2;
+        if (jp > 4 * nr) jp -= 4 * nr;
+        if (jp < 1) jp += 4 * nr;
+        n2r[(size_t)ip] = (int)(n_before + jp - 1);
+    }
+}
+
+static bool hp_valid_nside(int n) { return n >= 1 && n <= 8192 && (n & (n - 1)) == 0; }
+
+static int hp_upload(dangx_ctx* ctx, int nside, int** n2r_dev, int** r2n_dev) {
+    std::vector<int> n2r, r2n;
+    hp_nest2ring_table(nside, n2r);
+    r2n.resize(n2r.size());
+    for (size_t p = 0; p < n2r.size(); ++p) r2n[(size_t)n2r[p]] = (int)p;
+    if (*n2r_dev) { (void)hipFree(*n2r_dev); (void)hipFree(*r2n_dev); *n2r_dev = *r2n_dev = nullptr; }
+    HIPCHK(ctx, hipMalloc(n2r_dev, n2r.size() * sizeof(int)));
+    HIPCHK(ctx, hipMalloc(r2n_dev, n2r.size() * sizeof(int)));
+    HIPCHK(ctx, hipMemcpy(*n2r_dev, n2r.data(), n2r.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(*r2n_dev, r2n.data(), n2r.size() * sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// RING<->NEST maps of the two resolutions, cached in the context
+static int hp_tables(dangx_ctx* ctx, int nside_f, int nside_c) {
+    if (!hp_valid_nside(nside_f) || !hp_valid_nside(nside_c)) return fail(ctx, "nside must be a power of two in 1..8192");
+    if (ctx->hp_nside != nside_f) { if (hp_upload(ctx, nside_f, &ctx->hp_n2r_f, &ctx->hp_r2n_f)) return 1; ctx->hp_nside = nside_f; }
+    if (ctx->hp_cnside != nside_c) { if (hp_upload(ctx, nside_c, &ctx->hp_n2r_c, &ctx->hp_r2n_c)) return 1; ctx->hp_cnside = nside_c; }
+    return 0;
+}
+
+int dangx_udgrade(dangx_ctx* ctx, int mode, const double* map_in, int nside_in, double* map_out, int nside_out) {
+    if (!ctx || !map_in || !map_out) return 1;
+    (void)hipSetDevice(ctx->device);
+    if (mode < 0 || mode > 2) return fail(ctx, "udgrade mode must be 0 (ring), 1 (rms) or 2 (mask)");
+    if (nside_in == nside_out) return fail(ctx, "udgrade: nside_in == nside_out (the reference copies the maps, src/dang_sample_mod.f90:204-207)");
+    const bool degrade = nside_in > nside_out;
+    if (hp_tables(ctx, degrade ? nside_in : nside_out, degrade ? nside_out : nside_in)) return 1;
+    const long long npi = 12LL * nside_in * nside_in, npo = 12LL * nside_out * nside_out;
+    const int r1 = degrade ? nside_in / nside_out : nside_out / nside_in;
+    double *din = nullptr, *dout = nullptr;
+    HIPCHK(ctx, hipMalloc(&din, sizeof(double) * npi));
+    HIPCHK(ctx, hipMalloc(&dout, sizeof(double) * npo));
+    HIPCHK(ctx, hipMemcpyAsync(din, map_in, sizeof(double) * npi, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_udgrade, dim3(nblocks(npo), 1), dim3(BLOCK), 0, ctx->stream, din, dout,
+                       degrade ? ctx->hp_n2r_f : ctx->hp_n2r_c, degrade ? ctx->hp_r2n_c : ctx->hp_r2n_f, npi, npo, r1 * r1,
+                       degrade ? 1 : 0, mode, (double)nside_out * 1.0 / nside_in, 0, 1, 1, 1);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(map_out, dout, sizeof(double) * npo, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(din); (void)hipFree(dout);
+    return 0;
+}
+
+int dangx_index_sample_coarse(dangx_ctx* ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed,
+                              uint64_t stream, int nside, int sample_nside, int64_t* accepted) {
+    if (!ctx || check_comp(ctx, comp)) return 1;
+    (void)hipSetDevice(ctx->device);
+    const long long npix = ctx->dims.npix;
+    if (ctx->dims.pix0 != 0 || npix != 12LL * nside * nside || ctx->dims.npix_global != npix)
+        return fail(ctx, "coarse-Nside sampling needs ONE whole-sky context (npix = 12*nside^2): the children of a coarse pixel are scattered over the RING ranges of a sharded run");
+    if (!(sample_nside < nside)) return fail(ctx, "sample_nside must be smaller than nside (equal: dangx_index_sample)");
+    const dangx_comp_desc& d = ctx->desc[comp];
+    if (nind < 0 || nind >= d.nindices) return fail(ctx, "index number out of range");
+    if (d.type > DANGX_TCMB) return fail(ctx, "coarse-Nside sampling is built for the diffuse component types and T_cmb");
+    if (d.lnl_type[nind] < DANGX_LNL_CHISQ || d.lnl_type[nind] > DANGX_LNL_PRIOR) return fail(ctx, "bad lnl_type");
+    if (d.prior_type[nind] == DANGX_PRIOR_JEFFREYS) return fail(ctx, "coarse-Nside sampling with the Jeffreys prior is not built");
+    if (ml_mode != DANGX_ML_SAMPLE && ml_mode != DANGX_ML_OPTIMIZE) return fail(ctx, "bad ml_mode");
+    if (hp_tables(ctx, nside, sample_nside)) return 1;
+    // data_raw minus every other component at full resolution (:173-196): the full-sky mode's staging kernel
+    if (dangx_fullsky_prepare(ctx, comp, map_n)) return 1;
+    const int s1 = ctx->fs_s1, s2 = ctx->fs_s2, Sp = s2 - s1 + 1, nb = ctx->hm.nbands;
+    ctx->fs_comp = -1;  // the staging buffer is ours now
+    const long long npc = 12LL * sample_nside * sample_nside;
+    const int r1 = nside / sample_nside, ratio = r1 * r1;
+    const long long need = (long long)Sp * nb * npc;
+    if (need > ctx->cs_cap) {
+        for (double** b : {&ctx->cs_data, &ctx->cs_rms, &ctx->cs_mask, &ctx->cs_index}) { if (*b) (void)hipFree(*b); *b = nullptr; }
+        HIPCHK(ctx, hipMalloc(&ctx->cs_data, sizeof(double) * need));
+        HIPCHK(ctx, hipMalloc(&ctx->cs_rms, sizeof(double) * need));
+        HIPCHK(ctx, hipMalloc(&ctx->cs_mask, sizeof(double) * npc));
+        HIPCHK(ctx, hipMalloc(&ctx->cs_index, sizeof(double) * npc));
+        ctx->cs_cap = need;
+    }
+    const dim3 gq(nblocks(npc), Sp * nb), g1(nblocks(npc), 1);
+    const double scale = (double)sample_nside * 1.0 / nside;
+    hipLaunchKernelGGL(k_udgrade, gq, dim3(BLOCK), 0, ctx->stream, ctx->fs_data, ctx->cs_data, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
+                       ratio, 1, 0, scale, 0, nb, ctx->hm.nmaps, s1);
+    hipLaunchKernelGGL(k_udgrade, gq, dim3(BLOCK), 0, ctx->stream, ctx->rms, ctx->cs_rms, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
+                       ratio, 1, 1, scale, 1, nb, ctx->hm.nmaps, s1);
+    hipLaunchKernelGGL(k_udgrade, g1, dim3(BLOCK), 0, ctx->stream, ctx->mask, ctx->cs_mask, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
+                       ratio, 1, 2, scale, 0, nb, ctx->hm.nmaps, s1);
+    IndexArgs a{};
+    a.comp = comp; a.nind = nind; a.nsample = nsample; a.ml_mode = ml_mode; a.seed = seed; a.stream = stream;
+    a.s1 = s1; a.s2 = s2; a.mode = CH_GENERIC;
+    if (accepted) HIPCHK(ctx, hipMemsetAsync(ctx->counters + 1, 0, sizeof(unsigned long long), ctx->stream));
+    {
+        Timed t(ctx, DANGX_K_INDEX_MH);
+        hipLaunchKernelGGL(k_index_mh_coarse, dim3(nblocks(npc)), dim3(BLOCK), 0, ctx->stream, ctx->dm, a, npc, ctx->cs_data, ctx->cs_rms,
+                           ctx->cs_mask, ctx->cs_index, accepted ? ctx->counters + 1 : nullptr);
+    }
+    hipLaunchKernelGGL(k_coarse_writeback, dim3(nblocks(npix)), dim3(BLOCK), 0, ctx->stream, ctx->dm, comp, nind, s1, s2, ctx->cs_index,
+                       ctx->hp_r2n_f, ctx->hp_n2r_c, ratio);
+    HIPCHK(ctx, hipGetLastError());
+    for (int k = s1; k <= s2; ++k) {  // the planes changed: cached chi^2 and constant-index bookkeeping are stale
+        ctx->chi_before_valid[k - 1] = ctx->chi_after_valid[k - 1] = false;
+        ctx->touched_since_amp[k - 1] = true;
+        ctx->idx_const[comp] &= ~(1u << (k - 1));
+    }
+    ctx->dirty = true;
+    if (accepted) {
+        unsigned long long v = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&v, ctx->counters + 1, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        *accepted = (int64_t)v;
+    }
     return 0;
 }
 

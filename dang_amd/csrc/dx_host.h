@@ -101,6 +101,11 @@ struct dangx_ctx {
     long long fs_cap = 0;
     int fs_comp = -1, fs_s1 = 0, fs_s2 = 0;
     double* rows_out = nullptr;             // device [2*MAXB*2 + 8] row sums
+    // coarse-Nside index sampling: HEALPix RING<->NEST maps of both resolutions + degraded data / rms / mask
+    int hp_nside = 0, hp_cnside = 0;
+    int *hp_n2r_f = nullptr, *hp_r2n_f = nullptr, *hp_n2r_c = nullptr, *hp_r2n_c = nullptr;
+    double *cs_data = nullptr, *cs_rms = nullptr, *cs_mask = nullptr, *cs_index = nullptr;
+    long long cs_cap = 0;
     long long work_cap = 0;
     // profiling
     bool prof = false;

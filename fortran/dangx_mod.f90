@@ -157,6 +157,19 @@ module dangx_mod
        type(c_ptr), value :: ctx, out
        integer(c_int), value :: band
      end function
+     integer(c_int) function dangx_index_sample_coarse(ctx, comp, nind, map_n, nsample, ml_mode, seed, stream, &
+          nside, sample_nside, accepted) bind(C, name='dangx_index_sample_coarse')
+       import :: c_int, c_ptr, c_int64_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: comp, nind, map_n, nsample, ml_mode, nside, sample_nside
+       integer(c_int64_t), value :: seed, stream
+       integer(c_int64_t), intent(out) :: accepted
+     end function
+     integer(c_int) function dangx_udgrade(ctx, mode, map_in, nside_in, map_out, nside_out) bind(C, name='dangx_udgrade')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, map_in, map_out
+       integer(c_int), value :: mode, nside_in, nside_out
+     end function
      ! pixel-sharded (MPI) runs: fn = c_funloc of a bind(C) function that does
      ! MPI_Allreduce(MPI_IN_PLACE, buf, n, MPI_DOUBLE_PRECISION, MPI_SUM, comm) and returns 0
      integer(c_int) function dangx_set_allreduce(ctx, fn, user, is_root) bind(C, name='dangx_set_allreduce')

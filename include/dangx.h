@@ -185,6 +185,23 @@ int dangx_sky_model_chisq_dev(dangx_ctx *ctx, int pol_lo, int pol_hi, double *ch
 int dangx_chisq_cached(dangx_ctx *ctx, int which, int pol_lo, int pol_hi, double *chisq_sum);
 int dangx_chisq_cached_dev(dangx_ctx *ctx, int which, int pol_lo, int pol_hi, double *chisq_sum_dev);
 
+/* ---- index phase with sample_nside /= nside (src/dang_sample_mod.f90:199-217, 332-483) --------------------------
+ * One whole-sky context (npix = 12*nside^2, pix0 = 0).  As in the reference: the data minus every other component is
+ * formed at full resolution, then degraded with HEALPix's udgrade_ring (RING -> NEST, mean of the good children,
+ * NEST -> RING), the rms with dang's udgrade_rms (sqrt(mean(rms^2)) * nside_out/nside_in), the mask with udgrade_mask
+ * (mean >= 0.5); one chain per COARSE pixel i; the coarse index map is upgraded (children take the parent's value) and
+ * written to c%indices(:, s1:s2, nind) for EVERY pixel.  Also as in the reference, the chain of coarse pixel i reads
+ * the FULL-resolution arrays at the same index i (ddata%masks(i,1), c%indices(i,...), and eval_signal's
+ * c%amplitude(i,k): src/dang_sample_mod.f90:362, 372-377, 548-553): reproduced literally, see DESIGN.md section 7.
+ * HEALPix itself is absent from the reference tree (an external library): udgrade_ring / nest2ring are restated from
+ * the published algorithm (Gorski et al. 2005, ApJ 622, 759; HEALPix 3.x pix_tools / udgrade_nr).
+ * Likelihoods: chisq / marginal / prior; priors: gaussian / uniform; diffuse component types and T_cmb. */
+int dangx_index_sample_coarse(dangx_ctx *ctx, int comp, int nind, int map_n, int nsample, int ml_mode,
+                              uint64_t seed, uint64_t stream, int nside, int sample_nside, int64_t *accepted);
+/* the degrade / upgrade primitives on their own (whole-sky context): mode 0 = udgrade_ring, 1 = udgrade_rms,
+ * 2 = udgrade_mask(threshold 0.5); host pointers, one map each ([12*nside_in^2] -> [12*nside_out^2]) */
+int dangx_udgrade(dangx_ctx *ctx, int mode, const double *map_in, int nside_in, double *map_out, int nside_out);
+
 /* ---- full-sky index mode (index_mode == 1, src/dang_sample_mod.f90:229-329), tune_spectral_parameter_length
  * (:623-717) and fit_band_gain (:570-621).  With one index for the whole sky every Metropolis step is one pass
  * that yields a few global sums; the chain (proposal, prior, accept, step-size tuning) stays with the caller,

@@ -897,6 +897,158 @@ int64_t dgo_sample_index_mh(dgo_ctx *ctx, int comp, int nind, int map_n, int nsa
     return accepted;
 }
 
+/* ------------------------------------------------------------------ coarse-Nside index sampling
+ * HEALPix is an external library of the reference (not in its tree; linked as -lhealpix, any 3.x release): nest2ring
+ * and udgrade_ring are restated from the published algorithm (Gorski et al. 2005, ApJ 622, 759; pix_tools::nest2ring,
+ * udgrade_nr::udgrade_ring -> sub_udgrade_nest with pessimistic = .false.). */
+
+/* face f = ipnest / nside^2; (ix, iy) = even / odd bits of the in-face index; ring jr from the north pole; jp in ring */
+int64_t dgo_nest2ring(int nside, int64_t ipnest) {
+    static const int jrll[12] = {2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4}, jpll[12] = {1, 3, 5, 7, 0, 2, 4, 6, 1, 3, 5, 7};
+    const int64_t ns2 = (int64_t)nside * nside, npix = 12 * ns2, ncap = 2 * (int64_t)nside * (nside - 1);
+    const int face = (int)(ipnest / ns2);
+    const int64_t ipf = ipnest % ns2;
+    int ix = 0, iy = 0;
+    for (int b = 0; b < 16; ++b) {
+        ix |= (int)((ipf >> (2 * b)) & 1) << b;
+        iy |= (int)((ipf >> (2 * b + 1)) & 1) << b;
+    }
+    const int64_t jr = (int64_t)jrll[face] * nside - ix - iy - 1;
+    int64_t nr, n_before;
+    int kshift;
+    if (jr < nside) { nr = jr; n_before = 2 * nr * (nr - 1); kshift = 0; }
+    else if (jr > 3 * (int64_t)nside) { nr = 4 * (int64_t)nside - jr; n_before = npix - 2 * (nr + 1) * nr; kshift = 0; }
+    else { nr = nside; n_before = ncap + (jr - nside) * 4 * (int64_t)nside; kshift = (int)((jr - nside) & 1); }
+    int64_t jp = ((int64_t)jpll[face] * nr + ix - iy + 1 + kshift) / 2;
+    if (jp > 4 * nr) jp -= 4 * nr;
+    if (jp < 1) jp += 4 * nr;
+    return n_before + jp - 1;
+}
+
+/* udgrade_ring for one map: RING -> NEST, mean of the good children (degrade) or the parent's value (upgrade),
+ * NEST -> RING.  mode 0: as is; 1: udgrade_rms (src/dang_util_mod.f90:341-356); 2: udgrade_mask with threshold 0.5
+ * (:358-376) */
+void dgo_udgrade(int mode, const double *in, int nside_in, double *out, int nside_out) {
+    const int64_t npi = 12 * (int64_t)nside_in * nside_in, npo = 12 * (int64_t)nside_out * nside_out;
+    const int degrade = nside_in > nside_out;
+    const int r1 = degrade ? nside_in / nside_out : nside_out / nside_in;
+    const int64_t ratio = (int64_t)r1 * r1;
+    double *nin = (double *)malloc(sizeof(double) * (size_t)npi);
+    for (int64_t p = 0; p < npi; ++p) {
+        double v = in[dgo_nest2ring(nside_in, p)];
+        nin[p] = (mode == 1) ? v * v : v;
+    }
+    for (int64_t q = 0; q < npo; ++q) {
+        double v;
+        if (degrade) {
+            double total = 0.0;
+            int nobs = 0;
+            for (int64_t ip = 0; ip < ratio; ++ip) {
+                double x = nin[q * ratio + ip];
+                if (fabs(x - MISSVAL) > fabs(1e-5 * MISSVAL)) { total = total + x; ++nobs; }
+            }
+            v = nobs ? total / nobs : MISSVAL;
+        } else {
+            v = nin[q / ratio];
+        }
+        if (mode == 1) v = sqrt(v) * ((double)nside_out * 1.0 / nside_in);
+        if (mode == 2 && degrade) v = (v < 0.5) ? 0.0 : 1.0;
+        out[dgo_nest2ring(nside_out, q)] = v;
+    }
+    free(nin);
+}
+
+/* src/dang_sample_mod.f90:88-485, index_mode == 2 with sample_nside < nside -- literally: the chain of COARSE pixel i
+ * reads ddata%masks(i,1) (:362), c%indices(i, map_inds(1), :) (:372-377) and, inside eval_signal, c%amplitude(i,k)
+ * (:548-553 -> src/dang_component_mod.f90:773) from the FULL-resolution arrays at the same index i. */
+int64_t dgo_sample_index_mh_coarse(dgo_ctx *ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed,
+                                   uint64_t stream, int nside, int sample_nside) {
+    dgo_comp *c = &ctx->comps[comp];
+    const int npix = ctx->npix, nb = ctx->nbands;
+    const int s1 = (map_n == -1) ? 2 : map_n, s2 = (map_n == -1) ? 3 : map_n, Sp = s2 - s1 + 1;
+    const int64_t npc = 12 * (int64_t)sample_nside * sample_nside;
+    if (ctx->pix0 != 0 || npix != 12 * nside * nside || sample_nside >= nside) return -1;
+    double *full = (double *)malloc(sizeof(double) * (size_t)npix);
+    double *cdata = (double *)malloc(sizeof(double) * (size_t)(Sp * nb) * npc);
+    double *crms = (double *)malloc(sizeof(double) * (size_t)(Sp * nb) * npc);
+    double *cmask = (double *)malloc(sizeof(double) * (size_t)npc);
+    double *index_map = (double *)calloc((size_t)npc, sizeof(double));
+    double *index_full = (double *)malloc(sizeof(double) * (size_t)npix);
+    int64_t accepted = 0;
+    set_threads(ctx);
+    for (int kk = 0; kk < Sp; ++kk)
+        for (int j = 0; j < nb; ++j) {
+            const int k = s1 + kk;
+#pragma omp parallel for schedule(static)
+            for (int i = 0; i < npix; ++i) { /* :173-196 */
+                double d = (k == 1) ? (ctx->sig[IDX3(ctx, j, 1, i)] - ctx->offset[j]) / ctx->gain[j] : ctx->sig[IDX3(ctx, j, k, i)];
+                for (int l = 0; l < ctx->ncomp; ++l)
+                    if (l != comp) d = d - dgo_eval_signal(ctx, l, j, i, k, NULL);
+                full[i] = d;
+            }
+            dgo_udgrade(0, full, nside, cdata + ((int64_t)kk * nb + j) * npc, sample_nside);                 /* :213 */
+            dgo_udgrade(1, ctx->rms + IDX3(ctx, j, k, 0), nside, crms + ((int64_t)kk * nb + j) * npc, sample_nside); /* :214 */
+        }
+    dgo_udgrade(2, ctx->mask, nside, cmask, sample_nside); /* :209 */
+#pragma omp parallel for schedule(static) reduction(+ : accepted)
+    for (int64_t i = 0; i < npc; ++i) {
+        if (masked(ctx->mask[i])) continue; /* :362: the full-resolution mask at the coarse index */
+        double sample[DGO_MAX_IND] = {0, 0}, theta[DGO_MAX_IND] = {0, 0};
+        double data[3 * 64], model[3 * 64], rmsl[3 * 64];
+        for (int kk = 0; kk < Sp; ++kk)
+            for (int j = 0; j < nb; ++j) {
+                data[(s1 + kk - 1) * 64 + j] = cdata[((int64_t)kk * nb + j) * npc + i];
+                rmsl[(s1 + kk - 1) * 64 + j] = crms[((int64_t)kk * nb + j) * npc + i];
+            }
+        for (int l = 0; l < c->nindices; ++l) sample[l] = c->indices[((int64_t)l * ctx->nmaps + (s1 - 1)) * (int64_t)npix + i];
+        for (int l = 0; l < DGO_MAX_IND; ++l) theta[l] = sample[l];
+#define FILL_MODEL(th)                                                                     \
+        for (int k = s1; k <= s2; ++k)                                                     \
+            for (int j = 0; j < nb; ++j) model[(k - 1) * 64 + j] = dgo_eval_signal(ctx, comp, j, (int)i, k, (th));
+#define LNL()                                                                              \
+        (c->lnl_type[nind] == DGO_LNL_CHISQ    ? dgo_evaluate_lnL(nb, s1, s2, data, rmsl, model, 1, 64, 0, cmask[i]) \
+         : c->lnl_type[nind] == DGO_LNL_MARGINAL ? dgo_evaluate_marginal_lnL(nb, s1, s2, data, rmsl, model, 1, 64, 0) \
+                                                 : 0.0)
+#define PRIOR(v) (c->prior_type[nind] == DGO_PRIOR_GAUSSIAN ? log(dgo_eval_normal_prior((v), c->gauss_prior[nind][0], c->gauss_prior[nind][1])) : 0.0)
+        FILL_MODEL(sample)
+        int sample_it = 1;
+        double lnl = LNL();
+        if (c->lnl_type[nind] == DGO_LNL_PRIOR) {
+            double u[2];
+            sample_it = 0;
+            dgo_uniform2(seed, stream, (uint64_t)i, 0u, u);
+            sample[nind] = dgo_rand_normal(c->gauss_prior[nind][0], c->gauss_prior[nind][1], u[0], u[1]);
+        }
+        double lnl_old = lnl + PRIOR(sample[nind]);
+        if (sample_it) {
+            for (int l = 1; l <= nsample; ++l) {
+                double u[3];
+                dgo_uniform3(seed, stream, (uint64_t)i, (uint32_t)l, u);
+                theta[nind] = sample[nind] + dgo_rand_normal(0.0, c->step_size[nind], u[0], u[1]);
+                if (theta[nind] < c->uni_prior[nind][0] || theta[nind] > c->uni_prior[nind][1]) continue;
+                FILL_MODEL(theta)
+                lnl = LNL();
+                double lnl_new = lnl + PRIOR(theta[nind]);
+                double diff = lnl_new - lnl_old;
+                if (ml_mode == DGO_ML_OPTIMIZE) {
+                    if (diff > 0.0) { sample[nind] = theta[nind]; lnl_old = lnl_new; accepted += 1; }
+                } else {
+                    if (diff > log(u[2])) { sample[nind] = theta[nind]; lnl_old = lnl_new; accepted += 1; }
+                }
+            }
+        }
+        index_map[i] = sample[nind]; /* :465 */
+#undef FILL_MODEL
+#undef LNL
+#undef PRIOR
+    }
+    dgo_udgrade(0, index_map, sample_nside, index_full, nside); /* :480 */
+    for (int k = s1; k <= s2; ++k)
+        for (int i = 0; i < npix; ++i) c->indices[((int64_t)nind * ctx->nmaps + (k - 1)) * (int64_t)npix + i] = index_full[i]; /* :483 */
+    free(full); free(cdata); free(crms); free(cmask); free(index_map); free(index_full);
+    return accepted;
+}
+
 /* ------------------------------------------------------------------ full-sky index mode, tuner, gain fit */
 
 #define DGO_GLOBAL_PIX ((uint64_t)0xFFFFFFFFFFull)

@@ -151,6 +151,12 @@ double dgo_evaluate_marginal_lnL(int nbands, int s1, int s2, const double *data,
  * Writes c%indices(:, s1:s2, nind).  Returns number of accepted proposals (diagnostic). */
 int64_t dgo_sample_index_mh(dgo_ctx *ctx, int comp, int nind, int map_n, int nsample, int ml_mode,
                             uint64_t seed, uint64_t stream);
+/* coarse-Nside sampling (sample_nside < nside), the reference's behaviour reproduced literally; HEALPix pieces restated
+ * from the published algorithm (the library itself is not part of the reference tree) */
+int64_t dgo_nest2ring(int nside, int64_t ipnest);
+void dgo_udgrade(int mode, const double *in, int nside_in, double *out, int nside_out);
+int64_t dgo_sample_index_mh_coarse(dgo_ctx *ctx, int comp, int nind, int map_n, int nsample, int ml_mode,
+                                   uint64_t seed, uint64_t stream, int nside, int sample_nside);
 
 /* ---- "next" rows: full-sky index mode, step-size tuner, band-gain fit ------------- */
 /* Full-sky Metropolis for index `nind` of component `comp` (index_mode==1, src/dang_sample_mod.f90:229-329),

@@ -96,6 +96,13 @@ def lib():
         l.dgo_sample_index_mh.restype = C.c_int64
         l.dgo_sample_index_mh.argtypes = [C.POINTER(Ctx), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
                                           C.c_uint64]
+        l.dgo_nest2ring.restype = C.c_int64
+        l.dgo_nest2ring.argtypes = [C.c_int, C.c_int64]
+        l.dgo_udgrade.restype = None
+        l.dgo_udgrade.argtypes = [C.c_int, _D, C.c_int, _D, C.c_int]
+        l.dgo_sample_index_mh_coarse.restype = C.c_int64
+        l.dgo_sample_index_mh_coarse.argtypes = [C.POINTER(Ctx), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
+                                                 C.c_uint64, C.c_int, C.c_int]
         l.dgo_sample_index_fullsky.restype = C.c_int64
         l.dgo_sample_index_fullsky.argtypes = [C.POINTER(Ctx), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
                                                C.c_uint64, C.POINTER(C.c_int)]
@@ -258,6 +265,10 @@ class Oracle:
         v = self.L.dgo_compute_chisq(self.c, _p(np.ascontiguousarray(sky)), pol_lo, pol_hi, nump, _p(chi))
         return v, chi
 
+    def sample_index_mh_coarse(self, comp, nind, map_n, nsample, ml_mode, seed, stream, nside, sample_nside):
+        return self.L.dgo_sample_index_mh_coarse(self.c, comp, nind, map_n, nsample, ML_CODES[ml_mode], seed, stream,
+                                                 nside, sample_nside)
+
     def sample_index_fullsky(self, comp, nind, map_n, nsample, ml_mode, seed, stream, tuned=True):
         t = C.c_int(1 if tuned else 0)
         acc = self.L.dgo_sample_index_fullsky(self.c, comp, nind, map_n, nsample, ML_CODES[ml_mode], seed, stream, C.byref(t))
@@ -269,6 +280,17 @@ class Oracle:
 
     def sample_index_mh(self, comp, nind, map_n, nsample, ml_mode, seed, stream):
         return self.L.dgo_sample_index_mh(self.c, comp, nind, map_n, nsample, ML_CODES[ml_mode], seed, stream)
+
+
+def nest2ring(nside, ipnest):
+    return int(lib().dgo_nest2ring(nside, ipnest))
+
+
+def udgrade(mode, m, nside_in, nside_out):
+    m = np.ascontiguousarray(m, dtype=np.float64)
+    out = np.empty(12 * nside_out * nside_out)
+    lib().dgo_udgrade(mode, m.ctypes.data_as(_D), nside_in, out.ctypes.data_as(_D), nside_out)
+    return out
 
 
 def philox(ctr, key):

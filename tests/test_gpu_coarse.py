@@ -1,0 +1,82 @@
+"""GPU parity for SURVEY 8f rank 4 (first half): index sampling with sample_nside < nside -- the device udgrade
+primitives and the coarse chain against the oracle's restatement (reference behaviour reproduced literally, including
+its reading of the full-resolution amplitude / index / mask arrays at the coarse pixel number)."""
+import numpy as np
+import pytest
+
+import dang_amd as da
+from dang_amd import _lib as L
+
+import oracle_ffi as O
+from util import make_case, pair
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_udgrade_matches_the_restatement(built):
+    eng, _ = pair(make_case("C1", nside=4))
+    rng = np.random.default_rng(5)
+    for ni, no in ((16, 4), (8, 1), (2, 8), (4, 32)):
+        m = rng.normal(size=12 * ni * ni)
+        m[rng.integers(0, m.size, 5)] = -1.6375e30
+        assert np.array_equal(eng.udgrade(0, m, ni, no), O.udgrade(0, m, ni, no))
+        rms = rng.uniform(0.5, 2.0, m.size)
+        assert np.array_equal(eng.udgrade(1, rms, ni, no), O.udgrade(1, rms, ni, no))
+        mask = (rng.uniform(size=m.size) > 0.4).astype(float)
+        assert np.array_equal(eng.udgrade(2, mask, ni, no), O.udgrade(2, mask, ni, no))
+
+
+@pytest.mark.parametrize("lnl,ml_mode,cnside", [("chisq", "sample", 4), ("chisq", "optimize", 8), ("marginal", "sample", 2),
+                                                ("prior", "sample", 4)])
+def test_coarse_index_sampling_matches_oracle(built, lnl, ml_mode, cnside):
+    nside = 16
+
+    def tweak(dpar, ddata, bands, comps):
+        for c in comps:
+            c.lnl_type = [lnl] * c.nindices
+            c.sample_nside = [cnside] * c.nindices
+    case = make_case("C2", nside=nside, start="truth", tweak=tweak)
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+    for l, c in enumerate(comps):
+        for j in range(c.nindices):
+            if not c.sample_index[j]:
+                continue
+            f = c.pol_flag[j][0]
+            map_n = {1: 1, 8: -1}[f]
+            s = da.stream_id(2, 1, l, j, f)
+            ag = eng.index_sample_coarse(l, j, map_n, 10, ml_mode, 7, s, cnside)
+            ao = orc.sample_index_mh_coarse(l, j, map_n, 10, ml_mode, 7, s, nside, cnside)
+            assert ao >= 0 and ag == ao, (l, j, ag, ao)
+            a, b = eng.get_indices(l), orc.indices(l)
+            assert np.abs(a - b).max() <= 1e-12
+            planes = [0] if f == 1 else [1, 2]
+            # every full-resolution pixel carries its coarse parent's value: (nside/cnside)^2 copies of each
+            vals, counts = np.unique(a[j, planes[0]], return_counts=True)
+            assert np.all(counts % ((nside // cnside) ** 2) == 0)
+            if f == 8:
+                assert np.array_equal(a[j, 1], a[j, 2])
+    # the state is usable afterwards: chi^2 through the explicit pass, and a regular sweep
+    s = eng.sky_model_chisq(1, 3)
+    osky, _ = orc.sky_model()
+    ochisq, _ = orc.chisq(1, 3, ddata.nump, osky)
+    assert abs(s / meta["nbands"] / ddata.nump - ochisq) <= 1e-9 * ochisq
+
+
+def test_sample_spectral_parameters_dispatches_the_coarse_mode(built):
+    def tweak(dpar, ddata, bands, comps):
+        comps[1].sample_nside = [4]           # synch beta (T) at Nside 4, everything else at full resolution
+    case = make_case("C2", nside=8, start="truth", tweak=tweak)
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+    da.sample_spectral_parameters(dpar, ddata, it=2)
+    beta = eng.get_indices(1)[0, 0]
+    assert len(np.unique(beta)) <= 12 * 4 * 4 and len(np.unique(eng.get_indices(2)[0, 0])) > 12 * 4 * 4
+    assert np.isfinite(ddata.chisq)
+
+
+def test_coarse_mode_needs_a_whole_sky_context(built):
+    case = make_case("C2", nside=8, rank=0, nranks=2)
+    eng, _ = pair(case)
+    with pytest.raises(da.DangxError, match="whole-sky"):
+        eng.index_sample_coarse(1, 0, 1, 10, "sample", 7, 1, 4)
