@@ -60,6 +60,7 @@ SYMBOLS = {
     "dangx_index_sample_coarse": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
                                             C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "dangx_udgrade": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int]),
+    "dangx_index_masked_sum": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "dangx_set_band": (C.c_int, [_P, C.c_int, C.c_double, C.c_int, _P, _P]),
     "dangx_set_component": (C.c_int, [_P, C.c_int, C.POINTER(CompDesc)]),
     "dangx_set_tcmb": (C.c_int, [_P, C.c_double]),

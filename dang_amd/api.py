@@ -386,6 +386,11 @@ class Engine:
             raise DangxError("npix_global is not 12*nside^2")
         return n
 
+    def index_masked_sum(self, comp, nind, map_n):
+        s, n = C.c_double(0.0), C.c_int64(0)
+        self._chk(self.lib.dangx_index_masked_sum(self.h, comp, nind, map_n, C.byref(s), C.byref(n)))
+        return s.value, n.value
+
     def peek_indices(self, comp, map_n, pix=0):
         n = self.component_list[comp].nindices
         out = (C.c_double * max(n, 1))()
@@ -479,6 +484,20 @@ def initialize(bands, component_list, ddata, **kw):
     """What the driver does once after src/dang.f90:73: hand the static state to the device."""
     ddata.engine = Engine(bands, component_list, ddata, **kw)
     return ddata.engine
+
+
+def index_means(ddata, map_n):
+    """The per-iteration numbers of write_data (src/dang_data_mod.f90:716-731): mask_avg(c%indices(:,map_n,j), masks)
+    for every sampled index, from device reductions (no map leaves the GPU).  {(label, ind_label): mean}"""
+    eng = ddata.engine
+    out = {}
+    for l, c in enumerate(eng.component_list):
+        for j in range(c.nindices):
+            if c.sample_index[j]:
+                s, n = eng.index_masked_sum(l, j, map_n)
+                s, n = _dist.allreduce_sum_float(s), _dist.allreduce_sum_float(float(n))
+                out[(c.label, c.ind_label[j] if c.ind_label else str(j))] = s / n if n else float("nan")
+    return out
 
 
 def mask_hi_threshold(ddata, c, thresh):

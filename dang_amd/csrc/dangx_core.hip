@@ -491,6 +491,29 @@ __global__ __launch_bounds__(BLOCK) void k_coarse_writeback(const Model* __restr
     for (int k = s1; k <= s2; ++k) M.comp[comp].idx[((long long)nind * M.nmaps + (k - 1)) * M.npix + p] = v;
 }
 
+
+// mask_avg / mask_sum (src/dang_util_mod.f90:186-226) of c%indices(:, map_n, nind): rows 0: sum over unmasked pixels,
+// 1: their number -- what write_data prints every iteration (src/dang_data_mod.f90:716-731)
+__global__ __launch_bounds__(BLOCK) void k_index_masked_sum(const Model* __restrict__ Mp, int comp, int nind, int k,
+                                                            double* __restrict__ partial) {
+    __shared__ double sh[2][BLOCK / 64];
+    const Model& M = *Mp;
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    double v = 0.0, n = 0.0;
+    if (i < M.npix && !is_masked(M.mask[i])) {
+        v = M.comp[comp].idx[((long long)nind * M.nmaps + (k - 1)) * M.npix + i];
+        n = 1.0;
+    }
+    for (int o = 32; o > 0; o >>= 1) { v += __shfl_down(v, o, 64); n += __shfl_down(n, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = v; sh[1][threadIdx.x >> 6] = n; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double t = 0.0;
+        for (int w = 0; w < BLOCK / 64; ++w) t += sh[threadIdx.x][w];
+        partial[(long long)threadIdx.x * gridDim.x + blockIdx.x] = t;
+    }
+}
+
 // c%indices(:, s1:s2, nind) = value (src/dang_sample_mod.f90:329, 483: every pixel, masked ones too)
 __global__ __launch_bounds__(BLOCK) void k_fill_index(const Model* __restrict__ Mp, int comp, int nind, int s1, int s2, double value) {
     const Model& M = *Mp;
@@ -1696,6 +1719,27 @@ int dangx_index_sample_coarse(dangx_ctx* ctx, int comp, int nind, int map_n, int
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         *accepted = (int64_t)v;
     }
+    return 0;
+}
+
+
+// local (this shard's) sum of c%indices(:, map_n, nind) over unmasked pixels and their number: mask_avg = sum / count
+int dangx_index_masked_sum(dangx_ctx* ctx, int comp, int nind, int map_n, double* sum, int64_t* count) {
+    if (!ctx || !sum || !count || check_comp(ctx, comp)) return 1;
+    (void)hipSetDevice(ctx->device);
+    if (nind < 0 || nind >= ctx->desc[comp].nindices) return fail(ctx, "index number out of range");
+    if (map_n < 1 || map_n > ctx->dims.nmaps) return fail(ctx, "map_n must be a map number (1..nmaps)");
+    if (sync_model(ctx)) return 1;
+    const unsigned nblk = nblocks(ctx->hm.npix);
+    if (ensure_partial(ctx, 2ll * nblk)) return 1;
+    hipLaunchKernelGGL(k_index_masked_sum, dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->dm, comp, nind, map_n, ctx->partial);
+    hipLaunchKernelGGL(k_reduce_rows_final, dim3(2), dim3(BLOCK), 0, ctx->stream, ctx->partial, (long long)nblk, 2, ctx->rows_out);
+    HIPCHK(ctx, hipGetLastError());
+    double out[2] = {0.0, 0.0};
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->rows_out, sizeof(out), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *sum = out[0];
+    *count = (int64_t)out[1];
     return 0;
 }
 

@@ -170,6 +170,13 @@ module dangx_mod
        type(c_ptr), value :: ctx, map_in, map_out
        integer(c_int), value :: mode, nside_in, nside_out
      end function
+     integer(c_int) function dangx_index_masked_sum(ctx, comp, nind, map_n, sum, count) bind(C, name='dangx_index_masked_sum')
+       import :: c_int, c_ptr, c_double, c_int64_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: comp, nind, map_n
+       real(c_double), intent(out) :: sum
+       integer(c_int64_t), intent(out) :: count
+     end function
      ! pixel-sharded (MPI) runs: fn = c_funloc of a bind(C) function that does
      ! MPI_Allreduce(MPI_IN_PLACE, buf, n, MPI_DOUBLE_PRECISION, MPI_SUM, comm) and returns 0
      integer(c_int) function dangx_set_allreduce(ctx, fn, user, is_root) bind(C, name='dangx_set_allreduce')

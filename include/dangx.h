@@ -202,6 +202,11 @@ int dangx_index_sample_coarse(dangx_ctx *ctx, int comp, int nind, int map_n, int
  * 2 = udgrade_mask(threshold 0.5); host pointers, one map each ([12*nside_in^2] -> [12*nside_out^2]) */
 int dangx_udgrade(dangx_ctx *ctx, int mode, const double *map_in, int nside_in, double *map_out, int nside_out);
 
+/* ---- per-iteration trace output without pulling maps: mask_avg(c%indices(:,map_n,nind), masks) as printed by
+ * write_data every Gibbs iteration (src/dang_data_mod.f90:716-731, src/dang_util_mod.f90:186-206).  Returns this
+ * shard's sum over unmasked pixels and their number; mask_avg = (all-reduced sum) / (all-reduced count). */
+int dangx_index_masked_sum(dangx_ctx *ctx, int comp, int nind, int map_n, double *sum, int64_t *count);
+
 /* ---- full-sky index mode (index_mode == 1, src/dang_sample_mod.f90:229-329), tune_spectral_parameter_length
  * (:623-717) and fit_band_gain (:570-621).  With one index for the whole sky every Metropolis step is one pass
  * that yields a few global sums; the chain (proposal, prior, accept, step-size tuning) stays with the caller,

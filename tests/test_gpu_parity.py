@@ -357,3 +357,25 @@ def test_T_cmb_component_as_fixed_sky_signal(built):
     s, sky, res, chi = eng.sky_model_chisq(1, 1, want_maps=True)
     osky, ores = orc.sky_model()
     assert relmax(sky, osky) <= 1e-13 and relmax(res, ores) <= 1e-11
+
+
+def test_index_means_for_write_data(built):
+    """mask_avg(c%indices(:,map_n,j), masks) (src/dang_util_mod.f90:186-206), the number write_data prints every
+    iteration, from a device reduction instead of pulling the map."""
+    case = make_case("C2", nside=8, start="truth")
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+    m = np.asarray(ddata.masks)[0] != 0
+    for map_n in (1, 2, 3):
+        got = da.index_means(ddata, map_n)
+        for l, c in enumerate(comps):
+            for j in range(c.nindices):
+                if c.sample_index[j]:
+                    x = orc.indices(l)[j, map_n - 1]
+                    want = 0.0
+                    for v in x[m]:
+                        want = want + v      # the reference's sequential sum
+                    want /= m.sum()
+                    assert abs(got[(c.label, c.ind_label[j])] - want) <= 1e-13 * max(abs(want), 1.0)
+    s, n = eng.index_masked_sum(1, 0, 1)
+    assert n == int(m.sum())
