@@ -170,6 +170,12 @@ module dangx_mod
        type(c_ptr), value :: ctx, map_in, map_out
        integer(c_int), value :: mode, nside_in, nside_out
      end function
+     integer(c_int) function dangx_peek_indices(ctx, comp, map_n, pix, out) bind(C, name='dangx_peek_indices')
+       import :: c_int, c_ptr, c_int64_t
+       type(c_ptr), value :: ctx, out
+       integer(c_int), value :: comp, map_n
+       integer(c_int64_t), value :: pix
+     end function
      integer(c_int) function dangx_index_masked_sum(ctx, comp, nind, map_n, sum, count) bind(C, name='dangx_index_masked_sum')
        import :: c_int, c_ptr, c_double, c_int64_t
        type(c_ptr), value :: ctx

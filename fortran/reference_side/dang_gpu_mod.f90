@@ -10,7 +10,8 @@
 !     call dangx_init(dpar, ddata)                      ! once, after line 79
 !     call sample_cg_groups_gpu(dpar, ddata)            ! instead of line 101
 !     call sample_spectral_parameters_gpu(dpar, ddata)  ! instead of line 106
-!     call dangx_pull_state()                           ! before write_data / write_maps (116-121)
+!     call dangx_pull_state()                           ! before write_maps (119-121); write_data (116-118) needs scalars only:
+!                                                       ! gpu_index_mean(), ddata%chisq, template amplitudes
 module dang_gpu_mod
   use, intrinsic :: iso_c_binding
   use healpix_types
@@ -150,15 +151,10 @@ contains
     do i = 1, ncg_groups
        if (cg_groups(i)%p%sample) then
           write(*,fmt='(a,i4)') "Computing a CG search of CG group ", i
-          ! a group with template / monopole / hi_fit members is a coupled system: the reference's CG on the device
+          ! DIRECT: per-pixel block solve; groups with template / monopole / hi_fit members: Schur-complement solve
+          ! (iters = -k reports k global-amplitude directions absorbed by the diffuse members, left at their value).
+          ! DANGX_SOLVER_CG would run the reference's cg_search on the device instead.
           solver = DANGX_SOLVER_DIRECT
-          if (cg_groups(i)%p%ntemp > 0) then
-             do k = 1, cg_groups(i)%p%ncg_components
-                select case (trim(cg_groups(i)%p%cg_component(k)%p%type))
-                case ('template', 'monopole', 'hi_fit'); solver = DANGX_SOLVER_CG
-                end select
-             end do
-          end if
           do f = 1, cg_groups(i)%p%nflag
              call dangx_check(gpu_ctx, dangx_amp_sample(gpu_ctx, i, cg_groups(i)%p%pol_flag(f), mode, &
                   solver, DANGX_FLUCT_REFERENCE, gpu_seed, &
@@ -178,6 +174,7 @@ contains
     type(dang_comps), pointer :: c
     integer(i4b) :: i, j, k, map_n, mode
     integer(c_int64_t) :: nacc
+    real(c_double), target :: tpeek(2)
     logical(lgt) :: sampled
     sampled = .false.
     mode = merge(DANGX_ML_SAMPLE, DANGX_ML_OPTIMIZE, trim(dpar%ml_mode) == 'sample')
@@ -201,12 +198,118 @@ contains
                 write(*,*) "There is something wrong with the poltype flag"
                 cycle
              end if
-             call dangx_check(gpu_ctx, dangx_index_sample(gpu_ctx, i-1, j-1, map_n, nsample, mode, gpu_seed, &
-                  dangx_stream_id(iter, 1, i-1, j-1, c%pol_flag(j,k)), nacc), 'index_sample')
+             if (c%index_mode(j) == 1) then
+                ! full-sky value: keep the reference's chain (src/dang_sample_mod.f90:229-329) and take its three
+                ! evaluate_* / eval_jeffreys_prior calls from dangx_fullsky_sums (INTEGRATION.md section 4)
+                call sample_index_mh_fullsky_gpu(ddata, c, i-1, j, map_n)
+             else if (c%sample_nside(j) /= nside) then
+                call dangx_check(gpu_ctx, dangx_index_sample_coarse(gpu_ctx, i-1, j-1, map_n, nsample, mode, gpu_seed, &
+                     dangx_stream_id(iter, 1, i-1, j-1, c%pol_flag(j,k)), nside, c%sample_nside(j), nacc), 'index_sample_coarse')
+             else
+                call dangx_check(gpu_ctx, dangx_index_sample(gpu_ctx, i-1, j-1, map_n, nsample, mode, gpu_seed, &
+                     dangx_stream_id(iter, 1, i-1, j-1, c%pol_flag(j,k)), nacc), 'index_sample')
+             end if
           end do
        end do
+       ! "Update the global variable T_CMB" (src/dang_sample_mod.f90:75-78)
+       if (trim(c%type) == 'T_cmb') then
+          call dangx_check(gpu_ctx, dangx_peek_indices(gpu_ctx, i-1, 1, 0_c_int64_t, c_loc(tpeek)), 'peek_indices')
+          T_CMB = tpeek(1)
+          call dangx_check(gpu_ctx, dangx_set_tcmb(gpu_ctx, T_CMB), 'set_tcmb')
+       end if
     end do
     if (sampled) call gpu_chisq(ddata)
   end subroutine sample_spectral_parameters_gpu
+
+  ! sample_index_mh, index_mode == 1 (src/dang_sample_mod.f90:229-329): the reference's chain, with its sky-wide
+  ! evaluate_lnL / evaluate_marginal_lnL / eval_jeffreys_prior replaced by dangx_fullsky_sums (one memory-bound pass
+  ! each) and `index_full_res(:,...) = sample(nind)` by dangx_fill_index.  comp0 is 0-based, nind 1-based as in the
+  ! reference.  (The step-size tuner, :272-275, is the same substitution inside tune_spectral_parameter_length.)
+  subroutine sample_index_mh_fullsky_gpu(ddata, c, comp0, nind, map_n)
+    type(dang_data)            :: ddata
+    type(dang_comps), pointer  :: c
+    integer(i4b), intent(in)   :: comp0, nind, map_n
+    real(c_double), target     :: sample(2), theta(2), rows(4*nbands)
+    real(dp)                   :: lnl, lnl_old, lnl_new, diff, ratio, num
+    integer(i4b)               :: l, s1, sp
+    logical(lgt)               :: sample_it
+
+    s1 = merge(2, map_n, map_n == -1); sp = merge(2, 1, map_n == -1)
+    call dangx_check(gpu_ctx, dangx_fullsky_prepare(gpu_ctx, comp0, map_n), 'fullsky_prepare')       ! :173-196
+    sample = 0.d0
+    call dangx_check(gpu_ctx, dangx_peek_indices(gpu_ctx, comp0, s1, 0_c_int64_t, c_loc(sample)), 'peek_indices')  ! :240-242
+    theta = sample
+    lnl = 0.d0; sample_it = .true.
+    if (trim(c%lnl_type(nind)) == 'prior') then                                                        ! :255-257
+       sample_it = .false.
+       sample(nind) = rand_normal(c%gauss_prior(nind,1), c%gauss_prior(nind,2))
+    else
+       lnl = fullsky_lnl(sample)
+    end if
+    lnl_old = lnl + fullsky_prior(sample(nind))
+    if (sample_it) then
+       do l = 1, nsample                                                                               ! :282-324
+          theta(nind) = sample(nind) + rand_normal(0.d0, c%step_size(nind))
+          if (theta(nind) < c%uni_prior(nind,1) .or. theta(nind) > c%uni_prior(nind,2)) cycle
+          lnl_new = fullsky_lnl(theta) + fullsky_prior(theta(nind))
+          diff  = lnl_new - lnl_old
+          ratio = exp(diff)
+          if (trim(ml_mode) == 'optimize') then
+             if (ratio > 1.d0) then
+                sample(nind) = theta(nind); lnl_old = lnl_new
+             end if
+          else
+             call RANDOM_NUMBER(num)
+             if (ratio > num) then
+                sample(nind) = theta(nind); lnl_old = lnl_new
+             end if
+          end if
+       end do
+    end if
+    call dangx_check(gpu_ctx, dangx_fill_index(gpu_ctx, comp0, nind-1, map_n, sample(nind)), 'fill_index')   ! :329, :483
+
+  contains
+
+    function fullsky_lnl(th) result(v)
+      real(c_double), target, intent(in) :: th(2)
+      real(dp) :: v
+      integer(i4b) :: q
+      v = 0.d0
+      if (trim(c%lnl_type(nind)) == 'chisq') then
+         call dangx_check(gpu_ctx, dangx_fullsky_sums(gpu_ctx, 0, c_loc(th), c_loc(rows), 1), 'fullsky_sums')
+         v = rows(1)
+      else if (trim(c%lnl_type(nind)) == 'marginal') then                 ! -0.5*TNd*invTNT*TNd per (band, map), j outer
+         call dangx_check(gpu_ctx, dangx_fullsky_sums(gpu_ctx, 1, c_loc(th), c_loc(rows), 2*nbands*sp), 'fullsky_sums')
+         do q = 1, nbands*sp
+            v = v - 0.5d0*rows(2*q-1)*(1.d0/rows(2*q))*rows(2*q-1)
+         end do
+      end if
+    end function fullsky_lnl
+
+    function fullsky_prior(val) result(v)
+      real(dp), intent(in) :: val
+      real(dp) :: v
+      real(c_double), target :: th(2)
+      v = 0.d0
+      if (trim(c%prior_type(nind)) == 'gaussian') then
+         v = log(eval_normal_prior(val, c%gauss_prior(nind,1), c%gauss_prior(nind,2)))
+      else if (trim(c%prior_type(nind)) == 'jeffreys') then
+         th = [val, 0.d0]
+         call dangx_check(gpu_ctx, dangx_fullsky_sums(gpu_ctx, 2, c_loc(th), c_loc(rows), 1), 'fullsky_sums')
+         v = log(sqrt(rows(1)))
+      end if
+    end function fullsky_prior
+
+  end subroutine sample_index_mh_fullsky_gpu
+
+  ! mask_avg(c%indices(:,map_n,j), ddata%masks(:,1)) for write_data (src/dang_data_mod.f90:716-731) without pulling the map
+  function gpu_index_mean(comp, j, map_n) result(avg)
+    integer(i4b), intent(in) :: comp, j, map_n
+    real(dp) :: avg
+    real(c_double) :: s
+    integer(c_int64_t) :: n
+    call dangx_check(gpu_ctx, dangx_index_masked_sum(gpu_ctx, comp-1, j-1, map_n, s, n), 'index_masked_sum')
+    avg = s/n
+  end function gpu_index_mean
 
 end module dang_gpu_mod
