@@ -12,8 +12,11 @@
  * CFITSIO-F90 / MPI Fortran modules, which are absent; building it would need
  * stand-ins for those libraries, which is not allowed).  The oracle is therefore
  * pinned only by (i) published known-answer vectors for Philox4x32-10, (ii)
- * closed-form values of the SED formulas, and (iii) algebraic identities of the
- * solve (noise-free recovery, CG == direct block solve, posterior moments).
+ * closed-form values of the SED formulas, (iii) algebraic identities of the
+ * solve (noise-free recovery, CG == direct block solve, posterior moments), and
+ * (iv) for the HEALPix pieces of the coarse-Nside path (an external library of
+ * the reference, restated from the published algorithm) the documented nside = 2
+ * nest2ring table and the agreement of the RING / NESTED pixel-centre formulas.
  *
  * Array layout (= the Fortran arrays as they sit in memory, passed unchanged):
  *   sig/rms  : Fortran (0:npix-1, nmaps, nbands)  ->  C [band][map][pix]
