@@ -90,7 +90,37 @@ def seams_case(name, config, nside):
     print(name, "chisq", chisq)
 
 
+def paths_tweak(dpar, ddata, bands, comps):
+    """The model of the 'paths' fixture: C2 + a polarisation template fitted at bands 3, 4 in group 2."""
+    from test_oracle_templates_cpu import add_globals
+    add_globals(dpar, ddata, bands, comps, ("template",), 2, fit_bands=[3, 4])
+
+
+def paths_case(name, nside=8):
+    """The "next" rows: a template group (mixed operators), the full-sky index mode, coarse-Nside sampling."""
+    dpar, ddata, bands, comps, meta = synth.make_sky("C2", nside=nside, start="truth")
+    paths_tweak(dpar, ddata, bands, comps)
+    out = dict(sig=ddata.sig_map, rms=ddata.rms_map, mask=ddata.masks, nump=ddata.nump, nside=nside, config="C2")
+    orc = O.Oracle(bands, comps, ddata)
+    rng = np.random.default_rng(9)
+    n = orc.group_size(2, L.FLAG_QU)
+    x, eta = rng.standard_normal(n), orc.draw_eta(L.FLAG_QU, 5, 6)
+    out.update(x=x, eta=eta, rhs=orc.compute_rhs(2, L.FLAG_QU), Ax=orc.compute_Ax(2, L.FLAG_QU, x),
+               sv=orc.compute_sample_vector(2, L.FLAG_QU, eta))
+    it = orc.amp_sample_cg(2, L.FLAG_QU, "sample", 5, 6, i_max=600, converge=1e-8)
+    out.update(cg_iters=it, cg_ta=orc.template_amplitudes(len(comps) - 1).copy(), cg_amp3=orc.amplitude(3).copy())
+    o2 = O.Oracle(bands, comps, ddata)
+    acc, _, _ = o2.sample_index_fullsky(1, 0, 1, 10, "sample", 7, stream_id(2, 1, 1, 0, 1))
+    out.update(fullsky_acc=acc, fullsky_idx=o2.indices(1).copy())
+    o3 = O.Oracle(bands, comps, ddata)
+    acc = o3.sample_index_mh_coarse(5, 0, -1, 10, "sample", 7, stream_id(2, 1, 5, 0, 8), nside, 2)
+    out.update(coarse_acc=acc, coarse_idx=o3.indices(5).copy())
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "cg iters", it, "fullsky acc", out["fullsky_acc"], "coarse acc", out["coarse_acc"])
+
+
 if __name__ == "__main__":
+    paths_case("paths_C2_nside8")
     gibbs_case("gibbs_C1_nside8", "C1", 8, 3)
     gibbs_case("gibbs_C2_nside4", "C2", 4, 3)
     gibbs_case("gibbs_C5_nside2", "C5", 2, 2)

@@ -121,3 +121,62 @@ def test_hip_reproduces_golden_seams(built, path):
         for l, c in enumerate(comps):
             if c.cg_group == group:
                 assert relmax(eng.get_amplitude(l), g["cg_amp_%s_%d" % (name, l)]) <= tol
+
+
+# ---- the "next" rows: template group operators, full-sky index mode, coarse-Nside sampling
+
+PATHS = os.path.join(GOLD, "paths_C2_nside8.npz")
+
+
+def _paths_case():
+    import sys
+    sys.path.insert(0, GOLD)
+    from make_golden import paths_tweak
+    g = np.load(PATHS)
+    dpar, ddata, bands, comps, meta = synth.make_sky("C2", nside=int(g["nside"]), start="truth")
+    paths_tweak(dpar, ddata, bands, comps)
+    # the generator + tweak reproduce the fixture's inputs (to the last bits of the host's libm); the fixture's arrays
+    # are the inputs
+    assert np.allclose(ddata.sig_map, g["sig"], rtol=1e-12, atol=1e-9)
+    ddata.sig_map, ddata.rms_map, ddata.masks = g["sig"], g["rms"], g["mask"]
+    return g, dpar, ddata, bands, comps, meta
+
+
+def test_oracle_reproduces_golden_paths():
+    g, dpar, ddata, bands, comps, meta = _paths_case()
+    orc = O.Oracle(bands, comps, ddata)
+    assert relmax(orc.compute_rhs(2, L.FLAG_QU), g["rhs"]) <= 1e-13
+    assert relmax(orc.compute_Ax(2, L.FLAG_QU, g["x"]), g["Ax"]) <= 1e-13
+    assert relmax(orc.compute_sample_vector(2, L.FLAG_QU, g["eta"]), g["sv"]) <= 1e-13
+    assert orc.amp_sample_cg(2, L.FLAG_QU, "sample", 5, 6, i_max=600, converge=1e-8) == int(g["cg_iters"])
+    # (an unconverged CG trajectory amplifies the last-bit differences of another host's libm in the start state)
+    assert relmax(orc.template_amplitudes(len(comps) - 1), g["cg_ta"]) <= 1e-6
+    o2 = O.Oracle(bands, comps, ddata)
+    acc, _, _ = o2.sample_index_fullsky(1, 0, 1, 10, "sample", 7, da.stream_id(2, 1, 1, 0, 1))
+    assert acc == int(g["fullsky_acc"]) and np.abs(o2.indices(1) - g["fullsky_idx"]).max() <= 1e-13
+    o3 = O.Oracle(bands, comps, ddata)
+    acc = o3.sample_index_mh_coarse(5, 0, -1, 10, "sample", 7, da.stream_id(2, 1, 5, 0, 8), int(g["nside"]), 2)
+    assert acc == int(g["coarse_acc"]) and np.abs(o3.indices(5) - g["coarse_idx"]).max() <= 1e-13
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_golden_paths(built):
+    g, dpar, ddata, bands, comps, meta = _paths_case()
+    import copy
+    eng = da.initialize(bands, copy.deepcopy(comps), ddata, npix_global=meta["npix_global"], device=0)
+    assert relmax(eng.compute_rhs(2, L.FLAG_QU), g["rhs"]) <= 1e-12
+    assert relmax(eng.compute_Ax(2, L.FLAG_QU, g["x"]), g["Ax"]) <= 1e-12
+    assert relmax(eng.compute_sample_vector(2, L.FLAG_QU, g["eta"]), g["sv"]) <= 1e-12
+    it, _ = eng.amp_sample(2, L.FLAG_QU, "sample", 5, 6, solver="cg", i_max=600, converge=1e-8)
+    assert it == int(g["cg_iters"])
+    assert relmax(eng.get_template_amplitudes(len(comps) - 1), g["cg_ta"]) <= 1e-6
+    assert relmax(eng.get_amplitude(3), g["cg_amp3"]) <= 1e-6
+    eng = da.initialize(bands, copy.deepcopy(comps), ddata, npix_global=meta["npix_global"], device=0)
+    comps_fs = eng.component_list
+    comps_fs[1].index_mode = [1]
+    dpar.seed = 7
+    acc = da.sample_index_mh_fullsky(dpar, ddata, 1, 0, 1, da.stream_id(2, 1, 1, 0, 1))
+    assert acc == int(g["fullsky_acc"]) and np.abs(eng.get_indices(1) - g["fullsky_idx"]).max() <= 1e-12
+    eng = da.initialize(bands, copy.deepcopy(comps), ddata, npix_global=meta["npix_global"], device=0)
+    acc = eng.index_sample_coarse(5, 0, -1, 10, "sample", 7, da.stream_id(2, 1, 5, 0, 8), 2)
+    assert acc == int(g["coarse_acc"]) and np.abs(eng.get_indices(5) - g["coarse_idx"]).max() <= 1e-12
