@@ -710,7 +710,7 @@ __device__ __forceinline__ void fwd_subst(const double* A, double* v) {
 // rowpartial rows: [0, R*R): S[r][r'] ; [R*R, R*R+R): t[r] ; [R*R+R, R*R+2R): fluctuation sum of natural row r ;
 // [R*R+2R, R*R+3R): G[r][r], the diagonal before elimination (scale for the degeneracy test on the host)
 template <int NG>
-__global__ __launch_bounds__(BLOCK) void k_schur_pass1(const Model* __restrict__ Mp, GroupArgs a, SchurArgs sa,
+__global__ __launch_bounds__(BLOCK, NG <= 4 ? 3 : 1) void k_schur_pass1(const Model* __restrict__ Mp, GroupArgs a, SchurArgs sa,
                                                        double* __restrict__ rowpartial, unsigned long long* __restrict__ not_spd) {
     extern __shared__ double ldsall[];  // [nb*(NG+2)][BLOCK] columns + reduction scratch
     __shared__ double sh[BLOCK / 64];
