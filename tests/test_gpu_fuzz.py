@@ -84,3 +84,54 @@ def test_random_configuration_matches_oracle(built, seed):
     ochisq, _ = orc.chisq(1, meta["nmaps"], ddata.nump)
     # (nb == nc: the fit is exact and chi^2 is rounding noise ~1e-15 and below, hence the absolute floor)
     assert abs(s / meta["nbands"] / ddata.nump - ochisq) <= 1e-8 * abs(ochisq) * max(1.0, amax / 1e3) ** 2 + 1e-10, cfg
+
+
+def _packed(eng, comps, group, flag, nbands):
+    planes = {L.FLAG_T: [0], L.FLAG_QU: [1, 2]}[flag]
+    parts, rows = [], []
+    for l, c in enumerate(comps):
+        if c.cg_group != group or not c.sample_amplitude:
+            continue
+        if c.type in ("template", "monopole", "hi_fit"):
+            ta = eng.get_template_amplitudes(l)
+            rows.extend(ta[planes[0], j] for j in range(nbands) if c.corr[j])
+        else:
+            parts.append(eng.get_amplitude(l)[planes].ravel())
+    return np.concatenate(parts + [np.asarray(rows, dtype=np.float64)])
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_template_group_direct_solve(built, seed):
+    """Schur-complement solve of groups with global-amplitude members over random models: the answer satisfies the
+    reference's linear system (through the oracle's compute_Ax / compute_rhs / compute_sample_vector)."""
+    from test_oracle_templates_cpu import add_globals
+    rng = np.random.default_rng(5000 + seed)
+    nb = int(rng.choice([4, 5, 6, 8]))
+    pool = ["cmb", "synch", "dust", "ff"]
+    comps_l = ["synch"] + list(rng.permutation([p for p in pool if p != "synch"])[: int(rng.integers(0, min(3, nb - 3) + 1))])
+    pol = bool(rng.integers(0, 2))
+    which = ("template",) if pol else tuple(rng.permutation(["monopole", "hi_fit"])[: int(rng.integers(1, 3))])
+    group, flag = (2, L.FLAG_QU) if pol else (1, L.FLAG_T)
+    fit = sorted(rng.choice(nb, size=int(rng.integers(1, 3)), replace=False).tolist())
+    ml_mode = str(rng.choice(["sample", "optimize"]))
+
+    def tweak(dpar, ddata, bands, comps):
+        add_globals(dpar, ddata, bands, comps, which, group, fit_bands=fit)
+    case = make_case(None, nside=int(rng.choice([2, 4])), nbands=nb, comps=comps_l, nmaps=3, tweak=tweak, start="truth")
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+    b = orc.compute_rhs(group, flag)
+    if ml_mode == "sample":
+        b = b + orc.compute_sample_vector(group, flag, orc.draw_eta(flag, 8, 9))
+    it, bad = eng.amp_sample(group, flag, ml_mode, 8, 9, solver="direct")
+    assert bad == 0 and it <= 0
+    x = _packed(eng, comps, group, flag, nb)
+    assert x.size == eng.group_size(group, flag) and np.isfinite(x).all()
+    Ax = orc.compute_Ax(group, flag, x)
+    # row-wise: relative to the row's right-hand side, with a floor tied to the largest one (a template's entries have
+    # both signs, so A|x| is no bound on the size of the terms that cancel in a row)
+    # (a fitted monopole is nearly degenerate with the mean of the diffuse components: the Schur system is then
+    # conditioned ~1e8-1e10 and the residual carries that factor -- inside the pivot threshold, so it is solved)
+    loose = 1e3 if "monopole" in which else 1.0
+    tol = loose * (1e-7 * np.abs(b) + 1e-9 * np.abs(b).max())
+    assert np.all(np.abs(Ax - b) <= tol), (seed, which, fit, comps_l, it, (np.abs(Ax - b) / tol).max())
