@@ -47,7 +47,7 @@ __device__ __forceinline__ double chain_lnl(const ChainCtx& C, double th, int ln
     case CH_POW: s0 = th; break;
     case CH_MBB_BETA: s0 = th + 1.0; break;
     case CH_MBB_T: s0 = H_PLANCK / (K_B * th); s1 = exp(s0 * c.nu_ref) - 1.0; break;
-    case CH_LOGN_NUP: s0 = th * 1e9; s1 = C.other; break;
+    case CH_LOGN_NUP: s0 = log_pos(th); s1 = C.other; break;
     case CH_LOGN_W: s1 = th; break;
     default: pr = sed_prep(c, first ? th : C.other, first ? C.other : th); break;
     }
@@ -58,7 +58,7 @@ __device__ __forceinline__ double chain_lnl(const ChainCtx& C, double th, int ln
         case CH_POW: s = exp(s0 * c.lnr[j]); break;
         case CH_MBB_BETA: s = C.F(j) * exp(s0 * c.lnr[j]); break;
         case CH_MBB_T: s = s1 / (exp(s0 * M.band[j].nu_c) - 1.0) * C.F(j); break;
-        case CH_LOGN_NUP: { const double l = log_pos(M.band[j].nu_c / s0) / s1; s = exp(-0.5 * (l * l)) * c.cst[j]; break; }
+        case CH_LOGN_NUP: { const double l = (c.lnu9[j] - s0) / s1; s = exp(-0.5 * (l * l)) * c.cst[j]; break; }
         case CH_LOGN_W: { const double l = C.F(j) / s1; s = exp(-0.5 * (l * l)) * c.cst[j]; break; }
         default: s = (c.type == DANGX_HIFIT) ? 0.0 : sed_eval(M, c, j, pr); break;
         }
@@ -299,7 +299,10 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
     } else if (a.mode == CH_MBB_T) {
         for (int j = 0; j < nb; ++j) C.F(j) = exp((sample0 + 1.0) * tab[(TROWS * a.comp) * nb + j]);
     } else if (a.mode == CH_LOGN_W) {
-        for (int j = 0; j < nb; ++j) C.F(j) = log_pos(M.band[j].nu_c / (sample0 * 1e9));
+        {
+            const double lp = log_pos(sample0);
+            for (int j = 0; j < nb; ++j) C.F(j) = c.lnu9[j] - lp;
+        }
     }
     const int lnl_type = (MODE == CH_GENERIC) ? c.lnl_type[a.nind] : DANGX_LNL_CHISQ;
     const unsigned long long gpix = (unsigned long long)(M.pix0 + i);

@@ -25,7 +25,7 @@ struct RegChain {
         if (MODE == CH_POW) s0 = th;
         else if (MODE == CH_MBB_BETA) s0 = th + 1.0;
         else if (MODE == CH_MBB_T) { s0 = H_PLANCK / (K_B * th); s1 = exp(s0 * c.nu_ref) - 1.0; }
-        else if (MODE == CH_LOGN_NUP) { s0 = th * 1e9; s1 = other; }
+        else if (MODE == CH_LOGN_NUP) { s0 = log_pos(th); s1 = other; }  // log(nu/(nu_p*1e9)) = lnu9 - log(nu_p)
         else s1 = th;  // CH_LOGN_W
         acc0 = 0.0; acc1 = 0.0;
         // bands in tiles of TT: TT independent exp chains interleave, then accumulate in band order
@@ -37,7 +37,7 @@ struct RegChain {
             for (int t = 0; t < TT; ++t) {
                 const int j = j0 + t;
                 if (MODE == CH_LOGN_NUP) {
-                    const double l = log_pos(M.band[j].nu_c / s0) / s1;
+                    const double l = (c.lnu9[j] - s0) / s1;
                     s[t] = exp(-0.5 * (l * l)) * c.cst[j];
                 } else if (MODE == CH_LOGN_W) {
                     const double l = F[j] / s1;
@@ -90,7 +90,7 @@ __device__ __forceinline__ void subtract_other(const Model& M, const Comp& c2, i
     case DANGX_LOGNORMAL:
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const double l2 = log_pos(M.band[j].nu_c / pr.p0) / pr.p1;
+            const double l2 = (c2.lnu9[j] - pr.p2) / pr.p1;
             Dk[j] -= amp2 * (exp(-0.5 * (l2 * l2)) * c2.cst[j]);
         }
         break;
@@ -126,7 +126,7 @@ __device__ __forceinline__ void subtract_other_pair(const Model& M, const Comp& 
     case DANGX_LOGNORMAL:
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const double l2 = log_pos(M.band[j].nu_c / pr.p0) / pr.p1;
+            const double l2 = (c2.lnu9[j] - pr.p2) / pr.p1;
             const double s = exp(-0.5 * (l2 * l2)) * c2.cst[j];
             Da[j] -= ampa * s; Db[j] -= ampb * s;
         }
@@ -215,8 +215,11 @@ __device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, co
 #pragma unroll
         for (int j = 0; j < NB; ++j) R.F[j] = exp((sample0 + 1.0) * c.lnr[j]);
     } else if (MODE == CH_LOGN_W) {
+        {
+            const double lp = log_pos(sample0);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) R.F[j] = log_pos(M.band[j].nu_c / (sample0 * 1e9));
+            for (int j = 0; j < NB; ++j) R.F[j] = c.lnu9[j] - lp;
+        }
     }
     const double other = first ? sample1 : sample0;  // the index that is not sampled
     // --- chain (gaussian / uniform prior inline; jeffreys falls back to the LDS form on the host side)

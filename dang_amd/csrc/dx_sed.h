@@ -60,6 +60,7 @@ __device__ __forceinline__ Prep sed_prep(const Comp& c, double th0, double th1) 
     case DANGX_LOGNORMAL:  // :978-984
         p.p0 = th0 * 1e9;
         p.p1 = th1;
+        p.p2 = log_pos(th0);  // log(nu/(nu_p*1e9)) = log(nu/1e9) - log(nu_p): one log per pixel, the band part tabulated (lnu9)
         break;
     case DANGX_TCMB:  // :830-834
     case DANGX_HIFIT:  // :865-869
@@ -134,7 +135,7 @@ __device__ __forceinline__ double sed_eval(const Model& M, const Comp& c, int j,
     case DANGX_FREEFREE:  // :1026-1027
         return ff_gaunt(c.lnu9[j], p.p0) / p.p1 * c.cst[j];
     case DANGX_LOGNORMAL: {  // :988
-        const double l = log_pos(M.band[j].nu_c / p.p0) / p.p1;
+        const double l = (c.lnu9[j] - p.p2) / p.p1;
         return exp(-0.5 * (l * l)) * c.cst[j];
     }
     case DANGX_TCMB:  // :836-846
@@ -178,7 +179,7 @@ __device__ __forceinline__ double sed_eval_tab(int type, const double* tab, int 
     case DANGX_MBB: return p.p2 / (exp(p.p1 * tab[(TROWS * ncomp) * nb + j]) - 1.0) * exp(p.p0 * tc[0]);
     case DANGX_FREEFREE: return ff_gaunt(tc[2 * nb], p.p0) / p.p1 * tc[nb];
     case DANGX_LOGNORMAL: {
-        const double l2 = log_pos(tab[(TROWS * ncomp) * nb + j] / p.p0) / p.p1;
+        const double l2 = (tab[(TROWS * l + 2) * nb + j] - p.p2) / p.p1;
         return exp(-0.5 * (l2 * l2)) * tc[nb];
     }
     case DANGX_CMB: return tc[nb];
