@@ -72,7 +72,7 @@ def log(msg):
 _T0 = time.time()
 
 
-def cpu_baseline(config_name, nsample, nside_sample=64):
+def cpu_baseline(config_name, nsample, nside_sample=128):
     """Time the CPU oracle ("port" of the reference algorithm: global CG with per-iteration SED
     re-evaluation + per-pixel Metropolis) on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
