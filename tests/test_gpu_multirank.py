@@ -69,6 +69,29 @@ def _run(case, which, group, flag, solver, ml_mode, rank=0, world=1):
     return it, amps, tas
 
 
+def _fullsky_job(rank=0, world=1):
+    """Full-sky index chain, band-gain fit and the write_data means on a sharded sky: every sky-wide sum is all-reduced
+    by the host code (dang_amd/api.py), so each rank walks the same chain."""
+    import dang_amd as da
+    from util import make_case
+
+    def tweak(dpar, ddata, bands, comps):
+        for c in comps:
+            c.index_mode = [1] * c.nindices
+            c.step_size = [0.2 * g[1] for g in c.gauss_prior]
+    case = make_case("C2", nside=4, start="truth", tweak=tweak)
+    dpar, ddata, bands, comps, meta = case
+    ddata, comps, p0, n = _shard(case, rank, world)
+    ddata.gain = np.ones(meta["nbands"]); ddata.offset = np.zeros(meta["nbands"])
+    ddata.nump = case[1].nump
+    eng = da.initialize(bands, comps, ddata, npix_global=meta["npix_global"], pix0=p0, device=0)
+    acc = da.sample_index_mh_fullsky(dpar, ddata, 1, 0, 1, da.stream_id(2, 1, 1, 0, 1))
+    beta = eng.peek_indices(1, 1, 0)[0]
+    gain = da.fit_band_gain(dpar, ddata, 2, it=3)
+    means = da.index_means(ddata, 1)
+    return np.array([acc, beta, gain] + [means[k] for k in sorted(means)])
+
+
 def _worker(rank, world, port, out):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
@@ -87,8 +110,9 @@ def _worker(rank, world, port, out):
                 res["amp%d_%d" % (n, l)] = g.numpy()
         for l, t in enumerate(tas):
             res["ta%d_%d_r%d" % (n, l, rank)] = t
+    res["fullsky_r%d" % rank] = _fullsky_job(rank, world)
     gathered = [None] * world
-    td.all_gather_object(gathered, {k: v for k, v in res.items() if k.startswith("ta")})
+    td.all_gather_object(gathered, {k: v for k, v in res.items() if k.startswith("ta") or k.startswith("fullsky")})
     if rank == 0:
         for g in gathered:
             res.update(g)
@@ -112,3 +136,7 @@ def test_two_ranks_solve_the_same_coupled_systems_as_one(built, tmp_path):
             for r in range(2):  # replicated on every rank
                 assert np.abs(got["ta%d_%d_r%d" % (n, l, r)] - t).max() <= tol * max(np.abs(t).max(), 1e-300), (n, l, r)
             assert np.array_equal(got["ta%d_%d_r0" % (n, l)], got["ta%d_%d_r1" % (n, l)])
+    one = _fullsky_job()
+    assert np.array_equal(got["fullsky_r0"], got["fullsky_r1"])          # every rank walks the same chain
+    assert got["fullsky_r0"][0] == one[0]                                # same accept count
+    assert np.abs(got["fullsky_r0"][1:] - one[1:]).max() <= 1e-10 * np.abs(one[1:]).max()
