@@ -15,6 +15,12 @@ __device__ __forceinline__ double remove_others(const Model& M, const GroupArgs&
         load_theta(M, c, i, k, t0, t1);
         d = d - comp_signal(M, c, i, k, j, amp, sed_prep(c, t0, t1));
     }
+    // "Still subtract templates which exist but may not be fit here" (:445-460): EVERY template / monopole of the
+    // model, member of this group or not, is removed on its unfitted bands -- for a non-member a second time
+    for (int w = 0; w < a.nuc; ++w) {
+        const Comp& c = M.comp[a.uc[w]];
+        if (!((c.corr_mask >> j) & 1)) d = d - comp_signal(M, c, i, k, j, 0.0, Prep{0, 0, 0});
+    }
     return d;
 }
 __device__ __forceinline__ double rhs_data(const Model& M, const GroupArgs& a, int i, int k, int j) {
@@ -517,11 +523,7 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_mixed(const Model* __restrict__ M
             if (q.k == 1) d = d / M.gain[j];  // :371
             rms = M.rms[((long long)j * M.nmaps + (q.k - 1)) * npix + q.i];
             if (!q.msk) {
-                d = remove_others(M, a, q.i, q.k, j, d);  // :427-443
-                for (int w = 0; w < a.nuc; ++w) {         // :445-460
-                    const Comp& c = M.comp[a.uc[w]];
-                    if (!((c.corr_mask >> j) & 1)) d = d - comp_signal(M, c, q.i, q.k, j, 0.0, Prep{0, 0, 0});
-                }
+                d = remove_others(M, a, q.i, q.k, j, d);  // :427-460
             }
             if (!zero_mask) {
 #pragma unroll
@@ -644,10 +646,6 @@ __device__ __forceinline__ void mixed_normal_eq(const Model& M, const GroupArgs&
         double d = M.sig[((long long)j * M.nmaps + (q.k - 1)) * M.npix + q.i];
         if (q.k == 1) d = d / M.gain[j];
         d = remove_others(M, a, q.i, q.k, j, d);
-        for (int w = 0; w < a.nuc; ++w) {
-            const Comp& c = M.comp[a.uc[w]];
-            if (!((c.corr_mask >> j) & 1)) d = d - comp_signal(M, c, q.i, q.k, j, 0.0, Prep{0, 0, 0});
-        }
         if (SUBTRACT_MEMBERS)
             for (int t = 0; t < a.nt; ++t) {
                 const Comp& c = M.comp[a.tc[t]];

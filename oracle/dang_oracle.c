@@ -661,6 +661,11 @@ int dgo_amp_sample_direct(dgo_ctx *ctx, int group, int flag, int ml_mode, int fl
             for (int j = 0; j < nb; ++j) {
                 double d = (k == 1) ? ctx->sig[IDX3(ctx, j, k, i)] / ctx->gain[j] : ctx->sig[IDX3(ctx, j, k, i)];
                 for (int o = 0; o < no; ++o) d = d - dgo_eval_signal(ctx, oc[o], j, i, k, NULL);
+                for (int l = 0; l < ctx->ncomp; ++l) { /* :445-460: templates / monopoles on their unfitted bands, again */
+                    const dgo_comp *ct = &ctx->comps[l];
+                    if ((ct->type == DGO_TEMPLATE || ct->type == DGO_MONOPOLE) && !ct->corr[j])
+                        d = d - dgo_eval_signal(ctx, l, j, i, k, NULL);
+                }
                 for (int a = 0; a < ng; ++a) mrow[a] = dgo_eval_sed(ctx, gc[a], j, i, k, NULL);
                 const double is = 1.0 / ctx->rms[IDX3(ctx, j, k, i)];
                 const double inv = is * is;

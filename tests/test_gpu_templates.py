@@ -277,3 +277,27 @@ def test_gibbs_iterations_with_a_fitted_template(built):
     assert np.all(ta[1, :3] == 0.0)                          # bands 0-2 are not fitted
     # 3072 pixels x 2 planes of unit-variance template against ~1 uK noise: sigma(amplitude) ~ 0.01-0.05
     assert np.abs(ta[1, 3:] - truth[1, 3:]).max() < 0.3, (ta[1], truth[1])
+
+
+def test_templates_are_removed_on_their_unfitted_bands_in_every_group(built):
+    """compute_rhs subtracts every template / monopole on the bands it is NOT fitted at -- "Still subtract templates
+    which exist but may not be fit here", src/dang_cg_mod.f90:445-460 -- in every CG group; a template that is not a
+    member of the group (already removed as an "other" component, :427-443) is thereby removed a second time there.
+    Visible only when such a band carries an amplitude (e.g. read from file)."""
+    def tweak(dpar, ddata, bands, comps):
+        add_globals(dpar, ddata, bands, comps, ("template",), 6)     # not a member of group 2
+        comps[-1].template_amplitudes = comps[-1].truth_ta.copy()
+        comps[-1].template_amplitudes[1:, 0] = 7.5                    # an amplitude on the UNFITTED band 0
+    case = make_case("C2", nside=4, start="truth", tweak=tweak)
+    eng, orc = pair(case)
+    assert relmax(eng.compute_rhs(2, L.FLAG_QU), orc.compute_rhs(2, L.FLAG_QU)) <= 1e-12
+    eng.amp_sample(2, L.FLAG_QU, "optimize", 3, 4)
+    orc.amp_sample_direct(2, L.FLAG_QU, "optimize", 3, 4, "reference")
+    eng2, orc2 = pair(case)
+    i1, _ = eng2.amp_sample(2, L.FLAG_QU, "optimize", 3, 4, solver="cg", i_max=400, converge=1e-12)
+    i2 = orc2.amp_sample_cg(2, L.FLAG_QU, "optimize", 3, 4, i_max=400, converge=1e-12)
+    assert i1 < 400 and i2 < 400
+    for l in (3, 4, 5):
+        assert relmax(eng.get_amplitude(l), orc.amplitude(l)) <= 1e-11       # direct: GPU == oracle
+        assert relmax(orc.amplitude(l), orc2.amplitude(l)) <= 1e-6           # direct == the reference's CG fixed point
+        assert relmax(eng2.get_amplitude(l), orc2.amplitude(l)) <= 1e-6      # device CG == oracle CG
