@@ -6,7 +6,7 @@ from dang_amd import _lib as L
 from dang_amd.api import DangComps
 
 import oracle_ffi as O
-from util import make_case
+from util import make_case, relmax
 
 
 def add_globals(dpar, ddata, bands, comps, which=("monopole", "hi_fit"), group=1, skip_band0=False, fit_bands=None):
@@ -129,3 +129,47 @@ def test_monopole_sets_the_band_offsets_in_update_sky_model():
     # residual = (sig - offset)/gain - sky: the monopole is absorbed by the offset, not by the sky model
     chisq, _ = o.chisq(1, 1, float((ddata.masks[0] != 0).sum()), sky)   # plane 1 only
     assert 0.5 < chisq < 1.5
+
+
+def test_direct_block_solve_equals_the_converged_cg_over_random_models():
+    """The direct per-pixel block solve (what the GPU runs) must be the fixed point of the reference's cg_search for
+    every way the data are prepared in compute_rhs (src/dang_cg_mod.f90:367-460): gain on T without offset removal,
+    non-member components of every type (diffuse, T_cmb, template / monopole / hi_fit with amplitudes on fitted AND
+    unfitted bands -- the latter removed twice), masked pixels.  24 seeded models, optimize mode, CG run to 1e-16."""
+    from dang_amd.api import DangComps
+    for seed in range(24):
+        rng = np.random.default_rng(seed)
+        nb = int(rng.choice([4, 5, 6]))
+        comps_l = ["synch"] + list(rng.permutation(["cmb", "dust", "ff"])[: int(rng.integers(0, min(3, nb - 2)))])
+        extra = list(rng.permutation(["template", "monopole", "hi_fit", "tcmb", "none"])[:2])
+
+        def tweak(dpar, ddata, bands, comps):
+            npix = ddata.sig_map.shape[-1]
+            ddata.gain = rng.uniform(0.8, 1.2, nb)
+            ddata.offset = rng.normal(0, 3, nb)
+            for e in extra:
+                if e in ("template", "monopole", "hi_fit"):
+                    add_globals(dpar, ddata, bands, comps, (e,), 7, fit_bands=sorted(rng.choice(nb, 2, replace=False).tolist()))
+                    ta = rng.normal(0, 2, comps[-1].truth_ta.shape)
+                    if e == "hi_fit":
+                        ta *= 1e-6
+                    if e != "template":
+                        ta[1:] = 0
+                    comps[-1].template_amplitudes = ta
+                elif e == "tcmb":
+                    comps.append(DangComps(label="tcmb", type="T_cmb", nu_ref=100.0, cg_group=9, sample_amplitude=False,
+                                           nindices=1, ind_label=["T"], sample_index=[False], index_mode=[1],
+                                           lnl_type=["chisq"], prior_type=["uniform"], gauss_prior=[[0.5, 1.0]],
+                                           uni_prior=[[0.0, 10.0]], step_size=[0.0], pol_flag=[[L.FLAG_T]],
+                                           amplitude=np.zeros((3, npix)), indices=np.full((1, 3, npix), 0.5)))
+            ddata.masks[0, rng.integers(0, npix, 3)] = 0.0
+        case = make_case(None, nside=2, nbands=nb, comps=comps_l, nmaps=3, tweak=tweak, start="truth")
+        dpar, ddata, bands, comps, meta = case
+        for group, flag in ((1, L.FLAG_T), (2, L.FLAG_QU)):
+            o1, o2 = O.Oracle(bands, comps, ddata), O.Oracle(bands, comps, ddata)
+            o1.amp_sample_direct(group, flag, "optimize", 3, 4, "reference")
+            it = o2.amp_sample_cg(group, flag, "optimize", 3, 4, i_max=3000, converge=1e-16)
+            assert it < 3000, (seed, group)
+            for l, c in enumerate(comps):
+                if c.cg_group == group and c.type in ("power-law", "mbb", "freefree", "cmb"):
+                    assert relmax(o1.amplitude(l), o2.amplitude(l)) <= 1e-7, (seed, group, l, comps_l, extra)
