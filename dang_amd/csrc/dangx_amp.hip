@@ -1,34 +1,8 @@
-// dangx_amp.hip -- amplitude-phase kernels (direct block solve + the reference's CG building blocks).
-#include "dx_host.h"
+// dangx_amp.hip -- amplitude-phase kernels for groups of diffuse components (direct block solve + the
+// reference's CG building blocks).  Groups with global-amplitude members: dangx_mixed.hip.
+#include "dx_ampdata.h"
 
 namespace {
-
-// data(i,k,j) of compute_rhs (src/dang_cg_mod.f90:367-378, 427-443): the band map with every
-// component that is not solved for removed.  a.oc lists only the components whose amplitude
-// plane may be non-zero (the host tracks all-zero planes; subtracting 0*sed is skipped, which
-// differs from the reference only if that sed is not finite).
-__device__ __forceinline__ double remove_others(const Model& M, const GroupArgs& a, int i, int k, int j, double d) {
-    for (int o = 0; o < a.no; ++o) {
-        const Comp& c = M.comp[a.oc[o]];
-        const double amp = c.amp[(long long)(k - 1) * M.npix + i];
-        double t0, t1;
-        load_theta(M, c, i, k, t0, t1);
-        d = d - comp_signal(M, c, i, k, j, amp, sed_prep(c, t0, t1));
-    }
-    // "Still subtract templates which exist but may not be fit here" (:445-460): EVERY template / monopole of the
-    // model, member of this group or not, is removed on its unfitted bands -- for a non-member a second time
-    for (int w = 0; w < a.nuc; ++w) {
-        const Comp& c = M.comp[a.uc[w]];
-        if (!((c.corr_mask >> j) & 1)) d = d - comp_signal(M, c, i, k, j, 0.0, Prep{0, 0, 0});
-    }
-    return d;
-}
-__device__ __forceinline__ double rhs_data(const Model& M, const GroupArgs& a, int i, int k, int j) {
-    double d = M.sig[((long long)j * M.nmaps + (k - 1)) * M.npix + i];
-    if (k == 1) d = d / M.gain[j];
-    return remove_others(M, a, i, k, j, d);
-}
-
 // ---------------------------------------------------------------------------
 // Amplitude phase, direct solve.  Replaces compute_rhs + cg_search (compute_Ax,
 // compute_sample_vector) + unpack_amplitudes (src/dang_cg_mod.f90:166-171) for
@@ -376,500 +350,6 @@ struct LaunchSv {
 };
 
 
-// ---------------------------------------------------------------------------
-// CG building blocks for groups that contain global-amplitude components (template / monopole / hi_fit;
-// src/dang_cg_mod.f90:522-587, 717-768, 833-893, 1045-1096).  A global component contributes one row per fitted
-// band: its entries of T^t(...) are sums over pixels, formed here as block partials `rowpartial[row][block]`
-// (second stage: k_reduce_rows_final).  Restrictions checked on the host: global members follow the diffuse
-// ones in the group; hi_fit / monopole only under flag T (they read plane 1 whatever the flag in the reference).
-__device__ __forceinline__ int gl_nplanes(const Comp& c, int flag) { return (c.type == DANGX_TEMPLATE && (flag & DANGX_FLAG_QU)) ? 2 : 1; }
-
-// every thread of the block calls this; thread 0 writes the block's sum
-__device__ __forceinline__ void block_row_sum(double v, int row, double* rowpartial, double* sh) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int w = 0; w < BLOCK / 64; ++w) t += sh[w];
-        rowpartial[(long long)row * gridDim.x + blockIdx.x] = t;
-    }
-    __syncthreads();
-}
-
-struct UnitId { bool in; int p, i, k; bool msk; };
-__device__ __forceinline__ UnitId unit_of(const Model& M, int flag) {
-    UnitId q;
-    const long long u = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    q.in = u < (long long)flag_nplanes(flag) * M.npix;
-    q.p = q.in ? (int)(u / M.npix) : 0;
-    q.i = q.in ? (int)(u - (long long)q.p * M.npix) : 0;
-    q.k = flag_map(flag, q.p);
-    q.msk = !q.in || is_masked(M.mask[q.i]);
-    return q;
-}
-
-template <int NG>
-__global__ __launch_bounds__(BLOCK) void k_Ax_mixed(const Model* __restrict__ Mp, GroupArgs a, const double* __restrict__ x,
-                                                    double* __restrict__ res, double* __restrict__ rowpartial) {
-    __shared__ double sh[BLOCK / 64];
-    constexpr int NA = NG > 0 ? NG : 1;
-    const Model& M = *Mp;
-    const int npix = M.npix;
-    const long long SN = (long long)flag_nplanes(a.flag) * npix;
-    const long long u = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    const UnitId q = unit_of(M, a.flag);
-    const double* xg = x + (long long)NG * SN;
-    double acc[NA], xv[NA], mrow[NA];
-    Prep pr[NA], prt[MAXT];
-#pragma unroll
-    for (int g = 0; g < NA; ++g) { acc[g] = 0.0; xv[g] = 0.0; pr[g] = Prep{0, 0, 0}; }
-    if (!q.msk) {
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            xv[g] = x[(long long)g * SN + u];
-            double t0, t1;
-            load_theta(M, M.comp[a.gc[g]], q.i, q.k, t0, t1);
-            pr[g] = sed_prep(M.comp[a.gc[g]], t0, t1);
-        }
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t)
-            if (t < a.nt) {
-                double t0, t1;
-                load_theta(M, M.comp[a.tc[t]], q.i, q.k, t0, t1);
-                prt[t] = sed_prep(M.comp[a.tc[t]], t0, t1);
-            }
-    }
-    for (int j = 0; j < M.nbands; ++j) {
-        double temp1 = 0.0, st[MAXT];
-        if (!q.msk) {
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                mrow[g] = sed_eval(M, M.comp[a.gc[g]], j, pr[g]);
-                temp1 = temp1 + xv[g] * mrow[g];  // :697-704
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
-            st[t] = 0.0;
-            if (t < a.nt) {
-                const Comp& c = M.comp[a.tc[t]];
-                if (((c.corr_mask >> j) & 1) && !q.msk && q.p < gl_nplanes(c, a.flag)) {
-                    const int lt = __popc(c.corr_mask & ((1 << j) - 1));
-                    st[t] = comp_sed(M, c, q.i, q.k, j, prt[t]);
-                    temp1 = temp1 + xg[a.trow[t] + lt] * st[t];  // :723, :737, :752-759
-                }
-            }
-        }
-        if (!q.msk) {
-            const double rms = M.rms[((long long)j * M.nmaps + (q.k - 1)) * npix + q.i];
-            temp1 = temp1 / (rms * rms);  // :775-791
-#pragma unroll
-            for (int g = 0; g < NG; ++g) acc[g] = acc[g] + temp1 * mrow[g];  // :813-820
-        }
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t)
-            if (t < a.nt) {
-                const Comp& c = M.comp[a.tc[t]];
-                if ((c.corr_mask >> j) & 1) {  // uniform: every thread joins the row sum
-                    const int lt = __popc(c.corr_mask & ((1 << j) - 1));
-                    const bool on = !q.msk && q.p < gl_nplanes(c, a.flag);
-                    // :857 the monopole row sums temp1(i) WITHOUT its template factor
-                    const double v = on ? temp1 * ((c.type == DANGX_MONOPOLE) ? 1.0 : st[t]) : 0.0;
-                    block_row_sum(v, a.trow[t] + lt, rowpartial, sh);
-                }
-            }
-    }
-    if (q.in) {
-#pragma unroll
-        for (int g = 0; g < NG; ++g) res[(long long)g * SN + u] = acc[g];
-    }
-}
-
-template <int NG>
-__global__ __launch_bounds__(BLOCK) void k_rhs_mixed(const Model* __restrict__ Mp, GroupArgs a, double* __restrict__ b,
-                                                     double* __restrict__ rowpartial) {
-    __shared__ double sh[BLOCK / 64];
-    constexpr int NA = NG > 0 ? NG : 1;
-    const Model& M = *Mp;
-    const int npix = M.npix;
-    const long long SN = (long long)flag_nplanes(a.flag) * npix;
-    const long long u = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    const UnitId q = unit_of(M, a.flag);
-    const bool zero_mask = !q.in || M.mask[q.i] == 0.0;  // :474 tests ==0 only for the diffuse rows
-    double acc[NA];
-    Prep pr[NA], prt[MAXT];
-#pragma unroll
-    for (int g = 0; g < NA; ++g) { acc[g] = 0.0; pr[g] = Prep{0, 0, 0}; }
-    if (q.in) {
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            double t0, t1;
-            load_theta(M, M.comp[a.gc[g]], q.i, q.k, t0, t1);
-            pr[g] = sed_prep(M.comp[a.gc[g]], t0, t1);
-        }
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t)
-            if (t < a.nt) {
-                double t0, t1;
-                load_theta(M, M.comp[a.tc[t]], q.i, q.k, t0, t1);
-                prt[t] = sed_prep(M.comp[a.tc[t]], t0, t1);
-            }
-    }
-    for (int j = 0; j < M.nbands; ++j) {
-        double d = 0.0, rms = 1.0;
-        if (q.in) {
-            d = M.sig[((long long)j * M.nmaps + (q.k - 1)) * npix + q.i];
-            if (q.k == 1) d = d / M.gain[j];  // :371
-            rms = M.rms[((long long)j * M.nmaps + (q.k - 1)) * npix + q.i];
-            if (!q.msk) {
-                d = remove_others(M, a, q.i, q.k, j, d);  // :427-460
-            }
-            if (!zero_mask) {
-#pragma unroll
-                for (int g = 0; g < NG; ++g) acc[g] = acc[g] + (d * sed_eval(M, M.comp[a.gc[g]], j, pr[g])) / (rms * rms);  // :489-508
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t)
-            if (t < a.nt) {
-                const Comp& c = M.comp[a.tc[t]];
-                if ((c.corr_mask >> j) & 1) {
-                    const int lt = __popc(c.corr_mask & ((1 << j) - 1));
-                    const bool on = !q.msk && q.p < gl_nplanes(c, a.flag);
-                    const double v = on ? d / (rms * rms) * comp_sed(M, c, q.i, q.k, j, prt[t]) : 0.0;  // :531, :550, :571-578
-                    block_row_sum(v, a.trow[t] + lt, rowpartial, sh);
-                }
-            }
-    }
-    if (q.in) {
-#pragma unroll
-        for (int g = 0; g < NG; ++g) b[(long long)g * SN + u] = acc[g];
-    }
-}
-
-template <int NG>
-__global__ __launch_bounds__(BLOCK) void k_sv_mixed(const Model* __restrict__ Mp, GroupArgs a, const double* __restrict__ eta,
-                                                    double* __restrict__ res, double* __restrict__ rowpartial) {
-    __shared__ double sh[BLOCK / 64];
-    const Model& M = *Mp;
-    const int npix = M.npix;
-    const long long SN = (long long)flag_nplanes(a.flag) * npix;
-    const long long u = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    const UnitId q = unit_of(M, a.flag);
-    double acc = 0.0;
-    Prep prl = {0, 0, 0}, prt[MAXT];
-    double e = 0.0;
-    if (!q.msk) {
-        e = eta[u];
-        if (NG > 0) {
-            double t0, t1;
-            load_theta(M, M.comp[a.gc[NG > 0 ? NG - 1 : 0]], q.i, q.k, t0, t1);
-            prl = sed_prep(M.comp[a.gc[NG > 0 ? NG - 1 : 0]], t0, t1);
-        }
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t)
-            if (t < a.nt) {
-                double t0, t1;
-                load_theta(M, M.comp[a.tc[t]], q.i, q.k, t0, t1);
-                prt[t] = sed_prep(M.comp[a.tc[t]], t0, t1);
-            }
-    }
-    int lrun = 0;  // ONE running row counter over bands and components (:970, :1057, :1071, :1094)
-    for (int j = 0; j < M.nbands; ++j) {
-        double temp1 = 0.0;
-        if (!q.msk) {
-            temp1 = e / M.rms[((long long)j * M.nmaps + (q.k - 1)) * npix + q.i];  // :1008-1015
-            if (NG > 0) acc = acc + temp1 * sed_eval(M, M.comp[a.gc[NG > 0 ? NG - 1 : 0]], j, prl);  // :1033-1040 (quirk 2)
-        }
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t)
-            if (t < a.nt) {
-                const Comp& c = M.comp[a.tc[t]];
-                if ((c.corr_mask >> j) & 1) {
-                    const bool on = !q.msk && q.p < gl_nplanes(c, a.flag);
-                    const double v = on ? temp1 * ((c.type == DANGX_MONOPOLE) ? 1.0 : comp_sed(M, c, q.i, q.k, j, prt[t])) : 0.0;
-                    if (lrun < a.nglob) block_row_sum(v, lrun, rowpartial, sh);  // (the reference would run out of bounds)
-                    ++lrun;
-                }
-            }
-    }
-    if (q.in) {
-        if (NG > 0) res[u] = acc;
-#pragma unroll
-        for (int g = 1; g < NG; ++g) res[(long long)g * SN + u] = 0.0;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Direct solve of a group with global-amplitude members (the MI355X counterpart of the reference's CG for the
-// coupled system).  With x = [x_u per unit | g global rows] the matrix of compute_Ax is
-//     [ D_u   B_u ] [x_u]   [b_u]        D_u = sum_j M_j M_j^t / s_j^2           (NG x NG, per unit)
-//     [ C_u^t G   ] [ g ] = [b_g]        B_u[:,r] = M_jr s_r / s_jr^2,  C_u[:,r] = M_jr w_r / s_jr^2
-// with s_r the global member's SED at the row's band and w_r its row weight (1 for a monopole, :857).
-// Pass 1 eliminates every unit: with D_u = L L^t, Q_j = L^-1 (M_j/s_j^2) and yh = L^-1 (b_u + f_u) it accumulates
-//     S[r,r'] = sum_u ( [j_r = j_r'] w_r s_r'/s_j^2 - w_r s_r' Q_jr . Q_jr' ),   t[r] = sum_u ( d_jr s_r/s_jr^2 - w_r Q_jr . yh )
-// (and the fluctuation sums of the global rows) as deterministic block partials; the host solves S g = t; pass 2 is
-// the per-unit block solve with the global members' new signal removed from the data.
-template <int NG>
-struct MixedUnit {
-    double A[NG > 0 ? NG * (NG + 1) / 2 : 1], bv[NG > 0 ? NG : 1];  // NG == 0: a group of global members only
-    bool ok;
-};
-
-// data prep of compute_rhs for groups with global members + per-unit normal equations.  When lds != nullptr the
-// per-band vectors W_j = M_j/s_j^2 (NG), d_j/s_j^2 and eta/s_j of the bands that carry a global row are parked
-// in LDS columns [(bslot[j]*(NG+2)+q)*BLOCK].
-template <int NG, bool SUBTRACT_MEMBERS>
-__device__ __forceinline__ void mixed_normal_eq(const Model& M, const GroupArgs& a, const UnitId& q, double* lds,
-                                                const signed char* bslot, MixedUnit<NG>& U) {
-    constexpr int NA = NG > 0 ? NG : 1;
-    Prep pr[NA];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        double t0, t1;
-        load_theta(M, M.comp[a.gc[g]], q.i, q.k, t0, t1);
-        pr[g] = sed_prep(M.comp[a.gc[g]], t0, t1);
-    }
-#pragma unroll
-    for (int e = 0; e < NG * (NG + 1) / 2; ++e) U.A[e] = 0.0;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) U.bv[g] = 0.0;
-    const bool sample = (a.ml_mode == DANGX_ML_SAMPLE);
-    double eta = 0.0, f0 = 0.0;
-    if (sample) {
-        double u1, u2;
-        uniform2(a.seed, a.stream, (unsigned long long)(M.pix0 + q.i), (uint32_t)q.k, u1, u2);
-        eta = rand_normal(0.0, 1.0, u1, u2);
-    }
-    for (int j = 0; j < M.nbands; ++j) {
-        double d = M.sig[((long long)j * M.nmaps + (q.k - 1)) * M.npix + q.i];
-        if (q.k == 1) d = d / M.gain[j];
-        d = remove_others(M, a, q.i, q.k, j, d);
-        if (SUBTRACT_MEMBERS)
-            for (int t = 0; t < a.nt; ++t) {
-                const Comp& c = M.comp[a.tc[t]];
-                if (((c.corr_mask >> j) & 1) && q.p < gl_nplanes(c, a.flag)) {
-                    double t0, t1;
-                    load_theta(M, c, q.i, q.k, t0, t1);
-                    d = d - comp_signal(M, c, q.i, q.k, j, 0.0, sed_prep(c, t0, t1));
-                }
-            }
-        const double is = 1.0 / M.rms[((long long)j * M.nmaps + (q.k - 1)) * M.npix + q.i];
-        const double inv = is * is;
-        double mrow[NA];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) mrow[g] = sed_eval(M, M.comp[a.gc[g]], j, pr[g]);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const double t2 = mrow[g] * inv;
-            U.bv[g] += d * t2;
-#pragma unroll
-            for (int h = 0; h <= g; ++h) U.A[g * (g + 1) / 2 + h] += t2 * mrow[h];
-            if (lds && bslot[j] >= 0) lds[(bslot[j] * (NG + 2) + g) * BLOCK] = t2;
-        }
-        if (NG > 0 && sample) f0 += (eta * is) * mrow[NG > 0 ? NG - 1 : 0];  // :1033-1040 (reference fluctuation term)
-        if (lds && bslot[j] >= 0) {
-            lds[(bslot[j] * (NG + 2) + NG) * BLOCK] = d * inv;
-            lds[(bslot[j] * (NG + 2) + NG + 1) * BLOCK] = eta * is;
-        }
-    }
-    if (NG > 0) U.bv[0] += f0;
-    U.ok = true;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-#pragma unroll
-        for (int h = 0; h <= g; ++h) {
-            double s = U.A[g * (g + 1) / 2 + h];
-#pragma unroll
-            for (int t = 0; t < h; ++t) s -= U.A[g * (g + 1) / 2 + t] * U.A[h * (h + 1) / 2 + t];
-            if (h == g) {
-                if (!(s > 0.0)) U.ok = false;
-                U.A[g * (g + 1) / 2 + g] = sqrt(s);
-            } else {
-                U.A[g * (g + 1) / 2 + h] = s / U.A[h * (h + 1) / 2 + h];
-            }
-        }
-    }
-}
-
-// forward substitution v <- L^-1 v (packed lower L)
-template <int NG>
-__device__ __forceinline__ void fwd_subst(const double* A, double* v) {
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        double s = v[g];
-#pragma unroll
-        for (int t = 0; t < g; ++t) s -= A[g * (g + 1) / 2 + t] * v[t];
-        v[g] = s / A[g * (g + 1) / 2 + g];
-    }
-}
-
-// rowpartial rows: [0, R*R): S[r][r'] ; [R*R, R*R+R): t[r] ; [R*R+R, R*R+2R): fluctuation sum of natural row r ;
-// [R*R+2R, R*R+3R): G[r][r], the diagonal before elimination (scale for the degeneracy test on the host)
-template <int NG>
-__global__ __launch_bounds__(BLOCK, NG <= 4 ? 3 : 1) void k_schur_pass1(const Model* __restrict__ Mp, GroupArgs a, SchurArgs sa,
-                                                       double* __restrict__ rowpartial, unsigned long long* __restrict__ not_spd) {
-    extern __shared__ double ldsall[];  // [nb*(NG+2)][BLOCK] columns + reduction scratch
-    __shared__ double sh[BLOCK / 64];
-    const Model& M = *Mp;
-    const UnitId q = unit_of(M, a.flag);
-    double* lds = ldsall + threadIdx.x;
-    const int R = sa.nrows;
-    double* srow = lds + (long long)sa.nslots * (NG + 2) * BLOCK;  // s_r of this unit, R columns
-    MixedUnit<NG> U;
-    double yh[NG > 0 ? NG : 1];
-    bool live = !q.msk;
-    if (live) {
-        mixed_normal_eq<NG, false>(M, a, q, lds, sa.bslot, U);
-        if (!U.ok) { live = false; atomicAdd(not_spd, 1ull); }
-    }
-    if (live) {
-#pragma unroll
-        for (int g = 0; g < NG; ++g) yh[g] = U.bv[g];
-        fwd_subst<NG>(U.A, yh);
-        for (int sl = 0; sl < sa.nslots; ++sl) {  // Q_j = L^-1 W_j, in place
-            double v[NG > 0 ? NG : 1];
-#pragma unroll
-            for (int g = 0; g < NG; ++g) v[g] = lds[(sl * (NG + 2) + g) * BLOCK];
-            fwd_subst<NG>(U.A, v);
-#pragma unroll
-            for (int g = 0; g < NG; ++g) lds[(sl * (NG + 2) + g) * BLOCK] = v[g];
-        }
-        for (int r = 0; r < R; ++r) {  // SED of every global row on this unit
-            const Comp& cr = M.comp[a.tc[sa.rt[r]]];
-            double t0, t1;
-            load_theta(M, cr, q.i, q.k, t0, t1);
-            srow[r * BLOCK] = comp_sed(M, cr, q.i, q.k, sa.rj[r], sed_prep(cr, t0, t1));
-        }
-    }
-    for (int r = 0; r < R; ++r) {
-        const Comp& cr = M.comp[a.tc[sa.rt[r]]];
-        const int jr = sa.rj[r], sl = sa.bslot[jr];
-        const bool on_r = live && q.p < gl_nplanes(cr, a.flag);
-        const double s_r = on_r ? srow[r * BLOCK] : 0.0;
-        const double w_r = on_r ? ((cr.type == DANGX_MONOPOLE) ? 1.0 : s_r) : 0.0;  // :857
-        double tv = 0.0, fv = 0.0, inv_r = 0.0;
-        if (on_r) {
-            double dot = 0.0;
-#pragma unroll
-            for (int g = 0; g < NG; ++g) dot += lds[(sl * (NG + 2) + g) * BLOCK] * yh[g];
-            tv = lds[(sl * (NG + 2) + NG) * BLOCK] * s_r - w_r * dot;
-            fv = lds[(sl * (NG + 2) + NG + 1) * BLOCK] * w_r;
-            const double rms = M.rms[((long long)jr * M.nmaps + (q.k - 1)) * M.npix + q.i];
-            inv_r = 1.0 / (rms * rms);
-        }
-        block_row_sum(tv, R * R + r, rowpartial, sh);
-        block_row_sum(fv, R * R + R + r, rowpartial, sh);
-        block_row_sum(w_r * s_r * inv_r, R * R + 2 * R + r, rowpartial, sh);
-        for (int r2 = 0; r2 < R; ++r2) {
-            const Comp& c2 = M.comp[a.tc[sa.rt[r2]]];
-            const int sl2 = sa.bslot[sa.rj[r2]];
-            double v = 0.0;
-            if (on_r && q.p < gl_nplanes(c2, a.flag)) {
-                const double s2 = srow[r2 * BLOCK];
-                double dot = 0.0;
-#pragma unroll
-                for (int g = 0; g < NG; ++g) dot += lds[(sl * (NG + 2) + g) * BLOCK] * lds[(sl2 * (NG + 2) + g) * BLOCK];
-                v = ((sl == sl2) ? w_r * s2 * inv_r : 0.0) - w_r * s2 * dot;
-            }
-            block_row_sum(v, r * R + r2, rowpartial, sh);
-        }
-    }
-}
-
-// pass 2: block solve with the global members' (new) signal removed from the data; writes the amplitudes
-template <int NG>
-__global__ __launch_bounds__(BLOCK) void k_schur_pass2(const Model* __restrict__ Mp, GroupArgs a) {
-    const Model& M = *Mp;
-    const UnitId q = unit_of(M, a.flag);
-    if (q.msk) return;
-    MixedUnit<NG> U;
-    mixed_normal_eq<NG, true>(M, a, q, nullptr, nullptr, U);
-    if (!U.ok) return;
-    double v[NG > 0 ? NG : 1];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) v[g] = U.bv[g];
-    fwd_subst<NG>(U.A, v);
-#pragma unroll
-    for (int g = NG - 1; g >= 0; --g) {
-        double s = v[g];
-#pragma unroll
-        for (int t = g + 1; t < NG; ++t) s -= U.A[t * (t + 1) / 2 + g] * v[t];
-        v[g] = s / U.A[g * (g + 1) / 2 + g];
-    }
-#pragma unroll
-    for (int g = 0; g < NG; ++g) M.comp[a.gc[g]].amp[(long long)(q.k - 1) * M.npix + q.i] = v[g];
-}
-
-template <int NG>
-struct LaunchSchur {
-    static int run(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs* sa, long long SN, double* rows_dev) {
-        const unsigned nblk = nblocks(SN);
-        if (sa) {
-            const int R = sa->nrows, nrows = R * R + 3 * R;
-            if (ensure_partial(ctx, (long long)nrows * nblk)) return 1;
-            const size_t lds = ((size_t)sa->nslots * (NG + 2) + R) * BLOCK * sizeof(double);
-            if (lds > 150 * 1024) return fail(ctx, "too many bands x components for the direct solve of a template group: use DANGX_SOLVER_CG");
-            HIPCHK(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));
-            hipLaunchKernelGGL(k_schur_pass1<NG>, dim3(nblk), dim3(BLOCK), lds, ctx->stream, ctx->dm, a, *sa, ctx->partial, ctx->counters);
-            dx_reduce_rows_to(ctx, ctx->partial, nblk, nrows, rows_dev);
-        } else {
-            Timed t(ctx, DANGX_K_AMP_DIRECT);
-            hipLaunchKernelGGL(k_schur_pass2<NG>, dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->dm, a);
-        }
-        HIPCHK(ctx, hipGetLastError());
-        return 0;
-    }
-};
-int dispatch_schur(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs* sa, long long SN, double* rows_dev) {
-    switch (a.ng) {
-    case 0: return sa ? LaunchSchur<0>::run(ctx, a, sa, SN, rows_dev) : 0;  // no diffuse member: nothing to back-substitute
-    case 1: return LaunchSchur<1>::run(ctx, a, sa, SN, rows_dev);
-    case 2: return LaunchSchur<2>::run(ctx, a, sa, SN, rows_dev);
-    case 3: return LaunchSchur<3>::run(ctx, a, sa, SN, rows_dev);
-    case 4: return LaunchSchur<4>::run(ctx, a, sa, SN, rows_dev);
-    case 5: return LaunchSchur<5>::run(ctx, a, sa, SN, rows_dev);
-    case 6: return LaunchSchur<6>::run(ctx, a, sa, SN, rows_dev);
-    default: return fail(ctx, "direct solve of a template group supports up to 6 diffuse members: use DANGX_SOLVER_CG");
-    }
-}
-
-template <int NG>
-struct LaunchMixed {
-    static int run(dangx_ctx* ctx, const GroupArgs& a, long long SN, int what, const double* in, double* out) {
-        const unsigned nblk = nblocks(SN);
-        if (ensure_partial(ctx, (long long)std::max(a.nglob, 1) * nblk)) return 1;
-        double* og = out + (long long)NG * SN;
-        // rows that no kernel writes (sample vector: rows beyond the running counter) must read as zero
-        HIPCHK(ctx, hipMemsetAsync(ctx->partial, 0, sizeof(double) * (size_t)std::max(a.nglob, 1) * nblk, ctx->stream));
-        {
-            Timed t(ctx, what == 1 ? DANGX_K_CG_AX : DANGX_K_CG_VEC);
-            if (what == 0) hipLaunchKernelGGL(k_rhs_mixed<NG>, dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->dm, a, out, ctx->partial);
-            else if (what == 1) hipLaunchKernelGGL(k_Ax_mixed<NG>, dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->dm, a, in, out, ctx->partial);
-            else hipLaunchKernelGGL(k_sv_mixed<NG>, dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->dm, a, in, out, ctx->partial);
-        }
-        dx_reduce_rows_to(ctx, ctx->partial, nblk, a.nglob, og);
-        HIPCHK(ctx, hipGetLastError());
-        return 0;
-    }
-};
-
-int dispatch_mixed(dangx_ctx* ctx, const GroupArgs& a, long long SN, int what, const double* in, double* out) {
-    switch (a.ng) {
-    case 0: return LaunchMixed<0>::run(ctx, a, SN, what, in, out);
-    case 1: return LaunchMixed<1>::run(ctx, a, SN, what, in, out);
-    case 2: return LaunchMixed<2>::run(ctx, a, SN, what, in, out);
-    case 3: return LaunchMixed<3>::run(ctx, a, SN, what, in, out);
-    case 4: return LaunchMixed<4>::run(ctx, a, SN, what, in, out);
-    case 5: return LaunchMixed<5>::run(ctx, a, SN, what, in, out);
-    case 6: return LaunchMixed<6>::run(ctx, a, SN, what, in, out);
-    case 7: return LaunchMixed<7>::run(ctx, a, SN, what, in, out);
-    case 8: return LaunchMixed<8>::run(ctx, a, SN, what, in, out);
-    default: return fail(ctx, "unsupported group size");
-    }
-}
-
 }  // namespace
 
 int dx_launch_amp(dangx_ctx* ctx, const GroupArgs& a, long long SN) { return dispatch_ng<LaunchAmp>(ctx, a.ng, a, SN); }
@@ -880,10 +360,3 @@ int dx_launch_Ax(dangx_ctx* ctx, const GroupArgs& a, long long SN, const double*
 int dx_launch_sample_vector(dangx_ctx* ctx, const GroupArgs& a, long long SN, const double* eta, double* res) {
     return dispatch_ng<LaunchSv>(ctx, a.ng, a, SN, eta, res);
 }
-int dx_launch_rhs_mixed(dangx_ctx* ctx, const GroupArgs& a, long long SN, double* b) { return dispatch_mixed(ctx, a, SN, 0, nullptr, b); }
-int dx_launch_Ax_mixed(dangx_ctx* ctx, const GroupArgs& a, long long SN, const double* x, double* res) { return dispatch_mixed(ctx, a, SN, 1, x, res); }
-int dx_launch_sv_mixed(dangx_ctx* ctx, const GroupArgs& a, long long SN, const double* eta, double* res) { return dispatch_mixed(ctx, a, SN, 2, eta, res); }
-int dx_launch_schur_pass1(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev) {
-    return dispatch_schur(ctx, a, &sa, SN, rows_dev);
-}
-int dx_launch_schur_pass2(dangx_ctx* ctx, const GroupArgs& a, long long SN) { return dispatch_schur(ctx, a, nullptr, SN, nullptr); }

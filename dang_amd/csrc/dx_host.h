@@ -1,5 +1,6 @@
 // dx_host.h -- host-side context and launch-argument structs shared by the translation units of libdangx.so
-// (dangx_core.hip: context, C ABI, small kernels; dangx_amp.hip: amplitude kernels; dangx_mh.hip: LDS-form
+// (dangx_core.hip: context, C ABI, small kernels; dangx_amp.hip: amplitude kernels of diffuse groups; dangx_mixed.hip /
+// dangx_schur.hip: groups with template-type members (mixed CG operators / direct Schur solve); dangx_mh.hip: LDS-form
 // Metropolis kernels; dangx_mhreg.hip: register-resident Metropolis kernels, compiled once per chain mode).
 #pragma once
 #include <hip/hip_runtime.h>
