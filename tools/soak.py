@@ -1,19 +1,41 @@
-import sys, numpy as np
-sys.path.insert(0, "/root/repo")
-import dang_amd as da
-from dang_amd import synth
-for fluct in ("reference", "correct"):
-    dpar, ddata, bands, comps, meta = synth.make_sky("C3", nside=64, fluct_mode=fluct)
+#!/usr/bin/env python3
+"""Long Gibbs run as a sampler sanity check: python tools/soak.py [nside] [iterations] [reference|correct].
+Prints the chi^2 trajectory, the number of non-SPD blocks met, and the spread of the sampled indices."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dang_amd as da  # noqa: E402
+from dang_amd import synth  # noqa: E402
+
+nside = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+niter = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+modes = sys.argv[3:] or ["reference", "correct"]
+dev = torch.device("cuda", 0)
+for fluct in modes:
+    dpar, ddata, bands, comps, meta = synth.make_sky("C3", nside=nside, fluct_mode=fluct, device=dev, as_numpy=False)
     eng = da.initialize(bands, comps, ddata, npix_global=meta["npix_global"], device=0)
-    tr = []
-    for it in range(1, 401):
-        da.sample_cg_groups(dpar, ddata, it=it, defer_chisq=(it > 1))
+    marks = sorted(set([1, 2, 5, 10, 20, 50, 100, 200] + list(range(400, niter + 1, 400)) + [niter]))
+    tr, nbad = [], 0
+    for it in range(1, niter + 1):
+        info = da.sample_cg_groups(dpar, ddata, it=it, defer_chisq=(it > 1))
+        nbad += sum(b for (_, _, _, b) in info)
         if it > 1:
             da.sample_spectral_parameters(dpar, ddata, it=it)
-        if it in (1, 2, 5, 10, 20, 50, 100, 200, 300, 400):
+        if not np.isfinite(ddata.chisq):
+            print("non-finite chi^2 at iteration", it)
+            break
+        if it in marks:
             tr.append((it, round(ddata.chisq, 4)))
-    print(fluct, tr)
-    # index recovery: mean offset of beta_s from truth in units of the prior width
-    bs = eng.get_indices(1)[0, 0]
-    m = np.asarray(ddata.masks)[0] != 0
-    print("  synch beta T: mean %.4f std %.4f (truth mean -3.1, prior sigma 0.1)" % (bs[m].mean(), bs[m].std()))
+    print(fluct, "nside", nside, tr, "non-SPD blocks:", nbad)
+    m = (ddata.masks[0] != 0).cpu().numpy()
+    for l, c in enumerate(comps):
+        for j in range(c.nindices):
+            if c.sample_index[j]:
+                pl = 0 if c.pol_flag[j][0] == 1 else 1
+                x = eng.get_indices(l)[j, pl][m]
+                print("  %-8s %-5s mean %9.4f std %8.4f  min %9.4f max %9.4f (prior %g +- %g, bounds %s)" % (
+                    c.label, c.ind_label[j], x.mean(), x.std(), x.min(), x.max(), c.gauss_prior[j][0], c.gauss_prior[j][1], c.uni_prior[j]))
