@@ -108,6 +108,47 @@ def cpu_baseline(config_name, nsample, nside_sample=128):
                          synth.CONFIGS[config_name]["nside"])}
 
 
+def launch_ranks(n, backend):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, as torch.distributed.run would), wait for them, return the worst
+    exit code.  Fewer than N visible GPUs is an error (with --backend nccl; gloo rehearsals may share a GPU)."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < n:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible; refusing to measure fewer ranks than asked\n"
+                         % (n, ndev))
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    for q in pending:   # one rank failed: the others would wait in a collective for ever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,11 +168,18 @@ def main():
                                                       "the N>1 path with several ranks on ONE GPU)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "RANK" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher of N rank processes.  It has made
+        # no GPU call (device_count() does not initialise the runtime) and never execs: children are spawned.
+        raise SystemExit(launch_ranks(args.gpus, args.backend))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): refusing to report a line for a different rank count"
+                         % (world, args.gpus))
     ndev = torch.cuda.device_count()
     if ndev == 0:
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
@@ -234,10 +282,14 @@ def main():
             else:
                 prof[k] = v
         engP.profile(False)
+    ranks_seen = 1
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t.item())
+        ones = torch.ones(1, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        td.all_reduce(ones)   # every rank contributes 1 through the same process group the chi^2 uses
+        ranks_seen = int(round(float(ones.item())))
     chisq = (chisq_buf / nb / ddata.nump).tolist()
 
     if rank == 0:
@@ -252,7 +304,7 @@ def main():
         achieved = bytes_per_launch / (prof[dom]["avg_ms"] * 1e-3) / 1e9
         out = {
             "metric": "gibbs_iterations_per_sec", "value": args.steps / elapsed, "unit": "it/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "n_gpus": world, "ranks_seen": ranks_seen, "backend": (args.backend if world > 1 else None), "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: Nside=%d, %d bands, %d components (%s), %s, NUMSAMPLE=%d, per-pixel indices, "
                                    "direct block solve, reference fluctuation term; pixel-sharded over %d rank(s), %d stream(s) per rank%s"

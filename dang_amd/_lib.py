@@ -79,6 +79,8 @@ SYMBOLS = {
     "dangx_indices_devptr": (_P, [_P, C.c_int]),
     "dangx_amp_sample": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
                                    C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "dangx_schur_info": (C.c_int, [_P, _D, C.POINTER(C.c_int)]),
+    "dangx_amp_residual": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _D]),
     "dangx_index_sample": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
                                      C.POINTER(C.c_int64)]),
     "dangx_sky_model_chisq": (C.c_int, [_P, C.c_int, C.c_int, _D, _P, _P, _P]),

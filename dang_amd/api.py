@@ -313,6 +313,18 @@ class Engine:
             C.byref(it) if want_counts else None, C.byref(bad) if want_counts else None))
         return it.value, bad.value
 
+    def schur_info(self):
+        """(largest relative global-row residual, refinement steps) of the last direct solve of a template group."""
+        r, n = C.c_double(0.0), C.c_int(0)
+        self._chk(self.lib.dangx_schur_info(self.h, C.byref(r), C.byref(n)))
+        return r.value, n.value
+
+    def amp_residual(self, group, flag, ml_mode, seed, stream):
+        """(|b - A x| / |b|, largest relative global-row residual) of the reference's system at the current amplitudes."""
+        out = (C.c_double * 2)()
+        self._chk(self.lib.dangx_amp_residual(self.h, group, flag, L.ML_CODES[ml_mode], seed, stream, out))
+        return out[0], out[1]
+
     def index_sample(self, comp, nind, map_n, nsample, ml_mode, seed, stream, want_counts=True):
         acc = C.c_int64(0)
         self._chk(self.lib.dangx_index_sample(self.h, comp, nind, map_n, nsample, L.ML_CODES[ml_mode], seed, stream,

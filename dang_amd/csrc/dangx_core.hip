@@ -94,6 +94,32 @@ __global__ __launch_bounds__(BLOCK) void k_dot(const double* __restrict__ u, con
     }
 }
 
+// block partials of sum((b-q)^2) [row 0] and sum(b^2) [row 1] over the diffuse entries t < ndiff of unmasked units
+// (the rows of masked units are zero in A and keep whatever b holds: not part of the solve)
+__global__ __launch_bounds__(BLOCK) void k_resid_norm(const Model* __restrict__ Mp, const double* __restrict__ b,
+                                                      const double* __restrict__ q, long long ndiff, long long SN,
+                                                      double* __restrict__ partial) {
+    __shared__ double sh[2][BLOCK / 64];
+    const Model& M = *Mp;
+    const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    double rr = 0.0, bb = 0.0;
+    if (t < ndiff) {
+        const long long u = t % SN;
+        if (!is_masked(M.mask[u % M.npix])) {
+            const double r = b[t] - q[t];
+            rr = r * r; bb = b[t] * b[t];
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { rr += __shfl_down(rr, o, 64); bb += __shfl_down(bb, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = rr; sh[1][threadIdx.x >> 6] = bb; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double v = 0.0;
+        for (int w = 0; w < BLOCK / 64; ++w) v += sh[threadIdx.x][w];
+        partial[(long long)threadIdx.x * gridDim.x + blockIdx.x] = v;
+    }
+}
+
 // deterministic second stage: out[0] = sum(partial[0..n)) in a fixed order
 __global__ __launch_bounds__(BLOCK) void k_reduce(const double* __restrict__ partial, long long n, double* __restrict__ out) {
     __shared__ double sh[BLOCK];
@@ -638,9 +664,10 @@ int sync_model(dangx_ctx* ctx) {
         if (ctx->desc[l].type == DANGX_TCMB || is_global_type(ctx->desc[l].type)) M.all_delta = 0;  // generic paths only
     const size_t nbp = ctx->bp_nu0.size();
     if (nbp && ctx->bp_dirty) {
-        if (ctx->d_bp_nu0) { (void)hipFree(ctx->d_bp_nu0); (void)hipFree(ctx->d_bp_tau0); (void)hipFree(ctx->d_bp_lnr); }
-    for (int* b : {ctx->hp_n2r_f, ctx->hp_r2n_f, ctx->hp_n2r_c, ctx->hp_r2n_c}) if (b) (void)hipFree(b);
-    for (double* b : {ctx->cs_data, ctx->cs_rms, ctx->cs_mask, ctx->cs_index}) if (b) (void)hipFree(b);
+        if (ctx->d_bp_nu0) {
+            (void)hipFree(ctx->d_bp_nu0); (void)hipFree(ctx->d_bp_tau0); (void)hipFree(ctx->d_bp_lnr);
+            ctx->d_bp_nu0 = ctx->d_bp_tau0 = ctx->d_bp_lnr = nullptr;
+        }
         const size_t nbytes = nbp * sizeof(double);
         HIPCHK(ctx, hipMalloc(&ctx->d_bp_nu0, nbytes));
         HIPCHK(ctx, hipMalloc(&ctx->d_bp_tau0, nbytes));
@@ -958,12 +985,14 @@ int device_schur(dangx_ctx* ctx, const GroupArgs& a, long long SN, int64_t* n_no
     // consistent; the free directions keep their current value (d = 0 there), which is what the reference's CG does
     // with them too (a Krylov iterate never moves along the null space).  nullity is reported through cg_iters.
     std::vector<double> S(rows.begin(), rows.begin() + (size_t)R * R), t(rows.begin() + (size_t)R * R, rows.begin() + (size_t)R * R + R);
+    std::vector<double> fl(R, 0.0);  // fluctuation term of every row, through the running-counter mapping
     if (a.ml_mode == DANGX_ML_SAMPLE)
         for (int r = 0; r < R; ++r)
-            if (sa.ftarget[r] >= 0) t[sa.ftarget[r]] += rows[(size_t)R * R + R + r];
+            if (sa.ftarget[r] >= 0) fl[sa.ftarget[r]] += rows[(size_t)R * R + R + r];
+    for (int r = 0; r < R; ++r) t[r] += fl[r];
     std::vector<double> g0;
     globals_to_x(ctx, a, g0);
-    std::vector<double> sc(R), d(R, 0.0);
+    std::vector<double> sc(R);
     for (int r = 0; r < R; ++r) {
         const double dg = std::fabs(rows[(size_t)R * R + 2 * R + r]);  // G[r][r] = sum_u w_r s_r / sigma^2, before elimination
         if (!(dg > 0.0) || !std::isfinite(dg))
@@ -973,12 +1002,13 @@ int device_schur(dangx_ctx* ctx, const GroupArgs& a, long long SN, int64_t* n_no
     for (int r = 0; r < R; ++r) {
         double v = t[r];
         for (int k = 0; k < R; ++k) v -= S[(size_t)r * R + k] * g0[k];
-        t[r] = v * sc[r];  // scaled residual
+        t[r] = v;  // residual of the current amplitudes, as pass 1 sees it
     }
     for (int r = 0; r < R; ++r)
         for (int k = 0; k < R; ++k) S[(size_t)r * R + k] *= sc[r] * sc[k];
-    std::vector<int> perm(R);
-    for (int c = 0; c < R; ++c) perm[c] = c;
+    // LU with complete pivoting, multipliers kept: rp / cp are the row / column permutations, rank the number of pivots
+    std::vector<int> rp(R), cp(R);
+    for (int c = 0; c < R; ++c) rp[c] = cp[c] = c;
     int rank = 0;
     for (int c = 0; c < R; ++c) {
         int pr = c, pc = c;
@@ -992,30 +1022,79 @@ int device_schur(dangx_ctx* ctx, const GroupArgs& a, long long SN, int64_t* n_no
         if (!(best > 1e-10)) break;
         if (pr != c) {
             for (int k = 0; k < R; ++k) std::swap(S[(size_t)pr * R + k], S[(size_t)c * R + k]);
-            std::swap(t[pr], t[c]);
+            std::swap(rp[pr], rp[c]);
         }
         if (pc != c) {
             for (int r = 0; r < R; ++r) std::swap(S[(size_t)r * R + pc], S[(size_t)r * R + c]);
-            std::swap(perm[pc], perm[c]);
+            std::swap(cp[pc], cp[c]);
         }
         for (int r = c + 1; r < R; ++r) {
             const double f = S[(size_t)r * R + c] / S[(size_t)c * R + c];
-            for (int k = c; k < R; ++k) S[(size_t)r * R + k] -= f * S[(size_t)c * R + k];
-            t[r] -= f * t[c];
+            S[(size_t)r * R + c] = f;  // L below the diagonal
+            for (int k = c + 1; k < R; ++k) S[(size_t)r * R + k] -= f * S[(size_t)c * R + k];
         }
         ++rank;
     }
-    for (int r = rank - 1; r >= 0; --r) {  // free unknowns (columns rank..R-1) keep d = 0
-        double v = t[r];
-        for (int k = r + 1; k < rank; ++k) v -= S[(size_t)r * R + k] * d[perm[k]];
-        d[perm[r]] = v / S[(size_t)r * R + r];
-    }
-    std::vector<double> g(R);
-    for (int r = 0; r < R; ++r) g[r] = g0[r] + d[r] * sc[r];
+    // d = correction of the global amplitudes for a residual `res` of the (unscaled) global rows; free directions get 0
+    auto lu_solve = [&](const std::vector<double>& res, std::vector<double>& d) {
+        std::vector<double> y(R);
+        for (int r = 0; r < R; ++r) y[r] = res[rp[r]] * sc[rp[r]];
+        for (int r = 0; r < R; ++r)
+            for (int k = 0; k < std::min(r, rank); ++k) y[r] -= S[(size_t)r * R + k] * y[k];
+        std::vector<double> z(R, 0.0);
+        for (int r = rank - 1; r >= 0; --r) {
+            double v = y[r];
+            for (int k = r + 1; k < rank; ++k) v -= S[(size_t)r * R + k] * z[k];
+            z[r] = v / S[(size_t)r * R + r];
+        }
+        d.assign(R, 0.0);
+        for (int r = 0; r < rank; ++r) d[cp[r]] = z[r] * sc[cp[r]];
+    };
+    std::vector<double> d, g(R);
+    lu_solve(t, d);
+    for (int r = 0; r < R; ++r) g[r] = g0[r] + d[r];
     if (nullity) *nullity = R - rank;
     x_to_globals(ctx, a, g);
     if (sync_model(ctx)) return 1;
-    return dx_launch_schur_pass2(ctx, a, SN);
+    if (dx_launch_schur_pass2(ctx, a, SN)) return 1;
+    // Residual check + iterative refinement.  Pass 1 forms S and t as sums of per-unit differences that cancel to the
+    // part of a global row the diffuse members do NOT absorb; when they absorb nearly all of it (a fitted monopole
+    // beside the CMB) S keeps only a few digits and S g = t is solved for a slightly wrong S.  The true residual of the
+    // global rows, r = b - A x evaluated directly at the new state (k_schur_resid: no elimination, no cancellation),
+    // drives the correction g += S^-1 r; the diffuse rows are re-solved exactly by pass 2.  The contraction factor is
+    // cond(S) * (relative error of S); the loop stops at 1e-12 of the row of b, or when a step no longer helps.
+    ctx->schur_refine = 0;
+    double prev = INFINITY;
+    std::vector<double> rr(2 * R), res(R);
+    for (int step = 0; step <= 4; ++step) {
+        if (dx_launch_schur_resid(ctx, a, sa, SN, ctx->work[0])) return 1;
+        HIPCHK(ctx, hipMemcpyAsync(rr.data(), ctx->work[0], sizeof(double) * 2 * R, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (rank_sum(ctx, rr.data(), 2 * R)) return 1;
+        double worst = 0.0;
+        for (int r = 0; r < R; ++r) {
+            res[r] = rr[r] + fl[r];
+            const double brow = std::fabs(rr[R + r] + fl[r]);
+            // rows along a free (degenerate) direction cannot be reduced by the global amplitudes alone; they are
+            // consistent through the diffuse members, so their residual is reported like any other
+            worst = std::max(worst, std::fabs(res[r]) / std::max(brow, 1e-300));
+        }
+        if (step > 0 && !(worst < prev)) {  // the last correction did not help: take it back
+            for (int r = 0; r < R; ++r) g[r] -= d[r];
+            x_to_globals(ctx, a, g);
+            if (sync_model(ctx) || dx_launch_schur_pass2(ctx, a, SN)) return 1;
+            ctx->schur_refine -= 1;
+            break;
+        }
+        ctx->schur_resid = prev = worst;
+        if (worst <= 1e-12 || step == 4) break;
+        lu_solve(res, d);
+        for (int r = 0; r < R; ++r) g[r] += d[r];
+        x_to_globals(ctx, a, g);
+        if (sync_model(ctx) || dx_launch_schur_pass2(ctx, a, SN)) return 1;
+        ctx->schur_refine += 1;
+    }
+    return 0;
 }
 
 int check_comp(dangx_ctx* ctx, int comp) {
@@ -1045,6 +1124,8 @@ int ensure_state(dangx_ctx* ctx, int comp) {
 }  // namespace
 
 // ======================================================================= C ABI
+
+static int seam_common(dangx_ctx* ctx, int group, int flag, GroupArgs& a, long long& SN, long long& n);
 
 extern "C" {
 
@@ -1096,6 +1177,10 @@ int dangx_destroy(dangx_ctx* ctx) {
     for (int l = 0; l < MAXC; ++l) if (ctx->tmpl[l]) (void)hipFree(ctx->tmpl[l]);
     if (ctx->d_bp_nu0) { (void)hipFree(ctx->d_bp_nu0); (void)hipFree(ctx->d_bp_tau0); (void)hipFree(ctx->d_bp_lnr); }
     if (ctx->fs_data) (void)hipFree(ctx->fs_data);
+    // HEALPix index tables and the degraded maps of the coarse-Nside sweeps live as long as the context
+    for (int** b : {&ctx->hp_n2r_f, &ctx->hp_r2n_f, &ctx->hp_n2r_c, &ctx->hp_r2n_c}) { if (*b) (void)hipFree(*b); *b = nullptr; }
+    for (double** b : {&ctx->cs_data, &ctx->cs_rms, &ctx->cs_mask, &ctx->cs_index}) { if (*b) (void)hipFree(*b); *b = nullptr; }
+    ctx->hp_nside = ctx->hp_cnside = 0; ctx->cs_cap = 0;
     (void)hipFree(ctx->rows_out);
     (void)hipFree(ctx->dm); (void)hipFree(ctx->scalars); (void)hipFree(ctx->counters); (void)hipFree(ctx->chi_cache);
     for (auto& e : ctx->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -1134,6 +1219,7 @@ int dangx_set_band(dangx_ctx* ctx, int band, double nu_c, int n, const double* n
     for (int i = 0; i < n; ++i) { ctx->bp_nu0.push_back(nu0[i]); ctx->bp_tau0.push_back(tau0[i]); }
     ctx->band_set[band] = true;
     ctx->dirty = true; ctx->bp_dirty = true;
+    invalidate_chi(ctx);
     return 0;
 }
 
@@ -1153,6 +1239,7 @@ int dangx_set_component(dangx_ctx* ctx, int comp, const dangx_comp_desc* d) {
     if (ctx->desc[comp].nu_ref < 1e7) ctx->desc[comp].nu_ref *= 1e9;  // src/dang_param_mod.f90:571-573
     ctx->comp_set[comp] = true;
     ctx->dirty = true; ctx->bp_dirty = true;
+    invalidate_chi(ctx);
     return 0;
 }
 
@@ -1160,6 +1247,7 @@ int dangx_set_tcmb(dangx_ctx* ctx, double T) {
     if (!ctx) return 1;
     ctx->hm.tcmb = T;
     ctx->dirty = true;
+    invalidate_chi(ctx);
     return 0;
 }
 
@@ -1170,6 +1258,7 @@ int dangx_set_calibration(dangx_ctx* ctx, const double* gain, const double* offs
         if (offset) ctx->hm.offset[j] = offset[j];
     }
     ctx->dirty = true;
+    invalidate_chi(ctx);
     return 0;
 }
 
@@ -1189,6 +1278,7 @@ int dangx_upload_data(dangx_ctx* ctx, const double* sig, const double* rms, cons
     HIPCHK(ctx, hipMemcpy(ctx->rms, rms, nall, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->mask, mask, nmap, hipMemcpyHostToDevice));
     ctx->dirty = true;
+    invalidate_chi(ctx);
     return 0;
 }
 
@@ -1199,11 +1289,13 @@ int dangx_adopt_device_data(dangx_ctx* ctx, const double* sig, const double* rms
     ctx->rms = const_cast<double*>(rms);
     ctx->mask = const_cast<double*>(mask);
     ctx->dirty = true;
+    invalidate_chi(ctx);
     return 0;
 }
 
 int dangx_put_amplitude(dangx_ctx* ctx, int comp, const double* amp) {
     if (!ctx || !amp || check_comp(ctx, comp) || ensure_state(ctx, comp)) return 1;
+    invalidate_chi(ctx);
     ctx->plane_nz[comp] = 0;
     for (int k = 0; k < ctx->dims.nmaps; ++k)
         for (long long t = 0; t < ctx->dims.npix; ++t)
@@ -1221,6 +1313,7 @@ int dangx_get_amplitude(dangx_ctx* ctx, int comp, double* amp) {
 int dangx_put_indices(dangx_ctx* ctx, int comp, const double* ind) {
     if (!ctx || !ind || check_comp(ctx, comp) || ensure_state(ctx, comp)) return 1;
     if (!ctx->idx[comp]) return fail(ctx, "component has no indices");
+    invalidate_chi(ctx);
     {   // planes on which every index map is spatially constant
         const long long np = ctx->dims.npix;
         ctx->idx_const[comp] = 0;
@@ -1258,6 +1351,7 @@ int dangx_set_template(dangx_ctx* ctx, int comp, const double* tmpl, const int32
     HIPCHK(ctx, hipMemcpy(ctx->tmpl[comp], tmpl, bytes, hipMemcpyHostToDevice));
     ctx->corr_mask[comp] = mask; ctx->nfit[comp] = nfit;
     ctx->dirty = true;
+    invalidate_chi(ctx);
     return 0;
 }
 int dangx_put_template_amplitudes(dangx_ctx* ctx, int comp, const double* ta) {
@@ -1267,6 +1361,7 @@ int dangx_put_template_amplitudes(dangx_ctx* ctx, int comp, const double* ta) {
     if (ctx->desc[comp].type == DANGX_MONOPOLE)
         for (int j = 0; j < ctx->dims.nbands; ++j) ctx->hm.offset[j] = ctx->tamp[comp][0][j];
     ctx->dirty = true;
+    invalidate_chi(ctx);
     return 0;
 }
 int dangx_get_template_amplitudes(dangx_ctx* ctx, int comp, double* ta) {
@@ -1282,6 +1377,7 @@ int dangx_adopt_device_state(dangx_ctx* ctx, int comp, double* amp_dev, double* 
     if (ctx->desc[comp].nindices > 0 && !idx_dev) return fail(ctx, "component has indices: idx_dev required");
     if (ctx->amp[comp] && ctx->own_amp[comp]) (void)hipFree(ctx->amp[comp]);
     if (ctx->idx[comp] && ctx->own_idx[comp]) (void)hipFree(ctx->idx[comp]);
+    invalidate_chi(ctx);
     ctx->amp[comp] = amp_dev; ctx->own_amp[comp] = false;
     {   // which planes hold a non-zero amplitude right now (one small kernel, once)
         unsigned f = 0;
@@ -1367,6 +1463,72 @@ int dangx_amp_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solve
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         *n_not_spd = (int64_t)v;
     }
+    return 0;
+}
+
+int dangx_schur_info(dangx_ctx* ctx, double* rel_residual, int* refinements) {
+    if (!ctx) return 1;
+    if (rel_residual) *rel_residual = ctx->schur_resid;
+    if (refinements) *refinements = ctx->schur_refine;
+    return 0;
+}
+
+int dangx_amp_residual(dangx_ctx* ctx, int group, int flag, int ml_mode, uint64_t seed, uint64_t stream, double* out) {
+    if (!ctx || !out) return 1;
+    (void)hipSetDevice(ctx->device);
+    if (ml_mode != DANGX_ML_SAMPLE && ml_mode != DANGX_ML_OPTIMIZE) return fail(ctx, "bad ml_mode");
+    GroupArgs a;
+    long long SN, n;
+    if (seam_common(ctx, group, flag, a, SN, n)) return 1;
+    a.ml_mode = ml_mode; a.fluct = DANGX_FLUCT_REFERENCE; a.seed = seed; a.stream = stream;
+    const bool mixed = a.nt > 0;
+    const long long ndiff = SN * a.ng;
+    double *x = ctx->work[0], *eta = ctx->work[1], *q = ctx->work[3], *b2 = ctx->work[4], *b = ctx->work[5];
+    hipStream_t st = ctx->stream;
+    if (mixed ? dx_launch_rhs_mixed(ctx, a, SN, b) : dx_launch_rhs(ctx, a, SN, b)) return 1;
+    if (mixed && rank_sum_rows(ctx, b + ndiff, a.nglob)) return 1;
+    if (ml_mode == DANGX_ML_SAMPLE) {
+        hipLaunchKernelGGL(k_draw_eta, dim3(nblocks(SN)), dim3(BLOCK), 0, st, ctx->dm, a, eta);
+        if (mixed ? dx_launch_sv_mixed(ctx, a, SN, eta, q) : dx_launch_sample_vector(ctx, a, SN, eta, q)) return 1;
+        if (mixed && rank_sum_rows(ctx, q + ndiff, a.nglob)) return 1;
+        hipLaunchKernelGGL(k_cg_vec, dim3(nblocks(n)), dim3(BLOCK), 0, st, 3, n, n, 0.0, b2, nullptr, nullptr, q, b, nullptr);
+    } else {
+        HIPCHK(ctx, hipMemcpyAsync(b2, b, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    }
+    if (a.ng) hipLaunchKernelGGL(k_pack, dim3(nblocks(SN)), dim3(BLOCK), 0, st, ctx->dm, a, x, 0);
+    std::vector<double> xg;
+    if (mixed) {
+        globals_to_x(ctx, a, xg);
+        HIPCHK(ctx, hipMemcpyAsync(x + ndiff, xg.data(), sizeof(double) * a.nglob, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+    }
+    if (mixed ? dx_launch_Ax_mixed(ctx, a, SN, x, q) : dx_launch_Ax(ctx, a, SN, x, q, nullptr)) return 1;
+    if (mixed && rank_sum_rows(ctx, q + ndiff, a.nglob)) return 1;
+    double sums[2] = {0.0, 0.0};
+    if (ndiff > 0) {
+        const unsigned nblk = nblocks(ndiff);
+        if (ensure_partial(ctx, 2ll * nblk)) return 1;
+        hipLaunchKernelGGL(k_resid_norm, dim3(nblk), dim3(BLOCK), 0, st, ctx->dm, b2, q, ndiff, SN, ctx->partial);
+        hipLaunchKernelGGL(k_reduce_rows_final, dim3(2), dim3(BLOCK), 0, st, ctx->partial, (long long)nblk, 2, ctx->rows_out);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(sums, ctx->rows_out, sizeof(sums), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        if (rank_sum(ctx, sums, 2)) return 1;
+    }
+    double worst = 0.0;
+    if (a.nglob > 0) {
+        std::vector<double> bg(a.nglob), qg(a.nglob);
+        HIPCHK(ctx, hipMemcpyAsync(bg.data(), b2 + ndiff, sizeof(double) * a.nglob, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(qg.data(), q + ndiff, sizeof(double) * a.nglob, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        for (int r = 0; r < a.nglob; ++r) {
+            const double res = bg[r] - qg[r];
+            sums[0] += res * res; sums[1] += bg[r] * bg[r];
+            worst = std::max(worst, std::fabs(res) / std::max(std::fabs(bg[r]), 1e-300));
+        }
+    }
+    out[0] = (sums[1] > 0.0) ? std::sqrt(sums[0] / sums[1]) : 0.0;
+    out[1] = worst;
     return 0;
 }
 

@@ -204,11 +204,88 @@ __global__ __launch_bounds__(BLOCK) void k_schur_pass2(const Model* __restrict__
     for (int g = 0; g < NG; ++g) M.comp[a.gc[g]].amp[(long long)(q.k - 1) * M.npix + q.i] = v[g];
 }
 
+// Residual of the GLOBAL rows of the reference's system at the current state (amplitude maps + template amplitudes),
+// evaluated directly -- no elimination, hence none of pass 1's cancellation:
+//   rows [0, R):  sum_u ( d_j s_r / sigma_j^2  -  w_r * (sum_g a_g M_gj + sum_t' g_t' s_t') / sigma_j^2 )   (b - A x, without
+//                 the fluctuation term, which the host adds from pass 1's sums)
+//   rows [R, 2R): sum_u d_j s_r / sigma_j^2                                                                  (the row of b)
+// for row r = (global member t_r, band j = rj[r]); d_j is compute_rhs's data (src/dang_cg_mod.f90:367-460), the row weight
+// w_r is 1 for a monopole (:857) and s_r otherwise, as in k_rhs_mixed / k_Ax_mixed.
+template <int NG>
+__global__ __launch_bounds__(BLOCK) void k_schur_resid(const Model* __restrict__ Mp, GroupArgs a, SchurArgs sa,
+                                                       double* __restrict__ rowpartial) {
+    __shared__ double sh[BLOCK / 64];
+    constexpr int NA = NG > 0 ? NG : 1;
+    const Model& M = *Mp;
+    const UnitId q = unit_of(M, a.flag);
+    const int R = sa.nrows;
+    Prep pr[NA], prt[MAXT];
+    double av[NA];
+#pragma unroll
+    for (int g = 0; g < NA; ++g) { pr[g] = Prep{0, 0, 0}; av[g] = 0.0; }
+    if (!q.msk) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const Comp& c = M.comp[a.gc[g]];
+            double t0, t1;
+            load_theta(M, c, q.i, q.k, t0, t1);
+            pr[g] = sed_prep(c, t0, t1);
+            av[g] = c.amp[(long long)(q.k - 1) * M.npix + q.i];
+        }
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+            if (t < a.nt) {
+                double t0, t1;
+                load_theta(M, M.comp[a.tc[t]], q.i, q.k, t0, t1);
+                prt[t] = sed_prep(M.comp[a.tc[t]], t0, t1);
+            }
+    }
+    for (int j = 0; j < M.nbands; ++j) {
+        if (sa.bslot[j] < 0) continue;  // uniform: no global row at this band
+        double d = 0.0, inv = 0.0, model = 0.0, st[MAXT];
+        if (!q.msk) {
+            d = M.sig[((long long)j * M.nmaps + (q.k - 1)) * M.npix + q.i];
+            if (q.k == 1) d = d / M.gain[j];
+            d = remove_others(M, a, q.i, q.k, j, d);
+            const double rms = M.rms[((long long)j * M.nmaps + (q.k - 1)) * M.npix + q.i];
+            inv = 1.0 / (rms * rms);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) model = model + av[g] * sed_eval(M, M.comp[a.gc[g]], j, pr[g]);
+        }
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            st[t] = 0.0;
+            if (t < a.nt) {
+                const Comp& c = M.comp[a.tc[t]];
+                if (((c.corr_mask >> j) & 1) && !q.msk && q.p < gl_nplanes(c, a.flag)) {
+                    st[t] = comp_sed(M, c, q.i, q.k, j, prt[t]);
+                    model = model + c.tamp[q.k - 1][j] * st[t];
+                }
+            }
+        }
+        for (int r = 0; r < R; ++r) {
+            if (sa.rj[r] != j) continue;
+            const int t = sa.rt[r];
+            const Comp& c = M.comp[a.tc[t]];
+            const bool on = !q.msk && q.p < gl_nplanes(c, a.flag);
+            const double w = (c.type == DANGX_MONOPOLE) ? 1.0 : st[t];
+            const double bterm = on ? d * inv * st[t] : 0.0;
+            block_row_sum(on ? bterm - w * (model * inv) : 0.0, r, rowpartial, sh);
+            block_row_sum(bterm, R + r, rowpartial, sh);
+        }
+    }
+}
+
 template <int NG>
 struct LaunchSchur {
-    static int run(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs* sa, long long SN, double* rows_dev) {
+    static int run(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs* sa, long long SN, double* rows_dev, bool resid = false) {
         const unsigned nblk = nblocks(SN);
-        if (sa) {
+        if (sa && resid) {
+            const int nrows = 2 * sa->nrows;
+            if (ensure_partial(ctx, (long long)nrows * nblk)) return 1;
+            hipLaunchKernelGGL(k_schur_resid<NG>, dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->dm, a, *sa, ctx->partial);
+            dx_reduce_rows_to(ctx, ctx->partial, nblk, nrows, rows_dev);
+        } else if (sa) {
             const int R = sa->nrows, nrows = R * R + 3 * R;
             if (ensure_partial(ctx, (long long)nrows * nblk)) return 1;
             const size_t lds = ((size_t)sa->nslots * (NG + 2) + R) * BLOCK * sizeof(double);
@@ -224,15 +301,15 @@ struct LaunchSchur {
         return 0;
     }
 };
-int dispatch_schur(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs* sa, long long SN, double* rows_dev) {
+int dispatch_schur(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs* sa, long long SN, double* rows_dev, bool resid = false) {
     switch (a.ng) {
-    case 0: return sa ? LaunchSchur<0>::run(ctx, a, sa, SN, rows_dev) : 0;  // no diffuse member: nothing to back-substitute
-    case 1: return LaunchSchur<1>::run(ctx, a, sa, SN, rows_dev);
-    case 2: return LaunchSchur<2>::run(ctx, a, sa, SN, rows_dev);
-    case 3: return LaunchSchur<3>::run(ctx, a, sa, SN, rows_dev);
-    case 4: return LaunchSchur<4>::run(ctx, a, sa, SN, rows_dev);
-    case 5: return LaunchSchur<5>::run(ctx, a, sa, SN, rows_dev);
-    case 6: return LaunchSchur<6>::run(ctx, a, sa, SN, rows_dev);
+    case 0: return sa ? LaunchSchur<0>::run(ctx, a, sa, SN, rows_dev, resid) : 0;  // no diffuse member: nothing to back-substitute
+    case 1: return LaunchSchur<1>::run(ctx, a, sa, SN, rows_dev, resid);
+    case 2: return LaunchSchur<2>::run(ctx, a, sa, SN, rows_dev, resid);
+    case 3: return LaunchSchur<3>::run(ctx, a, sa, SN, rows_dev, resid);
+    case 4: return LaunchSchur<4>::run(ctx, a, sa, SN, rows_dev, resid);
+    case 5: return LaunchSchur<5>::run(ctx, a, sa, SN, rows_dev, resid);
+    case 6: return LaunchSchur<6>::run(ctx, a, sa, SN, rows_dev, resid);
     default: return fail(ctx, "direct solve of a template group supports up to 6 diffuse members: use DANGX_SOLVER_CG");
     }
 }
@@ -243,3 +320,6 @@ int dx_launch_schur_pass1(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& s
     return dispatch_schur(ctx, a, &sa, SN, rows_dev);
 }
 int dx_launch_schur_pass2(dangx_ctx* ctx, const GroupArgs& a, long long SN) { return dispatch_schur(ctx, a, nullptr, SN, nullptr); }
+int dx_launch_schur_resid(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev) {
+    return dispatch_schur(ctx, a, &sa, SN, rows_dev, true);
+}

@@ -108,6 +108,10 @@ struct dangx_ctx {
     double *cs_data = nullptr, *cs_rms = nullptr, *cs_mask = nullptr, *cs_index = nullptr;
     long long cs_cap = 0;
     long long work_cap = 0;
+    // last DANGX_SOLVER_DIRECT solve of a group with global-amplitude members: largest |b - A x| of a global row relative
+    // to that row of b after the last refinement, and the number of refinement steps taken
+    double schur_resid = 0.0;
+    int schur_refine = 0;
     // profiling
     bool prof = false;
     struct Ev { hipEvent_t a, b; int kid; };
@@ -124,6 +128,12 @@ struct dangx_ctx {
             return 1;                                                                             \
         }                                                                                         \
     } while (0)
+
+// the chi^2 sums cached by the index sweeps describe a model that no longer exists: every setter that changes the
+// model (T_CMB, calibration, host pushes of state, new data, new descriptors) calls this
+inline void invalidate_chi(dangx_ctx* ctx) {
+    for (int k = 0; k < 3; ++k) ctx->chi_before_valid[k] = ctx->chi_after_valid[k] = false;
+}
 
 inline int fail(dangx_ctx* ctx, const std::string& msg) {
     ctx->err = msg;
@@ -181,6 +191,8 @@ struct SchurArgs {
 };
 int dx_launch_schur_pass1(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
 int dx_launch_schur_pass2(dangx_ctx* ctx, const GroupArgs& a, long long SN);
+// rows_dev[0..R): global rows of b - A x at the current state (without the fluctuation term); [R..2R): those rows of b
+int dx_launch_schur_resid(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
 // groups with global-amplitude members (a.nt > 0): vectors are [diffuse | global rows]
 int dx_launch_rhs_mixed(dangx_ctx* ctx, const GroupArgs& a, long long SN, double* b);
 int dx_launch_Ax_mixed(dangx_ctx* ctx, const GroupArgs& a, long long SN, const double* x, double* res);

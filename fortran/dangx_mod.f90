@@ -107,6 +107,19 @@ module dangx_mod
        integer(c_int), intent(out) :: cg_iters
        integer(c_int64_t), intent(out) :: n_not_spd
      end function
+     integer(c_int) function dangx_schur_info(ctx, rel_residual, refinements) bind(C, name='dangx_schur_info')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: rel_residual
+       integer(c_int), intent(out) :: refinements
+     end function
+     integer(c_int) function dangx_amp_residual(ctx, group, flag, ml_mode, seed, stream, out) bind(C, name='dangx_amp_residual')
+       import :: c_int, c_ptr, c_double, c_int64_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: group, flag, ml_mode
+       integer(c_int64_t), value :: seed, stream
+       real(c_double), intent(out) :: out(2)
+     end function
      integer(c_int) function dangx_index_sample(ctx, comp, nind, map_n, nsample, ml_mode, seed, stream, accepted) &
           bind(C, name='dangx_index_sample')
        import :: c_int, c_ptr, c_int64_t

@@ -161,6 +161,18 @@ int dangx_amp_sample(dangx_ctx *ctx, int group, int flag, int ml_mode, int solve
                      uint64_t seed, uint64_t stream, int i_max, double converge,
                      int *cg_iters, int64_t *n_not_spd);
 
+/* Accuracy of the last DANGX_SOLVER_DIRECT solve of a group with template / monopole / hi_fit members: the largest
+ * |b - A x| over the global rows relative to that row of b (b, A: the system of compute_rhs / compute_sample_vector /
+ * compute_Ax, src/dang_cg_mod.f90:326-1096), measured directly at the new state after the last step of iterative
+ * refinement, and the number of refinement steps the solve took (0: the first solution already met 1e-12). */
+int dangx_schur_info(dangx_ctx *ctx, double *rel_residual, int *refinements);
+/* Residual of the reference's linear system at the CURRENT amplitudes, through the reference's own operators
+ * (dangx_compute_rhs + dangx_compute_sample_vector(eta(seed, stream)) - dangx_compute_Ax(x), vectors kept on the device):
+ * out[0] = |b - A x|_2 / |b|_2 over the rows of unmasked units and the global rows, out[1] = the largest global-row
+ * residual relative to that row of b (0 without global members).  What cg_search's delta_new measures
+ * (src/dang_cg_mod.f90:285, 303); call it with the seed / stream / ml_mode of the solve it checks. */
+int dangx_amp_residual(dangx_ctx *ctx, int group, int flag, int ml_mode, uint64_t seed, uint64_t stream, double *out);
+
 /* ---- index phase: sample_index_mh, per-pixel branch (src/dang_sample_mod.f90:88-485,
  * index_mode==2, sample_nside==nside).  nind 0-based; map_n = 1,2,3 or -1 (Q+U).
  * accepted (nullable): number of accepted proposals over the shard. */

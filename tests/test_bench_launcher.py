@@ -1,0 +1,51 @@
+"""bench.py --gpus N without a launcher starts its own N ranks, and never reports a line for fewer ranks than asked."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    return env
+
+
+def test_more_gpus_than_visible_is_an_error_not_a_one_gpu_line():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "64", "--steps", "1", "--warmup", "0"], env=_env(),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "--gpus 64" in r.stderr and "visible" in r.stderr
+    assert r.stdout.strip() == ""            # no JSON line at all
+
+
+def test_world_size_must_match_gpus():
+    env = dict(_env(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "1", "--warmup", "0"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE (1) != --gpus (8)" in r.stderr
+    assert r.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+def test_self_launched_ranks_report_their_count(built):
+    """Two self-spawned ranks (gloo process group, both on cuda:0 -- a rehearsal of the N-rank path on a one-GPU box;
+    on a node with N GPUs the same launcher runs N RCCL ranks): the line says n_gpus = 2 and the all-reduced rank
+    count agrees; chi^2 equals the one-rank run's (the sky is the same, sharded)."""
+    def run(*extra):
+        r = subprocess.run([sys.executable, BENCH, "--config", "C2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + list(extra),
+                           env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        return json.loads(lines[0])
+    two = run("--gpus", "2", "--backend", "gloo")
+    one = run("--gpus", "1")
+    assert two["n_gpus"] == 2 and two["ranks_seen"] == 2 and two["backend"] == "gloo"
+    assert one["n_gpus"] == 1 and one["ranks_seen"] == 1
+    for k in ("chisq_after_amp", "chisq_after_index"):
+        assert abs(two["config"][k] - one["config"][k]) <= 1e-12 * abs(one["config"][k])

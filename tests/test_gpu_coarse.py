@@ -80,3 +80,37 @@ def test_coarse_mode_needs_a_whole_sky_context(built):
     eng, _ = pair(case)
     with pytest.raises(da.DangxError, match="whole-sky"):
         eng.index_sample_coarse(1, 0, 1, 10, "sample", 7, 1, 4)
+
+
+def test_coarse_sweep_survives_a_descriptor_update_with_bandpass_bands(built):
+    """Regression (round-1 lifetime bug): with bandpass-integrated bands, dangx_set_component marks the bandpass tables
+    dirty; the re-upload in sync_model used to free the cached HEALPix index tables and the coarse staging buffers
+    without resetting them, so the NEXT coarse sweep ran on freed memory.  Coarse sweep -> new step size -> coarse
+    sweep again must equal the oracle; destroying the context afterwards frees the tables exactly once."""
+    import ctypes as C
+    from dang_amd.api import comp_desc
+    nside, cnside = 8, 4
+
+    def tweak(dpar, ddata, bands, comps):
+        for b in bands[1::2]:
+            b.id = "tophat"
+            b.nu0 = b.nu_c * 1e9 * np.linspace(0.9, 1.1, 4)
+            b.tau0 = np.full(4, 0.25)
+        for c in comps:
+            c.sample_nside = [cnside] * c.nindices
+    case = make_case("C2", nside=nside, start="truth", tweak=tweak)
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+    l, j, f = 1, 0, comps[1].pol_flag[0][0]
+    map_n = {1: 1, 8: -1}[f]
+    for rnd in range(3):
+        s = da.stream_id(2 + rnd, 1, l, j, f)
+        ag = eng.index_sample_coarse(l, j, map_n, 10, "sample", 7, s, cnside)
+        ao = orc.sample_index_mh_coarse(l, j, map_n, 10, "sample", 7, s, nside, cnside)
+        assert ag == ao, (rnd, ag, ao)
+        assert np.abs(eng.get_indices(l) - orc.indices(l)).max() <= 1e-12, rnd
+        # the tuner's effect: a new step size through dangx_set_component (sets bp_dirty) before the next sweep
+        comps[l].step_size[j] *= 0.5
+        orc._comps[l].step_size[j] = comps[l].step_size[j]
+        eng._chk(eng.lib.dangx_set_component(eng.h, l, C.byref(comp_desc(comps[l]))))
+    eng.close()

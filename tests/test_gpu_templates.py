@@ -251,6 +251,12 @@ def test_T_cmb_sampling_per_pixel_and_full_sky(built):
     assert cmb_after != cmb_before
     want = O.Oracle(bands, comps, ddata, tcmb=T).eval_sed_map(0, 1, 1)[0]
     assert abs(cmb_after - want) <= 1e-12 * abs(want)
+    # ddata%chisq is evaluated AFTER the T_CMB update (update_sky_model + compute_chisq, src/dang_sample_mod.f90:75-84):
+    # the chi^2 the sweep cached belongs to the old T_CMB and must not be reported
+    eng.pull_state()
+    ref, _ = O.Oracle(bands, comps, ddata, tcmb=T).chisq(ddata.pol_type[0], ddata.pol_type[-1], ddata.nump)
+    assert abs(ddata.chisq - ref) <= 1e-10 * abs(ref), (ddata.chisq, ref)
+    assert eng.chisq_cached(1, 1, 1) is None                 # invalidated by dangx_set_tcmb
 
 
 def test_gibbs_iterations_with_a_fitted_template(built):
