@@ -37,7 +37,7 @@ def hip_sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(ROOT, "include", "dangx.h")]
 
 
-UNITS = [("dangx_core", "dangx_core.hip", []), ("dangx_amp", "dangx_amp.hip", []), ("dangx_mixed", "dangx_mixed.hip", []), ("dangx_schur", "dangx_schur.hip", []),
+UNITS = [("dangx_core", "dangx_core.hip", []), ("dangx_amp", "dangx_amp.hip", []), ("dangx_ampreg", "dangx_ampreg.hip", []), ("dangx_mixed", "dangx_mixed.hip", []), ("dangx_schur", "dangx_schur.hip", []),
          ("dangx_mh", "dangx_mh.hip", []),
          ("dangx_mhreg", "dangx_mhreg.hip", [])] + \
         [("dangx_mhreg_m%d" % m, "dangx_mhreg.hip", ["-DDX_REG_MODE=%d" % m]) for m in (1, 2, 3, 4, 5)]

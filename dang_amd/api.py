@@ -314,10 +314,11 @@ class Engine:
         return it.value, bad.value
 
     def schur_info(self):
-        """(largest relative global-row residual, refinement steps) of the last direct solve of a template group."""
-        r, n = C.c_double(0.0), C.c_int(0)
-        self._chk(self.lib.dangx_schur_info(self.h, C.byref(r), C.byref(n)))
-        return r.value, n.value
+        """((global-row residual relative to b, relative to the size of the row's terms), refinement steps) of the last
+        direct solve of a template group."""
+        r, n = (C.c_double * 2)(), C.c_int(0)
+        self._chk(self.lib.dangx_schur_info(self.h, r, C.byref(n)))
+        return (r[0], r[1]), n.value
 
     def amp_residual(self, group, flag, ml_mode, seed, stream):
         """(|b - A x| / |b|, largest relative global-row residual) of the reference's system at the current amplitudes."""

@@ -352,7 +352,12 @@ struct LaunchSv {
 
 }  // namespace
 
-int dx_launch_amp(dangx_ctx* ctx, const GroupArgs& a, long long SN) { return dispatch_ng<LaunchAmp>(ctx, a.ng, a, SN); }
+int dx_launch_amp(dangx_ctx* ctx, const GroupArgs& a, long long SN) {
+    // DANGX_AMP_FORM=lds forces the LDS-column kernel (same-box A/B timing, tools/ab_bench.sh)
+    static const bool force_lds = [] { const char* e = std::getenv("DANGX_AMP_FORM"); return e && std::strcmp(e, "lds") == 0; }();
+    if (!force_lds && dx_launch_amp_reg(ctx, a, SN) == 0) return 0;
+    return dispatch_ng<LaunchAmp>(ctx, a.ng, a, SN);
+}
 int dx_launch_rhs(dangx_ctx* ctx, const GroupArgs& a, long long SN, double* b) { return dispatch_ng<LaunchRhs>(ctx, a.ng, a, SN, b); }
 int dx_launch_Ax(dangx_ctx* ctx, const GroupArgs& a, long long SN, const double* x, double* res, double* part) {
     return dispatch_ng<LaunchAx>(ctx, a.ng, a, SN, x, res, part);

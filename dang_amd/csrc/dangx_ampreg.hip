@@ -1,0 +1,275 @@
+// dangx_ampreg.hip -- amplitude phase, direct block solve, latency-hiding form (delta bandpasses, nothing to remove
+// from the data: the case every BASELINE configuration runs).
+//
+// Same mathematics as k_amp_direct (dangx_amp.hip): per (pixel, plane) unit the NG x NG normal equations of
+// compute_rhs / compute_Ax / compute_sample_vector (src/dang_cg_mod.f90:326-1096) are accumulated band by band and
+// solved by Cholesky.  What differs is the schedule inside one wave:
+//   * the data and rms of a tile of TB bands are loaded into registers at the top of the tile, before anything needs them;
+//   * phase A of a tile evaluates the SEDs of the components whose spectral indices vary over the sky -- the
+//     transcendental half of the kernel, which depends on the (few) index loads only -- component by component (one
+//     type switch per component, TB independent exp chains in flight) into the thread's own LDS column;
+//     components whose indices are spatially constant on the plane are rows of the block's constant table;
+//   * phase B is a fully unrolled rank-1 update per band that reads the mixing row through one (pointer, stride) pair
+//     per component -- stride 1 into the constant table (a broadcast read) or stride BLOCK into the column;
+// so the HBM latency of the 2*nb map loads is covered by phase A of the same wave instead of by other waves, and
+// the kernel needs no barrier after the table is built (a thread only ever reads the column it wrote).
+// Divisions by the rms, inside the mbb SED and in the Cholesky use v_rcp_f64 / v_rsq_f64 plus two Newton steps
+// (<= 1 ulp) instead of the IEEE division / sqrt sequences (12 / 18 fp64 instructions each).
+#include "dx_ampdata.h"
+
+namespace {
+
+// 1/x for finite normal x, <= 1 ulp (v_rcp_f64 is good to 2^-23; each Newton step squares the error)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+// 1/sqrt(x) for finite normal x > 0: Goldschmidt iteration on g ~ sqrt(x), h ~ 1/(2 sqrt(x))
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-g, h, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-g, h, 0.5);
+    h = fma(h, r, h);
+    return h + h;
+}
+
+struct AmpRegArgs {
+    signed char vslot[MAXG];  // LDS column slot of component g, -1: its SED is a row of the constant table
+    int nv;                   // components with a column
+};
+
+template <int TB>
+__device__ __forceinline__ void sed_tile(int type, const double* __restrict__ tab, int nb, int NG, int g, int j0, const Prep& p,
+                                         double* __restrict__ colg) {
+    const double* lnr = tab + (TROWS * g) * nb + j0;
+    const double* cst = lnr + nb;
+    const double* lnu9 = cst + nb;
+    const double* nuc = tab + (TROWS * NG) * nb + j0;
+    switch (type) {
+    case DANGX_POWERLAW:  // src/dang_component_mod.f90:908
+#pragma unroll
+        for (int t = 0; t < TB; ++t) colg[t * BLOCK] = exp(p.p0 * lnr[t]);
+        break;
+    case DANGX_MBB: {  // :947-948, in two passes of TB chains each (bounds the registers the scheduler may spend)
+        double f[TB];
+#pragma unroll
+        for (int t = 0; t < TB; ++t) f[t] = p.p2 * fast_rcp(exp(p.p1 * nuc[t]) - 1.0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TB; ++t) colg[t * BLOCK] = f[t] * exp(p.p0 * lnr[t]);
+        break;
+    }
+    case DANGX_FREEFREE: {  // :1026-1027
+        const double rp1 = fast_rcp(p.p1);
+#pragma unroll
+        for (int t = 0; t < TB; ++t) colg[t * BLOCK] = (ff_gaunt(lnu9[t], p.p0) * rp1) * cst[t];
+        break;
+    }
+    case DANGX_LOGNORMAL: {  // :988
+        const double rp1 = fast_rcp(p.p1);
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+            const double l = (lnu9[t] - p.p2) * rp1;
+            colg[t * BLOCK] = exp(-0.5 * (l * l)) * cst[t];
+        }
+        break;
+    }
+    default:  // cmb: 1/a2t(bp), :799-800
+#pragma unroll
+        for (int t = 0; t < TB; ++t) colg[t * BLOCK] = cst[t];
+        break;
+    }
+}
+
+template <int NG, int TB>
+__global__ __launch_bounds__(BLOCK, NG <= 4 ? 3 : 2) void k_amp_reg(const Model* __restrict__ Mp, GroupArgs a, AmpRegArgs ra,
+                                                                   unsigned long long* __restrict__ not_spd) {
+    extern __shared__ double lds[];  // [constant table | columns: nv*TB rows of BLOCK]
+    const Model& M = *Mp;
+    const int npix = M.npix, nb = M.nbands, tid = threadIdx.x;
+    double* tab = lds;
+    double* col = lds + (TROWS * NG + 3) * nb + tid;
+    sed_table_build(M, tab, tid, BLOCK, a.gc, NG);
+    const long long u = (long long)blockIdx.x * BLOCK + tid;
+    const bool in_range = u < (long long)flag_nplanes(a.flag) * npix;
+    const int p = in_range ? (int)(u / npix) : 0;
+    const int i = in_range ? (int)(u - (long long)p * npix) : 0;
+    const int k = flag_map(a.flag, p);
+    const bool live = in_range && !is_masked(M.mask[i]);  // masked rows/cols are zero: x keeps its value (:695)
+
+    // ---- loads: spectral indices of the varying components, then the first tile of data / rms
+    const long long bstride = (long long)M.nmaps * npix;
+    const double* sigp = M.sig + (long long)(k - 1) * npix + i;
+    const double* rmsp = M.rms + (long long)(k - 1) * npix + i;
+    double th0[NG], th1[NG];
+    int ty[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        th0[g] = th1[g] = 0.0;
+        ty[g] = M.comp[a.gc[g]].type;
+        if (live && ra.vslot[g] >= 0) load_theta(M, M.comp[a.gc[g]], i, k, th0[g], th1[g]);
+    }
+    __syncthreads();  // constant table complete (the only barrier)
+    if (!live) return;
+
+    // ---- fluctuation term of the reference: ONE eta per unit (:258-260), no memory dependency
+    const bool sample = (a.ml_mode == DANGX_ML_SAMPLE);
+    const unsigned long long gpix = (unsigned long long)(M.pix0 + i);
+    double eta = 0.0, f0 = 0.0;
+    if (sample) {
+        double u1, u2;
+        uniform2(a.seed, a.stream, gpix, (uint32_t)k, u1, u2);
+        eta = rand_normal(0.0, 1.0, u1, u2);
+    }
+    Prep pr[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        pr[g] = Prep{0.0, 0.0, 0.0};
+        if (ra.vslot[g] >= 0) pr[g] = sed_prep(M.comp[a.gc[g]], th0[g], th1[g]);
+    }
+    double A[NG * (NG + 1) / 2], bv[NG];
+#pragma unroll
+    for (int q = 0; q < NG * (NG + 1) / 2; ++q) A[q] = 0.0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) bv[g] = 0.0;
+    const double* gain = tab + (TROWS * NG + 1) * nb;
+
+#pragma unroll 1
+    for (int j0 = 0; j0 < nb; j0 += TB) {
+        // this tile's maps: issued now, consumed by phase B -- phase A below covers their latency
+        double dcur[TB], rcur[TB];
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+            dcur[t] = sigp[(j0 + t) * bstride];
+            rcur[t] = rmsp[(j0 + t) * bstride];
+        }
+        // phase A: SEDs of the varying components for this tile -> own LDS column
+        const double* mp[NG];
+        int ms[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (ra.vslot[g] >= 0) {
+                double* colg = col + (ra.vslot[g] * TB) * BLOCK;
+                sed_tile<TB>(ty[g], tab, nb, NG, g, j0, pr[g], colg);
+                __builtin_amdgcn_sched_barrier(0);  // one component's chains at a time
+                mp[g] = colg; ms[g] = BLOCK;
+            } else {
+                mp[g] = tab + (TROWS * g + 2 + k) * nb + j0; ms[g] = 1;  // csed of plane k (sed_const_tab)
+            }
+        }
+        // phase B: rank-1 updates, band by band
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+            double d = dcur[t];
+            if (k == 1) { const double gj = gain[j0 + t]; if (gj != 1.0) d = d / gj; }  // :371
+            const double is = fast_rcp(rcur[t]);
+            const double inv = is * is;
+            double mrow[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) mrow[g] = mp[g][t * ms[g]];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const double t2 = mrow[g] * inv;
+                bv[g] += d * t2;  // b = T^t N^-1 d, :489-508
+#pragma unroll
+                for (int h = 0; h <= g; ++h) A[g * (g + 1) / 2 + h] += t2 * mrow[h];  // T^t N^-1 T
+            }
+            f0 += (eta * is) * mrow[NG - 1];  // :1033-1040: slot 0 only, the LAST component's SED product
+        }
+    }
+    bv[0] += f0;
+
+    // ---- Cholesky A = L L^t (packed lower triangle; ri[g] = 1/L_gg, the diagonal itself is never needed)
+    bool ok = true;
+    double ri[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int h = 0; h <= g; ++h) {
+            double s = A[g * (g + 1) / 2 + h];
+#pragma unroll
+            for (int t = 0; t < h; ++t) s -= A[g * (g + 1) / 2 + t] * A[h * (h + 1) / 2 + t];
+            if (h == g) {
+                if (!(s > 0.0) || !(s < 1.0e300)) ok = false;
+                ri[g] = fast_rsqrt(s);
+            } else {
+                A[g * (g + 1) / 2 + h] = s * ri[h];
+            }
+        }
+    }
+    if (!ok) {
+        atomicAdd(not_spd, 1ull);
+        return;
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        double s = bv[g];
+#pragma unroll
+        for (int t = 0; t < g; ++t) s -= A[g * (g + 1) / 2 + t] * bv[t];
+        bv[g] = s * ri[g];
+    }
+#pragma unroll
+    for (int g = NG - 1; g >= 0; --g) {
+        double s = bv[g];
+#pragma unroll
+        for (int t = g + 1; t < NG; ++t) s -= A[t * (t + 1) / 2 + g] * bv[t];
+        bv[g] = s * ri[g];
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) M.comp[a.gc[g]].amp[(long long)(k - 1) * npix + i] = bv[g];  // unpack, :1327-1354
+}
+
+template <int NG, int TB>
+int launch_tb(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, long long SN) {
+    const int nb = ctx->hm.nbands;
+    const size_t ldsz = ((size_t)(TROWS * NG + 3) * nb + (size_t)ra.nv * TB * BLOCK) * sizeof(double);
+    if (ldsz > 64 * 1024) return -1;  // fewer than two blocks per CU: the LDS-column kernel is the better fit
+    Timed t(ctx, DANGX_K_AMP_DIRECT);
+    hipLaunchKernelGGL((k_amp_reg<NG, TB>), dim3(nblocks(SN)), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, ctx->counters);
+    return 0;
+}
+
+template <int NG>
+int launch_ng(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, long long SN) {
+    const int nb = ctx->hm.nbands;
+    if (nb % 5 == 0) return launch_tb<NG, 5>(ctx, a, ra, SN);
+    if (nb % 4 == 0) return launch_tb<NG, 4>(ctx, a, ra, SN);
+    if (nb % 3 == 0) return launch_tb<NG, 3>(ctx, a, ra, SN);
+    return -1;
+}
+
+}  // namespace
+
+// returns 0 when launched, -1 when this form does not cover the case (the caller falls back to k_amp_direct)
+int dx_launch_amp_reg(dangx_ctx* ctx, const GroupArgs& a, long long SN) {
+    if (!ctx->hm.all_delta || a.no != 0 || a.nuc != 0 || a.nt != 0) return -1;
+    // the textbook fluctuation term (one normal per band) stays with k_amp_direct: a Philox call per band does not fit
+    // the unrolled phase B without spilling
+    if (a.ml_mode == DANGX_ML_SAMPLE && a.fluct != DANGX_FLUCT_REFERENCE) return -1;
+    AmpRegArgs ra;
+    ra.nv = 0;
+    unsigned planes = 0;
+    for (int pl = 0; pl < flag_planes_h(a.flag); ++pl)
+        planes |= 1u << (((a.flag & DANGX_FLAG_QU) ? 2 + pl : (a.flag & DANGX_FLAG_T) ? 1 : (a.flag & DANGX_FLAG_Q) ? 2 : 3) - 1);
+    for (int g = 0; g < MAXG; ++g) ra.vslot[g] = -1;
+    for (int g = 0; g < a.ng; ++g) {
+        const Comp& c = ctx->hm.comp[a.gc[g]];
+        if (c.type < DANGX_POWERLAW || c.type > DANGX_CMB) return -1;
+        // constant on EVERY plane of this launch -> a table row; otherwise evaluated per unit
+        if (((unsigned)c.const_planes & planes) != planes) ra.vslot[g] = (signed char)ra.nv++;
+    }
+    switch (a.ng) {
+    case 1: return launch_ng<1>(ctx, a, ra, SN);
+    case 2: return launch_ng<2>(ctx, a, ra, SN);
+    case 3: return launch_ng<3>(ctx, a, ra, SN);
+    case 4: return launch_ng<4>(ctx, a, ra, SN);
+    case 5: return launch_ng<5>(ctx, a, ra, SN);
+    case 6: return launch_ng<6>(ctx, a, ra, SN);
+    default: return -1;
+    }
+}

@@ -1065,19 +1065,20 @@ int device_schur(dangx_ctx* ctx, const GroupArgs& a, long long SN, int64_t* n_no
     // cond(S) * (relative error of S); the loop stops at 1e-12 of the row of b, or when a step no longer helps.
     ctx->schur_refine = 0;
     double prev = INFINITY;
-    std::vector<double> rr(2 * R), res(R);
+    std::vector<double> rr(3 * R), res(R);
     for (int step = 0; step <= 4; ++step) {
         if (dx_launch_schur_resid(ctx, a, sa, SN, ctx->work[0])) return 1;
-        HIPCHK(ctx, hipMemcpyAsync(rr.data(), ctx->work[0], sizeof(double) * 2 * R, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(rr.data(), ctx->work[0], sizeof(double) * 3 * R, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        if (rank_sum(ctx, rr.data(), 2 * R)) return 1;
-        double worst = 0.0;
+        if (rank_sum(ctx, rr.data(), 3 * R)) return 1;
+        double worst = 0.0, worst_bw = 0.0;
         for (int r = 0; r < R; ++r) {
             res[r] = rr[r] + fl[r];
             const double brow = std::fabs(rr[R + r] + fl[r]);
             // rows along a free (degenerate) direction cannot be reduced by the global amplitudes alone; they are
             // consistent through the diffuse members, so their residual is reported like any other
             worst = std::max(worst, std::fabs(res[r]) / std::max(brow, 1e-300));
+            worst_bw = std::max(worst_bw, std::fabs(res[r]) / std::max(rr[2 * R + r] + std::fabs(fl[r]), 1e-300));
         }
         if (step > 0 && !(worst < prev)) {  // the last correction did not help: take it back
             for (int r = 0; r < R; ++r) g[r] -= d[r];
@@ -1087,7 +1088,8 @@ int device_schur(dangx_ctx* ctx, const GroupArgs& a, long long SN, int64_t* n_no
             break;
         }
         ctx->schur_resid = prev = worst;
-        if (worst <= 1e-12 || step == 4) break;
+        ctx->schur_backward = worst_bw;
+        if (worst <= 1e-12 || worst_bw <= 1e-15 || step == 4) break;
         lu_solve(res, d);
         for (int r = 0; r < R; ++r) g[r] += d[r];
         x_to_globals(ctx, a, g);
@@ -1468,7 +1470,7 @@ int dangx_amp_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solve
 
 int dangx_schur_info(dangx_ctx* ctx, double* rel_residual, int* refinements) {
     if (!ctx) return 1;
-    if (rel_residual) *rel_residual = ctx->schur_resid;
+    if (rel_residual) { rel_residual[0] = ctx->schur_resid; rel_residual[1] = ctx->schur_backward; }
     if (refinements) *refinements = ctx->schur_refine;
     return 0;
 }

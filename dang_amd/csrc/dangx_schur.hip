@@ -209,6 +209,7 @@ __global__ __launch_bounds__(BLOCK) void k_schur_pass2(const Model* __restrict__
 //   rows [0, R):  sum_u ( d_j s_r / sigma_j^2  -  w_r * (sum_g a_g M_gj + sum_t' g_t' s_t') / sigma_j^2 )   (b - A x, without
 //                 the fluctuation term, which the host adds from pass 1's sums)
 //   rows [R, 2R): sum_u d_j s_r / sigma_j^2                                                                  (the row of b)
+//   rows [2R,3R): sum_u ( |d_j s_r| + |w_r model| ) / sigma_j^2       (size of the terms that cancel: the rounding floor)
 // for row r = (global member t_r, band j = rj[r]); d_j is compute_rhs's data (src/dang_cg_mod.f90:367-460), the row weight
 // w_r is 1 for a monopole (:857) and s_r otherwise, as in k_rhs_mixed / k_Ax_mixed.
 template <int NG>
@@ -272,6 +273,7 @@ __global__ __launch_bounds__(BLOCK) void k_schur_resid(const Model* __restrict__
             const double bterm = on ? d * inv * st[t] : 0.0;
             block_row_sum(on ? bterm - w * (model * inv) : 0.0, r, rowpartial, sh);
             block_row_sum(bterm, R + r, rowpartial, sh);
+            block_row_sum(on ? fabs(bterm) + fabs(w * (model * inv)) : 0.0, 2 * R + r, rowpartial, sh);
         }
     }
 }
@@ -281,7 +283,7 @@ struct LaunchSchur {
     static int run(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs* sa, long long SN, double* rows_dev, bool resid = false) {
         const unsigned nblk = nblocks(SN);
         if (sa && resid) {
-            const int nrows = 2 * sa->nrows;
+            const int nrows = 3 * sa->nrows;
             if (ensure_partial(ctx, (long long)nrows * nblk)) return 1;
             hipLaunchKernelGGL(k_schur_resid<NG>, dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->dm, a, *sa, ctx->partial);
             dx_reduce_rows_to(ctx, ctx->partial, nblk, nrows, rows_dev);

@@ -110,7 +110,7 @@ struct dangx_ctx {
     long long work_cap = 0;
     // last DANGX_SOLVER_DIRECT solve of a group with global-amplitude members: largest |b - A x| of a global row relative
     // to that row of b after the last refinement, and the number of refinement steps taken
-    double schur_resid = 0.0;
+    double schur_resid = 0.0, schur_backward = 0.0;  // relative to the row of b / to the size of the row's terms
     int schur_refine = 0;
     // profiling
     bool prof = false;
@@ -176,6 +176,8 @@ void dx_reduce_rows_to(dangx_ctx* ctx, const double* partial, unsigned nblk, int
 
 // launchers defined next to their kernels
 int dx_launch_amp(dangx_ctx* ctx, const GroupArgs& a, long long SN);
+// latency-hiding form of the direct solve (dangx_ampreg.hip): 0 = launched, -1 = case not covered
+int dx_launch_amp_reg(dangx_ctx* ctx, const GroupArgs& a, long long SN);
 int dx_launch_rhs(dangx_ctx* ctx, const GroupArgs& a, long long SN, double* b);
 int dx_launch_Ax(dangx_ctx* ctx, const GroupArgs& a, long long SN, const double* x, double* res, double* part);
 int dx_launch_sample_vector(dangx_ctx* ctx, const GroupArgs& a, long long SN, const double* eta, double* res);

@@ -110,7 +110,7 @@ module dangx_mod
      integer(c_int) function dangx_schur_info(ctx, rel_residual, refinements) bind(C, name='dangx_schur_info')
        import :: c_int, c_ptr, c_double
        type(c_ptr), value :: ctx
-       real(c_double), intent(out) :: rel_residual
+       real(c_double), intent(out) :: rel_residual(2)
        integer(c_int), intent(out) :: refinements
      end function
      integer(c_int) function dangx_amp_residual(ctx, group, flag, ml_mode, seed, stream, out) bind(C, name='dangx_amp_residual')

@@ -161,11 +161,13 @@ int dangx_amp_sample(dangx_ctx *ctx, int group, int flag, int ml_mode, int solve
                      uint64_t seed, uint64_t stream, int i_max, double converge,
                      int *cg_iters, int64_t *n_not_spd);
 
-/* Accuracy of the last DANGX_SOLVER_DIRECT solve of a group with template / monopole / hi_fit members: the largest
- * |b - A x| over the global rows relative to that row of b (b, A: the system of compute_rhs / compute_sample_vector /
- * compute_Ax, src/dang_cg_mod.f90:326-1096), measured directly at the new state after the last step of iterative
- * refinement, and the number of refinement steps the solve took (0: the first solution already met 1e-12). */
-int dangx_schur_info(dangx_ctx *ctx, double *rel_residual, int *refinements);
+/* Accuracy of the last DANGX_SOLVER_DIRECT solve of a group with template / monopole / hi_fit members, measured
+ * directly at the new state after the last step of iterative refinement (b, A: the system of compute_rhs /
+ * compute_sample_vector / compute_Ax, src/dang_cg_mod.f90:326-1096): rel_residual[0] = the largest |b - A x| over the
+ * global rows relative to that row of b; rel_residual[1] = the same relative to the size of the row's terms
+ * (sum |b terms| + |A x terms|: rounding alone leaves ~1e-16 sqrt(npix) there, and weakly constrained amplitudes are
+ * large, so [0] can sit well above [1]); refinements = steps taken (0: the first solution already met 1e-12). */
+int dangx_schur_info(dangx_ctx *ctx, double *rel_residual /*[2]*/, int *refinements);
 /* Residual of the reference's linear system at the CURRENT amplitudes, through the reference's own operators
  * (dangx_compute_rhs + dangx_compute_sample_vector(eta(seed, stream)) - dangx_compute_Ax(x), vectors kept on the device):
  * out[0] = |b - A x|_2 / |b|_2 over the rows of unmasked units and the global rows, out[1] = the largest global-row

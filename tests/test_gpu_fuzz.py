@@ -3,6 +3,8 @@ prior types, step sizes, tight/wide hard bounds, NUMSAMPLE, sample/optimize, som
 through one amplitude pass + one sweep of every sampled index on the GPU and in the oracle.  The configurations
 are drawn from a fixed seed, so the test is deterministic; it exists to reach kernel-dispatch combinations the
 hand-written cases do not (register-resident / LDS / bandpass / generic chains, group sizes, plane counts)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -32,7 +34,7 @@ def _draw(seed):
     return cfg
 
 
-@pytest.mark.parametrize("seed", range(64))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DANGX_FUZZ_SEEDS", "64"))))
 def test_random_configuration_matches_oracle(built, seed):
     cfg = _draw(seed)
     if cfg["lnl"] == "marginal" and cfg["ml_mode"] == "optimize":
@@ -100,7 +102,7 @@ def _packed(eng, comps, group, flag, nbands):
     return np.concatenate(parts + [np.asarray(rows, dtype=np.float64)])
 
 
-@pytest.mark.parametrize("seed", range(32))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DANGX_FUZZ_SEEDS", "32"))))
 def test_random_template_group_direct_solve(built, seed):
     """Schur-complement solve of groups with global-amplitude members over random models: the answer satisfies the
     reference's linear system (through the oracle's compute_Ax / compute_rhs / compute_sample_vector)."""
@@ -129,15 +131,24 @@ def test_random_template_group_direct_solve(built, seed):
     assert x.size == eng.group_size(group, flag) and np.isfinite(x).all()
     Ax = orc.compute_Ax(group, flag, x)
     # row-wise: relative to the row's right-hand side, with a floor tied to the largest one (a template's entries have
-    # both signs, so A|x| is no bound on the size of the terms that cancel in a row)
-    # (a fitted monopole is nearly degenerate with the mean of the diffuse components: the Schur system then keeps only
-    # a few digits -- the solve measures the true residual of the global rows and refines until it is at rounding level)
-    tol = 1e-7 * np.abs(b) + 1e-9 * np.abs(b).max()
-    resid, nref = eng.schur_info()
-    assert np.all(np.abs(Ax - b) <= tol), (seed, which, fit, comps_l, it, (np.abs(Ax - b) / tol).max(), resid, nref)
-    # the library's own account of the solve agrees with the oracle's operators
+    # both signs, so A|x| is no bound on the size of the terms that cancel in a row).  The GLOBAL rows additionally get
+    # the rounding floor of their own terms, 16 eps (|A||x|)_row: a monopole fitted beside a pixel-independent SED is
+    # nearly degenerate with the diffuse members, the system is then numerically singular (cond ~ 1e18, amplitudes
+    # ~1e11) and NO fp64 solver can push those rows below eps |A||x| -- LAPACK's dense solve of the same system leaves
+    # the same residual (tests/test_oracle_templates_cpu.py::test_near_singular_monopole_system_rounding_floor).
     R = sum(c.nfit for c in comps if c.cg_group == group and c.type in ("template", "monopole", "hi_fit"))
+    mag = np.zeros(x.size)
+    for i in np.nonzero(x)[0]:
+        e = np.zeros(x.size)
+        e[i] = 1.0
+        mag[-R:] += np.abs(orc.compute_Ax(group, flag, e)[-R:]) * abs(x[i])
+    tol = 1e-7 * np.abs(b) + 1e-9 * np.abs(b).max() + 16 * np.finfo(float).eps * mag
+    (resid, backward), nref = eng.schur_info()
+    assert np.all(np.abs(Ax - b) <= tol), (seed, which, fit, comps_l, it, (np.abs(Ax - b) / tol).max(), resid, backward, nref)
+    # the library's own account of the solve: relative to the size of the rows' terms the residual is at rounding level;
+    # relative to b it is what the conditioning leaves, and the oracle's operators see the same order of magnitude
     worst = (np.abs(Ax - b)[-R:] / np.maximum(np.abs(b)[-R:], 1e-300)).max()
-    assert resid <= 1e-9 and worst <= 1e-8, (seed, which, resid, worst, nref)
+    assert backward <= 1e-10, (seed, which, resid, backward, nref)
+    assert resid <= 100 * worst + 1e-9 and worst <= 100 * resid + 1e-9, (seed, which, resid, worst, nref)
     rel, relg = eng.amp_residual(group, flag, ml_mode, 8, 9)
-    assert rel <= 1e-9 and relg <= 1e-8, (seed, which, rel, relg)
+    assert relg <= 100 * worst + 1e-9 and rel <= 1e-6, (seed, which, rel, relg, worst)

@@ -173,3 +173,49 @@ def test_direct_block_solve_equals_the_converged_cg_over_random_models():
             for l, c in enumerate(comps):
                 if c.cg_group == group and c.type in ("power-law", "mbb", "freefree", "cmb"):
                     assert relmax(o1.amplitude(l), o2.amplitude(l)) <= 1e-7, (seed, group, l, comps_l, extra)
+
+
+def test_near_singular_monopole_system_rounding_floor():
+    """Why the direct solve's residual is judged against eps*|A||x| and not against |b| alone: a monopole and the HI
+    fit both fitted at bands 0 and 1 beside synchrotron + free-free + CMB (fuzz seed 288 of tests/test_gpu_fuzz.py, 48
+    pixels) give a system of condition number ~1e18 whose solution carries amplitudes ~1e11.  LAPACK's dense solve of
+    that system -- and that solve refined with extended-precision residuals -- leaves |A x - b| of 1e-6..1e-5 |b| on the
+    HI rows: the terms of those rows are ~1e21, and eps * 1e21 is the floor of ANY fp64 solver."""
+    rng = np.random.default_rng(5000 + 288)
+    nb = int(rng.choice([4, 5, 6, 8]))
+    pool = ["cmb", "synch", "dust", "ff"]
+    comps_l = ["synch"] + list(rng.permutation([p for p in pool if p != "synch"])[: int(rng.integers(0, min(3, nb - 3) + 1))])
+    pol = bool(rng.integers(0, 2))
+    which = ("template",) if pol else tuple(rng.permutation(["monopole", "hi_fit"])[: int(rng.integers(1, 3))])
+    assert not pol and set(which) == {"monopole", "hi_fit"}
+    fit = sorted(rng.choice(nb, size=int(rng.integers(1, 3)), replace=False).tolist())
+    ml_mode = str(rng.choice(["sample", "optimize"]))
+
+    def tweak(dpar, ddata, bands, comps):
+        add_globals(dpar, ddata, bands, comps, which, 1, fit_bands=fit)
+    case = make_case(None, nside=int(rng.choice([2, 4])), nbands=nb, comps=comps_l, nmaps=3, tweak=tweak, start="truth")
+    dpar, ddata, bands, comps, meta = case
+    orc = O.Oracle(bands, comps, ddata)
+    n = orc.group_size(1, L.FLAG_T)
+    b = orc.compute_rhs(1, L.FLAG_T)
+    if ml_mode == "sample":
+        b = b + orc.compute_sample_vector(1, L.FLAG_T, orc.draw_eta(L.FLAG_T, 8, 9))
+    A = np.zeros((n, n))
+    for i in range(n):
+        e = np.zeros(n)
+        e[i] = 1.0
+        A[:, i] = orc.compute_Ax(1, L.FLAG_T, e)
+    live = np.abs(A).sum(1) > 0                      # rows / columns of masked pixels are zero
+    A, b = A[np.ix_(live, live)], b[live]
+    assert np.linalg.cond(A) > 1e16
+    x = np.linalg.solve(A, b)
+    xl = x.astype(np.longdouble)
+    for _ in range(3):                               # iterative refinement with extended-precision residuals
+        xl = xl + np.linalg.solve(A, (b.astype(np.longdouble) - A.astype(np.longdouble) @ xl).astype(np.float64))
+    eps = np.finfo(float).eps
+    for sol in (x, xl.astype(np.float64)):
+        r = np.abs(A @ sol - b)
+        mag = np.abs(A) @ np.abs(sol)
+        assert np.abs(sol).max() > 1e10
+        assert (r[-4:] / np.abs(b[-4:])).max() > 1e-7          # far above 1e-7 |b| ...
+        assert np.all(r <= 16 * eps * mag + 1e-9 * np.abs(b).max())   # ... and at the rounding floor of the rows' terms
