@@ -38,11 +38,24 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     return h + h;
 }
 
+// Map pointers come out of the Model block as generic pointers, which the compiler can only load through FLAT
+// instructions -- and a FLAT load counts on lgkmcnt as well as vmcnt, so every wait for an LDS read (the constant table,
+// the SED columns) would also wait for all map loads in flight.  Viewed through the global address space they are
+// global_load instructions (vmcnt only) and phase A really runs under the map loads.
+typedef const double __attribute__((address_space(1)))* gcptr;
+typedef double __attribute__((address_space(1)))* gptr;
+__device__ __forceinline__ gcptr as_global(const double* p) { return reinterpret_cast<gcptr>(reinterpret_cast<uintptr_t>(p)); }
+__device__ __forceinline__ gptr as_global_w(double* p) { return reinterpret_cast<gptr>(reinterpret_cast<uintptr_t>(p)); }
+
 struct AmpRegArgs {
-    signed char vslot[MAXG];  // LDS column slot of component g, -1: its SED is a row of the constant table
-    int nv;                   // components with a column
+    signed char vslot[MAXG];  // LDS column slot of group member g, -1: its SED is a row of the constant table
+    signed char vcomp[MAXG];  // group member of slot v
+    signed char vtype[MAXG];  // its component type
+    int nv;                   // members with a column
 };
 
+// SEDs of one varying component for the TB bands of a tile -> its LDS column.  Same expressions as sed_eval_tab
+// (dx_sed.h); the per-pixel state p comes from sed_prep.
 template <int TB>
 __device__ __forceinline__ void sed_tile(int type, const double* __restrict__ tab, int nb, int NG, int g, int j0, const Prep& p,
                                          double* __restrict__ colg) {
@@ -53,21 +66,21 @@ __device__ __forceinline__ void sed_tile(int type, const double* __restrict__ ta
     switch (type) {
     case DANGX_POWERLAW:  // src/dang_component_mod.f90:908
 #pragma unroll
-        for (int t = 0; t < TB; ++t) colg[t * BLOCK] = exp(p.p0 * lnr[t]);
+        for (int t = 0; t < TB; ++t) { colg[t * BLOCK] = exp(p.p0 * lnr[t]); }
         break;
     case DANGX_MBB: {  // :947-948, in two passes of TB chains each (bounds the registers the scheduler may spend)
         double f[TB];
 #pragma unroll
-        for (int t = 0; t < TB; ++t) f[t] = p.p2 * fast_rcp(exp(p.p1 * nuc[t]) - 1.0);
+        for (int t = 0; t < TB; ++t) { f[t] = p.p2 * fast_rcp(exp(p.p1 * nuc[t]) - 1.0); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < TB; ++t) colg[t * BLOCK] = f[t] * exp(p.p0 * lnr[t]);
+        for (int t = 0; t < TB; ++t) { colg[t * BLOCK] = f[t] * exp(p.p0 * lnr[t]); }
         break;
     }
     case DANGX_FREEFREE: {  // :1026-1027
         const double rp1 = fast_rcp(p.p1);
 #pragma unroll
-        for (int t = 0; t < TB; ++t) colg[t * BLOCK] = (ff_gaunt(lnu9[t], p.p0) * rp1) * cst[t];
+        for (int t = 0; t < TB; ++t) { colg[t * BLOCK] = (ff_gaunt(lnu9[t], p.p0) * rp1) * cst[t]; }
         break;
     }
     case DANGX_LOGNORMAL: {  // :988
@@ -76,6 +89,7 @@ __device__ __forceinline__ void sed_tile(int type, const double* __restrict__ ta
         for (int t = 0; t < TB; ++t) {
             const double l = (lnu9[t] - p.p2) * rp1;
             colg[t * BLOCK] = exp(-0.5 * (l * l)) * cst[t];
+           
         }
         break;
     }
@@ -87,34 +101,38 @@ __device__ __forceinline__ void sed_tile(int type, const double* __restrict__ ta
 }
 
 template <int NG, int TB>
-__global__ __launch_bounds__(BLOCK, NG <= 4 ? 3 : 2) void k_amp_reg(const Model* __restrict__ Mp, GroupArgs a, AmpRegArgs ra,
+__global__ __launch_bounds__(BLOCK, NG <= 4 ? 4 : 3) void k_amp_reg(const Model* __restrict__ Mp, GroupArgs a, AmpRegArgs ra,
                                                                    unsigned long long* __restrict__ not_spd) {
-    extern __shared__ double lds[];  // [constant table | columns: nv*TB rows of BLOCK]
+    extern __shared__ double lds[];  // [constant table | per-thread columns: 3*nv rows of sed_prep state, nv*TB rows of SEDs]
     const Model& M = *Mp;
     const int npix = M.npix, nb = M.nbands, tid = threadIdx.x;
     double* tab = lds;
-    double* col = lds + (TROWS * NG + 3) * nb + tid;
+    double* prl = lds + (TROWS * NG + 3) * nb + tid;  // row (3*v + q): sed_prep value q of the v-th varying member
+    double* col = prl + 3 * ra.nv * BLOCK;            // row (v*TB + t): its SED at band j0 + t
     sed_table_build(M, tab, tid, BLOCK, a.gc, NG);
     const long long u = (long long)blockIdx.x * BLOCK + tid;
     const bool in_range = u < (long long)flag_nplanes(a.flag) * npix;
     const int p = in_range ? (int)(u / npix) : 0;
     const int i = in_range ? (int)(u - (long long)p * npix) : 0;
     const int k = flag_map(a.flag, p);
-    const bool live = in_range && !is_masked(M.mask[i]);  // masked rows/cols are zero: x keeps its value (:695)
+    const bool live = in_range && !is_masked(as_global(M.mask)[i]);  // masked rows/cols are zero: x keeps its value (:695)
 
-    // ---- loads: spectral indices of the varying components, then the first tile of data / rms
-    const long long bstride = (long long)M.nmaps * npix;
-    const double* sigp = M.sig + (long long)(k - 1) * npix + i;
-    const double* rmsp = M.rms + (long long)(k - 1) * npix + i;
-    double th0[NG], th1[NG];
-    int ty[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        th0[g] = th1[g] = 0.0;
-        ty[g] = M.comp[a.gc[g]].type;
-        if (live && ra.vslot[g] >= 0) load_theta(M, M.comp[a.gc[g]], i, k, th0[g], th1[g]);
+    // ---- per-pixel SED state of the varying members (ONE copy of the code: the loop over members is not unrolled, which
+    // keeps the scalar registers free for the polynomial coefficients of exp)
+    if (live) {
+#pragma unroll 1
+        for (int v = 0; v < ra.nv; ++v) {
+            const Comp& c = M.comp[a.gc[ra.vcomp[v]]];
+            const gcptr ix = as_global(c.idx) + (long long)(k - 1) * npix + i;   // c%indices(i,k,:), as load_theta
+            const double t0 = (c.nind > 0) ? ix[0] : 0.0;
+            const double t1 = (c.nind > 1) ? ix[(long long)M.nmaps * npix] : 0.0;
+            const Prep pr = sed_prep(c, t0, t1);
+            prl[(3 * v + 0) * BLOCK] = pr.p0;
+            prl[(3 * v + 1) * BLOCK] = pr.p1;
+            prl[(3 * v + 2) * BLOCK] = pr.p2;
+        }
     }
-    __syncthreads();  // constant table complete (the only barrier)
+    __syncthreads();  // constant table complete (the only barrier; a thread only ever reads the columns it wrote)
     if (!live) return;
 
     // ---- fluctuation term of the reference: ONE eta per unit (:258-260), no memory dependency
@@ -126,18 +144,15 @@ __global__ __launch_bounds__(BLOCK, NG <= 4 ? 3 : 2) void k_amp_reg(const Model*
         uniform2(a.seed, a.stream, gpix, (uint32_t)k, u1, u2);
         eta = rand_normal(0.0, 1.0, u1, u2);
     }
-    Prep pr[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        pr[g] = Prep{0.0, 0.0, 0.0};
-        if (ra.vslot[g] >= 0) pr[g] = sed_prep(M.comp[a.gc[g]], th0[g], th1[g]);
-    }
     double A[NG * (NG + 1) / 2], bv[NG];
 #pragma unroll
     for (int q = 0; q < NG * (NG + 1) / 2; ++q) A[q] = 0.0;
 #pragma unroll
     for (int g = 0; g < NG; ++g) bv[g] = 0.0;
     const double* gain = tab + (TROWS * NG + 1) * nb;
+    const long long bstride = (long long)M.nmaps * npix;
+    const gcptr sigp = as_global(M.sig) + (long long)(k - 1) * npix + i;
+    const gcptr rmsp = as_global(M.rms) + (long long)(k - 1) * npix + i;
 
 #pragma unroll 1
     for (int j0 = 0; j0 < nb; j0 += TB) {
@@ -148,21 +163,21 @@ __global__ __launch_bounds__(BLOCK, NG <= 4 ? 3 : 2) void k_amp_reg(const Model*
             dcur[t] = sigp[(j0 + t) * bstride];
             rcur[t] = rmsp[(j0 + t) * bstride];
         }
-        // phase A: SEDs of the varying components for this tile -> own LDS column
+        // phase A: SEDs of the varying members for this tile -> own LDS columns
+#pragma unroll 1
+        for (int v = 0; v < ra.nv; ++v) {
+            const Prep pr = {prl[(3 * v + 0) * BLOCK], prl[(3 * v + 1) * BLOCK], prl[(3 * v + 2) * BLOCK]};
+            sed_tile<TB>(ra.vtype[v], tab, nb, NG, ra.vcomp[v], j0, pr, col + (v * TB) * BLOCK);
+        }
+        // phase B: rank-1 updates, band by band; the mixing row through one (pointer, stride) pair per member
         const double* mp[NG];
         int ms[NG];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            if (ra.vslot[g] >= 0) {
-                double* colg = col + (ra.vslot[g] * TB) * BLOCK;
-                sed_tile<TB>(ty[g], tab, nb, NG, g, j0, pr[g], colg);
-                __builtin_amdgcn_sched_barrier(0);  // one component's chains at a time
-                mp[g] = colg; ms[g] = BLOCK;
-            } else {
-                mp[g] = tab + (TROWS * g + 2 + k) * nb + j0; ms[g] = 1;  // csed of plane k (sed_const_tab)
-            }
+            const bool var = ra.vslot[g] >= 0;
+            mp[g] = var ? col + (ra.vslot[g] * TB) * BLOCK : tab + (TROWS * g + 2 + k) * nb + j0;  // else csed of plane k
+            ms[g] = var ? BLOCK : 1;
         }
-        // phase B: rank-1 updates, band by band
 #pragma unroll
         for (int t = 0; t < TB; ++t) {
             double d = dcur[t];
@@ -221,26 +236,32 @@ __global__ __launch_bounds__(BLOCK, NG <= 4 ? 3 : 2) void k_amp_reg(const Model*
         bv[g] = s * ri[g];
     }
 #pragma unroll
-    for (int g = 0; g < NG; ++g) M.comp[a.gc[g]].amp[(long long)(k - 1) * npix + i] = bv[g];  // unpack, :1327-1354
+    for (int g = 0; g < NG; ++g) as_global_w(M.comp[a.gc[g]].amp)[(long long)(k - 1) * npix + i] = bv[g];  // unpack, :1327-1354
 }
+
+template <int TB>
+size_t amp_reg_lds(int NG, int nb, int nv) { return ((size_t)(TROWS * NG + 3) * nb + (size_t)nv * (TB + 3) * BLOCK) * sizeof(double); }
 
 template <int NG, int TB>
 int launch_tb(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, long long SN) {
-    const int nb = ctx->hm.nbands;
-    const size_t ldsz = ((size_t)(TROWS * NG + 3) * nb + (size_t)ra.nv * TB * BLOCK) * sizeof(double);
-    if (ldsz > 64 * 1024) return -1;  // fewer than two blocks per CU: the LDS-column kernel is the better fit
+    const size_t ldsz = amp_reg_lds<TB>(NG, ctx->hm.nbands, ra.nv);
     Timed t(ctx, DANGX_K_AMP_DIRECT);
     hipLaunchKernelGGL((k_amp_reg<NG, TB>), dim3(nblocks(SN)), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, ctx->counters);
     return 0;
 }
 
+// band tile: the largest of 5 / 4 / 3 dividing nb whose LDS footprint lets as many blocks stay resident as the
+// registers allow (4 for NG <= 4, else 3); failing that the largest that leaves two blocks per CU
 template <int NG>
 int launch_ng(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, long long SN) {
     const int nb = ctx->hm.nbands;
-    if (nb % 5 == 0) return launch_tb<NG, 5>(ctx, a, ra, SN);
-    if (nb % 4 == 0) return launch_tb<NG, 4>(ctx, a, ra, SN);
-    if (nb % 3 == 0) return launch_tb<NG, 3>(ctx, a, ra, SN);
-    return -1;
+    const size_t want = (160u * 1024u) / (NG <= 4 ? 4 : 3), most = 80u * 1024u;
+    for (const size_t cap : {want, most}) {
+        if (nb % 5 == 0 && amp_reg_lds<5>(NG, nb, ra.nv) <= cap) return launch_tb<NG, 5>(ctx, a, ra, SN);
+        if (nb % 4 == 0 && amp_reg_lds<4>(NG, nb, ra.nv) <= cap) return launch_tb<NG, 4>(ctx, a, ra, SN);
+        if (nb % 3 == 0 && amp_reg_lds<3>(NG, nb, ra.nv) <= cap) return launch_tb<NG, 3>(ctx, a, ra, SN);
+    }
+    return -1;  // the LDS-column kernel is the better fit
 }
 
 }  // namespace
@@ -256,12 +277,15 @@ int dx_launch_amp_reg(dangx_ctx* ctx, const GroupArgs& a, long long SN) {
     unsigned planes = 0;
     for (int pl = 0; pl < flag_planes_h(a.flag); ++pl)
         planes |= 1u << (((a.flag & DANGX_FLAG_QU) ? 2 + pl : (a.flag & DANGX_FLAG_T) ? 1 : (a.flag & DANGX_FLAG_Q) ? 2 : 3) - 1);
-    for (int g = 0; g < MAXG; ++g) ra.vslot[g] = -1;
+    for (int g = 0; g < MAXG; ++g) { ra.vslot[g] = -1; ra.vcomp[g] = 0; ra.vtype[g] = 0; }
     for (int g = 0; g < a.ng; ++g) {
         const Comp& c = ctx->hm.comp[a.gc[g]];
         if (c.type < DANGX_POWERLAW || c.type > DANGX_CMB) return -1;
         // constant on EVERY plane of this launch -> a table row; otherwise evaluated per unit
-        if (((unsigned)c.const_planes & planes) != planes) ra.vslot[g] = (signed char)ra.nv++;
+        if (((unsigned)c.const_planes & planes) != planes) {
+            ra.vcomp[ra.nv] = (signed char)g; ra.vtype[ra.nv] = (signed char)c.type;
+            ra.vslot[g] = (signed char)ra.nv++;
+        }
     }
     switch (a.ng) {
     case 1: return launch_ng<1>(ctx, a, ra, SN);
