@@ -86,7 +86,7 @@ def build_fortran(force=False):
     if not os.path.exists(FLANG) or not os.path.isdir(FORTRAN_DIR):
         return None
     exe = os.path.join(FORTRAN_DIR, "dangx_fsmoke")
-    src = [os.path.join(FORTRAN_DIR, f) for f in ("dangx_mod.f90", "dangx_fsmoke.f90")]
+    src = [os.path.join(FORTRAN_DIR, f) for f in ("dangx_mod.f90", "dangx_multi_mod.f90", "dangx_fsmoke.f90")]
     if not all(os.path.exists(s) for s in src):
         return None
     if not force and not _newer(exe, src + [LIB]):

@@ -56,11 +56,14 @@ SYMBOLS = {
     "dangx_version": (C.c_char_p, []),
     "dangx_set_stream": (C.c_int, [_P, _P]),
     "dangx_synchronize": (C.c_int, [_P]),
+    "dangx_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "dangx_set_host_stride": (C.c_int, [_P, C.c_int64]),
     "dangx_set_allreduce": (C.c_int, [_P, _P, _P, C.c_int]),
     "dangx_index_sample_coarse": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
                                             C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "dangx_udgrade": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int]),
     "dangx_index_masked_sum": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "dangx_index_plain_sum": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dangx_set_band": (C.c_int, [_P, C.c_int, C.c_double, C.c_int, _P, _P]),
     "dangx_set_component": (C.c_int, [_P, C.c_int, C.POINTER(CompDesc)]),
     "dangx_set_tcmb": (C.c_int, [_P, C.c_double]),

@@ -404,6 +404,12 @@ class Engine:
         self._chk(self.lib.dangx_index_masked_sum(self.h, comp, nind, map_n, C.byref(s), C.byref(n)))
         return s.value, n.value
 
+    def index_plain_sum(self, comp, nind, map_n):
+        """(sum over every local pixel of c%indices(:,map_n,nind), sum of masks(:,1)): the per-pixel tuner's start."""
+        s, m = C.c_double(0.0), C.c_double(0.0)
+        self._chk(self.lib.dangx_index_plain_sum(self.h, comp, nind, map_n, C.byref(s), C.byref(m)))
+        return s.value, m.value
+
     def peek_indices(self, comp, map_n, pix=0):
         n = self.component_list[comp].nindices
         out = (C.c_double * max(n, 1))()
@@ -586,9 +592,13 @@ def sample_spectral_parameters(dpar: DangParams, ddata: DangData, it=2, verbose=
                         raise DangxError("full-sky index mode with sample_nside /= nside is not built")
                     acc = sample_index_mh_fullsky(dpar, ddata, l, j, _MAPN[f], stream_id(it, 1, l, j, f))
                 elif coarse and coarse != eng.nside:
+                    if c.tuned and not c.tuned[j]:
+                        raise DangxError("step-size tuning with sample_nside /= nside is not built")
                     acc = eng.index_sample_coarse(l, j, _MAPN[f], dpar.nsample, dpar.ml_mode, dpar.seed,
                                                   stream_id(it, 1, l, j, f), coarse)
                 else:
+                    if c.tuned and not c.tuned[j]:       # 'Tuning!', src/dang_sample_mod.f90:341-346
+                        tune_perpixel(dpar, ddata, l, j, _MAPN[f], stream_id(it, 1, l, j, f))
                     acc = eng.index_sample(l, j, _MAPN[f], dpar.nsample, dpar.ml_mode, dpar.seed,
                                            stream_id(it, 1, l, j, f))
                 info.append((l, j, f, acc))
@@ -672,7 +682,7 @@ def tune_spectral_parameter_length(dpar, eng, c, nind, theta_init, seed, stream,
     elif pt == "uniform":
         lnl_old = lnl
     rounds = 0
-    while not all(c.tuned) and rounds < max_rounds:
+    while not c.tuned[nind] and rounds < max_rounds:      # :663 do while (.not. c%tuned(nind)); bounded here
         rounds += 1
         accept = 0.0
         for _ in range(dpar.nsample):
@@ -702,6 +712,28 @@ def tune_spectral_parameter_length(dpar, eng, c, nind, theta_init, seed, stream,
         else:
             c.tuned = [True] * max(c.nindices, 1)
     return draw
+
+
+def tune_perpixel(dpar, ddata, l, nind, map_n, stream):
+    """The step-size tuning of the per-pixel branch, src/dang_sample_mod.f90:341-346: one pass of the tuner per index
+    of the component, each starting at sample(q) = sum(c%indices(:,map_inds(1),q)) / sum(mask(:,1)) with the entries
+    not yet reached still 0 (:337) -- literally as the reference runs it (the sums take every pixel and the mask's
+    VALUES; the tuner marks all indices tuned, so later passes only evaluate their starting likelihood).  The tuner's
+    sky-wide sums are device passes; the new step size reaches the device through dangx_set_component."""
+    eng = ddata.engine
+    c = eng.component_list[l]
+    s1 = 2 if map_n == -1 else map_n
+    eng._fs_Sp = 2 if map_n == -1 else 1
+    eng.fullsky_prepare(l, map_n)                          # data_raw minus every other component, :173-196
+    sample = [0.0, 0.0]
+    draw = 1
+    for q in range(c.nindices):
+        si, sm = eng.index_plain_sum(l, q, s1)
+        si, sm = _dist.allreduce_sum_float(si), _dist.allreduce_sum_float(sm)
+        sample[q] = si / sm
+        draw = tune_spectral_parameter_length(dpar, eng, c, nind, sample, dpar.seed, stream ^ 0x5555555555555555, draw0=draw)
+    eng._chk(eng.lib.dangx_set_component(eng.h, l, C.byref(comp_desc(c))))
+    return c.step_size[nind]
 
 
 def sample_index_mh_fullsky(dpar, ddata, l, nind, map_n, stream):

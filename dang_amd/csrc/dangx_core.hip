@@ -540,6 +540,29 @@ __global__ __launch_bounds__(BLOCK) void k_index_masked_sum(const Model* __restr
     }
 }
 
+// plain sums over EVERY local pixel: rows 0: sum(c%indices(:, k, nind)), 1: sum(masks(:,1)) -- the starting point of the
+// step-size tuner in the per-pixel branch, sample(l) = sum(c%indices(:,map_inds(1),l))/sum(mask(:,1))
+// (src/dang_sample_mod.f90:344: no mask test on the indices, the mask VALUES are summed)
+__global__ __launch_bounds__(BLOCK) void k_index_plain_sum(const Model* __restrict__ Mp, int comp, int nind, int k,
+                                                           double* __restrict__ partial) {
+    __shared__ double sh[2][BLOCK / 64];
+    const Model& M = *Mp;
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    double v = 0.0, m = 0.0;
+    if (i < M.npix) {
+        v = M.comp[comp].idx[((long long)nind * M.nmaps + (k - 1)) * M.npix + i];
+        m = M.mask[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) { v += __shfl_down(v, o, 64); m += __shfl_down(m, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = v; sh[1][threadIdx.x >> 6] = m; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double t = 0.0;
+        for (int w = 0; w < BLOCK / 64; ++w) t += sh[threadIdx.x][w];
+        partial[(long long)threadIdx.x * gridDim.x + blockIdx.x] = t;
+    }
+}
+
 // c%indices(:, s1:s2, nind) = value (src/dang_sample_mod.f90:329, 483: every pixel, masked ones too)
 __global__ __launch_bounds__(BLOCK) void k_fill_index(const Model* __restrict__ Mp, int comp, int nind, int s1, int s2, double value) {
     const Model& M = *Mp;
@@ -1099,6 +1122,26 @@ int device_schur(dangx_ctx* ctx, const GroupArgs& a, long long SN, int64_t* n_no
     return 0;
 }
 
+// host <-> device copy of `planes` maps of this shard.  The host side is either a packed [planes][npix] array or, after
+// dangx_set_host_stride, a window into full-sky arrays: plane q starts host_stride doubles after plane q-1.
+int copy_planes(dangx_ctx* ctx, void* dst, const void* src, size_t planes, bool to_device) {
+    const size_t row = (size_t)ctx->dims.npix * sizeof(double);
+    const size_t hs = (size_t)(ctx->host_stride > 0 ? ctx->host_stride : ctx->dims.npix) * sizeof(double);
+    if (hs == row) {
+        HIPCHK(ctx, hipMemcpyAsync(dst, src, row * planes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    } else if (to_device) {
+        HIPCHK(ctx, hipMemcpy2DAsync(dst, row, src, hs, row, planes, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        HIPCHK(ctx, hipMemcpy2DAsync(dst, hs, src, row, row, planes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+// element (plane q, pixel t) of a host map array under the current host layout
+inline double host_at(const dangx_ctx* ctx, const double* a, long long q, long long t) {
+    return a[q * (ctx->host_stride > 0 ? ctx->host_stride : ctx->dims.npix) + t];
+}
+
 int check_comp(dangx_ctx* ctx, int comp) {
     if (comp < 0 || comp >= ctx->dims.ncomp) return fail(ctx, "component index out of range");
     return 0;
@@ -1204,6 +1247,21 @@ int dangx_set_allreduce(dangx_ctx* ctx, dangx_allreduce_fn fn, void* user, int i
     return 0;
 }
 
+int dangx_device_count(int* n) {
+    if (!n) return 1;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+    *n = c;
+    return 0;
+}
+
+int dangx_set_host_stride(dangx_ctx* ctx, int64_t plane_stride) {
+    if (!ctx) return 1;
+    if (plane_stride != 0 && plane_stride < ctx->dims.npix) return fail(ctx, "host plane stride smaller than the shard");
+    ctx->host_stride = plane_stride;
+    return 0;
+}
+
 int dangx_synchronize(dangx_ctx* ctx) {
     if (!ctx) return 1;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1276,9 +1334,10 @@ int dangx_upload_data(dangx_ctx* ctx, const double* sig, const double* rms, cons
         HIPCHK(ctx, hipMalloc(&ctx->mask, nmap));
         ctx->own_data = true;
     }
-    HIPCHK(ctx, hipMemcpy(ctx->sig, sig, nall, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(ctx->rms, rms, nall, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(ctx->mask, mask, nmap, hipMemcpyHostToDevice));
+    const size_t nplanes = (size_t)ctx->dims.nmaps * ctx->dims.nbands;
+    if (copy_planes(ctx, ctx->sig, sig, nplanes, true) || copy_planes(ctx, ctx->rms, rms, nplanes, true) ||
+        copy_planes(ctx, ctx->mask, mask, (size_t)ctx->dims.nmaps, true))
+        return 1;
     ctx->dirty = true;
     invalidate_chi(ctx);
     return 0;
@@ -1301,16 +1360,12 @@ int dangx_put_amplitude(dangx_ctx* ctx, int comp, const double* amp) {
     ctx->plane_nz[comp] = 0;
     for (int k = 0; k < ctx->dims.nmaps; ++k)
         for (long long t = 0; t < ctx->dims.npix; ++t)
-            if (amp[(long long)k * ctx->dims.npix + t] != 0.0) { ctx->plane_nz[comp] |= 1u << k; break; }
-    HIPCHK(ctx, hipMemcpyAsync(ctx->amp[comp], amp, (size_t)ctx->dims.npix * ctx->dims.nmaps * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
+            if (host_at(ctx, amp, k, t) != 0.0) { ctx->plane_nz[comp] |= 1u << k; break; }
+    return copy_planes(ctx, ctx->amp[comp], amp, (size_t)ctx->dims.nmaps, true);
 }
 int dangx_get_amplitude(dangx_ctx* ctx, int comp, double* amp) {
     if (!ctx || !amp || check_comp(ctx, comp) || ensure_state(ctx, comp)) return 1;
-    HIPCHK(ctx, hipMemcpyAsync(amp, ctx->amp[comp], (size_t)ctx->dims.npix * ctx->dims.nmaps * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
+    return copy_planes(ctx, amp, ctx->amp[comp], (size_t)ctx->dims.nmaps, false);
 }
 int dangx_put_indices(dangx_ctx* ctx, int comp, const double* ind) {
     if (!ctx || !ind || check_comp(ctx, comp) || ensure_state(ctx, comp)) return 1;
@@ -1322,24 +1377,21 @@ int dangx_put_indices(dangx_ctx* ctx, int comp, const double* ind) {
         for (int k = 0; k < ctx->dims.nmaps; ++k) {
             bool cst = true;
             for (int q = 0; q < ctx->desc[comp].nindices && cst; ++q) {
-                const double* m = ind + ((long long)q * ctx->dims.nmaps + k) * np;
-                for (long long t = 1; t < np; ++t) if (m[t] != m[0]) { cst = false; break; }
-                ctx->idx_val[comp][k][q] = m[0];
+                const long long pl = (long long)q * ctx->dims.nmaps + k;
+                const double m0 = host_at(ctx, ind, pl, 0);
+                for (long long t = 1; t < np; ++t) if (host_at(ctx, ind, pl, t) != m0) { cst = false; break; }
+                ctx->idx_val[comp][k][q] = m0;
             }
             if (cst) ctx->idx_const[comp] |= 1u << k;
         }
         ctx->dirty = true;
     }
-    HIPCHK(ctx, hipMemcpyAsync(ctx->idx[comp], ind, (size_t)ctx->dims.npix * ctx->dims.nmaps * ctx->desc[comp].nindices * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
+    return copy_planes(ctx, ctx->idx[comp], ind, (size_t)ctx->dims.nmaps * ctx->desc[comp].nindices, true);
 }
 int dangx_get_indices(dangx_ctx* ctx, int comp, double* ind) {
     if (!ctx || !ind || check_comp(ctx, comp) || ensure_state(ctx, comp)) return 1;
     if (!ctx->idx[comp]) return fail(ctx, "component has no indices");
-    HIPCHK(ctx, hipMemcpyAsync(ind, ctx->idx[comp], (size_t)ctx->dims.npix * ctx->dims.nmaps * ctx->desc[comp].nindices * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
+    return copy_planes(ctx, ind, ctx->idx[comp], (size_t)ctx->dims.nmaps * ctx->desc[comp].nindices, false);
 }
 int dangx_set_template(dangx_ctx* ctx, int comp, const double* tmpl, const int32_t* corr, int nfit) {
     if (!ctx || !tmpl || !corr || check_comp(ctx, comp)) return 1;
@@ -1350,7 +1402,7 @@ int dangx_set_template(dangx_ctx* ctx, int comp, const double* tmpl, const int32
     if (cnt != nfit) return fail(ctx, "nfit does not match the number of fitted (corr) bands");
     const size_t bytes = (size_t)ctx->dims.npix * ctx->dims.nmaps * sizeof(double);
     if (!ctx->tmpl[comp]) HIPCHK(ctx, hipMalloc(&ctx->tmpl[comp], bytes));
-    HIPCHK(ctx, hipMemcpy(ctx->tmpl[comp], tmpl, bytes, hipMemcpyHostToDevice));
+    if (copy_planes(ctx, ctx->tmpl[comp], tmpl, (size_t)ctx->dims.nmaps, true)) return 1;
     ctx->corr_mask[comp] = mask; ctx->nfit[comp] = nfit;
     ctx->dirty = true;
     invalidate_chi(ctx);
@@ -1681,10 +1733,11 @@ int dangx_sky_model_chisq(dangx_ctx* ctx, int pol_lo, int pol_hi, double* chisq_
     rc = sky_chisq_launch(ctx, pol_lo, pol_hi, sky_d, res_d, chi_d, ctx->scalars);
     if (!rc) {
         double v = 0.0;
+        const size_t nplanes = (size_t)ctx->dims.nmaps * ctx->dims.nbands;
         if (hipMemcpyAsync(&v, ctx->scalars, sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = 1;
-        if (sky && hipMemcpyAsync(sky, sky_d, nall, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = 1;
-        if (res && hipMemcpyAsync(res, res_d, nall, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = 1;
-        if (chi_map && hipMemcpyAsync(chi_map, chi_d, nmap, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = 1;
+        if (sky && copy_planes(ctx, sky, sky_d, nplanes, false)) rc = 1;
+        if (res && copy_planes(ctx, res, res_d, nplanes, false)) rc = 1;
+        if (chi_map && copy_planes(ctx, chi_map, chi_d, (size_t)ctx->dims.nmaps, false)) rc = 1;
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = 1;
         if (rc) ctx->err = "copy-back failed in dangx_sky_model_chisq";
         if (chisq_sum) *chisq_sum = v;
@@ -1904,6 +1957,26 @@ int dangx_index_masked_sum(dangx_ctx* ctx, int comp, int nind, int map_n, double
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     *sum = out[0];
     *count = (int64_t)out[1];
+    return 0;
+}
+
+// local sums over every pixel of c%indices(:, map_n, nind) and of masks(:,1) (see k_index_plain_sum)
+int dangx_index_plain_sum(dangx_ctx* ctx, int comp, int nind, int map_n, double* sum_index, double* sum_mask) {
+    if (!ctx || !sum_index || !sum_mask || check_comp(ctx, comp)) return 1;
+    (void)hipSetDevice(ctx->device);
+    if (nind < 0 || nind >= ctx->desc[comp].nindices) return fail(ctx, "index number out of range");
+    if (map_n < 1 || map_n > ctx->dims.nmaps) return fail(ctx, "map_n must be a map number (1..nmaps)");
+    if (sync_model(ctx)) return 1;
+    const unsigned nblk = nblocks(ctx->hm.npix);
+    if (ensure_partial(ctx, 2ll * nblk)) return 1;
+    hipLaunchKernelGGL(k_index_plain_sum, dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->dm, comp, nind, map_n, ctx->partial);
+    hipLaunchKernelGGL(k_reduce_rows_final, dim3(2), dim3(BLOCK), 0, ctx->stream, ctx->partial, (long long)nblk, 2, ctx->rows_out);
+    HIPCHK(ctx, hipGetLastError());
+    double out[2] = {0.0, 0.0};
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->rows_out, sizeof(out), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *sum_index = out[0];
+    *sum_mask = out[1];
     return 0;
 }
 

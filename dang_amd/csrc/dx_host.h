@@ -94,6 +94,7 @@ struct dangx_ctx {
     double* chi_cache = nullptr;            // device [6]: chi^2 before/after of planes 1..3 (fused in k_index_mh)
     bool chi_before_valid[3] = {}, chi_after_valid[3] = {}, touched_since_amp[3] = {};
     unsigned long long* counters = nullptr; // device counters [4]
+    long long host_stride = 0;              // doubles between consecutive planes of host map arrays (0 = npix: packed)
     dangx_allreduce_fn allreduce = nullptr; // sum over ranks of host doubles (pixel-sharded runs); null = single rank
     void* allreduce_user = nullptr;
     bool is_root = true;

@@ -104,8 +104,10 @@ module dangx_mod
        integer(c_int), value :: group, flag, ml_mode, solver, fluct_mode, i_max
        integer(c_int64_t), value :: seed, stream
        real(c_double), value :: converge
-       integer(c_int), intent(out) :: cg_iters
-       integer(c_int64_t), intent(out) :: n_not_spd
+       ! absent optional = C null pointer (F2018 15.3.7): without its count outputs the call only enqueues work on the
+       ! context's device and returns, so one host thread can keep several devices busy
+       integer(c_int), intent(out), optional :: cg_iters
+       integer(c_int64_t), intent(out), optional :: n_not_spd
      end function
      integer(c_int) function dangx_schur_info(ctx, rel_residual, refinements) bind(C, name='dangx_schur_info')
        import :: c_int, c_ptr, c_double
@@ -126,7 +128,7 @@ module dangx_mod
        type(c_ptr), value :: ctx
        integer(c_int), value :: comp, nind, map_n, nsample, ml_mode
        integer(c_int64_t), value :: seed, stream
-       integer(c_int64_t), intent(out) :: accepted
+       integer(c_int64_t), intent(out), optional :: accepted
      end function
      integer(c_int) function dangx_set_template(ctx, comp, tmpl, corr, nfit) bind(C, name='dangx_set_template')
        import :: c_int, c_ptr
@@ -195,6 +197,26 @@ module dangx_mod
        integer(c_int), value :: comp, nind, map_n
        real(c_double), intent(out) :: sum
        integer(c_int64_t), intent(out) :: count
+     end function
+     integer(c_int) function dangx_device_count(n) bind(C, name='dangx_device_count')
+       import :: c_int
+       integer(c_int), intent(out) :: n
+     end function
+     integer(c_int) function dangx_set_host_stride(ctx, plane_stride) bind(C, name='dangx_set_host_stride')
+       import :: c_int, c_ptr, c_int64_t
+       type(c_ptr), value :: ctx
+       integer(c_int64_t), value :: plane_stride
+     end function
+     integer(c_int) function dangx_synchronize(ctx) bind(C, name='dangx_synchronize')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function
+     integer(c_int) function dangx_index_plain_sum(ctx, comp, nind, map_n, sum_index, sum_mask) &
+          bind(C, name='dangx_index_plain_sum')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: comp, nind, map_n
+       real(c_double), intent(out) :: sum_index, sum_mask
      end function
      ! pixel-sharded (MPI) runs: fn = c_funloc of a bind(C) function that does
      ! MPI_Allreduce(MPI_IN_PLACE, buf, n, MPI_DOUBLE_PRECISION, MPI_SUM, comm) and returns 0

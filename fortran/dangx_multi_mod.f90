@@ -1,0 +1,369 @@
+! dangx_multi_mod.f90 -- one sky, several pixel-shard contexts, driven by ONE host thread.
+!
+! The reference is a single process (numprocs is never used, src/dang_util_mod.f90:48-57); a node has eight GPUs.
+! This layer gives a single-process driver all of them: the sky's RING pixels are cut into contiguous ranges, one
+! dangx context per device, every context works on the driver's FULL-SKY host arrays through a window
+! (dangx_set_host_stride) -- no copy, no re-packing on the Fortran side -- and every per-pixel call is enqueued on
+! all devices before the first result is awaited (the count outputs of dangx_amp_sample / dangx_index_sample are
+! nullable: without them the call does not synchronise).  Sky-wide sums (chi^2, index means, gain sums, the sums of
+! the full-sky Metropolis chain) are added over the contexts in shard order, which makes them independent of timing.
+!
+! Only plain arrays and ISO_C_BINDING here: the wrapper with the reference's derived types is
+! fortran/reference_side/dang_gpu_mod.f90; fortran/dangx_fsmoke.f90 drives this module on a GPU in the tests.
+module dangx_multi_mod
+  use, intrinsic :: iso_c_binding
+  use dangx_mod
+  implicit none
+
+  integer, parameter :: DANGX_MAX_CTX = 16
+
+  type :: dangx_sky
+     integer :: nctx = 0
+     type(c_ptr) :: ctx(DANGX_MAX_CTX) = c_null_ptr
+     integer(c_int64_t) :: pix0(DANGX_MAX_CTX) = 0, npix(DANGX_MAX_CTX) = 0
+     integer(c_int64_t) :: npix_global = 0
+     integer(c_int32_t) :: nmaps = 0, nbands = 0, ncomp = 0
+  end type dangx_sky
+
+contains
+
+  ! contiguous RING range of shard r (0-based) of n, as dang_amd/dist.py:shard_range
+  subroutine dangx_shard_range(npix_global, r, n, pix0, npix)
+    integer(c_int64_t), intent(in)  :: npix_global
+    integer, intent(in)             :: r, n
+    integer(c_int64_t), intent(out) :: pix0, npix
+    integer(c_int64_t) :: base, rem
+    base = npix_global/n
+    rem  = mod(npix_global, int(n, c_int64_t))
+    pix0 = r*base + min(int(r, c_int64_t), rem)
+    npix = base + merge(1_c_int64_t, 0_c_int64_t, r < rem)
+  end subroutine dangx_shard_range
+
+  ! nctx contexts over the sky; context r runs on device devices(r) (or r modulo the device count)
+  subroutine dangx_sky_create(sky, npix_global, nmaps, nbands, ncomp, nctx, devices)
+    type(dangx_sky), intent(out)   :: sky
+    integer(c_int64_t), intent(in) :: npix_global
+    integer, intent(in)            :: nmaps, nbands, ncomp, nctx
+    integer, intent(in), optional  :: devices(:)
+    type(dangx_dims) :: dims
+    integer(c_int) :: ndev
+    integer :: r, dev
+    if (nctx < 1 .or. nctx > DANGX_MAX_CTX) then
+       write(*,*) 'dangx_sky_create: bad number of contexts ', nctx
+       stop 1
+    end if
+    call dangx_check(c_null_ptr, dangx_device_count(ndev), 'dangx_device_count')
+    if (ndev < 1) then
+       write(*,*) 'dangx_sky_create: no HIP device (the GPU path has no CPU fallback)'
+       stop 1
+    end if
+    sky%nctx = nctx; sky%npix_global = npix_global
+    sky%nmaps = nmaps; sky%nbands = nbands; sky%ncomp = ncomp
+    do r = 1, nctx
+       call dangx_shard_range(npix_global, r-1, nctx, sky%pix0(r), sky%npix(r))
+       dev = mod(r-1, ndev)
+       if (present(devices)) dev = devices(r)
+       dims = dangx_dims(int(sky%npix(r), c_int32_t), nmaps, nbands, ncomp, sky%pix0(r), npix_global, dev, 0)
+       call dangx_check(c_null_ptr, dangx_create(sky%ctx(r), dims), 'dangx_create')
+       ! host arrays are the driver's full-sky arrays: plane stride = full-sky pixel count
+       call dangx_check(sky%ctx(r), dangx_set_host_stride(sky%ctx(r), npix_global), 'dangx_set_host_stride')
+    end do
+  end subroutine dangx_sky_create
+
+  subroutine dangx_sky_destroy(sky)
+    type(dangx_sky), intent(inout) :: sky
+    integer :: r
+    do r = 1, sky%nctx
+       call dangx_check(sky%ctx(r), dangx_destroy(sky%ctx(r)), 'dangx_destroy')
+       sky%ctx(r) = c_null_ptr
+    end do
+    sky%nctx = 0
+  end subroutine dangx_sky_destroy
+
+  ! address of pixel pix0 of a full-sky map array whose first dimension is the pixel (0-based)
+  function at_pix(base, pix0) result(p)
+    type(c_ptr), intent(in) :: base
+    integer(c_int64_t), intent(in) :: pix0
+    type(c_ptr) :: p
+    p = transfer(transfer(base, 0_c_intptr_t) + 8_c_intptr_t*pix0, p)
+  end function at_pix
+
+  ! ---- static description, identical on every context
+  subroutine dangx_sky_set_band(sky, band, nu_c, n, nu0, tau0)
+    type(dangx_sky), intent(in) :: sky
+    integer, intent(in) :: band, n
+    real(c_double), intent(in) :: nu_c
+    type(c_ptr), intent(in) :: nu0, tau0
+    integer :: r
+    do r = 1, sky%nctx
+       call dangx_check(sky%ctx(r), dangx_set_band(sky%ctx(r), band, nu_c, n, nu0, tau0), 'dangx_set_band')
+    end do
+  end subroutine dangx_sky_set_band
+
+  subroutine dangx_sky_set_component(sky, comp, d)
+    type(dangx_sky), intent(in) :: sky
+    integer, intent(in) :: comp
+    type(dangx_comp_desc), intent(in) :: d
+    integer :: r
+    do r = 1, sky%nctx
+       call dangx_check(sky%ctx(r), dangx_set_component(sky%ctx(r), comp, d), 'dangx_set_component')
+    end do
+  end subroutine dangx_sky_set_component
+
+  subroutine dangx_sky_set_tcmb(sky, T)
+    type(dangx_sky), intent(in) :: sky
+    real(c_double), intent(in) :: T
+    integer :: r
+    do r = 1, sky%nctx
+       call dangx_check(sky%ctx(r), dangx_set_tcmb(sky%ctx(r), T), 'dangx_set_tcmb')
+    end do
+  end subroutine dangx_sky_set_tcmb
+
+  subroutine dangx_sky_set_calibration(sky, gain, offset)
+    type(dangx_sky), intent(in) :: sky
+    type(c_ptr), intent(in) :: gain, offset
+    integer :: r
+    do r = 1, sky%nctx
+       call dangx_check(sky%ctx(r), dangx_set_calibration(sky%ctx(r), gain, offset), 'dangx_set_calibration')
+    end do
+  end subroutine dangx_sky_set_calibration
+
+  ! ---- maps: c_loc of the FULL-SKY arrays (first element); every context takes its window
+  subroutine dangx_sky_upload_data(sky, sig, rms, mask)
+    type(dangx_sky), intent(in) :: sky
+    type(c_ptr), intent(in) :: sig, rms, mask
+    integer :: r
+    do r = 1, sky%nctx
+       call dangx_check(sky%ctx(r), dangx_upload_data(sky%ctx(r), at_pix(sig, sky%pix0(r)), at_pix(rms, sky%pix0(r)), &
+            at_pix(mask, sky%pix0(r))), 'dangx_upload_data')
+    end do
+  end subroutine dangx_sky_upload_data
+
+  subroutine dangx_sky_put_state(sky, comp, amp, ind)
+    type(dangx_sky), intent(in) :: sky
+    integer, intent(in) :: comp
+    type(c_ptr), intent(in) :: amp, ind      ! ind = c_null_ptr for a component without indices
+    integer :: r
+    do r = 1, sky%nctx
+       call dangx_check(sky%ctx(r), dangx_put_amplitude(sky%ctx(r), comp, at_pix(amp, sky%pix0(r))), 'dangx_put_amplitude')
+       if (c_associated(ind)) call dangx_check(sky%ctx(r), dangx_put_indices(sky%ctx(r), comp, at_pix(ind, sky%pix0(r))), &
+            'dangx_put_indices')
+    end do
+  end subroutine dangx_sky_put_state
+
+  subroutine dangx_sky_get_state(sky, comp, amp, ind)
+    type(dangx_sky), intent(in) :: sky
+    integer, intent(in) :: comp
+    type(c_ptr), intent(in) :: amp, ind
+    integer :: r
+    do r = 1, sky%nctx
+       call dangx_check(sky%ctx(r), dangx_get_amplitude(sky%ctx(r), comp, at_pix(amp, sky%pix0(r))), 'dangx_get_amplitude')
+       if (c_associated(ind)) call dangx_check(sky%ctx(r), dangx_get_indices(sky%ctx(r), comp, at_pix(ind, sky%pix0(r))), &
+            'dangx_get_indices')
+    end do
+  end subroutine dangx_sky_get_state
+
+  subroutine dangx_sky_set_template(sky, comp, tmpl, corr, nfit, ta)
+    type(dangx_sky), intent(in) :: sky
+    integer, intent(in) :: comp, nfit
+    type(c_ptr), intent(in) :: tmpl, corr, ta
+    integer :: r
+    do r = 1, sky%nctx
+       call dangx_check(sky%ctx(r), dangx_set_template(sky%ctx(r), comp, at_pix(tmpl, sky%pix0(r)), corr, nfit), 'dangx_set_template')
+       call dangx_check(sky%ctx(r), dangx_put_template_amplitudes(sky%ctx(r), comp, ta), 'dangx_put_template_amplitudes')
+    end do
+  end subroutine dangx_sky_set_template
+
+  ! ---- the two per-pixel phases: enqueue on every device, then wait for all
+  subroutine dangx_sky_wait(sky)
+    type(dangx_sky), intent(in) :: sky
+    integer :: r
+    do r = 1, sky%nctx
+       call dangx_check(sky%ctx(r), dangx_synchronize(sky%ctx(r)), 'dangx_synchronize')
+    end do
+  end subroutine dangx_sky_wait
+
+  ! one (group, flag) pass of sample_cg_groups (src/dang_cg_mod.f90:166-171) with the direct block solve.  Groups with
+  ! template / monopole / hi_fit members couple all pixels: they need a sum over the contexts INSIDE the solve, which
+  ! one host thread cannot serve for several blocking calls -- run those with nctx = 1 or one process per GPU
+  ! (dangx_set_allreduce); diffuse groups, i.e. every BASELINE configuration, shard freely.
+  subroutine dangx_sky_amp_sample(sky, group, flag, ml_mode, fluct_mode, seed, stream, n_not_spd)
+    type(dangx_sky), intent(in) :: sky
+    integer, intent(in) :: group, flag, ml_mode, fluct_mode
+    integer(c_int64_t), intent(in) :: seed, stream
+    integer(c_int64_t), intent(out), optional :: n_not_spd
+    integer(c_int) :: iters
+    integer(c_int64_t) :: nbad
+    integer :: r
+    if (present(n_not_spd)) then
+       n_not_spd = 0
+       do r = 1, sky%nctx
+          call dangx_check(sky%ctx(r), dangx_amp_sample(sky%ctx(r), group, flag, ml_mode, DANGX_SOLVER_DIRECT, fluct_mode, &
+               seed, stream, 0, 0.d0, iters, nbad), 'dangx_amp_sample')
+          n_not_spd = n_not_spd + nbad
+       end do
+    else
+       do r = 1, sky%nctx
+          call dangx_check(sky%ctx(r), dangx_amp_sample(sky%ctx(r), group, flag, ml_mode, DANGX_SOLVER_DIRECT, fluct_mode, &
+               seed, stream, 0, 0.d0), 'dangx_amp_sample')
+       end do
+    end if
+  end subroutine dangx_sky_amp_sample
+
+  ! sample_index_mh, per-pixel branch (src/dang_sample_mod.f90:332-483), for (comp, nind, map_n), 0-based comp / nind
+  subroutine dangx_sky_index_sample(sky, comp, nind, map_n, nsample, ml_mode, seed, stream, accepted)
+    type(dangx_sky), intent(in) :: sky
+    integer, intent(in) :: comp, nind, map_n, nsample, ml_mode
+    integer(c_int64_t), intent(in) :: seed, stream
+    integer(c_int64_t), intent(out), optional :: accepted
+    integer(c_int64_t) :: nacc
+    integer :: r
+    if (present(accepted)) then
+       accepted = 0
+       do r = 1, sky%nctx
+          call dangx_check(sky%ctx(r), dangx_index_sample(sky%ctx(r), comp, nind, map_n, nsample, ml_mode, seed, stream, nacc), &
+               'dangx_index_sample')
+          accepted = accepted + nacc
+       end do
+    else
+       do r = 1, sky%nctx
+          call dangx_check(sky%ctx(r), dangx_index_sample(sky%ctx(r), comp, nind, map_n, nsample, ml_mode, seed, stream), &
+               'dangx_index_sample')
+       end do
+    end if
+  end subroutine dangx_sky_index_sample
+
+  ! ---- sky-wide numbers: sums over the contexts in shard order
+  ! update_sky_model + compute_chisq (src/dang_data_mod.f90:339-396, 494-526): chisq = sum/nbands/nump.  With the three
+  ! optional full-sky host arrays (c_loc of sky_model / res_map / chi_map) it also refreshes them -- the state
+  ! write_maps reads (:573-664).
+  function dangx_sky_chisq(sky, pol_lo, pol_hi, nump, sky_model, res_map, chi_map) result(chisq)
+    type(dangx_sky), intent(in) :: sky
+    integer, intent(in) :: pol_lo, pol_hi
+    real(c_double), intent(in) :: nump
+    type(c_ptr), intent(in), optional :: sky_model, res_map, chi_map
+    real(c_double) :: chisq, s
+    type(c_ptr) :: ps, pr, pc
+    integer :: r
+    chisq = 0.d0
+    do r = 1, sky%nctx
+       ps = c_null_ptr; pr = c_null_ptr; pc = c_null_ptr
+       if (present(sky_model)) ps = at_pix(sky_model, sky%pix0(r))
+       if (present(res_map))   pr = at_pix(res_map, sky%pix0(r))
+       if (present(chi_map))   pc = at_pix(chi_map, sky%pix0(r))
+       call dangx_check(sky%ctx(r), dangx_sky_model_chisq(sky%ctx(r), pol_lo, pol_hi, s, ps, pr, pc), 'dangx_sky_model_chisq')
+       chisq = chisq + s
+    end do
+    chisq = chisq/sky%nbands/nump
+  end function dangx_sky_chisq
+
+  ! the same number from the sums the index sweeps leave behind (which = 0: state after the amplitude phase, 1: now);
+  ! ok = .false. when some plane was not swept since its last change (the caller then uses dangx_sky_chisq)
+  function dangx_sky_chisq_cached(sky, which, pol_lo, pol_hi, nump, ok) result(chisq)
+    type(dangx_sky), intent(in) :: sky
+    integer, intent(in) :: which, pol_lo, pol_hi
+    real(c_double), intent(in) :: nump
+    logical, intent(out) :: ok
+    real(c_double) :: chisq, s
+    integer(c_int) :: st
+    integer :: r
+    chisq = 0.d0; ok = .true.
+    do r = 1, sky%nctx
+       st = dangx_chisq_cached(sky%ctx(r), which, pol_lo, pol_hi, s)
+       if (st == 2) then
+          ok = .false.
+          return
+       end if
+       call dangx_check(sky%ctx(r), st, 'dangx_chisq_cached')
+       chisq = chisq + s
+    end do
+    chisq = chisq/sky%nbands/nump
+  end function dangx_sky_chisq_cached
+
+  ! mask_avg(c%indices(:,map_n,nind), masks(:,1)) (src/dang_util_mod.f90:186-206) without moving a map
+  function dangx_sky_index_mean(sky, comp, nind, map_n) result(avg)
+    type(dangx_sky), intent(in) :: sky
+    integer, intent(in) :: comp, nind, map_n
+    real(c_double) :: avg, s, tot
+    integer(c_int64_t) :: n, ntot
+    integer :: r
+    tot = 0.d0; ntot = 0
+    do r = 1, sky%nctx
+       call dangx_check(sky%ctx(r), dangx_index_masked_sum(sky%ctx(r), comp, nind, map_n, s, n), 'dangx_index_masked_sum')
+       tot = tot + s; ntot = ntot + n
+    end do
+    avg = tot/ntot
+  end function dangx_sky_index_mean
+
+  ! sum(c%indices(:,map_n,nind))/sum(mask(:,1)) over every pixel: the per-pixel tuner's start (src/dang_sample_mod.f90:344)
+  function dangx_sky_index_plain_mean(sky, comp, nind, map_n) result(avg)
+    type(dangx_sky), intent(in) :: sky
+    integer, intent(in) :: comp, nind, map_n
+    real(c_double) :: avg, s, m, st, mt
+    integer :: r
+    st = 0.d0; mt = 0.d0
+    do r = 1, sky%nctx
+       call dangx_check(sky%ctx(r), dangx_index_plain_sum(sky%ctx(r), comp, nind, map_n, s, m), 'dangx_index_plain_sum')
+       st = st + s; mt = mt + m
+    end do
+    avg = st/mt
+  end function dangx_sky_index_plain_mean
+
+  ! the two sums of fit_band_gain (src/dang_sample_mod.f90:606-607), band 0-based
+  subroutine dangx_sky_gain_sums(sky, band, mu, sigma)
+    type(dangx_sky), intent(in) :: sky
+    integer, intent(in) :: band
+    real(c_double), intent(out) :: mu, sigma
+    real(c_double), target :: o(2)
+    integer :: r
+    mu = 0.d0; sigma = 0.d0
+    do r = 1, sky%nctx
+       call dangx_check(sky%ctx(r), dangx_gain_sums(sky%ctx(r), band, c_loc(o)), 'dangx_gain_sums')
+       mu = mu + o(1); sigma = sigma + o(2)
+    end do
+  end subroutine dangx_sky_gain_sums
+
+  ! full-sky chain primitives (index_mode == 1 and the tuner): prepare once, then sums at a trial theta
+  subroutine dangx_sky_fullsky_prepare(sky, comp, map_n)
+    type(dangx_sky), intent(in) :: sky
+    integer, intent(in) :: comp, map_n
+    integer :: r
+    do r = 1, sky%nctx
+       call dangx_check(sky%ctx(r), dangx_fullsky_prepare(sky%ctx(r), comp, map_n), 'dangx_fullsky_prepare')
+    end do
+  end subroutine dangx_sky_fullsky_prepare
+
+  subroutine dangx_sky_fullsky_sums(sky, what, theta, rows, nrows)
+    type(dangx_sky), intent(in) :: sky
+    integer, intent(in) :: what, nrows
+    real(c_double), intent(in), target :: theta(2)
+    real(c_double), intent(out) :: rows(nrows)
+    real(c_double), target :: part(nrows)
+    integer :: r
+    rows = 0.d0
+    do r = 1, sky%nctx
+       call dangx_check(sky%ctx(r), dangx_fullsky_sums(sky%ctx(r), what, c_loc(theta), c_loc(part), nrows), 'dangx_fullsky_sums')
+       rows = rows + part
+    end do
+  end subroutine dangx_sky_fullsky_sums
+
+  subroutine dangx_sky_fill_index(sky, comp, nind, map_n, value)
+    type(dangx_sky), intent(in) :: sky
+    integer, intent(in) :: comp, nind, map_n
+    real(c_double), intent(in) :: value
+    integer :: r
+    do r = 1, sky%nctx
+       call dangx_check(sky%ctx(r), dangx_fill_index(sky%ctx(r), comp, nind, map_n, value), 'dangx_fill_index')
+    end do
+  end subroutine dangx_sky_fill_index
+
+  ! c%indices(0, map_n, :) -- pixel 0 lives on the first context (src/dang_sample_mod.f90:240-242)
+  subroutine dangx_sky_peek_first(sky, comp, map_n, out)
+    type(dangx_sky), intent(in) :: sky
+    integer, intent(in) :: comp, map_n
+    real(c_double), intent(out), target :: out(2)
+    out = 0.d0
+    call dangx_check(sky%ctx(1), dangx_peek_indices(sky%ctx(1), comp, map_n, 0_c_int64_t, c_loc(out)), 'dangx_peek_indices')
+  end subroutine dangx_sky_peek_first
+
+end module dangx_multi_mod

@@ -116,6 +116,15 @@ int dangx_set_stream(dangx_ctx *ctx, void *hip_stream);
 typedef int (*dangx_allreduce_fn)(void *user, double *buf, int64_t n);
 int dangx_set_allreduce(dangx_ctx *ctx, dangx_allreduce_fn fn, void *user, int is_root);
 int dangx_synchronize(dangx_ctx *ctx);
+/* number of HIP devices visible to the process (a single-process driver creates one context per device) */
+int dangx_device_count(int *n);
+/* Host map arrays of the calls below (dangx_upload_data, dangx_put / get_amplitude / indices, dangx_set_template, the
+ * sky / res / chi_map outputs of dangx_sky_model_chisq) are by default packed per shard, [planes][npix].  A driver
+ * that keeps FULL-SKY arrays -- the reference's sig_map(0:npix-1,nmaps,nbands) etc. -- and runs several pixel-shard
+ * contexts over them (one per GPU) passes, for each context, the address of the shard's FIRST pixel in plane 1 and sets
+ * plane_stride = the full-sky pixel count here: plane q of the shard then starts plane_stride doubles after plane
+ * q-1.  plane_stride = 0 returns to the packed layout. */
+int dangx_set_host_stride(dangx_ctx *ctx, int64_t plane_stride);
 
 /* ---- static description (once, after src/dang.f90:73) ------------------------ */
 /* bp(j): src/dang_bp_mod.f90:7-15,31-57.  n = 0 for a 'delta' bandpass, else n
@@ -220,6 +229,11 @@ int dangx_udgrade(dangx_ctx *ctx, int mode, const double *map_in, int nside_in, 
  * write_data every Gibbs iteration (src/dang_data_mod.f90:716-731, src/dang_util_mod.f90:186-206).  Returns this
  * shard's sum over unmasked pixels and their number; mask_avg = (all-reduced sum) / (all-reduced count). */
 int dangx_index_masked_sum(dangx_ctx *ctx, int comp, int nind, int map_n, double *sum, int64_t *count);
+
+/* Step-size tuning in the per-pixel branch (src/dang_sample_mod.f90:341-346) starts the tuner's sky-wide chain at
+ * sample(l) = sum(c%indices(:,map_inds(1),l)) / sum(mask(:,1)): both sums run over EVERY pixel and the mask VALUES are
+ * summed.  Returns this shard's two sums; the chain itself is dangx_fullsky_prepare / dangx_fullsky_sums (below). */
+int dangx_index_plain_sum(dangx_ctx *ctx, int comp, int nind, int map_n, double *sum_index, double *sum_mask);
 
 /* ---- full-sky index mode (index_mode == 1, src/dang_sample_mod.f90:229-329), tune_spectral_parameter_length
  * (:623-717) and fit_band_gain (:570-621).  With one index for the whole sky every Metropolis step is one pass

@@ -1226,6 +1226,46 @@ int64_t dgo_sample_index_fullsky(dgo_ctx *ctx, int comp, int nind, int map_n, in
     return accepted;
 }
 
+/* The step-size tuning of the PER-PIXEL branch, src/dang_sample_mod.f90:341-346:
+ *     if (.not. c%tuned(nind)) then
+ *        do l = 1, c%nindices
+ *           sample(l) = sum(c%indices(:,map_inds(1),l))/sum(mask(:,1))
+ *           call tune_spectral_parameter_length(c,nind,sample,data,rms,model,map_inds,mask(:,1))
+ *        end do
+ *     end if
+ * `sample` starts as zeros (:337) and is filled one entry per pass, so the first pass tunes index nind of a two-index
+ * component with the OTHER index at 0 when nind is the first one; the tuner marks all indices tuned (:712), so later
+ * passes only evaluate the starting likelihood.  The sums run over every pixel, the mask VALUES are summed.  The data
+ * are data_raw minus every other component (:173-196), as in the full-sky mode (sample_nside == nside here).
+ * Draw counter and stream follow dgo_sample_index_fullsky's tuner call. */
+void dgo_tune_perpixel(dgo_ctx *ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed,
+                       uint64_t stream, int *tuned) {
+    dgo_comp *c = &ctx->comps[comp];
+    const int npix = ctx->npix, nb = ctx->nbands, nmaps = ctx->nmaps;
+    fs_state S = {ctx, comp, nind, (map_n == -1) ? 2 : map_n, (map_n == -1) ? 3 : map_n, NULL};
+    if (*tuned) return;
+    S.data = (double *)malloc(sizeof(double) * (size_t)nb * nmaps * npix);
+    for (int i = 0; i < npix; ++i)
+        for (int k = 1; k <= nmaps; ++k)
+            for (int j = 0; j < nb; ++j) {
+                double d = (k == 1) ? (ctx->sig[IDX3(ctx, j, 1, i)] - ctx->offset[j]) / ctx->gain[j] : ctx->sig[IDX3(ctx, j, k, i)];
+                for (int l = 0; l < ctx->ncomp; ++l)
+                    if (l != comp) d = d - dgo_eval_signal(ctx, l, j, i, k, NULL);
+                S.data[IDX3(ctx, j, k, i)] = d;
+            }
+    double msum = 0.0;
+    for (int i = 0; i < npix; ++i) msum += ctx->mask[i];
+    double sample[DGO_MAX_IND] = {0.0, 0.0};
+    uint32_t draw = 1;
+    for (int l = 0; l < c->nindices; ++l) {
+        double isum = 0.0;
+        for (int i = 0; i < npix; ++i) isum += c->indices[((int64_t)l * nmaps + (S.s1 - 1)) * (int64_t)npix + i];
+        sample[l] = isum / msum;
+        fs_tune(&S, c, sample, nsample, ml_mode, seed, stream ^ 0x5555555555555555ull, &draw, tuned);
+    }
+    free(S.data);
+}
+
 /* fit_band_gain, src/dang_sample_mod.f90:570-621 (map_n = 1) */
 double dgo_fit_band_gain(const dgo_ctx *ctx, const double *sky, const double *res, int band, int ml_mode, uint64_t seed,
                          uint64_t stream) {

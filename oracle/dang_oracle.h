@@ -172,6 +172,9 @@ int64_t dgo_sample_index_fullsky(dgo_ctx *ctx, int comp, int nind, int map_n, in
  * exposed through dgo_sample_index_fullsky. */
 /* fit_band_gain(ddata, map_n=1, band) (src/dang_sample_mod.f90:570-621): returns the new gain; sky/res are
  * the arrays update_sky_model left (dgo_update_sky_model). */
+/* step-size tuning of the per-pixel branch (src/dang_sample_mod.f90:341-346); *tuned in/out, c->step_size updated */
+void dgo_tune_perpixel(dgo_ctx *ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed,
+                       uint64_t stream, int *tuned);
 double dgo_fit_band_gain(const dgo_ctx *ctx, const double *sky, const double *res, int band, int ml_mode,
                          uint64_t seed, uint64_t stream);
 

@@ -106,6 +106,9 @@ def lib():
         l.dgo_sample_index_fullsky.restype = C.c_int64
         l.dgo_sample_index_fullsky.argtypes = [C.POINTER(Ctx), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
                                                C.c_uint64, C.POINTER(C.c_int)]
+        l.dgo_tune_perpixel.restype = None
+        l.dgo_tune_perpixel.argtypes = [C.POINTER(Ctx), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
+                                        C.POINTER(C.c_int)]
         l.dgo_fit_band_gain.restype = C.c_double
         l.dgo_fit_band_gain.argtypes = [C.POINTER(Ctx), _D, _D, C.c_int, C.c_int, C.c_uint64, C.c_uint64]
         _lib = l
@@ -273,6 +276,11 @@ class Oracle:
         t = C.c_int(1 if tuned else 0)
         acc = self.L.dgo_sample_index_fullsky(self.c, comp, nind, map_n, nsample, ML_CODES[ml_mode], seed, stream, C.byref(t))
         return acc, bool(t.value), self._comps[comp].step_size[nind]
+
+    def tune_perpixel(self, comp, nind, map_n, nsample, ml_mode, seed, stream, tuned=False):
+        t = C.c_int(1 if tuned else 0)
+        self.L.dgo_tune_perpixel(self.c, comp, nind, map_n, nsample, ML_CODES[ml_mode], seed, stream, C.byref(t))
+        return bool(t.value), self._comps[comp].step_size[nind]
 
     def fit_band_gain(self, band, ml_mode, seed, stream):
         sky, res = self.sky_model()

@@ -114,3 +114,34 @@ def test_fit_band_gain_matches_oracle(built, ml_mode):
             assert abs(gg - [1.0, 1.03, 0.98, 1.0, 1.05][j]) < 2e-3
         orc.gain[j] = go                   # ddata%gain(band) = gain (:619)
     assert da.sample_calibrators(dpar, ddata, it=4)
+
+
+@pytest.mark.parametrize("ml_mode", ["sample", "optimize"])
+def test_perpixel_branch_tunes_the_step_size_like_the_reference(built, ml_mode):
+    """The 'Tuning!' block of the per-pixel branch (src/dang_sample_mod.f90:341-346): when c%tuned(nind) is false the
+    tuner's sky-wide chain runs first (start: sum(indices)/sum(mask) over every pixel), the step size it leaves is the
+    one the per-pixel chains then use.  Step size, tuned flags and the sweep itself against the oracle."""
+    def tweak(dpar, ddata, bands, comps):
+        dpar.ml_mode = ml_mode
+        comps[1].step_size = [2.0]            # synch beta (one index): far too large a step for the sky-wide chain
+        comps[1].tuned = [False]
+    case = make_case("C2", nside=8, start="truth", tweak=tweak)
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+    for c in comps:                           # only the synchrotron index, on the T plane
+        c.sample_index = [False] * c.nindices
+    comps[1].sample_index = [True]
+    step0 = comps[1].step_size[0]
+    s = da.stream_id(3, 1, 1, 0, L.FLAG_T)
+    otuned, ostep = orc.tune_perpixel(1, 0, 1, dpar.nsample, ml_mode, dpar.seed, s)
+    oacc = orc.sample_index_mh(1, 0, 1, dpar.nsample, ml_mode, dpar.seed, s)
+    info = da.sample_spectral_parameters(dpar, ddata, it=3)
+    # (optimize mode: once the chain sits at the optimum nothing is accepted any more and the step only ever halves --
+    # the reference's `do while (.not. c%tuned(nind))` would not return; both restatements stop after 64 rounds)
+    assert comps[1].tuned == [otuned] and (otuned or ml_mode == "optimize")
+    assert comps[1].step_size[0] == ostep and ostep < step0, (comps[1].step_size, ostep)
+    assert info == [(1, 0, L.FLAG_T, oacc)]
+    assert np.abs(eng.get_indices(1) - orc.indices(1)).max() <= 1e-12
+    if otuned:   # a second call finds the index tuned: no tuner pass, same step
+        da.sample_spectral_parameters(dpar, ddata, it=4)
+        assert comps[1].step_size[0] == ostep
