@@ -96,10 +96,28 @@ def build_fortran(force=False):
     return exe
 
 
+def check_reference_side():
+    """Type-check fortran/reference_side/dang_gpu_mod.f90 -- the wrapper with the reference's own signatures, which can
+    only be COMPILED inside the reference's tree -- with flang against stub modules that declare just the names it
+    touches (fortran/reference_side/stubs/).  Catches syntax / type errors; says nothing about the reference.
+    Returns True when the check ran and passed, None without flang; raises on errors."""
+    import tempfile
+    ref = os.path.join(FORTRAN_DIR, "reference_side")
+    if not os.path.exists(FLANG) or not os.path.isdir(ref):
+        return None
+    with tempfile.TemporaryDirectory() as tmp:
+        for f in ("dangx_mod.f90", "dangx_multi_mod.f90"):
+            _run([FLANG, "-c", "-J", tmp, os.path.join(FORTRAN_DIR, f), "-o", os.path.join(tmp, f + ".o")])
+        _run([FLANG, "-c", "-J", tmp, os.path.join(ref, "stubs", "stubs.f90"), "-o", os.path.join(tmp, "stubs.o")])
+        _run([FLANG, "-fsyntax-only", "-J", tmp, os.path.join(ref, "dang_gpu_mod.f90")])
+    return True
+
+
 def build_all(force=False):
     build_hip(force)
     build_oracle(force)
     build_fortran(force)
+    check_reference_side()
 
 
 if __name__ == "__main__":
