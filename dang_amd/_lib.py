@@ -20,6 +20,8 @@ ML_SAMPLE, ML_OPTIMIZE = 1, 2
 FLAG_T, FLAG_Q, FLAG_U, FLAG_QU = 1, 2, 4, 8
 SOLVER_DIRECT, SOLVER_CG = 0, 1
 FLUCT_CORRECT, FLUCT_REFERENCE = 0, 1
+A2T, A2F, F2T = 0, 1, 2
+UNIT_CODES = {"uK_RJ": 0, "uK_cmb": 1, "MJy/sr": 2}
 K_AMP_DIRECT, K_INDEX_MH, K_SKY_CHISQ, K_REDUCE, K_CG_AX, K_CG_VEC = range(6)
 KERNEL_NAMES = {K_AMP_DIRECT: "k_amp_direct", K_INDEX_MH: "k_index_mh", K_SKY_CHISQ: "k_sky_chisq",
                 K_REDUCE: "k_reduce", K_CG_AX: "k_Ax", K_CG_VEC: "k_cg_vec"}
@@ -64,6 +66,9 @@ SYMBOLS = {
     "dangx_udgrade": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int]),
     "dangx_index_masked_sum": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "dangx_index_plain_sum": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dangx_unit_conversion": (C.c_int, [_P, C.c_int, C.c_int, _D]),
+    "dangx_normalize_bandpass": (C.c_int, [_P, C.c_int, _P]),
+    "dangx_convert_maps": (C.c_int, [_P, _P, _P, _P]),
     "dangx_set_band": (C.c_int, [_P, C.c_int, C.c_double, C.c_int, _P, _P]),
     "dangx_set_component": (C.c_int, [_P, C.c_int, C.POINTER(CompDesc)]),
     "dangx_set_tcmb": (C.c_int, [_P, C.c_double]),

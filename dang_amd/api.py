@@ -102,6 +102,10 @@ class DangData:
     chisq: float = 0.0
     chisq_after_amp: float = 0.0      # chi^2 of the state the amplitude phase left (when deferred)
     fit_gain: List[bool] = field(default_factory=list)   # ddata%fit_gain(:)
+    conversion: np.ndarray = None     # ddata%conversion(:), set by convert_maps
+    sky_model: object = None          # refreshed by refresh_host_state (map-output cadence)
+    res_map: object = None
+    chi_map: object = None
     engine: object = None
 
 
@@ -421,6 +425,20 @@ class Engine:
         self._chk(self.lib.dangx_gain_sums(self.h, band, out))
         return out[0], out[1]
 
+    def unit_conversion(self, band, which):
+        """a2t / a2f / f2t of a band (src/dang_bp_mod.f90:181-274); which in 'a2t', 'a2f', 'f2t'."""
+        out = C.c_double(0.0)
+        self._chk(self.lib.dangx_unit_conversion(self.h, band, {"a2t": L.A2T, "a2f": L.A2F, "f2t": L.F2T}[which], C.byref(out)))
+        return out.value
+
+    def convert_maps(self, units, cg_map=None):
+        """convert_maps (src/dang_data_mod.f90:429-463) on the resident maps; returns ddata%conversion."""
+        u = np.ascontiguousarray([L.UNIT_CODES[x] if x in L.UNIT_CODES else 99 for x in units], dtype=np.int32)
+        cg = None if cg_map is None else np.ascontiguousarray(np.asarray(cg_map, dtype=bool).astype(np.int32))
+        conv = np.ones(self.nbands)
+        self._chk(self.lib.dangx_convert_maps(self.h, u.ctypes.data, None if cg is None else cg.ctypes.data, conv.ctypes.data))
+        return conv
+
     def set_tcmb(self, T):
         """The global T_CMB (src/dang_util_mod.f90:15): enters a2t of the 'cmb' component."""
         self._chk(self.lib.dangx_set_tcmb(self.h, float(T)))
@@ -530,6 +548,41 @@ def mask_hi_threshold(ddata, c, thresh):
     m[0] = np.where(bad, 0.0, 1.0)
     c.template = t / thresh
     return ddata.masks
+
+
+def normalize_bandpass(tau_in):
+    """normalize_bandpass, src/dang_bp_mod.f90:62-81."""
+    t = np.ascontiguousarray(tau_in, dtype=np.float64)
+    out = np.empty_like(t)
+    if L.load().dangx_normalize_bandpass(t.ctypes.data, t.size, out.ctypes.data):
+        raise DangxError("normalize_bandpass: empty bandpass")
+    return out
+
+
+def convert_maps(ddata, units, cg_map=None):
+    """ddata%convert_maps (src/dang_data_mod.f90:429-463) with the maps already resident: sets ddata.conversion, scales
+    the device copies of sig_map / rms_map and the offsets; the host copy of ddata.offset follows."""
+    eng = ddata.engine
+    ddata.conversion = eng.convert_maps(units, cg_map)
+    off = np.zeros(eng.nbands) if ddata.offset is None else np.asarray(ddata.offset, dtype=np.float64)
+    skip = np.zeros(eng.nbands, dtype=bool) if cg_map is None else np.asarray(cg_map, dtype=bool)
+    ddata.offset = np.where(skip, off, off * ddata.conversion)
+    return ddata.conversion
+
+
+def refresh_host_state(ddata):
+    """What the output side of the Gibbs loop reads from the host (write_maps, src/dang_data_mod.f90:573-664): the
+    components' amplitude / index maps and template amplitudes, ddata.sky_model / res_map / chi_map / chisq, and the
+    band offsets a fitted monopole sets.  Call at the map-output cadence; nothing else moves maps off the device."""
+    eng = ddata.engine
+    eng.pull_state()
+    for c in eng.component_list:
+        if c.type == "monopole":
+            ddata.offset = np.array(c.template_amplitudes[0], dtype=np.float64)
+    s, sky, res, chi = eng.sky_model_chisq(ddata.pol_type[0], ddata.pol_type[-1], want_maps=True)
+    ddata.sky_model, ddata.res_map, ddata.chi_map = sky, res, chi
+    ddata.chisq = _dist.allreduce_sum_float(s) / eng.nbands / ddata.nump
+    return ddata
 
 
 def compute_chisq(ddata):

@@ -563,6 +563,12 @@ __global__ __launch_bounds__(BLOCK) void k_index_plain_sum(const Model* __restri
     }
 }
 
+// convert_maps, src/dang_data_mod.f90:429-463: sig_map(:,:,j) and rms_map(:,:,j) times conversion(j), on the resident maps
+__global__ __launch_bounds__(BLOCK) void k_scale_band(double* __restrict__ sig, double* __restrict__ rms, long long n, double f) {
+    const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (t < n) { sig[t] = sig[t] * f; rms[t] = rms[t] * f; }
+}
+
 // c%indices(:, s1:s2, nind) = value (src/dang_sample_mod.f90:329, 483: every pixel, masked ones too)
 __global__ __launch_bounds__(BLOCK) void k_fill_index(const Model* __restrict__ Mp, int comp, int nind, int s1, int s2, double value) {
     const Model& M = *Mp;
@@ -637,6 +643,46 @@ double host_a2t(const dangx_ctx* ctx, int j) {
             if (nu > 1e7f) y = (H_PLANCK * nu) / (K_B * ctx->hm.tcmb);
             else y = (H_PLANCK * nu * 1e9) / (K_B * ctx->hm.tcmb);
             sum = sum + tau * ((std::exp(y) - 1.0) * (std::exp(y) - 1.0)) / ((y * y) * std::exp(y));
+        }
+    }
+    return sum;
+}
+
+// compute_bnu_prime_RJ / compute_bnu_prime, src/dang_bp_mod.f90:160-179 (nu in Hz)
+double host_bnu_prime_RJ(double nu) { return 2.0 * K_B * std::pow(nu, 2.0) / std::pow(C_LIGHT, 2.0); }
+double host_bnu_prime(double nu, double tcmb) {
+    const double y = H_PLANCK * nu / (K_B * tcmb);
+    return (2.0 * H_PLANCK * (nu * nu * nu)) / (std::pow(C_LIGHT, 2.0) * (std::exp(y) - 1)) * (std::exp(y) / (std::exp(y) - 1)) * H_PLANCK * nu /
+           (K_B * (tcmb * tcmb));
+}
+// a2f(bp) [MJy/sr / uK_RJ], src/dang_bp_mod.f90:181-209.  `sum*1e14` multiplies by a SINGLE-precision literal: 1e14 is
+// not representable in real(4), the factor is 100000000376832 -- kept, it is what the reference's maps are scaled by
+double host_a2f(const dangx_ctx* ctx, int j) {
+    const Band& b = ctx->hm.band[j];
+    double sum = 0.0;
+    if (b.n == 0) {
+        sum = (b.nu_c > 1e7f) ? host_bnu_prime_RJ(b.nu_c) : host_bnu_prime_RJ(b.nu_c * 1e9);
+    } else {
+        for (int i = 0; i < b.n; ++i) {
+            const double nu = ctx->bp_nu0[b.off + i], tau = ctx->bp_tau0[b.off + i];
+            if (nu == 0.0) continue;
+            sum = sum + tau * ((nu > 1e7f) ? host_bnu_prime_RJ(nu) : host_bnu_prime_RJ(nu * 1e9));
+        }
+    }
+    return sum * (double)1e14f;
+}
+// f2t(bp) [uK_cmb / MJy sr-1], src/dang_bp_mod.f90:245-274
+double host_f2t(const dangx_ctx* ctx, int j) {
+    const Band& b = ctx->hm.band[j];
+    const double T = ctx->hm.tcmb;
+    double sum = 0.0;
+    if (b.n == 0) {
+        sum = 1.0 / ((b.nu_c > 1e7f) ? host_bnu_prime(b.nu_c, T) : host_bnu_prime(b.nu_c * 1e9, T)) * 1.0e-14;
+    } else {
+        for (int i = 0; i < b.n; ++i) {
+            const double nu = ctx->bp_nu0[b.off + i], tau = ctx->bp_tau0[b.off + i];
+            if (nu == 0.0) continue;
+            sum = sum + tau / ((nu > 1e7f) ? host_bnu_prime(nu, T) : host_bnu_prime(nu * 1e9, T)) * 1.0e-14;
         }
     }
     return sum;
@@ -1977,6 +2023,57 @@ int dangx_index_plain_sum(dangx_ctx* ctx, int comp, int nind, int map_n, double*
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     *sum_index = out[0];
     *sum_mask = out[1];
+    return 0;
+}
+
+int dangx_unit_conversion(dangx_ctx* ctx, int band, int which, double* out) {
+    if (!ctx || !out) return 1;
+    if (band < 0 || band >= ctx->dims.nbands || !ctx->band_set[band]) return fail(ctx, "band index out of range / band not set");
+    switch (which) {
+    case DANGX_A2T: *out = host_a2t(ctx, band); return 0;
+    case DANGX_A2F: *out = host_a2f(ctx, band); return 0;
+    case DANGX_F2T: *out = host_f2t(ctx, band); return 0;
+    default: return fail(ctx, "unit conversion selector must be DANGX_A2T, DANGX_A2F or DANGX_F2T");
+    }
+}
+
+int dangx_normalize_bandpass(const double* tau_in, int n, double* tau_out) {
+    if (!tau_in || !tau_out || n <= 0) return 1;
+    double total = 0.0;
+    for (int i = 0; i < n; ++i) total += tau_in[i];   // total = sum(tau_in)
+    for (int i = 0; i < n; ++i) tau_out[i] = tau_in[i] / total;
+    return 0;
+}
+
+int dangx_convert_maps(dangx_ctx* ctx, const int32_t* unit, const int32_t* cg_map, double* conversion) {
+    if (!ctx || !unit || !conversion) return 1;
+    (void)hipSetDevice(ctx->device);
+    if (!ctx->sig || !ctx->rms) return fail(ctx, "map data not uploaded");
+    const int nb = ctx->dims.nbands;
+    for (int j = 0; j < nb; ++j)
+        if (!ctx->band_set[j]) return fail(ctx, "band " + std::to_string(j) + " not set");
+    const long long plane = (long long)ctx->dims.nmaps * ctx->dims.npix;
+    for (int j = 0; j < nb; ++j) {
+        if (cg_map && cg_map[j]) continue;  // :435 `if (.not. self%cg_map(j))`: swapped-in maps are converted by convert_cg_maps
+        double f;
+        if (unit[j] == DANGX_UNIT_UK_RJ) f = 1.0;
+        else if (unit[j] == DANGX_UNIT_UK_CMB) f = 1.0 / host_a2t(ctx, j);
+        else if (unit[j] == DANGX_UNIT_MJY_SR) f = 1.0 / host_a2f(ctx, j);
+        else return fail(ctx, "Not a unit, dumbass! (unit code " + std::to_string(unit[j]) + ")");
+        conversion[j] = f;
+        hipLaunchKernelGGL(k_scale_band, dim3(nblocks(plane)), dim3(BLOCK), 0, ctx->stream, const_cast<double*>(ctx->sig) + (long long)j * plane,
+                           const_cast<double*>(ctx->rms) + (long long)j * plane, plane, f);
+        ctx->hm.offset[j] = ctx->hm.offset[j] * f;
+        // "Set the loaded monopole values into the monopole component" (:453-457): after EVERY converted band the whole
+        // offset vector goes into template_amplitudes(:,1) of every monopole
+        for (int l = 0; l < ctx->dims.ncomp; ++l)
+            if (ctx->comp_set[l] && ctx->desc[l].type == DANGX_MONOPOLE)
+                for (int jj = 0; jj < nb; ++jj) ctx->tamp[l][0][jj] = ctx->hm.offset[jj];
+    }
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->dirty = true;
+    invalidate_chi(ctx);
     return 0;
 }
 

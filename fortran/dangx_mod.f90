@@ -22,6 +22,8 @@ module dangx_mod
   integer(c_int), parameter :: DANGX_FLAG_T = 1, DANGX_FLAG_Q = 2, DANGX_FLAG_U = 4, DANGX_FLAG_QU = 8
   integer(c_int), parameter :: DANGX_SOLVER_DIRECT = 0, DANGX_SOLVER_CG = 1
   integer(c_int), parameter :: DANGX_FLUCT_CORRECT = 0, DANGX_FLUCT_REFERENCE = 1
+  integer(c_int), parameter :: DANGX_A2T = 0, DANGX_A2F = 1, DANGX_F2T = 2
+  integer(c_int), parameter :: DANGX_UNIT_UK_RJ = 0, DANGX_UNIT_UK_CMB = 1, DANGX_UNIT_MJY_SR = 2
 
   type, bind(C) :: dangx_dims
      integer(c_int32_t) :: npix, nmaps, nbands, ncomp
@@ -210,6 +212,22 @@ module dangx_mod
      integer(c_int) function dangx_synchronize(ctx) bind(C, name='dangx_synchronize')
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx
+     end function
+     integer(c_int) function dangx_unit_conversion(ctx, band, which, out) bind(C, name='dangx_unit_conversion')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: band, which          ! which: DANGX_A2T / DANGX_A2F / DANGX_F2T
+       real(c_double), intent(out) :: out
+     end function
+     integer(c_int) function dangx_normalize_bandpass(tau_in, n, tau_out) bind(C, name='dangx_normalize_bandpass')
+       import :: c_int, c_double
+       integer(c_int), value :: n
+       real(c_double), intent(in) :: tau_in(n)
+       real(c_double), intent(out) :: tau_out(n)
+     end function
+     integer(c_int) function dangx_convert_maps(ctx, unit, cg_map, conversion) bind(C, name='dangx_convert_maps')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, unit, cg_map, conversion   ! integer(c_int32_t)(nbands) x2 (cg_map may be c_null_ptr), real(c_double)(nbands)
      end function
      integer(c_int) function dangx_index_plain_sum(ctx, comp, nind, map_n, sum_index, sum_mask) &
           bind(C, name='dangx_index_plain_sum')

@@ -136,6 +136,22 @@ int dangx_set_tcmb(dangx_ctx *ctx, double T_cmb);
 /* ddata%gain(:), ddata%offset(:) (src/dang_data_mod.f90:31-32) */
 int dangx_set_calibration(dangx_ctx *ctx, const double *gain, const double *offset);
 
+/* Unit conversions of a band (src/dang_bp_mod.f90): a2t [uK_cmb/uK_RJ] :211-243, a2f [MJy sr-1/uK_RJ] :181-209 (its
+ * single-precision `1e14` literal included), f2t [uK_cmb/(MJy sr-1)] :245-274, evaluated on the host from the band set
+ * with dangx_set_band (delta: at nu_c; otherwise the tau0-weighted sum over the samples) and the current T_CMB. */
+enum { DANGX_A2T = 0, DANGX_A2F = 1, DANGX_F2T = 2 };
+int dangx_unit_conversion(dangx_ctx *ctx, int band, int which, double *out);
+/* normalize_bandpass, src/dang_bp_mod.f90:62-81: tau_out = tau_in / sum(tau_in) (what init_bp_mod applies to tau0
+ * before the hot path sees it); no context needed */
+int dangx_normalize_bandpass(const double *tau_in, int n, double *tau_out);
+/* convert_maps, src/dang_data_mod.f90:429-463, on the RESIDENT maps: for every band with cg_map[j] == 0 (cg_map may be
+ * NULL = none swapped) conversion[j] = 1 (uK_RJ), 1/a2t (uK_cmb) or 1/a2f (MJy/sr); sig_map(:,:,j), rms_map(:,:,j) and
+ * offset(j) are multiplied by it and the offsets are copied into template_amplitudes(:,1) of every monopole.
+ * conversion[nbands] is an output (ddata%conversion).  Call after dangx_upload_data / dangx_adopt_device_data (adopted
+ * buffers are scaled in place). */
+enum { DANGX_UNIT_UK_RJ = 0, DANGX_UNIT_UK_CMB = 1, DANGX_UNIT_MJY_SR = 2 };
+int dangx_convert_maps(dangx_ctx *ctx, const int32_t *unit, const int32_t *cg_map, double *conversion);
+
 /* ---- map data ------------------------------------------------------------------ */
 /* ddata%sig_map, rms_map, masks: host pointers, copied to HBM */
 int dangx_upload_data(dangx_ctx *ctx, const double *sig, const double *rms, const double *mask);

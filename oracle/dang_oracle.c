@@ -129,6 +129,78 @@ double dgo_a2t(const dgo_ctx *ctx, int band) {
     return sum;
 }
 
+/* src/dang_bp_mod.f90:160-179 (nu in Hz); double defined below with B_nu */
+double dgo_bnu_prime_RJ(double nu);
+double dgo_bnu_prime(double nu, double T_CMB) {
+    const double h = planck_h();
+    double y = h * nu / (K_B * T_CMB);
+    return (2.0 * h * (nu * nu * nu)) / (pow(C_LIGHT, 2.0) * (exp(y) - 1)) * (exp(y) / (exp(y) - 1)) * h * nu / (K_B * (T_CMB * T_CMB));
+}
+
+/* a2f, src/dang_bp_mod.f90:181-209.  `a2f = sum*1e14`: the literal is SINGLE precision (1e14 -> 100000000376832) */
+double dgo_a2f(const dgo_ctx *ctx, int band) {
+    const dgo_band *b = &ctx->bands[band];
+    double sum = 0.0;
+    if (b->n == 0) {
+        if (b->nu_c > 1e7f) sum = dgo_bnu_prime_RJ(b->nu_c);
+        else sum = dgo_bnu_prime_RJ(b->nu_c * 1e9);
+    } else {
+        for (int i = 0; i < b->n; ++i) {
+            if (b->nu0[i] == 0.0) continue;
+            if (b->nu0[i] > 1e7f) sum = sum + b->tau0[i] * dgo_bnu_prime_RJ(b->nu0[i]);
+            else sum = sum + b->tau0[i] * dgo_bnu_prime_RJ(b->nu0[i] * 1e9);
+        }
+    }
+    return sum * 1e14f;
+}
+
+/* f2t, src/dang_bp_mod.f90:245-274 */
+double dgo_f2t(const dgo_ctx *ctx, int band) {
+    const dgo_band *b = &ctx->bands[band];
+    double sum = 0.0;
+    if (b->n == 0) {
+        if (b->nu_c > 1e7f) sum = 1.0 / (dgo_bnu_prime(b->nu_c, ctx->T_CMB)) * 1.0e-14;
+        else sum = 1.0 / (dgo_bnu_prime(b->nu_c * 1e9, ctx->T_CMB)) * 1.0e-14;
+    } else {
+        for (int i = 0; i < b->n; ++i) {
+            if (b->nu0[i] == 0.0) continue;
+            if (b->nu0[i] > 1e7f) sum = sum + b->tau0[i] / (dgo_bnu_prime(b->nu0[i], ctx->T_CMB)) * 1.0e-14;
+            else sum = sum + b->tau0[i] / (dgo_bnu_prime(b->nu0[i] * 1e9, ctx->T_CMB)) * 1.0e-14;
+        }
+    }
+    return sum;
+}
+
+/* normalize_bandpass, src/dang_bp_mod.f90:62-81 */
+void dgo_normalize_bandpass(const double *tau_in, int n, double *tau_out) {
+    double total = 0.0;
+    for (int i = 0; i < n; ++i) total += tau_in[i];
+    for (int i = 0; i < n; ++i) tau_out[i] = tau_in[i] / total;
+}
+
+/* convert_maps, src/dang_data_mod.f90:429-463: unit 0 uK_RJ, 1 uK_cmb, 2 MJy/sr; cg_map may be NULL.  Scales ctx->sig,
+ * ctx->rms, ctx->offset in place and copies the offsets into template_amplitudes(:,1) of every monopole after each band. */
+int dgo_convert_maps(dgo_ctx *ctx, const int *unit, const int *cg_map, double *conversion) {
+    for (int j = 0; j < ctx->nbands; ++j) {
+        if (cg_map && cg_map[j]) continue;
+        if (unit[j] == 0) conversion[j] = 1.0;
+        else if (unit[j] == 1) conversion[j] = 1.0 / dgo_a2t(ctx, j);
+        else if (unit[j] == 2) conversion[j] = 1.0 / dgo_a2f(ctx, j);
+        else return 1; /* "Not a unit" -> stop */
+        double *sig = (double *)ctx->sig, *rms = (double *)ctx->rms; /* the maps are the caller's writable arrays */
+        for (int k = 1; k <= ctx->nmaps; ++k)
+            for (int i = 0; i < ctx->npix; ++i) {
+                sig[IDX3(ctx, j, k, i)] = sig[IDX3(ctx, j, k, i)] * conversion[j];
+                rms[IDX3(ctx, j, k, i)] = rms[IDX3(ctx, j, k, i)] * conversion[j];
+            }
+        ctx->offset[j] = ctx->offset[j] * conversion[j];
+        for (int l = 0; l < ctx->ncomp; ++l)
+            if (ctx->comps[l].type == DGO_MONOPOLE)
+                for (int jj = 0; jj < ctx->nbands; ++jj) ctx->comps[l].template_amplitudes[jj] = ctx->offset[jj];
+    }
+    return 0;
+}
+
 static void get_theta(const dgo_ctx *ctx, const dgo_comp *c, int pix, int map_n, const double *theta, double th[DGO_MAX_IND]) {
     for (int l = 0; l < c->nindices && l < DGO_MAX_IND; ++l)
         th[l] = theta ? theta[l] : c->indices[((int64_t)l * ctx->nmaps + (map_n - 1)) * (int64_t)ctx->npix + pix];

@@ -106,6 +106,15 @@ def lib():
         l.dgo_sample_index_fullsky.restype = C.c_int64
         l.dgo_sample_index_fullsky.argtypes = [C.POINTER(Ctx), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
                                                C.c_uint64, C.POINTER(C.c_int)]
+        l.dgo_bnu_prime.restype = C.c_double
+        l.dgo_bnu_prime.argtypes = [C.c_double, C.c_double]
+        for name in ("dgo_a2f", "dgo_f2t"):
+            getattr(l, name).restype = C.c_double
+            getattr(l, name).argtypes = [C.POINTER(Ctx), C.c_int]
+        l.dgo_normalize_bandpass.restype = None
+        l.dgo_normalize_bandpass.argtypes = [_D, C.c_int, _D]
+        l.dgo_convert_maps.restype = C.c_int
+        l.dgo_convert_maps.argtypes = [C.POINTER(Ctx), C.POINTER(C.c_int), C.POINTER(C.c_int), _D]
         l.dgo_tune_perpixel.restype = None
         l.dgo_tune_perpixel.argtypes = [C.POINTER(Ctx), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
                                         C.POINTER(C.c_int)]
@@ -276,6 +285,23 @@ class Oracle:
         t = C.c_int(1 if tuned else 0)
         acc = self.L.dgo_sample_index_fullsky(self.c, comp, nind, map_n, nsample, ML_CODES[ml_mode], seed, stream, C.byref(t))
         return acc, bool(t.value), self._comps[comp].step_size[nind]
+
+    def a2t(self, band):
+        return self.L.dgo_a2t(self.c, band)
+
+    def a2f(self, band):
+        return self.L.dgo_a2f(self.c, band)
+
+    def f2t(self, band):
+        return self.L.dgo_f2t(self.c, band)
+
+    def convert_maps(self, units, cg_map=None):
+        u = (C.c_int * self.nb)(*[{"uK_RJ": 0, "uK_cmb": 1, "MJy/sr": 2}.get(x, 99) for x in units])
+        cg = None if cg_map is None else (C.c_int * self.nb)(*[int(bool(x)) for x in cg_map])
+        conv = np.ones(self.nb)
+        rc = self.L.dgo_convert_maps(self.c, u, cg, _p(conv))
+        assert rc == 0, "Not a unit"
+        return conv
 
     def tune_perpixel(self, comp, nind, map_n, nsample, ml_mode, seed, stream, tuned=False):
         t = C.c_int(1 if tuned else 0)

@@ -315,3 +315,41 @@ def test_return_poltype_flag():
     assert da.return_poltype_flag("T,Q+U") == [1, 8]
     assert da.return_poltype_flag("T,Q,U") == [1, 2, 4]
     assert da.return_poltype_flag("T+Q+U") == []      # quirk 1: flag 0 can never be matched
+
+
+def test_unit_conversions_closed_forms_and_identities():
+    """a2t / a2f / f2t (src/dang_bp_mod.f90:181-274) against closed forms evaluated independently in Python, for a delta
+    band and for a bandpass: a2t = (e^y-1)^2/(y^2 e^y); a2f = 2 k nu^2/c^2 * 1e14 with the reference's SINGLE-precision
+    literal (1e14 -> 100000000376832); f2t = 1e-14 / B'_nu(T_CMB); and the identity a2f * f2t = a2t * (1e14f/1e14)
+    (B'_RJ / B'_nu = 1/a2t), which ties the three together without reference to any of them."""
+    import math
+    from dang_amd.api import BandInfo, DangComps, DangData
+    h, k, c, T = 1.0545726691251021e-34 * 2.0 * math.pi, 1.3806503e-23, 2.99792458e8, 2.7255
+    nu0 = np.array([90.0, 100.0, 110.0]) * 1e9
+    tau = np.array([0.2, 0.5, 0.3])
+    bands = [BandInfo(label="d", nu_c=143.0), BandInfo(label="b", nu_c=100.0, id="hfi", nu0=nu0, tau0=tau)]
+    comp = DangComps(label="cmb", type="cmb", nu_ref=100.0, nindices=0)
+    dd = DangData(sig_map=np.zeros((2, 1, 4)), rms_map=np.ones((2, 1, 4)), masks=np.ones((1, 4)))
+    orc = O.Oracle(bands, [comp], dd)
+    f14 = float(np.float32(1e14))
+    assert f14 == 100000000376832.0
+
+    def closed(nu):
+        y = h * nu / (k * T)
+        a2t = (math.exp(y) - 1.0) ** 2 / (y * y * math.exp(y))
+        a2f = 2.0 * k * nu * nu / (c * c)
+        bprime = (2.0 * h * nu ** 3) / (c * c * (math.exp(y) - 1.0)) * (math.exp(y) / (math.exp(y) - 1.0)) * h * nu / (k * T * T)
+        return a2t, a2f, 1.0 / bprime
+    a2t, a2f, ib = closed(143e9)
+    assert abs(orc.a2t(0) - a2t) <= 1e-14 * a2t
+    assert abs(orc.a2f(0) - a2f * f14) <= 1e-14 * a2f * f14
+    assert abs(orc.f2t(0) - ib * 1e-14) <= 1e-14 * ib * 1e-14
+    assert abs(orc.a2f(0) * orc.f2t(0) / orc.a2t(0) - f14 / 1e14) <= 1e-14
+    parts = [closed(v) for v in nu0]
+    assert abs(orc.a2t(1) - sum(t * p[0] for t, p in zip(tau, parts))) <= 1e-14 * orc.a2t(1)
+    assert abs(orc.a2f(1) - sum(t * p[1] for t, p in zip(tau, parts)) * f14) <= 1e-14 * orc.a2f(1)
+    assert abs(orc.f2t(1) - sum(t * p[2] for t, p in zip(tau, parts)) * 1e-14) <= 1e-14 * orc.f2t(1)
+    # normalize_bandpass (:62-81)
+    out = np.empty(3)
+    O.lib().dgo_normalize_bandpass(O._p(np.array([2.0, 5.0, 3.0])), 3, O._p(out))
+    assert np.array_equal(out, np.array([2.0, 5.0, 3.0]) / 10.0)
