@@ -96,6 +96,7 @@ SYMBOLS = {
     "dangx_chisq_cached": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _D]),
     "dangx_chisq_cached_dev": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "dangx_fullsky_prepare": (C.c_int, [_P, C.c_int, C.c_int]),
+    "dangx_fullsky_prepare_coarse": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dangx_fullsky_sums": (C.c_int, [_P, C.c_int, _P, _P, C.c_int]),
     "dangx_fill_index": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_double]),
     "dangx_gain_sums": (C.c_int, [_P, C.c_int, _P]),

@@ -373,6 +373,9 @@ class Engine:
     def fullsky_prepare(self, comp, map_n):
         self._chk(self.lib.dangx_fullsky_prepare(self.h, comp, map_n))
 
+    def fullsky_prepare_coarse(self, comp, map_n, sample_nside):
+        self._chk(self.lib.dangx_fullsky_prepare_coarse(self.h, comp, map_n, self.nside, int(sample_nside)))
+
     def fullsky_sums(self, what, theta, nrows):
         th = (C.c_double * 2)(float(theta[0]), float(theta[1]) if len(theta) > 1 else 0.0)
         out = (C.c_double * nrows)()
@@ -641,9 +644,8 @@ def sample_spectral_parameters(dpar: DangParams, ddata: DangData, it=2, verbose=
                     raise DangxError("There is something wrong with the poltype flag for component " + c.label)
                 coarse = c.sample_nside[j] if c.sample_nside else 0
                 if c.index_mode and c.index_mode[j] == 1:
-                    if coarse and coarse != eng.nside:
-                        raise DangxError("full-sky index mode with sample_nside /= nside is not built")
-                    acc = sample_index_mh_fullsky(dpar, ddata, l, j, _MAPN[f], stream_id(it, 1, l, j, f))
+                    acc = sample_index_mh_fullsky(dpar, ddata, l, j, _MAPN[f], stream_id(it, 1, l, j, f),
+                                                  sample_nside=coarse if (coarse and coarse != eng.nside) else None)
                 elif coarse and coarse != eng.nside:
                     if c.tuned and not c.tuned[j]:
                         raise DangxError("step-size tuning with sample_nside /= nside is not built")
@@ -789,8 +791,9 @@ def tune_perpixel(dpar, ddata, l, nind, map_n, stream):
     return c.step_size[nind]
 
 
-def sample_index_mh_fullsky(dpar, ddata, l, nind, map_n, stream):
-    """sample_index_mh, index_mode == 1 (src/dang_sample_mod.f90:229-329): one spectral index for the whole sky."""
+def sample_index_mh_fullsky(dpar, ddata, l, nind, map_n, stream, sample_nside=None):
+    """sample_index_mh, index_mode == 1 (src/dang_sample_mod.f90:229-329): one spectral index for the whole sky.
+    sample_nside (/= nside): the chain's sums run over the degraded maps (:199-217); one whole-sky context."""
     eng = ddata.engine
     c = eng.component_list[l]
     s1 = 2 if map_n == -1 else map_n
@@ -799,7 +802,10 @@ def sample_index_mh_fullsky(dpar, ddata, l, nind, map_n, stream):
     nb = eng.nbands
     if not c.tuned:
         c.tuned = [True] * max(c.nindices, 1)
-    eng.fullsky_prepare(l, map_n)                         # :173-196
+    if sample_nside:
+        eng.fullsky_prepare_coarse(l, map_n, sample_nside)  # :173-217
+    else:
+        eng.fullsky_prepare(l, map_n)                     # :173-196
     first = _dist.bcast_from_rank0(eng.peek_indices(l, s1, 0))  # c%indices(0, map_inds(1), l), :240-242
     sample = list(first) + [0.0] * (2 - c.nindices)
     theta = list(sample)

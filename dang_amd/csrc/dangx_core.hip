@@ -277,20 +277,29 @@ __global__ __launch_bounds__(BLOCK) void k_fullsky_prepare(const Model* __restri
 // row sums for one evaluation at theta: what = 0: evaluate_lnL (1 row: -1/2 sum ((d-m)/rms)^2, unmasked);
 // what = 1: evaluate_marginal_lnL (2*nb*Sp rows: TNd(j,k), TNT(j,k), all pixels); what = 2: jeffreys (1 row).
 // partial[row][gridDim.x]
+// With sample_nside /= nside (crms /= nullptr) the sums run over the npix_c pixels of the DEGRADED data / rms / mask
+// ([kk][j][npix_c] and [npix_c]) while eval_signal reads c%amplitude at the coarse pixel number in the full-resolution
+// array, as the reference does (src/dang_sample_mod.f90:199-217, 548-563).
 __global__ __launch_bounds__(BLOCK) void k_fullsky_rows(const Model* __restrict__ Mp, int comp, int s1, int s2, int what,
                                                         double th0, double th1, const double* __restrict__ data,
-                                                        double* __restrict__ partial) {
+                                                        const double* __restrict__ crms, const double* __restrict__ cmask,
+                                                        long long npix_c, double* __restrict__ partial) {
     __shared__ double sh[BLOCK / 64];
     const Model& M = *Mp;
     const Comp& c = M.comp[comp];
-    const int npix = M.npix, nb = M.nbands, Sp = s2 - s1 + 1;
+    const int nb = M.nbands, Sp = s2 - s1 + 1;
+    const bool coarse = crms != nullptr;
+    const int npix = coarse ? (int)npix_c : M.npix;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     const bool in = i < npix;
-    const bool msk = in ? is_masked(M.mask[i]) : true;
+    const bool msk = in ? is_masked(coarse ? cmask[i] : M.mask[i]) : true;
     const Prep pr = sed_prep(c, th0, th1);
     const int nrows = (what == 1) ? 2 * nb * Sp : 1;
     double amp[2] = {0.0, 0.0};
-    if (in) for (int kk = 0; kk < Sp; ++kk) amp[kk] = c.amp[(long long)(s1 + kk - 1) * npix + i];
+    if (in) for (int kk = 0; kk < Sp; ++kk) amp[kk] = c.amp[(long long)(s1 + kk - 1) * M.npix + i];
+    auto rms_at = [&](int kk, int j) -> double {
+        return coarse ? crms[((long long)kk * nb + j) * npix + i] : M.rms[((long long)j * M.nmaps + (s1 + kk - 1)) * npix + i];
+    };
     for (int row = 0; row < nrows; ++row) {
         double v = 0.0;
         if (in) {
@@ -298,20 +307,20 @@ __global__ __launch_bounds__(BLOCK) void k_fullsky_rows(const Model* __restrict_
                 for (int kk = 0; kk < Sp; ++kk)
                     for (int j = 0; j < nb; ++j) {
                         const double m = signal_of(c, amp[kk], sed_eval(M, c, j, pr));
-                        const double t = (data[((long long)kk * nb + j) * npix + i] - m) / M.rms[((long long)j * M.nmaps + (s1 + kk - 1)) * npix + i];
+                        const double t = (data[((long long)kk * nb + j) * npix + i] - m) / rms_at(kk, j);
                         v = v - 0.5 * (t * t);
                     }
             } else if (what == 1) {
                 const int q = row >> 1, j = q / Sp, kk = q - j * Sp;  // (j outer, k inner) as the reference sums
                 const double m = signal_of(c, amp[kk], sed_eval(M, c, j, pr));
-                const double rms = M.rms[((long long)j * M.nmaps + (s1 + kk - 1)) * npix + i];
+                const double rms = rms_at(kk, j);
                 const double TN = m / (rms * rms);
                 v = (row & 1) ? TN * m : TN * data[((long long)kk * nb + j) * npix + i];
             } else if (what == 2 && !msk && c.is_synch) {
                 for (int kk = 0; kk < Sp; ++kk)
                     for (int j = 0; j < nb; ++j) {
                         const double ss = signal_of(c, amp[kk], sed_eval(M, c, j, pr));
-                        const double rr = 1.0 / M.rms[((long long)j * M.nmaps + (s1 + kk - 1)) * npix + i];
+                        const double rr = 1.0 / rms_at(kk, j);
                         const double t = (rr * rr) * (ss / amp[kk]) * c.lnr[j];
                         v = v + t * t;
                     }
@@ -470,6 +479,22 @@ __global__ __launch_bounds__(BLOCK) void k_index_mh_coarse(const Model* __restri
                 return lnL;
             };
             auto prior = [&](double v) -> double {
+                if (c.prior_type[q] == DANGX_PRIOR_JEFFREYS) {
+                    // eval_jeffreys_prior(c, data, rms, model, map_inds, i, mask(:,1), val), src/dang_lnl_mod.f90:242-304:
+                    // the DEGRADED rms and mask, eval_signal / c%amplitude at the coarse pixel number, theta = (val, -)
+                    double sum = 0.0;
+                    if (c.is_synch && !cmasked) {
+                        const Prep pr = sed_prep(c, v, 0.0);
+                        for (int kk = 0; kk < Sp; ++kk)
+                            for (int j = 0; j < nb; ++j) {
+                                const double ss = signal_of(c, amp[kk], sed_eval(M, c, j, pr));
+                                const double rr = 1.0 / crms[((long long)kk * nb + j) * npix_c + i];
+                                const double tt = (rr * rr) * (ss / amp[kk]) * c.lnr[j];
+                                sum = sum + tt * tt;
+                            }
+                    }
+                    return log(sqrt(sum));
+                }
                 if (c.prior_type[q] != DANGX_PRIOR_GAUSSIAN) return 0.0;
                 const double arg = ((v - c.gauss[q][0]) * (v - c.gauss[q][0])) / (2 * (c.gauss[q][1] * c.gauss[q][1]));
                 return (arg > 745.0) ? -INFINITY : -arg - c.lgden[q];
@@ -1822,7 +1847,7 @@ int dangx_fullsky_prepare(dangx_ctx* ctx, int comp, int map_n) {
         if (l != comp && ((ctx->plane_nz[l] & ((1u << (s1 - 1)) | (1u << (s2 - 1)))) || ctx->desc[l].type == DANGX_TCMB || is_global_type(ctx->desc[l].type))) others |= 1u << l;
     hipLaunchKernelGGL(k_fullsky_prepare, dim3(nblocks(ctx->hm.npix)), dim3(BLOCK), 0, ctx->stream, ctx->dm, comp, s1, s2, others, ctx->fs_data);
     HIPCHK(ctx, hipGetLastError());
-    ctx->fs_comp = comp; ctx->fs_s1 = s1; ctx->fs_s2 = s2;
+    ctx->fs_comp = comp; ctx->fs_s1 = s1; ctx->fs_s2 = s2; ctx->fs_npc = 0;
     return 0;
 }
 
@@ -1837,10 +1862,12 @@ int dangx_fullsky_sums(dangx_ctx* ctx, int what, const double* theta, double* ou
     const int Sp = ctx->fs_s2 - ctx->fs_s1 + 1;
     const int rows = (what == 1) ? 2 * ctx->hm.nbands * Sp : 1;
     if (nout < rows) return fail(ctx, "output buffer too small");
-    const unsigned nblk = nblocks(ctx->hm.npix);
+    const bool coarse = ctx->fs_npc > 0;
+    const unsigned nblk = nblocks(coarse ? ctx->fs_npc : ctx->hm.npix);
     if (ensure_partial(ctx, (long long)rows * nblk)) return 1;
     hipLaunchKernelGGL(k_fullsky_rows, dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->dm, ctx->fs_comp, ctx->fs_s1, ctx->fs_s2, what,
-                       theta[0], theta[1], ctx->fs_data, ctx->partial);
+                       theta[0], theta[1], coarse ? ctx->cs_data : ctx->fs_data, coarse ? ctx->cs_rms : (const double*)nullptr,
+                       coarse ? ctx->cs_mask : (const double*)nullptr, coarse ? ctx->fs_npc : 0ll, ctx->partial);
     hipLaunchKernelGGL(k_reduce_rows_final, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->partial, (long long)nblk, rows, ctx->rows_out);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(out, ctx->rows_out, sizeof(double) * rows, hipMemcpyDeviceToHost, ctx->stream));
@@ -1920,22 +1947,11 @@ int dangx_udgrade(dangx_ctx* ctx, int mode, const double* map_in, int nside_in, 
     return 0;
 }
 
-int dangx_index_sample_coarse(dangx_ctx* ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed,
-                              uint64_t stream, int nside, int sample_nside, int64_t* accepted) {
-    if (!ctx || check_comp(ctx, comp)) return 1;
-    (void)hipSetDevice(ctx->device);
+// data_raw minus every other component at full resolution (:173-196, the full-sky mode's staging kernel), degraded with
+// udgrade_ring; the rms with udgrade_rms, the mask with udgrade_mask (:199-217) -> cs_data / cs_rms / cs_mask
+static int coarse_stage(dangx_ctx* ctx, int comp, int map_n, int nside, int sample_nside) {
     const long long npix = ctx->dims.npix;
-    if (ctx->dims.pix0 != 0 || npix != 12LL * nside * nside || ctx->dims.npix_global != npix)
-        return fail(ctx, "coarse-Nside sampling needs ONE whole-sky context (npix = 12*nside^2): the children of a coarse pixel are scattered over the RING ranges of a sharded run");
-    if (!(sample_nside < nside)) return fail(ctx, "sample_nside must be smaller than nside (equal: dangx_index_sample)");
-    const dangx_comp_desc& d = ctx->desc[comp];
-    if (nind < 0 || nind >= d.nindices) return fail(ctx, "index number out of range");
-    if (d.type > DANGX_TCMB) return fail(ctx, "coarse-Nside sampling is built for the diffuse component types and T_cmb");
-    if (d.lnl_type[nind] < DANGX_LNL_CHISQ || d.lnl_type[nind] > DANGX_LNL_PRIOR) return fail(ctx, "bad lnl_type");
-    if (d.prior_type[nind] == DANGX_PRIOR_JEFFREYS) return fail(ctx, "coarse-Nside sampling with the Jeffreys prior is not built");
-    if (ml_mode != DANGX_ML_SAMPLE && ml_mode != DANGX_ML_OPTIMIZE) return fail(ctx, "bad ml_mode");
     if (hp_tables(ctx, nside, sample_nside)) return 1;
-    // data_raw minus every other component at full resolution (:173-196): the full-sky mode's staging kernel
     if (dangx_fullsky_prepare(ctx, comp, map_n)) return 1;
     const int s1 = ctx->fs_s1, s2 = ctx->fs_s2, Sp = s2 - s1 + 1, nb = ctx->hm.nbands;
     ctx->fs_comp = -1;  // the staging buffer is ours now
@@ -1958,6 +1974,44 @@ int dangx_index_sample_coarse(dangx_ctx* ctx, int comp, int nind, int map_n, int
                        ratio, 1, 1, scale, 1, nb, ctx->hm.nmaps, s1);
     hipLaunchKernelGGL(k_udgrade, g1, dim3(BLOCK), 0, ctx->stream, ctx->mask, ctx->cs_mask, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
                        ratio, 1, 2, scale, 0, nb, ctx->hm.nmaps, s1);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+// full-sky index mode with sample_nside /= nside (src/dang_sample_mod.f90:199-217, 229-329): the chain's sky-wide sums run
+// over the degraded maps.  After this call dangx_fullsky_sums evaluates on them; the chain ends with dangx_fill_index
+// (udgrade_ring of a constant coarse map is that constant everywhere, :480-483).
+int dangx_fullsky_prepare_coarse(dangx_ctx* ctx, int comp, int map_n, int nside, int sample_nside) {
+    if (!ctx || check_comp(ctx, comp)) return 1;
+    (void)hipSetDevice(ctx->device);
+    const long long npix = ctx->dims.npix;
+    if (ctx->dims.pix0 != 0 || npix != 12LL * nside * nside || ctx->dims.npix_global != npix)
+        return fail(ctx, "coarse-Nside sampling needs ONE whole-sky context (npix = 12*nside^2): the children of a coarse pixel are scattered over the RING ranges of a sharded run");
+    if (!(sample_nside < nside)) return fail(ctx, "sample_nside must be smaller than nside (equal: dangx_fullsky_prepare)");
+    if (ctx->desc[comp].type > DANGX_TCMB) return fail(ctx, "coarse-Nside sampling is built for the diffuse component types and T_cmb");
+    if (coarse_stage(ctx, comp, map_n, nside, sample_nside)) return 1;
+    ctx->fs_comp = comp;
+    ctx->fs_npc = 12LL * sample_nside * sample_nside;
+    return 0;
+}
+
+int dangx_index_sample_coarse(dangx_ctx* ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed,
+                              uint64_t stream, int nside, int sample_nside, int64_t* accepted) {
+    if (!ctx || check_comp(ctx, comp)) return 1;
+    (void)hipSetDevice(ctx->device);
+    const long long npix = ctx->dims.npix;
+    if (ctx->dims.pix0 != 0 || npix != 12LL * nside * nside || ctx->dims.npix_global != npix)
+        return fail(ctx, "coarse-Nside sampling needs ONE whole-sky context (npix = 12*nside^2): the children of a coarse pixel are scattered over the RING ranges of a sharded run");
+    if (!(sample_nside < nside)) return fail(ctx, "sample_nside must be smaller than nside (equal: dangx_index_sample)");
+    const dangx_comp_desc& d = ctx->desc[comp];
+    if (nind < 0 || nind >= d.nindices) return fail(ctx, "index number out of range");
+    if (d.type > DANGX_TCMB) return fail(ctx, "coarse-Nside sampling is built for the diffuse component types and T_cmb");
+    if (d.lnl_type[nind] < DANGX_LNL_CHISQ || d.lnl_type[nind] > DANGX_LNL_PRIOR) return fail(ctx, "bad lnl_type");
+    if (ml_mode != DANGX_ML_SAMPLE && ml_mode != DANGX_ML_OPTIMIZE) return fail(ctx, "bad ml_mode");
+    if (coarse_stage(ctx, comp, map_n, nside, sample_nside)) return 1;
+    const int s1 = ctx->fs_s1, s2 = ctx->fs_s2;
+    const long long npc = 12LL * sample_nside * sample_nside;
+    const int r1 = nside / sample_nside, ratio = r1 * r1;
     IndexArgs a{};
     a.comp = comp; a.nind = nind; a.nsample = nsample; a.ml_mode = ml_mode; a.seed = seed; a.stream = stream;
     a.s1 = s1; a.s2 = s2; a.mode = CH_GENERIC;

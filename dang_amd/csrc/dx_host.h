@@ -102,6 +102,7 @@ struct dangx_ctx {
     double* fs_data = nullptr;              // full-sky mode: cleaned data [Sp][nb][npix]
     long long fs_cap = 0;
     int fs_comp = -1, fs_s1 = 0, fs_s2 = 0;
+    long long fs_npc = 0;                   // > 0: the full-sky sums run over the degraded maps (cs_*) of that many pixels
     double* rows_out = nullptr;             // device [2*MAXB*2 + 8] row sums
     // coarse-Nside index sampling: HEALPix RING<->NEST maps of both resolutions + degraded data / rms / mask
     int hp_nside = 0, hp_cnside = 0;

@@ -158,6 +158,12 @@ module dangx_mod
        type(c_ptr), value :: ctx
        integer(c_int), value :: comp, map_n
      end function
+     integer(c_int) function dangx_fullsky_prepare_coarse(ctx, comp, map_n, nside, sample_nside) &
+          bind(C, name='dangx_fullsky_prepare_coarse')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: comp, map_n, nside, sample_nside
+     end function
      integer(c_int) function dangx_fullsky_sums(ctx, what, theta, out, nout) bind(C, name='dangx_fullsky_sums')
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx, theta, out

@@ -374,8 +374,8 @@ contains
              end if
              if (cc%index_mode(j) == 1) then
                 write(*,*) 'Sampling fullsky'
-                if (cc%sample_nside(j) /= nside) then
-                   write(*,*) 'dang_gpu_mod: full-sky index mode with sample_nside /= nside is not on the GPU path'
+                if (cc%sample_nside(j) /= nside .and. (gpu_sky%nctx > 1 .or. numprocs > 1)) then
+                   write(*,*) 'dang_gpu_mod: sample_nside /= nside needs the whole sky in one context (dangx_init(..., ngpu=1))'
                    stop
                 end if
                 call sample_index_mh_fullsky_gpu(cc, i-1, j, map_n)
@@ -532,7 +532,12 @@ contains
     type(dangx_comp_desc)      :: d
 
     s1 = merge(2, map_n, map_n == -1); sp = merge(2, 1, map_n == -1)
-    call dangx_sky_fullsky_prepare(gpu_sky, comp0, map_n)                                          ! :173-196
+    if (cc%sample_nside(nind) /= nside) then                                                        ! :173-217, degraded maps
+       call dangx_check(gpu_sky%ctx(1), dangx_fullsky_prepare_coarse(gpu_sky%ctx(1), comp0, map_n, nside, cc%sample_nside(nind)), &
+            'fullsky_prepare_coarse')
+    else
+       call dangx_sky_fullsky_prepare(gpu_sky, comp0, map_n)                                       ! :173-196
+    end if
     sample = 0.d0
     if (gpu_pix0 == 0) call dangx_sky_peek_first(gpu_sky, comp0, s1, sample)                       ! :240-242
     sample(1) = rank_sum(sample(1)); sample(2) = rank_sum(sample(2))

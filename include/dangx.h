@@ -234,7 +234,7 @@ int dangx_chisq_cached_dev(dangx_ctx *ctx, int which, int pol_lo, int pol_hi, do
  * c%amplitude(i,k): src/dang_sample_mod.f90:362, 372-377, 548-553): reproduced literally, see DESIGN.md section 7.
  * HEALPix itself is absent from the reference tree (an external library): udgrade_ring / nest2ring are restated from
  * the published algorithm (Gorski et al. 2005, ApJ 622, 759; HEALPix 3.x pix_tools / udgrade_nr).
- * Likelihoods: chisq / marginal / prior; priors: gaussian / uniform; diffuse component types and T_cmb. */
+ * Likelihoods: chisq / marginal / prior; priors: gaussian / uniform / jeffreys; diffuse component types and T_cmb. */
 int dangx_index_sample_coarse(dangx_ctx *ctx, int comp, int nind, int map_n, int nsample, int ml_mode,
                               uint64_t seed, uint64_t stream, int nside, int sample_nside, int64_t *accepted);
 /* the degrade / upgrade primitives on their own (whole-sky context): mode 0 = udgrade_ring, 1 = udgrade_rms,
@@ -263,6 +263,11 @@ int dangx_index_plain_sum(dangx_ctx *ctx, int comp, int nind, int map_n, double 
  *   dangx_fill_index     : c%indices(:, s1:s2, nind) = value for every pixel (:329, :483).
  *   dangx_gain_sums      : out[0] = sum map2*N_inv*map1, out[1] = sum map1*N_inv*map1 of fit_band_gain (:606-607). */
 int dangx_fullsky_prepare(dangx_ctx *ctx, int comp, int map_n);
+/* the same mode with c%sample_nside(nind) /= nside (:199-217): the cleaned data, the rms and the mask are degraded first
+ * (udgrade_ring / udgrade_rms / udgrade_mask), dangx_fullsky_sums then runs over the 12*sample_nside^2 coarse pixels --
+ * with eval_signal's c%amplitude read from the full-resolution array at the coarse pixel number, as in the reference
+ * (see dangx_index_sample_coarse).  One whole-sky context. */
+int dangx_fullsky_prepare_coarse(dangx_ctx *ctx, int comp, int map_n, int nside, int sample_nside);
 int dangx_fullsky_sums(dangx_ctx *ctx, int what, const double *theta, double *out, int nout);
 int dangx_fill_index(dangx_ctx *ctx, int comp, int nind, int map_n, double value);
 int dangx_gain_sums(dangx_ctx *ctx, int band, double *out);

@@ -1086,7 +1086,27 @@ int64_t dgo_sample_index_mh_coarse(dgo_ctx *ctx, int comp, int nind, int map_n, 
         (c->lnl_type[nind] == DGO_LNL_CHISQ    ? dgo_evaluate_lnL(nb, s1, s2, data, rmsl, model, 1, 64, 0, cmask[i]) \
          : c->lnl_type[nind] == DGO_LNL_MARGINAL ? dgo_evaluate_marginal_lnL(nb, s1, s2, data, rmsl, model, 1, 64, 0) \
                                                  : 0.0)
-#define PRIOR(v) (c->prior_type[nind] == DGO_PRIOR_GAUSSIAN ? log(dgo_eval_normal_prior((v), c->gauss_prior[nind][0], c->gauss_prior[nind][1])) : 0.0)
+/* eval_jeffreys_prior(c,data,rms,model,map_inds,i,mask(:,1),val), src/dang_lnl_mod.f90:242-304: rms and mask are the
+ * DEGRADED ones, c%eval_signal(j,i,k,theta) and c%amplitude(i,k) the full-resolution arrays at the coarse pixel number */
+#define JEFFREYS(v, out)                                                                                         \
+        do {                                                                                                     \
+            double sum_ = 0.0, th_[DGO_MAX_IND] = {(v), 0.0};                                                    \
+            if (c->is_synch && !masked(cmask[i]))                                                                \
+                for (int k = s1; k <= s2; ++k)                                                                   \
+                    for (int j = 0; j < nb; ++j) {                                                               \
+                        double ss_ = dgo_eval_signal(ctx, comp, j, (int)i, k, th_);                              \
+                        double rr_ = 1.0 / rmsl[(k - 1) * 64 + j];                                               \
+                        double t_ = ((rr_ * rr_) * (ss_ / c->amplitude[IDX2(ctx, k, i)]) * log(ctx->bands[j].nu_c / c->nu_ref)); \
+                        sum_ = sum_ + t_ * t_;                                                                   \
+                    }                                                                                            \
+            (out) = log(sqrt(sum_));                                                                             \
+        } while (0)
+#define PRIOR(v, out)                                                                                            \
+        do {                                                                                                     \
+            if (c->prior_type[nind] == DGO_PRIOR_GAUSSIAN) (out) = log(dgo_eval_normal_prior((v), c->gauss_prior[nind][0], c->gauss_prior[nind][1])); \
+            else if (c->prior_type[nind] == DGO_PRIOR_JEFFREYS) JEFFREYS((v), (out));                            \
+            else (out) = 0.0;                                                                                    \
+        } while (0)
         FILL_MODEL(sample)
         int sample_it = 1;
         double lnl = LNL();
@@ -1096,7 +1116,9 @@ int64_t dgo_sample_index_mh_coarse(dgo_ctx *ctx, int comp, int nind, int map_n, 
             dgo_uniform2(seed, stream, (uint64_t)i, 0u, u);
             sample[nind] = dgo_rand_normal(c->gauss_prior[nind][0], c->gauss_prior[nind][1], u[0], u[1]);
         }
-        double lnl_old = lnl + PRIOR(sample[nind]);
+        double lnl_prior;
+        PRIOR(sample[nind], lnl_prior);
+        double lnl_old = lnl + lnl_prior;
         if (sample_it) {
             for (int l = 1; l <= nsample; ++l) {
                 double u[3];
@@ -1105,7 +1127,8 @@ int64_t dgo_sample_index_mh_coarse(dgo_ctx *ctx, int comp, int nind, int map_n, 
                 if (theta[nind] < c->uni_prior[nind][0] || theta[nind] > c->uni_prior[nind][1]) continue;
                 FILL_MODEL(theta)
                 lnl = LNL();
-                double lnl_new = lnl + PRIOR(theta[nind]);
+                PRIOR(theta[nind], lnl_prior);
+                double lnl_new = lnl + lnl_prior;
                 double diff = lnl_new - lnl_old;
                 if (ml_mode == DGO_ML_OPTIMIZE) {
                     if (diff > 0.0) { sample[nind] = theta[nind]; lnl_old = lnl_new; accepted += 1; }
@@ -1118,6 +1141,7 @@ int64_t dgo_sample_index_mh_coarse(dgo_ctx *ctx, int comp, int nind, int map_n, 
 #undef FILL_MODEL
 #undef LNL
 #undef PRIOR
+#undef JEFFREYS
     }
     dgo_udgrade(0, index_map, sample_nside, index_full, nside); /* :480 */
     for (int k = s1; k <= s2; ++k)
@@ -1134,21 +1158,34 @@ typedef struct {
     const dgo_ctx *ctx;
     int comp, nind, s1, s2;
     double *data; /* [nb][nmaps][npix] data_raw minus every other component (:173-196) */
+    /* sample_nside /= nside (:199-217): npc > 0 coarse pixels, degraded data / rms [kk][j][npc] and mask [npc]; the model
+     * (eval_signal) still reads c%amplitude of the full-resolution array at the coarse pixel number */
+    int64_t npc;
+    double *cdata, *crms, *cmask;
 } fs_state;
+
+static int fs_npix(const fs_state *S) { return S->npc > 0 ? (int)S->npc : S->ctx->npix; }
+static double fs_d(const fs_state *S, int j, int k, int i) {
+    return S->npc > 0 ? S->cdata[((int64_t)(k - S->s1) * S->ctx->nbands + j) * S->npc + i] : S->data[IDX3(S->ctx, j, k, i)];
+}
+static double fs_r(const fs_state *S, int j, int k, int i) {
+    return S->npc > 0 ? S->crms[((int64_t)(k - S->s1) * S->ctx->nbands + j) * S->npc + i] : S->ctx->rms[IDX3(S->ctx, j, k, i)];
+}
+static double fs_m(const fs_state *S, int i) { return S->npc > 0 ? S->cmask[i] : S->ctx->mask[i]; }
 
 /* update_sample_model without pixel (:555-563) + evaluate_lnL / evaluate_marginal_lnL over the sky */
 static double fs_lnl(const fs_state *S, const double *theta) {
     const dgo_ctx *ctx = S->ctx;
     const dgo_comp *c = &ctx->comps[S->comp];
-    const int npix = ctx->npix, nb = ctx->nbands;
+    const int npix = fs_npix(S), nb = ctx->nbands;
     if (c->lnl_type[S->nind] == DGO_LNL_CHISQ) { /* src/dang_lnl_mod.f90:168-180: i outer, k, j inner */
         double lnL = 0.0;
         for (int i = 0; i < npix; ++i) {
-            if (masked(ctx->mask[i])) continue;
+            if (masked(fs_m(S, i))) continue;
             for (int k = S->s1; k <= S->s2; ++k)
                 for (int j = 0; j < nb; ++j) {
                     double m = dgo_eval_signal(ctx, S->comp, j, i, k, theta);
-                    double t = (S->data[IDX3(ctx, j, k, i)] - m) / ctx->rms[IDX3(ctx, j, k, i)];
+                    double t = (fs_d(S, j, k, i) - m) / fs_r(S, j, k, i);
                     lnL = lnL - 0.5 * (t * t);
                 }
         }
@@ -1161,9 +1198,9 @@ static double fs_lnl(const fs_state *S, const double *theta) {
                 double TNd = 0.0, TNT = 0.0;
                 for (int i = 0; i < npix; ++i) {
                     double m = dgo_eval_signal(ctx, S->comp, j, i, k, theta);
-                    double rms = ctx->rms[IDX3(ctx, j, k, i)];
+                    double rms = fs_r(S, j, k, i);
                     double TN = m / (rms * rms);
-                    TNd += TN * S->data[IDX3(ctx, j, k, i)];
+                    TNd += TN * fs_d(S, j, k, i);
                     TNT += TN * m;
                 }
                 lnL = lnL - 0.5 * TNd * (1.0 / TNT) * TNd;
@@ -1179,12 +1216,12 @@ static double fs_jeffreys(const fs_state *S, double val) {
     const dgo_comp *c = &ctx->comps[S->comp];
     double sum = 0.0, theta[DGO_MAX_IND] = {val, 0.0};
     if (c->is_synch)
-        for (int i = 0; i < ctx->npix; ++i) {
-            if (masked(ctx->mask[i])) continue;
+        for (int i = 0; i < fs_npix(S); ++i) {
+            if (masked(fs_m(S, i))) continue;
             for (int k = S->s1; k <= S->s2; ++k)
                 for (int j = 0; j < ctx->nbands; ++j) {
                     double ss = dgo_eval_signal(ctx, S->comp, j, i, k, theta);
-                    double rr = 1.0 / ctx->rms[IDX3(ctx, j, k, i)];
+                    double rr = 1.0 / fs_r(S, j, k, i);
                     double t = ((rr * rr) * (ss / c->amplitude[IDX2(ctx, k, i)]) * log(ctx->bands[j].nu_c / c->nu_ref));
                     sum = sum + t * t;
                 }
@@ -1242,11 +1279,26 @@ static void fs_tune(fs_state *S, dgo_comp *c, const double *theta_init, int nsam
     }
 }
 
+static int64_t sample_index_fullsky_impl(dgo_ctx *ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed,
+                                         uint64_t stream, int *tuned, int nside, int sample_nside);
+
 int64_t dgo_sample_index_fullsky(dgo_ctx *ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed,
                                  uint64_t stream, int *tuned) {
+    return sample_index_fullsky_impl(ctx, comp, nind, map_n, nsample, ml_mode, seed, stream, tuned, 0, 0);
+}
+
+/* index_mode == 1 with c%sample_nside(nind) /= nside (src/dang_sample_mod.f90:199-217, 229-329) */
+int64_t dgo_sample_index_fullsky_coarse(dgo_ctx *ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed,
+                                        uint64_t stream, int *tuned, int nside, int sample_nside) {
+    if (ctx->pix0 != 0 || ctx->npix != 12 * nside * nside || sample_nside >= nside) return -1;
+    return sample_index_fullsky_impl(ctx, comp, nind, map_n, nsample, ml_mode, seed, stream, tuned, nside, sample_nside);
+}
+
+static int64_t sample_index_fullsky_impl(dgo_ctx *ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed,
+                                         uint64_t stream, int *tuned, int nside, int sample_nside) {
     dgo_comp *c = &ctx->comps[comp];
     const int npix = ctx->npix, nb = ctx->nbands, nmaps = ctx->nmaps;
-    fs_state S = {ctx, comp, nind, (map_n == -1) ? 2 : map_n, (map_n == -1) ? 3 : map_n, NULL};
+    fs_state S = {ctx, comp, nind, (map_n == -1) ? 2 : map_n, (map_n == -1) ? 3 : map_n, NULL, 0, NULL, NULL, NULL};
     uint32_t draw = 1;
     int64_t accepted = 0;
     S.data = (double *)malloc(sizeof(double) * (size_t)nb * nmaps * npix);
@@ -1259,6 +1311,19 @@ int64_t dgo_sample_index_fullsky(dgo_ctx *ctx, int comp, int nind, int map_n, in
                     if (l != comp) d = d - dgo_eval_signal(ctx, l, j, i, k, NULL);
                 S.data[IDX3(ctx, j, k, i)] = d;
             }
+    if (sample_nside > 0) { /* :204-217: udgrade_ring(data), udgrade_rms(rms), udgrade_mask(mask) */
+        const int Sp = S.s2 - S.s1 + 1;
+        S.npc = 12 * (int64_t)sample_nside * sample_nside;
+        S.cdata = (double *)malloc(sizeof(double) * (size_t)(Sp * nb) * S.npc);
+        S.crms = (double *)malloc(sizeof(double) * (size_t)(Sp * nb) * S.npc);
+        S.cmask = (double *)malloc(sizeof(double) * (size_t)S.npc);
+        for (int k = S.s1; k <= S.s2; ++k)
+            for (int j = 0; j < nb; ++j) {
+                dgo_udgrade(0, S.data + IDX3(ctx, j, k, 0), nside, S.cdata + ((int64_t)(k - S.s1) * nb + j) * S.npc, sample_nside);
+                dgo_udgrade(1, ctx->rms + IDX3(ctx, j, k, 0), nside, S.crms + ((int64_t)(k - S.s1) * nb + j) * S.npc, sample_nside);
+            }
+        dgo_udgrade(2, ctx->mask, nside, S.cmask, sample_nside);
+    }
     double sample[DGO_MAX_IND] = {0, 0}, theta[DGO_MAX_IND] = {0, 0};
     for (int l = 0; l < c->nindices; ++l) sample[l] = c->indices[((int64_t)l * nmaps + (S.s1 - 1)) * (int64_t)npix + 0]; /* :240-242 */
     for (int l = 0; l < DGO_MAX_IND; ++l) theta[l] = sample[l];
@@ -1295,6 +1360,7 @@ int64_t dgo_sample_index_fullsky(dgo_ctx *ctx, int comp, int nind, int map_n, in
     for (int k = S.s1; k <= S.s2; ++k)
         for (int i = 0; i < npix; ++i) c->indices[((int64_t)nind * nmaps + (k - 1)) * (int64_t)npix + i] = sample[nind];
     free(S.data);
+    free(S.cdata); free(S.crms); free(S.cmask);
     return accepted;
 }
 
@@ -1314,7 +1380,7 @@ void dgo_tune_perpixel(dgo_ctx *ctx, int comp, int nind, int map_n, int nsample,
                        uint64_t stream, int *tuned) {
     dgo_comp *c = &ctx->comps[comp];
     const int npix = ctx->npix, nb = ctx->nbands, nmaps = ctx->nmaps;
-    fs_state S = {ctx, comp, nind, (map_n == -1) ? 2 : map_n, (map_n == -1) ? 3 : map_n, NULL};
+    fs_state S = {ctx, comp, nind, (map_n == -1) ? 2 : map_n, (map_n == -1) ? 3 : map_n, NULL, 0, NULL, NULL, NULL};
     if (*tuned) return;
     S.data = (double *)malloc(sizeof(double) * (size_t)nb * nmaps * npix);
     for (int i = 0; i < npix; ++i)

@@ -172,6 +172,8 @@ int64_t dgo_sample_index_fullsky(dgo_ctx *ctx, int comp, int nind, int map_n, in
  * exposed through dgo_sample_index_fullsky. */
 /* fit_band_gain(ddata, map_n=1, band) (src/dang_sample_mod.f90:570-621): returns the new gain; sky/res are
  * the arrays update_sky_model left (dgo_update_sky_model). */
+int64_t dgo_sample_index_fullsky_coarse(dgo_ctx *ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed,
+                                        uint64_t stream, int *tuned, int nside, int sample_nside);
 /* unit conversions and bandpass normalisation, src/dang_bp_mod.f90:62-81, 160-274; convert_maps src/dang_data_mod.f90:429-463 */
 double dgo_bnu_prime(double nu, double T_CMB);
 double dgo_a2f(const dgo_ctx *ctx, int band);

@@ -106,6 +106,9 @@ def lib():
         l.dgo_sample_index_fullsky.restype = C.c_int64
         l.dgo_sample_index_fullsky.argtypes = [C.POINTER(Ctx), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
                                                C.c_uint64, C.POINTER(C.c_int)]
+        l.dgo_sample_index_fullsky_coarse.restype = C.c_int64
+        l.dgo_sample_index_fullsky_coarse.argtypes = [C.POINTER(Ctx), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
+                                                      C.c_uint64, C.POINTER(C.c_int), C.c_int, C.c_int]
         l.dgo_bnu_prime.restype = C.c_double
         l.dgo_bnu_prime.argtypes = [C.c_double, C.c_double]
         for name in ("dgo_a2f", "dgo_f2t"):
@@ -307,6 +310,12 @@ class Oracle:
         t = C.c_int(1 if tuned else 0)
         self.L.dgo_tune_perpixel(self.c, comp, nind, map_n, nsample, ML_CODES[ml_mode], seed, stream, C.byref(t))
         return bool(t.value), self._comps[comp].step_size[nind]
+
+    def sample_index_fullsky_coarse(self, comp, nind, map_n, nsample, ml_mode, seed, stream, nside, sample_nside, tuned=True):
+        t = C.c_int(1 if tuned else 0)
+        acc = self.L.dgo_sample_index_fullsky_coarse(self.c, comp, nind, map_n, nsample, ML_CODES[ml_mode], seed, stream,
+                                                     C.byref(t), nside, sample_nside)
+        return acc, bool(t.value), self._comps[comp].step_size[nind]
 
     def fit_band_gain(self, band, ml_mode, seed, stream):
         sky, res = self.sky_model()

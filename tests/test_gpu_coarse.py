@@ -26,15 +26,18 @@ def test_device_udgrade_matches_the_restatement(built):
         assert np.array_equal(eng.udgrade(2, mask, ni, no), O.udgrade(2, mask, ni, no))
 
 
-@pytest.mark.parametrize("lnl,ml_mode,cnside", [("chisq", "sample", 4), ("chisq", "optimize", 8), ("marginal", "sample", 2),
-                                                ("prior", "sample", 4)])
-def test_coarse_index_sampling_matches_oracle(built, lnl, ml_mode, cnside):
-    nside = 16
+@pytest.mark.parametrize("lnl,ml_mode,cnside,prior", [("chisq", "sample", 4, None), ("chisq", "optimize", 8, None),
+                                                      ("marginal", "sample", 2, None), ("prior", "sample", 4, None),
+                                                      ("chisq", "sample", 2, "jeffreys"), ("chisq", "optimize", 4, "jeffreys")])
+def test_coarse_index_sampling_matches_oracle(built, lnl, ml_mode, cnside, prior):
+    nside = 16 if prior is None else 8
 
     def tweak(dpar, ddata, bands, comps):
         for c in comps:
             c.lnl_type = [lnl] * c.nindices
             c.sample_nside = [cnside] * c.nindices
+            if prior:        # eval_jeffreys_prior is non-trivial for the component labelled 'synch' only; the others
+                c.prior_type = [prior] * c.nindices   # get log(0) = -inf and never move (reproduced)
     case = make_case("C2", nside=nside, start="truth", tweak=tweak)
     dpar, ddata, bands, comps, meta = case
     eng, orc = pair(case)

@@ -145,3 +145,40 @@ def test_perpixel_branch_tunes_the_step_size_like_the_reference(built, ml_mode):
     if otuned:   # a second call finds the index tuned: no tuner pass, same step
         da.sample_spectral_parameters(dpar, ddata, it=4)
         assert comps[1].step_size[0] == ostep
+
+
+@pytest.mark.parametrize("lnl,prior,ml_mode", [("chisq", "gaussian", "sample"), ("chisq", "jeffreys", "sample"),
+                                               ("marginal", "uniform", "sample"), ("chisq", "gaussian", "optimize")])
+def test_fullsky_index_mode_at_a_coarser_nside_matches_oracle(built, lnl, prior, ml_mode):
+    """index_mode == 1 with sample_nside /= nside (src/dang_sample_mod.f90:199-217, 229-329): the chain's sky-wide sums
+    run over the degraded data / rms / mask (Nside 8 -> 2), eval_signal reads the full-resolution amplitude at the coarse
+    pixel number (reproduced literally, as in the per-pixel coarse mode); through the orchestrator's dispatch."""
+    nside, cnside = 8, 2
+    case = _fullsky_case(lnl, prior, ml_mode=ml_mode, nside=nside)
+    dpar, ddata, bands, comps, meta = case
+    for c in comps:
+        c.sample_nside = [cnside] * c.nindices
+        c.step_size = [0.6 * g[1] for g in c.gauss_prior]        # 48 coarse pixels: a broader posterior than the full sky's
+    eng, orc = pair(case)
+    info = da.sample_spectral_parameters(dpar, ddata, it=2)
+    k = 0
+    for l, c in enumerate(comps):
+        for j in range(c.nindices):
+            if not c.sample_index[j]:
+                continue
+            f = c.pol_flag[j][0]
+            map_n = {1: 1, 8: -1}[f]
+            ao, _, _ = orc.sample_index_fullsky_coarse(l, j, map_n, dpar.nsample, ml_mode, dpar.seed, da.stream_id(2, 1, l, j, f),
+                                                       nside, cnside)
+            assert ao >= 0 and info[k] == (l, j, f, ao), (info[k], ao)
+            k += 1
+    assert k == len(info) and np.isfinite(ddata.chisq)
+    for l, c in enumerate(comps):
+        if not c.nindices:
+            continue
+        a, b = eng.get_indices(l), orc.indices(l)
+        assert np.abs(a - b).max() <= 1e-13
+        for j in range(c.nindices):
+            if c.sample_index[j]:
+                for kk in ([0] if c.pol_flag[j][0] == 1 else [1, 2]):
+                    assert np.all(a[j, kk] == a[j, kk, 0])
