@@ -28,7 +28,18 @@ import torch  # noqa: E402
 import torch.distributed as td  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic_r01.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary
+# VALU issue peak: one vector instruction per SIMD every 4 cycles (16 lanes x 4 passes per wave64 instruction, fp64 FMA
+# included), 256 CUs x 4 SIMDs, at the 2.4 GHz peak engine clock = 39.3e12 lane-ops/s; the clock the part holds under a
+# pure fp64-FMA load gives 30.9e12 (measured: profiles/r01_ubench_valu.txt)
+VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9
+VALU_SUSTAINED_FMA = 30.9e12
+# rocprofv3 --pmc summaries of the SAME command (tools/profile_round.sh): FETCH_SIZE / WRITE_SIZE and the SQ_* pass
+PROFILE_TAG = {"C3": "r02_z", "C5": "r02_c5z"}
+
+
+def _profile_json(config, kind):
+    tag = PROFILE_TAG.get(config)
+    return os.path.join(ROOT, "profiles", "%s_%s.json" % (tag, kind)) if tag else None
 
 
 def measured_traffic(config, kernel):
@@ -36,10 +47,28 @@ def measured_traffic(config, kernel):
     WRITE_SIZE collected in separate passes, FETCH corrected by the factor calibrated on kernels of known byte
     count: profiles/r01_z_final.md).  None when no profile of this configuration is committed."""
     try:
-        t = json.load(open(TRAFFIC_JSON))
+        t = json.load(open(_profile_json(config, "traffic")))
         if t.get("config") != config:
             return None
         return float(t["kernels"][kernel]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
+def measured_valu(config, kernel, avg_launch_s):
+    """VALU-side roofline of `kernel` from the committed SQ-counter profile of the same command: share of the issue
+    cycles of a SIMD in which a vector instruction issues (`busy`), and vector lane-operations per second = the
+    profile's lane-ops per launch / THIS run's average launch duration, against the issue peak.  None without a
+    committed profile of the configuration."""
+    try:
+        t = json.load(open(_profile_json(config, "valu")))
+        if t.get("config") != config:
+            return None
+        k = t["kernels"][kernel]
+        rate = float(k["valu_lane_ops_per_launch"]) / avg_launch_s
+        return {"busy": float(k["valu_issue_busy"]), "lane_ops_per_s": rate, "peak": VALU_PEAK_LANE_OPS,
+                "frac": rate / VALU_PEAK_LANE_OPS, "sustained_fp64_fma": VALU_SUSTAINED_FMA,
+                "source": os.path.relpath(_profile_json(config, "valu"), ROOT)}
     except Exception:
         return None
 
@@ -302,6 +331,12 @@ def main():
         launches_per_step = max(prof[dom]["launches"] // args.steps, 1)
         bytes_per_launch = algorithmic_bytes(meta, comps, dom, units_per_step.get(dom, meta["npix"] * nmaps)) / launches_per_step
         achieved = bytes_per_launch / (prof[dom]["avg_ms"] * 1e-3) / 1e9
+        standard = world == 1 and args.nside is None and not args.bandpass   # the configuration the committed profiles are of
+        # B_iter = 8 N_sp [(2nb + nidx + 1 + nc) + (2nb + nc + nidx + 1 + nidx_s)] over the WHOLE sky
+        nphys = len(meta["phys"])
+        nidx = sum(c.nindices for c in comps[:nphys])
+        nidx_s = sum(1 for c in comps[:nphys] for j in range(c.nindices) if c.sample_index[j])
+        iter_bytes = 8.0 * meta["npix_global"] * nmaps * ((2 * nb + nidx + 1 + nphys) + (2 * nb + nphys + nidx + 1 + nidx_s))
         out = {
             "metric": "gibbs_iterations_per_sec", "value": args.steps / elapsed, "unit": "it/s",
             "n_gpus": world, "ranks_seen": ranks_seen, "backend": (args.backend if world > 1 else None), "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -313,12 +348,17 @@ def main():
                                       "; DIAGNOSTIC: every second band integrated over a %d-sample bandpass" % args.bandpass
                                       if args.bandpass else ""),
                        "npix": meta["npix_global"], "chisq_after_amp": chisq[0], "chisq_after_index": chisq[1]},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # achieved / peak / frac: the HBM roofline (algorithmic bytes per launch / measured launch duration).  The
+            # dominant kernel is bound by fp64 vector issue, not by HBM: `valu` carries that roofline; `iter_frac` is
+            # SURVEY 8d's per-ITERATION figure (one amplitude pass + one fused index sweep) against the time of a step
+            "roofline": {"bound": "fp64-valu", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(args.config, dom) if (world == 1 and args.nside is None) else None,
+                         "traffic": measured_traffic(args.config, dom) if standard else None,
                          "avg_launch_ms": prof[dom]["avg_ms"], "bytes_per_launch": bytes_per_launch,
-                         "note": "the kernel is fp64-VALU bound (VALU issue ~92-98% busy, profiles/r01_z_final.md); "
-                                 "HBM traffic <= algorithmic bytes, so the HBM fraction is what the arithmetic leaves"},
+                         "valu": measured_valu(args.config, dom, prof[dom]["avg_ms"] * 1e-3) if standard else None,
+                         "iter_bytes": iter_bytes, "iter_frac": iter_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS / world,
+                         "note": "fp64 VALU issue bound (valu.busy of the issue cycles carry a vector instruction); HBM "
+                                 "traffic <= algorithmic bytes, so the HBM fraction is what the arithmetic leaves"},
             "kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"],
                             "ms_per_step": round(v["total_ms"] / args.steps, 4)} for k, v in prof.items()},
         }

@@ -73,9 +73,15 @@ def gather_maps(local, npix_global, dst=0):
         return local
     sizes = [shard_range(npix_global, r, n)[1] for r in range(n)]
     lead = local.shape[:-1]
+    # gloo and nccl both want equal-size tensors: shards of a pixel count that the rank count does not divide differ by
+    # one pixel, so every shard is padded to the largest and trimmed on dst
+    big = max(sizes)
+    send = local.contiguous()
+    if send.shape[-1] < big:
+        send = torch.cat([send, send.new_zeros(*lead, big - send.shape[-1])], dim=-1)
     if rank == dst:
-        parts = [torch.empty(*lead, s, dtype=local.dtype, device=local.device) for s in sizes]
+        parts = [torch.empty(*lead, big, dtype=local.dtype, device=local.device) for _ in sizes]
     else:
         parts = None
-    td.gather(local.contiguous(), parts, dst=dst)
-    return torch.cat(parts, dim=-1) if rank == dst else None
+    td.gather(send, parts, dst=dst)
+    return torch.cat([p[..., :s] for p, s in zip(parts, sizes)], dim=-1) if rank == dst else None

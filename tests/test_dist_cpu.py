@@ -53,3 +53,29 @@ def test_two_rank_sharded_path_matches_single_rank(tmp_path):
     assert np.array_equal(got["amp"], orc.amplitude(1))     # RNG keyed by global pixel: bitwise
     assert np.array_equal(got["idx"], orc.indices(1))
     assert abs(float(got["chisq"]) - chisq) <= 1e-12 * chisq
+
+
+def _ragged_worker(rank, world, port, out):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), here]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from dang_amd import dist
+    npix = 12 * 4 * 4 + 1 - 1   # 192 pixels over 5 ranks: shards of 39, 39, 38, 38, 38
+    p0, n = dist.shard_range(npix, rank, world)
+    local = torch.arange(p0, p0 + n, dtype=torch.float64).repeat(2, 3, 1) + torch.tensor([0.0, 1000.0]).view(2, 1, 1)
+    full = dist.gather_maps(local, npix, dst=0)
+    if rank == 0:
+        np.save(out, full.numpy())
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_gather_maps_with_a_rank_count_that_does_not_divide_the_sky(tmp_path):
+    """shard_range gives shards that differ by one pixel when nranks does not divide npix; gather_maps pads and trims."""
+    out = str(tmp_path / "full.npy")
+    mp.spawn(_ragged_worker, args=(5, _free_port(), out), nprocs=5, join=True)
+    full = np.load(out)
+    want = np.arange(192, dtype=np.float64)[None, None, :] + np.array([0.0, 1000.0])[:, None, None] + np.zeros((2, 3, 1))
+    assert full.shape == (2, 3, 192) and np.array_equal(full, want)

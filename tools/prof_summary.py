@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--pmc", action="append", default=[])
     ap.add_argument("--only", default="k_", help="keep kernels whose short name starts with this")
     ap.add_argument("--sq", help="dir with the SQ_* counter pass (VALU issue occupancy table)")
+    ap.add_argument("--valu-json", help="write {kernel family: VALU issue busy, VALU lane-ops per launch} from the SQ pass")
     ap.add_argument("--traffic-json", help="write {kernel family: HBM bytes per launch} from the FETCH_SIZE/WRITE_SIZE passes")
     ap.add_argument("--fetch-factor", type=float, default=2.0, help="FETCH_SIZE correction (tools/pmc_calib.py: 2.000 here)")
     ap.add_argument("--config", default="C3")
@@ -98,6 +99,33 @@ def main():
                 100.0 * m.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, valu, 100.0 * m.get("SQ_WAIT_ANY", 0.0) / wc,
                 100.0 * m.get("SQ_WAIT_INST_ANY", 0.0) / wc, w, min(100.0, w * valu)))
         lines.append("")
+    if a.valu_json and a.sq:
+        import json
+        f = glob.glob(os.path.join(a.sq, "**", "*counter_collection.csv"), recursive=True)[0]
+        disp = collections.OrderedDict()          # one entry per dispatch
+        for r in csv.DictReader(open(f)):
+            s = short(r["Kernel_Name"])
+            k = "k_amp_direct" if s.startswith("k_amp_") else "k_index_mh" if s.startswith("k_index_mh") else None
+            if not k:
+                continue
+            d = disp.setdefault((k, r["Dispatch_Id"]), {"meta": r})
+            d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        fam = collections.OrderedDict()
+        for (k, _), d in disp.items():
+            r = d["meta"]
+            vg = 2 * (int(r["VGPR_Count"]) + int(r["Accum_VGPR_Count"]))
+            w = max(1, min(8, 512 // max(8 * ((vg + 7) // 8), 8)))
+            busy = min(1.0, w * d.get("SQ_ACTIVE_INST_VALU", 0.0) / max(d.get("SQ_WAVE_CYCLES", 1.0), 1.0))
+            e = fam.setdefault(k, {"busy": [], "lane_ops": []})
+            e["busy"].append(busy)
+            e["lane_ops"].append(64.0 * d.get("SQ_INSTS_VALU", 0.0))
+        out = {"source": "%s (rocprofv3 --pmc SQ_* pass; busy = resident waves/SIMD x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per "
+                         "dispatch, lane-ops = 64 x SQ_INSTS_VALU)" % a.out,
+               "config": a.config, "kernels": {}}
+        for k, e in fam.items():
+            out["kernels"][k] = {"valu_issue_busy": sum(e["busy"]) / len(e["busy"]),
+                                 "valu_lane_ops_per_launch": sum(e["lane_ops"]) / len(e["lane_ops"]), "dispatches": len(e["busy"])}
+        json.dump(out, open(a.valu_json, "w"), indent=1)
     if a.traffic_json:
         import json
         fam = collections.OrderedDict()
@@ -110,7 +138,7 @@ def main():
                 if r["Counter_Name"] != cname:
                     continue
                 s = short(r["Kernel_Name"])
-                k = "k_amp_direct" if s.startswith("k_amp_direct") else "k_index_mh" if s.startswith("k_index_mh") else None
+                k = "k_amp_direct" if s.startswith("k_amp_") else "k_index_mh" if s.startswith("k_index_mh") else None
                 if k:
                     fam.setdefault(k, {}).setdefault(cname, []).append(float(r["Counter_Value"]) * 1024.0)
         out = {"source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH corrected by the measured "

@@ -20,7 +20,7 @@ rocprofv3 --kernel-include-regex "k_(amp|index|schur|sky|cg|Ax|rhs|reduce)" --ou
 echo "[c5] WRITE_SIZE"
 rocprofv3 --kernel-include-regex "k_(amp|index|schur|sky|cg|Ax|rhs|reduce)" --output-format csv --pmc WRITE_SIZE -d "$out/pmc_write" -o run -- $B --steps 1 --warmup 1 > /dev/null 2> "$out/write.err"
 python3 $R/tools/prof_summary.py --stats "$out/trace" --pmc FETCH_SIZE="$out/pmc_fetch" --pmc WRITE_SIZE="$out/pmc_write" --sq "$out/sq" \
-    --config C5 --traffic-json "$out/${tag}_traffic.json" -o "$out/${tag}_profile.md" \
+    --config C5 --traffic-json "$out/${tag}_traffic.json" --valu-json "$out/${tag}_valu.json" -o "$out/${tag}_profile.md" \
     --title "$tag: python3 bench.py --config C5 --steps 5 --warmup 2 (Nside 2048, 20 bands, 6 components, IQU, 1x MI355X); PMC passes: --steps 1 --warmup 1" > /dev/null
 cp "$(find "$out/trace" -name '*kernel_stats.csv' | head -1)" "$out/${tag}_kernel_stats.csv"
 rm -rf "$out/trace" "$out/sq" "$out/pmc_fetch" "$out/pmc_write"

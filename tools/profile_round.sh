@@ -27,7 +27,7 @@ echo "[profile] FETCH/WRITE calibration on kernels of known byte count"
 rocprofv3 --kernel-include-regex "k_(amp|index|schur|sky|cg|Ax|rhs|reduce)" --output-format csv --pmc FETCH_SIZE -d "$out/cal_fetch" -o run -- python3 $R/tools/pmc_calib.py > "$out/cal.log" 2> "$out/cal_fetch.err"
 rocprofv3 --kernel-include-regex "k_(amp|index|schur|sky|cg|Ax|rhs|reduce)" --output-format csv --pmc WRITE_SIZE -d "$out/cal_write" -o run -- python3 $R/tools/pmc_calib.py >> "$out/cal.log" 2> "$out/cal_write.err"
 python3 $R/tools/prof_summary.py --stats "$out/trace" --pmc FETCH_SIZE="$out/pmc_fetch" --pmc WRITE_SIZE="$out/pmc_write" \
-    --sq "$out/sq" --traffic-json "$out/${tag}_traffic.json" -o "$out/${tag}_profile.md" \
+    --sq "$out/sq" --traffic-json "$out/${tag}_traffic.json" --valu-json "$out/${tag}_valu.json" -o "$out/${tag}_profile.md" \
     --title "$tag: python3 bench.py --steps 20 --warmup 3 (C3, 1x MI355X); PMC passes: --steps 2 --warmup 1" > /dev/null
 python3 $R/tools/prof_summary.py --only k_cg_vec --pmc FETCH_SIZE="$out/cal_fetch" --pmc WRITE_SIZE="$out/cal_write" \
     -o "$out/${tag}_calibration.md" --title "$tag: FETCH_SIZE / WRITE_SIZE on k_cg_vec (8 B per lane, coalesced, known byte count)" > /dev/null
