@@ -120,7 +120,7 @@ def main():
             e["busy"].append(busy)
             e["lane_ops"].append(64.0 * d.get("SQ_INSTS_VALU", 0.0))
         out = {"source": "%s (rocprofv3 --pmc SQ_* pass; busy = resident waves/SIMD x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per "
-                         "dispatch, lane-ops = 64 x SQ_INSTS_VALU)" % a.out,
+                         "dispatch, lane-ops = 64 x SQ_INSTS_VALU)" % os.path.join("profiles", os.path.basename(a.out)),
                "config": a.config, "kernels": {}}
         for k, e in fam.items():
             out["kernels"][k] = {"valu_issue_busy": sum(e["busy"]) / len(e["busy"]),
@@ -142,7 +142,7 @@ def main():
                 if k:
                     fam.setdefault(k, {}).setdefault(cname, []).append(float(r["Counter_Value"]) * 1024.0)
         out = {"source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH corrected by the measured "
-                         "k_cg_vec calibration factor %.3f)" % (a.out, a.fetch_factor),
+                         "k_cg_vec calibration factor %.3f)" % (os.path.join("profiles", os.path.basename(a.out)), a.fetch_factor),
                "config": a.config, "fetch_correction": a.fetch_factor, "kernels": {}}
         for k, v in fam.items():
             fr = sum(v.get("FETCH_SIZE", [0.0])) / max(len(v.get("FETCH_SIZE", [0.0])), 1)
