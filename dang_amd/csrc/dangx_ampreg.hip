@@ -19,25 +19,6 @@
 
 namespace {
 
-// 1/x for finite normal x, <= 1 ulp (v_rcp_f64 is good to 2^-23; each Newton step squares the error)
-__device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    double e = fma(-x, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-x, r, 1.0);
-    return fma(r, e, r);
-}
-// 1/sqrt(x) for finite normal x > 0: Goldschmidt iteration on g ~ sqrt(x), h ~ 1/(2 sqrt(x))
-__device__ __forceinline__ double fast_rsqrt(double x) {
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = 0.5 * y;
-    double r = fma(-g, h, 0.5);
-    g = fma(g, r, g); h = fma(h, r, h);
-    r = fma(-g, h, 0.5);
-    h = fma(h, r, h);
-    return h + h;
-}
-
 // Map pointers come out of the Model block as generic pointers, which the compiler can only load through FLAT
 // instructions -- and a FLAT load counts on lgkmcnt as well as vmcnt, so every wait for an LDS read (the constant table,
 // the SED columns) would also wait for all map loads in flight.  Viewed through the global address space they are
@@ -66,15 +47,15 @@ __device__ __forceinline__ void sed_tile(int type, const double* __restrict__ ta
     switch (type) {
     case DANGX_POWERLAW:  // src/dang_component_mod.f90:908
 #pragma unroll
-        for (int t = 0; t < TB; ++t) { colg[t * BLOCK] = exp(p.p0 * lnr[t]); }
+        for (int t = 0; t < TB; ++t) { colg[t * BLOCK] = exp_nr(p.p0 * lnr[t]); }
         break;
     case DANGX_MBB: {  // :947-948, in two passes of TB chains each (bounds the registers the scheduler may spend)
         double f[TB];
 #pragma unroll
-        for (int t = 0; t < TB; ++t) { f[t] = p.p2 * fast_rcp(exp(p.p1 * nuc[t]) - 1.0); }
+        for (int t = 0; t < TB; ++t) { f[t] = p.p2 * fast_rcp(exp_nr(p.p1 * nuc[t]) - 1.0); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < TB; ++t) { colg[t * BLOCK] = f[t] * exp(p.p0 * lnr[t]); }
+        for (int t = 0; t < TB; ++t) { colg[t * BLOCK] = f[t] * exp_nr(p.p0 * lnr[t]); }
         break;
     }
     case DANGX_FREEFREE: {  // :1026-1027
@@ -88,7 +69,7 @@ __device__ __forceinline__ void sed_tile(int type, const double* __restrict__ ta
 #pragma unroll
         for (int t = 0; t < TB; ++t) {
             const double l = (lnu9[t] - p.p2) * rp1;
-            colg[t * BLOCK] = exp(-0.5 * (l * l)) * cst[t];
+            colg[t * BLOCK] = exp_nr(-0.5 * (l * l)) * cst[t];
            
         }
         break;

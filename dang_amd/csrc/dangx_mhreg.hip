@@ -2,6 +2,21 @@
 // (-DDX_REG_MODE=1..5) so the instantiations build in parallel, and once without it for the dispatcher.
 #include "dx_host.h"
 
+// the chain's exp: dx::exp_nr = the library routine minus its range selects (dx_math.h); -DDX_CHAIN_LIBEXP restores
+// the library call for A/B timing
+#ifdef DX_CHAIN_LIBEXP
+#define CEXP(x) exp(x)
+#else
+#define CEXP(x) exp_nr(x)
+#endif
+// reciprocals of the rms and inside the modified-blackbody SED: v_rcp_f64 + two Newton steps (<= 1 ulp, 6 vector
+// instructions) instead of the IEEE division sequence (11); -DDX_CHAIN_IEEEDIV restores a / b
+#ifdef DX_CHAIN_IEEEDIV
+#define CDIV(a, b) ((a) / (b))
+#else
+#define CDIV(a, b) ((a) * fast_rcp(b))
+#endif
+
 #ifdef DX_REG_MODE
 namespace {
 
@@ -24,7 +39,7 @@ struct RegChain {
         double s0 = 0.0, s1 = 0.0;
         if (MODE == CH_POW) s0 = th;
         else if (MODE == CH_MBB_BETA) s0 = th + 1.0;
-        else if (MODE == CH_MBB_T) { s0 = H_PLANCK / (K_B * th); s1 = exp(s0 * c.nu_ref) - 1.0; }
+        else if (MODE == CH_MBB_T) { s0 = H_PLANCK / (K_B * th); s1 = CEXP(s0 * c.nu_ref) - 1.0; }
         else if (MODE == CH_LOGN_NUP) { s0 = log_pos(th); s1 = other; }  // log(nu/(nu_p*1e9)) = lnu9 - log(nu_p)
         else s1 = th;  // CH_LOGN_W
         acc0 = 0.0; acc1 = 0.0;
@@ -38,15 +53,15 @@ struct RegChain {
                 const int j = j0 + t;
                 if (MODE == CH_LOGN_NUP) {
                     const double l = (c.lnu9[j] - s0) / s1;
-                    s[t] = exp(-0.5 * (l * l)) * c.cst[j];
+                    s[t] = CEXP(-0.5 * (l * l)) * c.cst[j];
                 } else if (MODE == CH_LOGN_W) {
                     const double l = F[j] / s1;
-                    s[t] = exp(-0.5 * (l * l)) * c.cst[j];
+                    s[t] = CEXP(-0.5 * (l * l)) * c.cst[j];
                 } else {
-                    const double e = exp((MODE == CH_MBB_T) ? s0 * M.band[j].nu_c : s0 * c.lnr[j]);
+                    const double e = CEXP((MODE == CH_MBB_T) ? s0 * M.band[j].nu_c : s0 * c.lnr[j]);
                     if (MODE == CH_POW) s[t] = e;
                     else if (MODE == CH_MBB_BETA) s[t] = F[j] * e;
-                    else s[t] = s1 / (e - 1.0) * F[j];
+                    else s[t] = CDIV(s1, e - 1.0) * F[j];
                 }
             }
 #pragma unroll
@@ -77,11 +92,11 @@ __device__ __forceinline__ void subtract_other(const Model& M, const Comp& c2, i
     switch (c2.type) {
     case DANGX_POWERLAW:
 #pragma unroll
-        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * exp(pr.p0 * c2.lnr[j]);
+        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * CEXP(pr.p0 * c2.lnr[j]);
         break;
     case DANGX_MBB:
 #pragma unroll
-        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * (pr.p2 / (exp(pr.p1 * M.band[j].nu_c) - 1.0) * exp(pr.p0 * c2.lnr[j]));
+        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * (CDIV(pr.p2, CEXP(pr.p1 * M.band[j].nu_c) - 1.0) * CEXP(pr.p0 * c2.lnr[j]));
         break;
     case DANGX_FREEFREE:
 #pragma unroll
@@ -91,7 +106,7 @@ __device__ __forceinline__ void subtract_other(const Model& M, const Comp& c2, i
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const double l2 = (c2.lnu9[j] - pr.p2) / pr.p1;
-            Dk[j] -= amp2 * (exp(-0.5 * (l2 * l2)) * c2.cst[j]);
+            Dk[j] -= amp2 * (CEXP(-0.5 * (l2 * l2)) * c2.cst[j]);
         }
         break;
     default:  // cmb
@@ -110,12 +125,12 @@ __device__ __forceinline__ void subtract_other_pair(const Model& M, const Comp& 
     switch (c2.type) {
     case DANGX_POWERLAW:
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { const double s = exp(pr.p0 * c2.lnr[j]); Da[j] -= ampa * s; Db[j] -= ampb * s; }
+        for (int j = 0; j < NB; ++j) { const double s = CEXP(pr.p0 * c2.lnr[j]); Da[j] -= ampa * s; Db[j] -= ampb * s; }
         break;
     case DANGX_MBB:
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const double s = pr.p2 / (exp(pr.p1 * M.band[j].nu_c) - 1.0) * exp(pr.p0 * c2.lnr[j]);
+            const double s = CDIV(pr.p2, CEXP(pr.p1 * M.band[j].nu_c) - 1.0) * CEXP(pr.p0 * c2.lnr[j]);
             Da[j] -= ampa * s; Db[j] -= ampb * s;
         }
         break;
@@ -127,7 +142,7 @@ __device__ __forceinline__ void subtract_other_pair(const Model& M, const Comp& 
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const double l2 = (c2.lnu9[j] - pr.p2) / pr.p1;
-            const double s = exp(-0.5 * (l2 * l2)) * c2.cst[j];
+            const double s = CEXP(-0.5 * (l2 * l2)) * c2.cst[j];
             Da[j] -= ampa * s; Db[j] -= ampb * s;
         }
         break;
@@ -169,7 +184,7 @@ __device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, co
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if (k == 1) R.D[kk][j] = (R.D[kk][j] - M.offset[j]) / M.gain[j];
-            R.set_is(kk, j, 1.0 / rv[j]);
+            R.set_is(kk, j, CDIV(1.0, rv[j]));
         }
     }
     // --- remove every OTHER component (:180-196) in component_list order, next one prefetched
@@ -208,12 +223,12 @@ __device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, co
     // --- chain-invariant SED factor
     if (MODE == CH_MBB_BETA) {
         const double z = H_PLANCK / (K_B * sample1);
-        const double A = exp(z * c.nu_ref) - 1.0;
+        const double A = CEXP(z * c.nu_ref) - 1.0;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) R.F[j] = A / (exp(z * M.band[j].nu_c) - 1.0);
+        for (int j = 0; j < NB; ++j) R.F[j] = CDIV(A, CEXP(z * M.band[j].nu_c) - 1.0);
     } else if (MODE == CH_MBB_T) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) R.F[j] = exp((sample0 + 1.0) * c.lnr[j]);
+        for (int j = 0; j < NB; ++j) R.F[j] = CEXP((sample0 + 1.0) * c.lnr[j]);
     } else if (MODE == CH_LOGN_W) {
         {
             const double lp = log_pos(sample0);
@@ -247,7 +262,7 @@ __device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, co
         lnl = R.lnl(M, c, prop, other, c0, c1);
         const double lnl_new = lnl + prior(prop);
         const double diff = lnl_new - lnl_old;
-        const bool acc = (a.ml_mode == DANGX_ML_OPTIMIZE) ? (diff > 0.0) : ((diff >= 0.0) || (exp(diff) > u3));  // :443-454
+        const bool acc = (a.ml_mode == DANGX_ML_OPTIMIZE) ? (diff > 0.0) : ((diff >= 0.0) || (CEXP(diff) > u3));  // :443-454
         if (acc) { cur = prop; lnl_old = lnl_new; a0 = c0; a1 = c1; ++nacc; }
     }
 #pragma unroll

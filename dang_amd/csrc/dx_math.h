@@ -10,6 +10,37 @@
 
 namespace dx {
 
+// 1/x for finite normal x, <= 1 ulp (v_rcp_f64 is good to 2^-23; each Newton step squares the error)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+// 1/sqrt(x) for finite normal x > 0: Goldschmidt iteration on g ~ sqrt(x), h ~ 1/(2 sqrt(x))
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-g, h, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-g, h, 0.5);
+    h = fma(h, r, h);
+    return h + h;
+}
+
+// sqrt(x) for finite normal x > 0 by the same Goldschmidt iteration (<= 1 ulp; 8 vector instructions, the IEEE sqrt
+// sequence is 15)
+__device__ __forceinline__ double fast_sqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-g, h, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-g, h, 0.5);
+    return fma(g, r, g);
+}
+
+
 // Natural logarithm for x > 0, finite and NORMAL (uniform deviates in (0,1), frequencies,
 // temperatures).  fdlibm's e_log.c scheme: x = 2^k * (1+f), sqrt(1/2) <= 1+f < sqrt(2),
 // s = f/(2+f), log(1+f) = f - (f^2/2 - s*(f^2/2 + R(s^2))), |error| < 1 ulp.
@@ -24,7 +55,7 @@ __device__ __forceinline__ double log_pos(double x) {
     double m = __longlong_as_double((long long)ix);
     if (m > 1.4142135623730951) { m *= 0.5; k += 1; }
     const double f = m - 1.0;
-    const double s = f / (2.0 + f);
+    const double s = f * fast_rcp(2.0 + f);
     const double dk = (double)k;
     const double z = s * s;
     const double w = z * z;
@@ -33,6 +64,29 @@ __device__ __forceinline__ double log_pos(double x) {
     const double R = t2 + t1;
     const double hfsq = 0.5 * f * f;
     return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+// exp(x) with the device library's own reduction and polynomial (ocml expD: n = rint(x log2e), r = x - n ln2 in two
+// pieces, degree-11 Horner, ldexp) WITHOUT its two range selects (x > 1024 -> inf, x < -1075 -> 0): ldexp saturates to
+// inf / 0 by itself, so every finite argument gives the library's result bit for bit; only x = +-inf differ (NaN instead
+// of inf / 0), and the kernels never compare such a value with an outcome that depends on it (an accept test
+// `exp(diff) > u` is false either way; `diff >= 0` is tested first).  Six of the library routine's 22 vector
+// instructions are those selects: the Metropolis chains are vector-issue bound, so this is 1/8 of their proposal loop.
+__device__ __forceinline__ double exp_nr(double x) {
+    const double dn = rint(x * 0x1.71547652b82fep+0);
+    const double r = fma(dn, -0x1.abc9e3b39803fp-56, fma(dn, -0x1.62e42fefa39efp-1, x));
+    double p = fma(r, 0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22);
+    p = fma(r, p, 0x1.71dee623fde64p-19);
+    p = fma(r, p, 0x1.a01997c89e6b0p-16);
+    p = fma(r, p, 0x1.a01a014761f6ep-13);
+    p = fma(r, p, 0x1.6c16c1852b7b0p-10);
+    p = fma(r, p, 0x1.1111111122322p-7);
+    p = fma(r, p, 0x1.55555555502a1p-5);
+    p = fma(r, p, 0x1.5555555555511p-3);
+    p = fma(r, p, 0x1.000000000000bp-1);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    return ldexp(p, (int)dn);
 }
 
 // sin(2*pi*u) for u in [0,1): exact range reduction on u (no 2*pi*u rounding)

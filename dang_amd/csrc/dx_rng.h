@@ -67,7 +67,7 @@ __device__ __forceinline__ void uniform3(unsigned long long seed, unsigned long 
 //   r = (-2 log u1)**0.5 ; theta = 2 pi u2 ; c = mean + stdev*r*sin(theta)
 // sin(2 pi u2) is evaluated as sinpi(2 u2) (no rounding of theta); log by log_pos (u1 is normal).
 __device__ __forceinline__ double rand_normal(double mean, double stdev, double u1, double u2) {
-    const double r = sqrt(-2.0 * log_pos(u1));
+    const double r = fast_sqrt(-2.0 * log_pos(u1));  // u1 in (0,1): the argument is in [1e-16, 75]
     return mean + stdev * r * sin_2pi(u2);
 }
 
