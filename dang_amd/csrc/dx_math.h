@@ -89,7 +89,28 @@ __device__ __forceinline__ double exp_nr(double x) {
     return ldexp(p, (int)dn);
 }
 
-// sin(2*pi*u) for u in [0,1): exact range reduction on u (no 2*pi*u rounding)
-__device__ __forceinline__ double sin_2pi(double u) { return sinpi(2.0 * u); }
+// sin(2*pi*u) for u in [0,1): exact range reduction on u (t = 2u, k = rint(t) in {0,1,2}, r = t - k in [-1/2, 1/2] are
+// all exact; sin(pi t) = (-1)^k sin(pi r)) and ONE odd polynomial for sin(pi r) on [-1/2, 1/2] (Taylor to r^21, truncation
+// 1e-18; measured |error| <= 3.4e-16 against extended precision, libm's sin(2*pi*u) has 7e-16 from rounding 2*pi*u).
+// 20 vector instructions and 11 coefficients; the library's sinpi evaluates a sine AND a cosine polynomial and selects
+// (~36 instructions, twice the coefficients -- scalar registers the chain kernels do not have to spare).
+__device__ __forceinline__ double sin_2pi(double u) {
+    const double t = u + u;
+    const double k = rint(t);
+    double r = t - k;
+    r = (k == 1.0) ? -r : r;
+    const double z = r * r;
+    double p = fma(z, 0x1.2877020d52cf0p-31, -0x1.8a404211f9547p-26);
+    p = fma(z, p, 0x1.aaec32af93359p-21);
+    p = fma(z, p, -0x1.6fadb9f155744p-16);
+    p = fma(z, p, 0x1.e8f434d018d63p-12);
+    p = fma(z, p, -0x1.e3074fde8871fp-8);
+    p = fma(z, p, 0x1.50783487ee782p-4);
+    p = fma(z, p, -0x1.32d2cce62bd86p-1);
+    p = fma(z, p, 0x1.466bc6775aae2p+1);
+    p = fma(z, p, -0x1.4abbce625be53p+2);
+    p = fma(z, p, 0x1.921fb54442d18p+1);
+    return r * p;
+}
 
 }  // namespace dx
