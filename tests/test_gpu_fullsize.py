@@ -37,8 +37,15 @@ def _sweeps(eng, comps, dpar, it, ml_mode):
                     eng.index_sample(l, j, MAPN[f], dpar.nsample, ml_mode, dpar.seed, da.stream_id(it, 1, l, j, f))
 
 
-@pytest.mark.parametrize("config,nside", [("C2", None), ("C3", None), ("C5", 512)])
+def _free_device_memory():
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("config,nside", [("C2", None), ("C3", None), ("C5", 512), ("C5", None)])
 def test_noise_free_recovery_and_chisq_expectation(built, config, nside):
+    _free_device_memory()
     dpar, ddata, bands, comps, meta, eng = _device_case(config, nside, start="truth")
     nb, nmaps = meta["nbands"], meta["nmaps"]
     truth = meta["truth"]
@@ -99,10 +106,12 @@ def test_optimize_sweeps_lower_chisq_and_respect_mask_and_bounds(built, config, 
                     assert bool(((m[~masked] >= lo) & (m[~masked] <= hi)).all())
 
 
-@pytest.mark.parametrize("config", ["C2", "C3"])
+@pytest.mark.parametrize("config", ["C2", "C3", "C5"])
 def test_sharding_invariance_fullsize(built, config):
-    """BASELINE config 4 is config 3 pixel-sharded: two half-sky contexts must reproduce the one-context maps bit for
-    bit (the random streams are keyed by the GLOBAL pixel) and their chi^2 sums must add up to the whole-sky sum."""
+    """BASELINE config 4 is config 3 pixel-sharded, config 5 (Nside 2048, 20 bands, 6 components) is the 8-GPU one: two
+    half-sky contexts must reproduce the one-context maps bit for bit (the random streams are keyed by the GLOBAL
+    pixel) and their chi^2 sums must add up to the whole-sky sum.  (C5: 80 GB for the whole sky + 80 GB for the halves.)"""
+    _free_device_memory()
     dev = torch.device("cuda", 0)
     full = synth.make_sky(config, device=dev, as_numpy=False)
     halves = [synth.make_sky(config, device=dev, as_numpy=False, rank=r, nranks=2) for r in range(2)]
