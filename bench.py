@@ -192,7 +192,9 @@ def main():
     ap.add_argument("--streams", type=int, default=0, choices=[0, 1, 2], help="2: the temperature chain (group 1, T sweeps) and the "
                     "polarisation chain (group 2, Q+U sweeps) of one Gibbs iteration are independent: run them on two HIP "
                     "streams (two contexts over the same resident maps), which fills the launch tails of small shards "
-                    "(+5%% at the 8-rank shard size, +0.4%% on a whole C3 sky).  0 = auto: 1 on one rank, 2 on several")
+                    "(+2.5%% at the 8-rank shard size, -2%% at the 2- and 4-rank sizes).  0 = auto: 2 from 8 ranks on")
+    ap.add_argument("--shard-of", type=int, default=0, help="diagnostic: with --gpus 1, run ONE rank's shard of an N-rank run "
+                    "(rank 0 of N, no process group): the per-rank time at that shard size on one GPU")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for rehearsing "
                                                       "the N>1 path with several ranks on ONE GPU)")
     args = ap.parse_args()
@@ -228,8 +230,9 @@ def main():
     from dang_amd import synth
 
     log("building synthetic sky %s on %s" % (args.config, dev))
-    dpar, ddata, bands, comps, meta = synth.make_sky(args.config, nside=args.nside, device=dev, rank=rank, nranks=world,
-                                                     nsample=args.nsample, as_numpy=False)
+    shard_of = args.shard_of if (args.shard_of > 1 and world == 1) else 0
+    dpar, ddata, bands, comps, meta = synth.make_sky(args.config, nside=args.nside, device=dev, rank=rank,
+                                                     nranks=shard_of if shard_of else world, nsample=args.nsample, as_numpy=False)
     if args.bandpass > 0:
         import numpy as np
         for b in bands[1::2]:
@@ -242,7 +245,9 @@ def main():
     nmaps, nb = meta["nmaps"], meta["nbands"]
     chisq_buf = torch.zeros(2, dtype=torch.float64, device=dev)
     mapn = {1: 1, 2: 2, 4: 3, 8: -1}
-    two = (args.streams == 2 or (args.streams == 0 and world > 1)) and nmaps == 3
+    # auto: two streams from 8 ranks on (measured per-rank time at the N-rank shard size, one GPU, --shard-of N:
+    # N=2 8.09 / 8.29 ms with 1 / 2 streams, N=4 4.57 / 4.64, N=8 2.36 / 2.30)
+    two = (args.streams == 2 or (args.streams == 0 and max(world, shard_of) >= 8)) and nmaps == 3
     if two:
         side = torch.cuda.Stream(device=dev)
         engP = da.Engine(bands, comps, ddata, npix_global=meta["npix_global"], pix0=meta["pix0"], device=dev_index,
@@ -331,7 +336,7 @@ def main():
         launches_per_step = max(prof[dom]["launches"] // args.steps, 1)
         bytes_per_launch = algorithmic_bytes(meta, comps, dom, units_per_step.get(dom, meta["npix"] * nmaps)) / launches_per_step
         achieved = bytes_per_launch / (prof[dom]["avg_ms"] * 1e-3) / 1e9
-        standard = world == 1 and args.nside is None and not args.bandpass   # the configuration the committed profiles are of
+        standard = world == 1 and args.nside is None and not args.bandpass and not shard_of   # what the committed profiles are of
         # B_iter = 8 N_sp [(2nb + nidx + 1 + nc) + (2nb + nc + nidx + 1 + nidx_s)] over the WHOLE sky
         nphys = len(meta["phys"])
         nidx = sum(c.nindices for c in comps[:nphys])
@@ -345,8 +350,9 @@ def main():
                                    "direct block solve, reference fluctuation term; pixel-sharded over %d rank(s), %d stream(s) per rank%s"
                                    % (args.config, meta["nside"], nb, len(meta["phys"]), "+".join(meta["phys"]),
                                       "IQU" if nmaps == 3 else "I", args.nsample, world, 2 if two else 1,
-                                      "; DIAGNOSTIC: every second band integrated over a %d-sample bandpass" % args.bandpass
-                                      if args.bandpass else ""),
+                                      ("; DIAGNOSTIC: every second band integrated over a %d-sample bandpass" % args.bandpass
+                                       if args.bandpass else "") +
+                                      ("; DIAGNOSTIC: ONE rank's shard of a %d-rank run" % shard_of if shard_of else "")),
                        "npix": meta["npix_global"], "chisq_after_amp": chisq[0], "chisq_after_index": chisq[1]},
             # achieved / peak / frac: the HBM roofline (algorithmic bytes per launch / measured launch duration).  The
             # dominant kernel is bound by fp64 vector issue, not by HBM: `valu` carries that roofline; `iter_frac` is
