@@ -63,6 +63,10 @@ SYMBOLS = {
     "dangx_set_allreduce": (C.c_int, [_P, _P, _P, C.c_int]),
     "dangx_index_sample_coarse": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
                                             C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "dangx_coarse_sizes": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "dangx_coarse_partials": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "dangx_coarse_chains": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, _P, _P]),
+    "dangx_coarse_writeback": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "dangx_udgrade": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int]),
     "dangx_index_masked_sum": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "dangx_index_plain_sum": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -392,6 +392,30 @@ class Engine:
                                                      self.nside, int(sample_nside), C.byref(acc) if want_counts else None))
         return acc.value
 
+    # the three phases of a coarse-Nside sweep on a pixel shard (one process driving several contexts adds the buffers)
+    def coarse_sizes(self, map_n, sample_nside):
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._chk(self.lib.dangx_coarse_sizes(self.h, map_n, int(sample_nside), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def coarse_partials(self, comp, map_n, sample_nside):
+        n, _ = self.coarse_sizes(map_n, sample_nside)
+        buf = np.empty(n)
+        self._chk(self.lib.dangx_coarse_partials(self.h, comp, map_n, self.nside, int(sample_nside), buf.ctypes.data))
+        return buf
+
+    def coarse_chains(self, comp, nind, map_n, nsample, ml_mode, seed, stream, sample_nside, partials_sum):
+        _, n = self.coarse_sizes(map_n, sample_nside)
+        p = np.ascontiguousarray(partials_sum, dtype=np.float64)
+        out = np.empty(n)
+        self._chk(self.lib.dangx_coarse_chains(self.h, comp, nind, map_n, nsample, L.ML_CODES[ml_mode], seed, stream, self.nside,
+                                               int(sample_nside), p.ctypes.data, out.ctypes.data))
+        return out
+
+    def coarse_writeback(self, comp, nind, map_n, sample_nside, index_sum):
+        x = np.ascontiguousarray(index_sum, dtype=np.float64)
+        self._chk(self.lib.dangx_coarse_writeback(self.h, comp, nind, map_n, self.nside, int(sample_nside), x.ctypes.data))
+
     def udgrade(self, mode, m, nside_in, nside_out):
         """udgrade_ring (0) / udgrade_rms (1) / udgrade_mask (2) of one RING map on the device."""
         m = np.ascontiguousarray(m, dtype=np.float64)
@@ -586,6 +610,23 @@ def refresh_host_state(ddata):
     ddata.sky_model, ddata.res_map, ddata.chi_map = sky, res, chi
     ddata.chisq = _dist.allreduce_sum_float(s) / eng.nbands / ddata.nump
     return ddata
+
+
+def index_sample_coarse_multi(engines, comp, nind, map_n, nsample, ml_mode, seed, stream, sample_nside):
+    """sample_index_mh with sample_nside < nside over several pixel-shard contexts of ONE process (e.g. one per GPU):
+    the three phases of dangx_index_sample_coarse with the shards' buffers added in shard order between them.
+    Returns the number of accepted proposals."""
+    part = None
+    for e in engines:
+        b = e.coarse_partials(comp, map_n, sample_nside)
+        part = b if part is None else part + b
+    idx = None
+    for e in engines:
+        b = e.coarse_chains(comp, nind, map_n, nsample, ml_mode, seed, stream, sample_nside, part)
+        idx = b if idx is None else idx + b
+    for e in engines:
+        e.coarse_writeback(comp, nind, map_n, sample_nside, idx)
+    return int(idx[-1])
 
 
 def compute_chisq(ddata):

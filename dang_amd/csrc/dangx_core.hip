@@ -429,10 +429,48 @@ __global__ __launch_bounds__(BLOCK) void k_udgrade(const double* __restrict__ in
     out[(long long)q * npix_out + o] = v;
 }
 
+// Pixel-sharded form of the degrade step: coarse pixel o collects, in NEST child order, only those of its children whose
+// RING index lies in this shard [pix0, pix0 + npix_loc); it emits the sum of the good ones and their number.  The sums
+// of all shards (added by the caller) are finished by k_udgrade_finish -- with one shard that is k_udgrade bit for bit.
+__global__ __launch_bounds__(BLOCK) void k_udgrade_part(const double* __restrict__ in, double* __restrict__ tot, double* __restrict__ cnt,
+                                                        const int* __restrict__ n2r_in, const int* __restrict__ r2n_out,
+                                                        long long pix0, long long npix_loc, long long npix_out, int ratio, int mode,
+                                                        int layout, int nb, int nmaps, int s1) {
+    const long long o = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (o >= npix_out) return;
+    const int q = blockIdx.y;
+    const double* src = in + (layout == 0 ? (long long)q * npix_loc
+                                          : ((long long)(q % nb) * nmaps + (s1 + q / nb - 1)) * npix_loc);
+    const long long nest = r2n_out[o];
+    double total = 0.0;
+    int nobs = 0;
+    for (int ip = 0; ip < ratio; ++ip) {
+        const long long ring = n2r_in[nest * ratio + ip];
+        if (ring < pix0 || ring >= pix0 + npix_loc) continue;
+        double x = src[ring - pix0];
+        if (mode == 1) x = x * x;
+        if (fabs(x - MISSVAL) > fabs(1e-5 * MISSVAL)) { total = total + x; ++nobs; }
+    }
+    tot[(long long)q * npix_out + o] = total;
+    cnt[(long long)q * npix_out + o] = (double)nobs;
+}
+__global__ __launch_bounds__(BLOCK) void k_udgrade_finish(const double* __restrict__ tot, const double* __restrict__ cnt,
+                                                          double* __restrict__ out, long long n, int mode, double scale) {
+    const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= n) return;
+    const double nobs = cnt[t];
+    double v = (nobs > 0.0) ? tot[t] / nobs : MISSVAL;
+    if (mode == 1) v = sqrt(v) * scale;
+    if (mode == 2) v = (v < 0.5) ? 0.0 : 1.0;
+    out[t] = v;
+}
+
 // One Metropolis chain per COARSE pixel i, literally as the reference runs it: ddata%masks(i,1), c%indices(i,..) and
 // eval_signal's c%amplitude(i,k) are the FULL-resolution arrays read at the coarse index (:362, :372-377, :548-553);
 // data / rms / mask(:,1) are the degraded maps.  evaluate_lnL sums k outer, j inner with ((d-m)/rms)**2 (:171-177),
 // evaluate_marginal_lnL j outer, k inner (:113-122).  index_map(i) -> idxmap[i] (0 where the chain is skipped, :223).
+// On a pixel shard the chain of coarse pixel i runs where the full-resolution pixel i lives (M.pix0 <= i < M.pix0 + npix);
+// the other shards leave idxmap[i] = 0 and the caller adds the maps.
 __global__ __launch_bounds__(BLOCK) void k_index_mh_coarse(const Model* __restrict__ Mp, IndexArgs a, long long npix_c,
                                                            const double* __restrict__ cdata, const double* __restrict__ crms,
                                                            const double* __restrict__ cmask, double* __restrict__ idxmap,
@@ -442,15 +480,16 @@ __global__ __launch_bounds__(BLOCK) void k_index_mh_coarse(const Model* __restri
     unsigned long long nacc = 0;
     if (i < npix_c) {
         idxmap[i] = 0.0;
-        if (!is_masked(M.mask[i])) {
+        const long long il = i - M.pix0;  // index of full-resolution pixel i in this shard's arrays
+        if (il >= 0 && il < M.npix && !is_masked(M.mask[il])) {
             const Comp& c = M.comp[a.comp];
             const int nb = M.nbands, Sp = a.s2 - a.s1 + 1, q = a.nind;
             double sample0, sample1;
-            load_theta(M, c, (int)i, a.s1, sample0, sample1);
+            load_theta(M, c, (int)il, a.s1, sample0, sample1);
             const bool first = (q == 0);
             const double other = first ? sample1 : sample0;
             double amp[2] = {0.0, 0.0};
-            for (int kk = 0; kk < Sp; ++kk) amp[kk] = c.amp[(long long)(a.s1 + kk - 1) * M.npix + i];
+            for (int kk = 0; kk < Sp; ++kk) amp[kk] = c.amp[(long long)(a.s1 + kk - 1) * M.npix + il];
             const int lnl_type = c.lnl_type[q];
             const bool cmasked = is_masked(cmask[i]);
             auto lnl_of = [&](double th) -> double {
@@ -538,7 +577,7 @@ __global__ __launch_bounds__(BLOCK) void k_coarse_writeback(const Model* __restr
     const Model& M = *Mp;
     const int p = blockIdx.x * BLOCK + threadIdx.x;
     if (p >= M.npix) return;
-    const double v = idxmap[n2r_c[r2n_f[p] / ratio]];
+    const double v = idxmap[n2r_c[r2n_f[M.pix0 + p] / ratio]];
     for (int k = s1; k <= s2; ++k) M.comp[comp].idx[((long long)nind * M.nmaps + (k - 1)) * M.npix + p] = v;
 }
 
@@ -1296,6 +1335,8 @@ int dangx_destroy(dangx_ctx* ctx) {
     // HEALPix index tables and the degraded maps of the coarse-Nside sweeps live as long as the context
     for (int** b : {&ctx->hp_n2r_f, &ctx->hp_r2n_f, &ctx->hp_n2r_c, &ctx->hp_r2n_c}) { if (*b) (void)hipFree(*b); *b = nullptr; }
     for (double** b : {&ctx->cs_data, &ctx->cs_rms, &ctx->cs_mask, &ctx->cs_index}) { if (*b) (void)hipFree(*b); *b = nullptr; }
+    if (ctx->cs_part) (void)hipFree(ctx->cs_part);
+    ctx->cs_part = nullptr; ctx->cs_part_cap = 0;
     ctx->hp_nside = ctx->hp_cnside = 0; ctx->cs_cap = 0;
     (void)hipFree(ctx->rows_out);
     (void)hipFree(ctx->dm); (void)hipFree(ctx->scalars); (void)hipFree(ctx->counters); (void)hipFree(ctx->chi_cache);
@@ -1978,6 +2019,138 @@ static int coarse_stage(dangx_ctx* ctx, int comp, int map_n, int nside, int samp
     return 0;
 }
 
+// ---- coarse-Nside sampling on a PIXEL SHARD, in three phases with a sum over the shards between them (the children of
+// a coarse pixel are scattered over the RING ranges).  A: every shard degrades what it holds -- per coarse pixel and
+// plane the sum of its own good children and their number (data, rms^2, mask); B: with the sums of all shards the coarse
+// data / rms / mask are finished, and each shard runs the chains of the coarse pixels i whose full-resolution pixel i
+// it holds (the reference reads masks(i), indices(i), amplitude(i) there), leaving 0 elsewhere; C: with the summed
+// coarse index map every shard writes its own pixels.  dangx_index_sample_coarse runs A, B, C through the
+// dangx_set_allreduce callback; a single-process driver with several contexts calls them itself and adds the buffers.
+static long long coarse_partials_len(const dangx_ctx* ctx, int Sp, long long npc) { return 2 * (2ll * Sp * ctx->hm.nbands + 1) * npc; }
+
+static int coarse_check(dangx_ctx* ctx, int comp, int nside, int sample_nside) {
+    if (check_comp(ctx, comp)) return 1;
+    if (ctx->dims.npix_global != 12LL * nside * nside) return fail(ctx, "npix_global is not 12*nside^2");
+    if (!(sample_nside < nside)) return fail(ctx, "sample_nside must be smaller than nside");
+    if (ctx->desc[comp].type > DANGX_TCMB) return fail(ctx, "coarse-Nside sampling is built for the diffuse component types and T_cmb");
+    return 0;
+}
+
+int dangx_coarse_sizes(dangx_ctx* ctx, int map_n, int sample_nside, int64_t* n_partials, int64_t* n_index) {
+    if (!ctx || !n_partials || !n_index) return 1;
+    int s1, s2;
+    if (map_planes(ctx, map_n, s1, s2)) return 1;
+    const long long npc = 12LL * sample_nside * sample_nside;
+    *n_partials = coarse_partials_len(ctx, s2 - s1 + 1, npc);
+    *n_index = npc + 1;
+    return 0;
+}
+
+static int coarse_alloc(dangx_ctx* ctx, int Sp, long long npc) {
+    const long long need = (long long)Sp * ctx->hm.nbands * npc;
+    if (need > ctx->cs_cap) {
+        for (double** b : {&ctx->cs_data, &ctx->cs_rms, &ctx->cs_mask, &ctx->cs_index}) { if (*b) (void)hipFree(*b); *b = nullptr; }
+        HIPCHK(ctx, hipMalloc(&ctx->cs_data, sizeof(double) * need));
+        HIPCHK(ctx, hipMalloc(&ctx->cs_rms, sizeof(double) * need));
+        HIPCHK(ctx, hipMalloc(&ctx->cs_mask, sizeof(double) * npc));
+        HIPCHK(ctx, hipMalloc(&ctx->cs_index, sizeof(double) * npc));
+        ctx->cs_cap = need;
+    }
+    const long long np = coarse_partials_len(ctx, Sp, npc);
+    if (np > ctx->cs_part_cap) {
+        if (ctx->cs_part) (void)hipFree(ctx->cs_part);
+        ctx->cs_part = nullptr;
+        HIPCHK(ctx, hipMalloc(&ctx->cs_part, sizeof(double) * np));
+        ctx->cs_part_cap = np;
+    }
+    return 0;
+}
+
+int dangx_coarse_partials(dangx_ctx* ctx, int comp, int map_n, int nside, int sample_nside, double* buf) {
+    if (!ctx || !buf || coarse_check(ctx, comp, nside, sample_nside)) return 1;
+    (void)hipSetDevice(ctx->device);
+    if (hp_tables(ctx, nside, sample_nside)) return 1;
+    if (dangx_fullsky_prepare(ctx, comp, map_n)) return 1;   // data_raw minus every other component, this shard's pixels
+    const int s1 = ctx->fs_s1, s2 = ctx->fs_s2, Sp = s2 - s1 + 1, nb = ctx->hm.nbands;
+    ctx->fs_comp = -1;
+    const long long npc = 12LL * sample_nside * sample_nside, npl = ctx->dims.npix, p0 = ctx->dims.pix0;
+    const int r1 = nside / sample_nside, ratio = r1 * r1;
+    if (coarse_alloc(ctx, Sp, npc)) return 1;
+    const long long nq = (long long)Sp * nb * npc;
+    double *dt = ctx->cs_part, *dc = dt + nq, *rt = dc + nq, *rc = rt + nq, *mt = rc + nq, *mc = mt + npc;
+    const dim3 gq(nblocks(npc), Sp * nb), g1(nblocks(npc), 1);
+    hipLaunchKernelGGL(k_udgrade_part, gq, dim3(BLOCK), 0, ctx->stream, ctx->fs_data, dt, dc, ctx->hp_n2r_f, ctx->hp_r2n_c, p0, npl, npc,
+                       ratio, 0, 0, nb, ctx->hm.nmaps, s1);
+    hipLaunchKernelGGL(k_udgrade_part, gq, dim3(BLOCK), 0, ctx->stream, ctx->rms, rt, rc, ctx->hp_n2r_f, ctx->hp_r2n_c, p0, npl, npc,
+                       ratio, 1, 1, nb, ctx->hm.nmaps, s1);
+    hipLaunchKernelGGL(k_udgrade_part, g1, dim3(BLOCK), 0, ctx->stream, ctx->mask, mt, mc, ctx->hp_n2r_f, ctx->hp_r2n_c, p0, npl, npc,
+                       ratio, 2, 0, nb, ctx->hm.nmaps, s1);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(buf, ctx->cs_part, sizeof(double) * coarse_partials_len(ctx, Sp, npc), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int dangx_coarse_chains(dangx_ctx* ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed, uint64_t stream,
+                        int nside, int sample_nside, const double* partials_sum, double* index_out) {
+    if (!ctx || !partials_sum || !index_out || coarse_check(ctx, comp, nside, sample_nside)) return 1;
+    (void)hipSetDevice(ctx->device);
+    const dangx_comp_desc& d = ctx->desc[comp];
+    if (nind < 0 || nind >= d.nindices) return fail(ctx, "index number out of range");
+    if (d.lnl_type[nind] < DANGX_LNL_CHISQ || d.lnl_type[nind] > DANGX_LNL_PRIOR) return fail(ctx, "bad lnl_type");
+    if (ml_mode != DANGX_ML_SAMPLE && ml_mode != DANGX_ML_OPTIMIZE) return fail(ctx, "bad ml_mode");
+    int s1, s2;
+    if (map_planes(ctx, map_n, s1, s2) || sync_model(ctx)) return 1;
+    const int Sp = s2 - s1 + 1, nb = ctx->hm.nbands;
+    const long long npc = 12LL * sample_nside * sample_nside, nq = (long long)Sp * nb * npc;
+    if (coarse_alloc(ctx, Sp, npc)) return 1;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->cs_part, partials_sum, sizeof(double) * coarse_partials_len(ctx, Sp, npc), hipMemcpyHostToDevice, ctx->stream));
+    const double *dt = ctx->cs_part, *dc = dt + nq, *rt = dc + nq, *rc = rt + nq, *mt = rc + nq, *mc = mt + npc;
+    const double scale = (double)sample_nside * 1.0 / nside;
+    hipLaunchKernelGGL(k_udgrade_finish, dim3(nblocks(nq)), dim3(BLOCK), 0, ctx->stream, dt, dc, ctx->cs_data, nq, 0, scale);
+    hipLaunchKernelGGL(k_udgrade_finish, dim3(nblocks(nq)), dim3(BLOCK), 0, ctx->stream, rt, rc, ctx->cs_rms, nq, 1, scale);
+    hipLaunchKernelGGL(k_udgrade_finish, dim3(nblocks(npc)), dim3(BLOCK), 0, ctx->stream, mt, mc, ctx->cs_mask, npc, 2, scale);
+    IndexArgs a{};
+    a.comp = comp; a.nind = nind; a.nsample = nsample; a.ml_mode = ml_mode; a.seed = seed; a.stream = stream;
+    a.s1 = s1; a.s2 = s2; a.mode = CH_GENERIC;
+    HIPCHK(ctx, hipMemsetAsync(ctx->counters + 1, 0, sizeof(unsigned long long), ctx->stream));
+    {
+        Timed t(ctx, DANGX_K_INDEX_MH);
+        hipLaunchKernelGGL(k_index_mh_coarse, dim3(nblocks(npc)), dim3(BLOCK), 0, ctx->stream, ctx->dm, a, npc, ctx->cs_data, ctx->cs_rms,
+                           ctx->cs_mask, ctx->cs_index, ctx->counters + 1);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    unsigned long long v = 0;
+    HIPCHK(ctx, hipMemcpyAsync(index_out, ctx->cs_index, sizeof(double) * npc, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&v, ctx->counters + 1, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    index_out[npc] = (double)v;  // accepted proposals of this shard's chains
+    return 0;
+}
+
+int dangx_coarse_writeback(dangx_ctx* ctx, int comp, int nind, int map_n, int nside, int sample_nside, const double* index_sum) {
+    if (!ctx || !index_sum || coarse_check(ctx, comp, nside, sample_nside)) return 1;
+    (void)hipSetDevice(ctx->device);
+    if (nind < 0 || nind >= ctx->desc[comp].nindices) return fail(ctx, "index number out of range");
+    int s1, s2;
+    if (map_planes(ctx, map_n, s1, s2) || hp_tables(ctx, nside, sample_nside) || sync_model(ctx)) return 1;
+    const long long npc = 12LL * sample_nside * sample_nside;
+    const int r1 = nside / sample_nside, ratio = r1 * r1;
+    if (coarse_alloc(ctx, s2 - s1 + 1, npc)) return 1;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->cs_index, index_sum, sizeof(double) * npc, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_coarse_writeback, dim3(nblocks(ctx->dims.npix)), dim3(BLOCK), 0, ctx->stream, ctx->dm, comp, nind, s1, s2, ctx->cs_index,
+                       ctx->hp_r2n_f, ctx->hp_n2r_c, ratio);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = s1; k <= s2; ++k) {
+        ctx->chi_before_valid[k - 1] = ctx->chi_after_valid[k - 1] = false;
+        ctx->touched_since_amp[k - 1] = true;
+        ctx->idx_const[comp] &= ~(1u << (k - 1));
+    }
+    ctx->dirty = true;
+    return 0;
+}
+
 // full-sky index mode with sample_nside /= nside (src/dang_sample_mod.f90:199-217, 229-329): the chain's sky-wide sums run
 // over the degraded maps.  After this call dangx_fullsky_sums evaluates on them; the chain ends with dangx_fill_index
 // (udgrade_ring of a constant coarse map is that constant everywhere, :480-483).
@@ -2000,8 +2173,20 @@ int dangx_index_sample_coarse(dangx_ctx* ctx, int comp, int nind, int map_n, int
     if (!ctx || check_comp(ctx, comp)) return 1;
     (void)hipSetDevice(ctx->device);
     const long long npix = ctx->dims.npix;
-    if (ctx->dims.pix0 != 0 || npix != 12LL * nside * nside || ctx->dims.npix_global != npix)
-        return fail(ctx, "coarse-Nside sampling needs ONE whole-sky context (npix = 12*nside^2): the children of a coarse pixel are scattered over the RING ranges of a sharded run");
+    if (ctx->dims.pix0 != 0 || npix != 12LL * nside * nside || ctx->dims.npix_global != npix) {
+        // a pixel shard: the three phases, with the sum over the ranks between them
+        if (!ctx->allreduce)
+            return fail(ctx, "coarse-Nside sampling on a pixel shard needs the sum over the shards: register dangx_set_allreduce (one process per GPU), or call dangx_coarse_partials / _chains / _writeback and add the buffers (several contexts in one process)");
+        int64_t np = 0, ni = 0;
+        if (dangx_coarse_sizes(ctx, map_n, sample_nside, &np, &ni)) return 1;
+        std::vector<double> part((size_t)np), idx((size_t)ni);
+        if (dangx_coarse_partials(ctx, comp, map_n, nside, sample_nside, part.data()) || rank_sum(ctx, part.data(), np)) return 1;
+        if (dangx_coarse_chains(ctx, comp, nind, map_n, nsample, ml_mode, seed, stream, nside, sample_nside, part.data(), idx.data()) ||
+            rank_sum(ctx, idx.data(), ni))
+            return 1;
+        if (accepted) *accepted = (int64_t)idx[(size_t)ni - 1];   // all ranks' chains
+        return dangx_coarse_writeback(ctx, comp, nind, map_n, nside, sample_nside, idx.data());
+    }
     if (!(sample_nside < nside)) return fail(ctx, "sample_nside must be smaller than nside (equal: dangx_index_sample)");
     const dangx_comp_desc& d = ctx->desc[comp];
     if (nind < 0 || nind >= d.nindices) return fail(ctx, "index number out of range");

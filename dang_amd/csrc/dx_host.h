@@ -109,6 +109,8 @@ struct dangx_ctx {
     int *hp_n2r_f = nullptr, *hp_r2n_f = nullptr, *hp_n2r_c = nullptr, *hp_r2n_c = nullptr;
     double *cs_data = nullptr, *cs_rms = nullptr, *cs_mask = nullptr, *cs_index = nullptr;
     long long cs_cap = 0;
+    double* cs_part = nullptr;              // per-shard sums / counts of the degrade step (pixel-sharded coarse sampling)
+    long long cs_part_cap = 0;
     long long work_cap = 0;
     // last DANGX_SOLVER_DIRECT solve of a group with global-amplitude members: largest |b - A x| of a global row relative
     // to that row of b after the last refinement, and the number of refinement steps taken

@@ -188,6 +188,31 @@ module dangx_mod
        integer(c_int64_t), value :: seed, stream
        integer(c_int64_t), intent(out) :: accepted
      end function
+     ! coarse-Nside sampling on a pixel shard, in three phases (include/dangx.h): the caller adds the buffers of all shards
+     integer(c_int) function dangx_coarse_sizes(ctx, map_n, sample_nside, n_partials, n_index) bind(C, name='dangx_coarse_sizes')
+       import :: c_int, c_ptr, c_int64_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: map_n, sample_nside
+       integer(c_int64_t), intent(out) :: n_partials, n_index
+     end function
+     integer(c_int) function dangx_coarse_partials(ctx, comp, map_n, nside, sample_nside, buf) bind(C, name='dangx_coarse_partials')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, buf
+       integer(c_int), value :: comp, map_n, nside, sample_nside
+     end function
+     integer(c_int) function dangx_coarse_chains(ctx, comp, nind, map_n, nsample, ml_mode, seed, stream, nside, sample_nside, &
+          partials_sum, index_out) bind(C, name='dangx_coarse_chains')
+       import :: c_int, c_ptr, c_int64_t
+       type(c_ptr), value :: ctx, partials_sum, index_out
+       integer(c_int), value :: comp, nind, map_n, nsample, ml_mode, nside, sample_nside
+       integer(c_int64_t), value :: seed, stream
+     end function
+     integer(c_int) function dangx_coarse_writeback(ctx, comp, nind, map_n, nside, sample_nside, index_sum) &
+          bind(C, name='dangx_coarse_writeback')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, index_sum
+       integer(c_int), value :: comp, nind, map_n, nside, sample_nside
+     end function
      integer(c_int) function dangx_udgrade(ctx, mode, map_in, nside_in, map_out, nside_out) bind(C, name='dangx_udgrade')
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx, map_in, map_out

@@ -233,6 +233,41 @@ contains
     end if
   end subroutine dangx_sky_index_sample
 
+  ! sample_index_mh with sample_nside /= nside (src/dang_sample_mod.f90:199-217, 332-483) over the contexts: the three
+  ! phases of dangx_index_sample_coarse, the shards' buffers added in shard order between them
+  subroutine dangx_sky_index_sample_coarse(sky, comp, nind, map_n, nsample, ml_mode, seed, stream, nside, sample_nside, accepted)
+    type(dangx_sky), intent(in) :: sky
+    integer, intent(in) :: comp, nind, map_n, nsample, ml_mode, nside, sample_nside
+    integer(c_int64_t), intent(in) :: seed, stream
+    integer(c_int64_t), intent(out) :: accepted
+    integer(c_int64_t) :: np, ni
+    real(c_double), allocatable, target :: part(:), psum(:), idx(:), isum(:)
+    integer :: r
+    if (sky%nctx == 1 .and. sky%npix(1) == sky%npix_global) then     ! one whole-sky context: the direct form
+       call dangx_check(sky%ctx(1), dangx_index_sample_coarse(sky%ctx(1), comp, nind, map_n, nsample, ml_mode, seed, stream, &
+            nside, sample_nside, accepted), 'dangx_index_sample_coarse')
+       return
+    end if
+    call dangx_check(sky%ctx(1), dangx_coarse_sizes(sky%ctx(1), map_n, sample_nside, np, ni), 'dangx_coarse_sizes')
+    allocate(part(np), psum(np), idx(ni), isum(ni))
+    psum = 0.d0; isum = 0.d0
+    do r = 1, sky%nctx
+       call dangx_check(sky%ctx(r), dangx_coarse_partials(sky%ctx(r), comp, map_n, nside, sample_nside, c_loc(part)), &
+            'dangx_coarse_partials')
+       psum = psum + part
+    end do
+    do r = 1, sky%nctx
+       call dangx_check(sky%ctx(r), dangx_coarse_chains(sky%ctx(r), comp, nind, map_n, nsample, ml_mode, seed, stream, nside, &
+            sample_nside, c_loc(psum), c_loc(idx)), 'dangx_coarse_chains')
+       isum = isum + idx
+    end do
+    do r = 1, sky%nctx
+       call dangx_check(sky%ctx(r), dangx_coarse_writeback(sky%ctx(r), comp, nind, map_n, nside, sample_nside, c_loc(isum)), &
+            'dangx_coarse_writeback')
+    end do
+    accepted = int(isum(ni), c_int64_t)
+  end subroutine dangx_sky_index_sample_coarse
+
   ! ---- sky-wide numbers: sums over the contexts in shard order
   ! update_sky_model + compute_chisq (src/dang_data_mod.f90:339-396, 494-526): chisq = sum/nbands/nump.  With the three
   ! optional full-sky host arrays (c_loc of sky_model / res_map / chi_map) it also refreshes them -- the state

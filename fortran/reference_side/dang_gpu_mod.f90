@@ -381,13 +381,14 @@ contains
                 call sample_index_mh_fullsky_gpu(cc, i-1, j, map_n)
              else if (cc%sample_nside(j) /= nside) then
                 write(*,fmt='(a,i4)') 'Sampling per-pixel at nside ', cc%sample_nside(j)
-                if (gpu_sky%nctx > 1 .or. numprocs > 1) then
-                   write(*,*) 'dang_gpu_mod: sample_nside /= nside needs the whole sky in one context (dangx_init(..., ngpu=1))'
-                   stop
+                if (numprocs > 1) then      ! one context per process: the sums over the shards go through dang_allreduce
+                   call dangx_check(gpu_sky%ctx(1), dangx_index_sample_coarse(gpu_sky%ctx(1), i-1, j-1, map_n, nsample, mode, &
+                        gpu_seed, dangx_stream_id(iter, 1, i-1, j-1, cc%pol_flag(j,k)), nside, cc%sample_nside(j), nacc), &
+                        'index_sample_coarse')
+                else                        ! one process, one or several contexts
+                   call dangx_sky_index_sample_coarse(gpu_sky, i-1, j-1, map_n, nsample, mode, gpu_seed, &
+                        dangx_stream_id(iter, 1, i-1, j-1, cc%pol_flag(j,k)), nside, cc%sample_nside(j), nacc)
                 end if
-                call dangx_check(gpu_sky%ctx(1), dangx_index_sample_coarse(gpu_sky%ctx(1), i-1, j-1, map_n, nsample, mode, &
-                     gpu_seed, dangx_stream_id(iter, 1, i-1, j-1, cc%pol_flag(j,k)), nside, cc%sample_nside(j), nacc), &
-                     'index_sample_coarse')
              else
                 write(*,fmt='(a,i4)') 'Sampling per-pixel at nside ', cc%sample_nside(j)
                 if (.not. cc%tuned(j)) then              ! 'Tuning!', src/dang_sample_mod.f90:341-346

@@ -109,7 +109,7 @@ int dangx_set_stream(dangx_ctx *ctx, void *hip_stream);
 /* Pixel-sharded runs (one context per rank, dangx_dims.pix0/npix = the rank's RING range): the few places where the
  * reference sums over the WHOLE sky inside a call -- the dot products of cg_search (src/dang_cg_mod.f90:279-312) and
  * the global-amplitude rows of compute_rhs / compute_Ax / compute_sample_vector (:522-587, :833-893, :1045-1096) --
- * hand their local sums (host doubles, n <= 32*32+96) to this callback, which must replace buf[0..n) by its sum over
+ * hand their local sums (host doubles, n <= 32*32+96; the coarse-Nside sweeps of a pixel shard: their degrade buffers) to this callback, which must replace buf[0..n) by its sum over
  * all ranks and return 0 (an MPI_Allreduce(MPI_IN_PLACE, buf, n, MPI_DOUBLE, MPI_SUM) or a torch.distributed
  * all_reduce).  is_root != 0 on exactly one rank: the replicated global rows are counted there in dot products.
  * fn == NULL (the default) = single rank.  Every rank must make the same sequence of calls. */
@@ -225,7 +225,7 @@ int dangx_chisq_cached(dangx_ctx *ctx, int which, int pol_lo, int pol_hi, double
 int dangx_chisq_cached_dev(dangx_ctx *ctx, int which, int pol_lo, int pol_hi, double *chisq_sum_dev);
 
 /* ---- index phase with sample_nside /= nside (src/dang_sample_mod.f90:199-217, 332-483) --------------------------
- * One whole-sky context (npix = 12*nside^2, pix0 = 0).  As in the reference: the data minus every other component is
+ * One whole-sky context (npix = 12*nside^2, pix0 = 0), or a pixel shard with an all-reduce (see below).  As in the reference: the data minus every other component is
  * formed at full resolution, then degraded with HEALPix's udgrade_ring (RING -> NEST, mean of the good children,
  * NEST -> RING), the rms with dang's udgrade_rms (sqrt(mean(rms^2)) * nside_out/nside_in), the mask with udgrade_mask
  * (mean >= 0.5); one chain per COARSE pixel i; the coarse index map is upgraded (children take the parent's value) and
@@ -237,6 +237,25 @@ int dangx_chisq_cached_dev(dangx_ctx *ctx, int which, int pol_lo, int pol_hi, do
  * Likelihoods: chisq / marginal / prior; priors: gaussian / uniform / jeffreys; diffuse component types and T_cmb. */
 int dangx_index_sample_coarse(dangx_ctx *ctx, int comp, int nind, int map_n, int nsample, int ml_mode,
                               uint64_t seed, uint64_t stream, int nside, int sample_nside, int64_t *accepted);
+/* On a PIXEL SHARD (pix0 /= 0 or npix /= 12*nside^2) dangx_index_sample_coarse needs sums over all shards -- the
+ * children of a coarse pixel are scattered over the RING ranges -- and takes them through the dangx_set_allreduce callback
+ * (one process per GPU; the buffers below, i.e. up to 2*(2*Sp*nbands+1)*12*sample_nside^2 doubles, not the few of the
+ * amplitude solves).  A single process that drives several contexts calls the three phases itself and ADDS the buffers
+ * of all contexts between them, in shard order:
+ *   dangx_coarse_sizes     : lengths of the two buffers (n_partials; n_index = 12*sample_nside^2 + 1)
+ *   dangx_coarse_partials  : A -- per coarse pixel and plane the sum of this shard's good children and their number, for the
+ *                            cleaned data, rms^2 and the mask -> buf[n_partials]
+ *   dangx_coarse_chains    : B -- finish data / rms / mask from the SUMMED partials; run the chains of the coarse pixels i
+ *                            whose full-resolution pixel i this shard holds -> index_out[0..npc) (0 elsewhere),
+ *                            index_out[npc] = accepted proposals
+ *   dangx_coarse_writeback : C -- c%indices(:, s1:s2, nind) of this shard's pixels from the SUMMED coarse index map
+ * With one shard the result equals the whole-sky call bit for bit; with several the child sums are associated
+ * differently (each shard's children first), i.e. the degraded maps agree to rounding. */
+int dangx_coarse_sizes(dangx_ctx *ctx, int map_n, int sample_nside, int64_t *n_partials, int64_t *n_index);
+int dangx_coarse_partials(dangx_ctx *ctx, int comp, int map_n, int nside, int sample_nside, double *buf);
+int dangx_coarse_chains(dangx_ctx *ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed, uint64_t stream,
+                        int nside, int sample_nside, const double *partials_sum, double *index_out);
+int dangx_coarse_writeback(dangx_ctx *ctx, int comp, int nind, int map_n, int nside, int sample_nside, const double *index_sum);
 /* the degrade / upgrade primitives on their own (whole-sky context): mode 0 = udgrade_ring, 1 = udgrade_rms,
  * 2 = udgrade_mask(threshold 0.5); host pointers, one map each ([12*nside_in^2] -> [12*nside_out^2]) */
 int dangx_udgrade(dangx_ctx *ctx, int mode, const double *map_in, int nside_in, double *map_out, int nside_out);

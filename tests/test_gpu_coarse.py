@@ -78,11 +78,46 @@ def test_sample_spectral_parameters_dispatches_the_coarse_mode(built):
     assert np.isfinite(ddata.chisq)
 
 
-def test_coarse_mode_needs_a_whole_sky_context(built):
+def test_coarse_mode_on_a_shard_needs_the_sum_over_shards(built):
     case = make_case("C2", nside=8, rank=0, nranks=2)
     eng, _ = pair(case)
-    with pytest.raises(da.DangxError, match="whole-sky"):
+    with pytest.raises(da.DangxError, match="sum over the shards"):
         eng.index_sample_coarse(1, 0, 1, 10, "sample", 7, 1, 4)
+
+
+@pytest.mark.parametrize("nshards", [1, 3])
+def test_coarse_sampling_over_several_contexts_of_one_process(built, nshards):
+    """The three phases of the coarse sweep (partials / chains / write-back) over pixel-shard contexts of ONE process,
+    buffers added in shard order: one shard reproduces the whole-sky call bit for bit, three shards agree with the
+    oracle to the parity tolerance (their child sums are associated differently)."""
+    nside, cnside = 8, 2
+
+    def tweak(dpar, ddata, bands, comps):
+        for c in comps:
+            c.sample_nside = [cnside] * c.nindices
+    whole = make_case("C2", nside=nside, start="truth", tweak=tweak)
+    dpar, ddata, bands, comps, meta = whole
+    ref, orc = pair(whole)
+    shards = [make_case("C2", nside=nside, start="truth", tweak=tweak, rank=r, nranks=nshards) for r in range(nshards)]
+    engs = [da.Engine(x[2], x[3], x[1], npix_global=x[4]["npix_global"], pix0=x[4]["pix0"], device=0) for x in shards]
+    for l, c in enumerate(comps):
+        for j in range(c.nindices):
+            if not c.sample_index[j]:
+                continue
+            f = c.pol_flag[j][0]
+            map_n = {1: 1, 8: -1}[f]
+            s = da.stream_id(2, 1, l, j, f)
+            a_ref = ref.index_sample_coarse(l, j, map_n, 10, "sample", 7, s, cnside)
+            a_orc = orc.sample_index_mh_coarse(l, j, map_n, 10, "sample", 7, s, nside, cnside)
+            a_multi = da.index_sample_coarse_multi(engs, l, j, map_n, 10, "sample", 7, s, cnside)
+            assert a_ref == a_orc == a_multi, (l, j, a_ref, a_orc, a_multi)
+    for l, c in enumerate(comps):
+        if not c.nindices:
+            continue
+        got = np.concatenate([e.get_indices(l) for e in engs], axis=-1)
+        if nshards == 1:
+            assert np.array_equal(got, ref.get_indices(l))
+        assert np.abs(got - orc.indices(l)).max() <= 1e-12
 
 
 def test_coarse_sweep_survives_a_descriptor_update_with_bandpass_bands(built):

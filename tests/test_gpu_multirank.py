@@ -92,6 +92,28 @@ def _fullsky_job(rank=0, world=1):
     return np.array([acc, beta, gain] + [means[k] for k in sorted(means)])
 
 
+def _coarse_job(rank=0, world=1):
+    """Coarse-Nside (8 -> 2) per-pixel sweeps on a sharded sky: the children of a coarse pixel are scattered over the
+    RING ranges, so the degrade step and the coarse index map are summed over the ranks (dangx_set_allreduce)."""
+    import dang_amd as da
+    from util import make_case
+
+    def tweak(dpar, ddata, bands, comps):
+        for c in comps:
+            c.sample_nside = [2] * c.nindices
+    case = make_case("C2", nside=8, start="truth", tweak=tweak)
+    dpar, ddata, bands, comps, meta = case
+    ddata, comps, p0, n = _shard(case, rank, world)
+    ddata.nump = case[1].nump
+    eng = da.initialize(bands, comps, ddata, npix_global=meta["npix_global"], pix0=p0, device=0)
+    info = da.sample_spectral_parameters(dpar, ddata, it=2)
+    out = {"acc": np.array([a for (_, _, _, a) in info], dtype=np.float64), "chisq": np.array([ddata.chisq])}
+    for l, c in enumerate(comps):
+        if c.nindices:
+            out["idx%d" % l] = eng.get_indices(l)
+    return out
+
+
 def _worker(rank, world, port, out):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
@@ -111,8 +133,17 @@ def _worker(rank, world, port, out):
         for l, t in enumerate(tas):
             res["ta%d_%d_r%d" % (n, l, rank)] = t
     res["fullsky_r%d" % rank] = _fullsky_job(rank, world)
+    cj = _coarse_job(rank, world)
+    res["coarse_acc_r%d" % rank] = cj["acc"]
+    res["coarse_chisq_r%d" % rank] = cj["chisq"]
+    for k, v in cj.items():
+        if k.startswith("idx"):
+            g = dist.gather_maps(torch.from_numpy(v), 768, dst=0)
+            if rank == 0:
+                res["coarse_" + k] = g.numpy()
     gathered = [None] * world
-    td.all_gather_object(gathered, {k: v for k, v in res.items() if k.startswith("ta") or k.startswith("fullsky")})
+    td.all_gather_object(gathered, {k: v for k, v in res.items() if k.startswith("ta") or k.startswith("fullsky") or
+                                    k.startswith("coarse_acc") or k.startswith("coarse_chisq")})
     if rank == 0:
         for g in gathered:
             res.update(g)
@@ -136,6 +167,13 @@ def test_two_ranks_solve_the_same_coupled_systems_as_one(built, tmp_path):
             for r in range(2):  # replicated on every rank
                 assert np.abs(got["ta%d_%d_r%d" % (n, l, r)] - t).max() <= tol * max(np.abs(t).max(), 1e-300), (n, l, r)
             assert np.array_equal(got["ta%d_%d_r0" % (n, l)], got["ta%d_%d_r1" % (n, l)])
+    one = _coarse_job()
+    assert np.array_equal(got["coarse_acc_r0"], got["coarse_acc_r1"]) and np.array_equal(got["coarse_acc_r0"], one["acc"])
+    for k, v in one.items():
+        if k.startswith("idx"):   # (the child sums are associated per shard first: the degraded maps agree to rounding)
+            assert np.abs(got["coarse_" + k] - v).max() <= 1e-12, k
+    assert abs(got["coarse_chisq_r0"][0] - one["chisq"][0]) <= 1e-10 * one["chisq"][0]
+    assert got["coarse_chisq_r0"][0] == got["coarse_chisq_r1"][0]
     one = _fullsky_job()
     assert np.array_equal(got["fullsky_r0"], got["fullsky_r1"])          # every rank walks the same chain
     assert got["fullsky_r0"][0] == one[0]                                # same accept count
