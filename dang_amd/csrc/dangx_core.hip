@@ -1402,8 +1402,6 @@ int dangx_set_component(dangx_ctx* ctx, int comp, const dangx_comp_desc* d) {
         return fail(ctx, "Error - unrecognized component type (only diffuse types are built)");
     const int want = (d->type == DANGX_MBB || d->type == DANGX_LOGNORMAL) ? 2
                      : (d->type == DANGX_CMB || d->type == DANGX_TEMPLATE || d->type == DANGX_MONOPOLE) ? 0 : 1;
-    if (d->type == DANGX_TCMB && d->sample_amplitude)
-        return fail(ctx, "T_cmb cannot be amplitude-sampled on the device yet (SURVEY 8f rank 1)");
     if (d->nindices != want) return fail(ctx, "nindices does not match the component type");
     // the amplitude / index maps are allocated on first use (ensure_state): a caller that adopts its own device
     // buffers (dangx_adopt_device_state) never holds two copies

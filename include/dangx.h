@@ -41,8 +41,10 @@ extern "C" {
 
 /* component type == c%type string, src/dang_component_mod.f90:791-809 */
 /* DANGX_TCMB: 'T_cmb' -- evaluate_T_cmb (:815-848); its eval_signal is the bare sed (:770-771).  Supported by
- * dangx_eval_sed, wherever a component is REMOVED from the data / summed into the sky model, and as an
- * index-sampled component (per pixel or full sky); it cannot be an amplitude-sampled member of a CG group. */
+ * dangx_eval_sed, wherever a component is REMOVED from the data / summed into the sky model, as an index-sampled
+ * component (per pixel or full sky), and as an amplitude-sampled member of a CG group: there the reference treats it as
+ * a diffuse member whose mixing element is eval_sed (src/dang_cg_mod.f90:469, 691, 807 test only for template / hi_fit /
+ * monopole), i.e. it solves for a c%amplitude that eval_signal then ignores -- reproduced as it is. */
 enum { DANGX_POWERLAW = 1, DANGX_MBB = 2, DANGX_FREEFREE = 3, DANGX_LOGNORMAL = 4, DANGX_CMB = 5, DANGX_TCMB = 6,
        /* global-amplitude types: one amplitude per fitted band instead of one per pixel (c%template,
         * c%template_amplitudes, c%corr, c%nfit; src/dang_component_mod.f90:536-710).  A CG group that contains

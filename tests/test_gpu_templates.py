@@ -307,3 +307,42 @@ def test_templates_are_removed_on_their_unfitted_bands_in_every_group(built):
         assert relmax(eng.get_amplitude(l), orc.amplitude(l)) <= 1e-11       # direct: GPU == oracle
         assert relmax(orc.amplitude(l), orc2.amplitude(l)) <= 1e-6           # direct == the reference's CG fixed point
         assert relmax(eng2.get_amplitude(l), orc2.amplitude(l)) <= 1e-6      # device CG == oracle CG
+
+
+def test_T_cmb_as_an_amplitude_sampled_group_member(built):
+    """The reference's CG code tests only for template / hi_fit / monopole (src/dang_cg_mod.f90:469, 691, 807), so a
+    'T_cmb' component with sample_amplitude in a CG group is a DIFFUSE member whose mixing element is evaluate_T_cmb
+    (B_nu(T)/B'_RJ*1e6) -- although eval_signal ignores its amplitude (:770-771).  Reproduced as it is: operators' seams,
+    the direct block solve and the device CG against the oracle."""
+    from dang_amd.api import DangComps
+
+    def tweak(dpar, ddata, bands, comps):
+        npix = ddata.sig_map.shape[-1]
+        rng = np.random.default_rng(17)
+        comps.insert(3, DangComps(label="tcmb", type="T_cmb", nu_ref=100.0, cg_group=1, sample_amplitude=True, nindices=1,
+                                  ind_label=["T"], sample_index=[False], index_mode=[2], lnl_type=["chisq"],
+                                  prior_type=["gaussian"], gauss_prior=[[2.7, 0.1]], uni_prior=[[1.0, 5.0]], step_size=[1e-3],
+                                  pol_flag=[[L.FLAG_T]], amplitude=np.zeros((3, npix)),
+                                  indices=2.7 + 0.05 * rng.normal(size=(1, 3, npix))))
+    case = make_case("C2", nside=4, start="truth", tweak=tweak)
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+    assert eng.group_size(1, L.FLAG_T) == 4 * meta["npix"]
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=4 * meta["npix"])
+    assert relmax(eng.compute_rhs(1, L.FLAG_T), orc.compute_rhs(1, L.FLAG_T)) <= 1e-12
+    assert relmax(eng.compute_Ax(1, L.FLAG_T, x), orc.compute_Ax(1, L.FLAG_T, x)) <= 1e-12
+    eta = orc.draw_eta(L.FLAG_T, 8, 9)
+    assert relmax(eng.compute_sample_vector(1, L.FLAG_T, eta), orc.compute_sample_vector(1, L.FLAG_T, eta)) <= 1e-12
+    _, bad = eng.amp_sample(1, L.FLAG_T, "sample", 8, 9)
+    assert bad == orc.amp_sample_direct(1, L.FLAG_T, "sample", 8, 9, "reference") == 0
+    for l in range(4):
+        b = orc.amplitude(l)
+        assert np.abs(eng.get_amplitude(l) - b).max() <= 1e-8 * np.abs(b).max(), l
+    # the solved system is the reference's: residual through its own operators
+    rel, _ = eng.amp_residual(1, L.FLAG_T, "sample", 8, 9)
+    assert rel <= 1e-9
+    eng2, orc2 = pair(case)
+    it_g, _ = eng2.amp_sample(1, L.FLAG_T, "optimize", 8, 9, solver="cg", i_max=60, converge=1e-8)
+    it_o = orc2.amp_sample_cg(1, L.FLAG_T, "optimize", 8, 9, i_max=60, converge=1e-8)
+    assert abs(it_g - it_o) <= 1
