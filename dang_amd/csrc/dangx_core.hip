@@ -557,7 +557,7 @@ __global__ __launch_bounds__(BLOCK) void k_index_mh_coarse(const Model* __restri
                     if (prop < lo || prop > hi) continue;
                     const double lnl_new = lnl_of(prop) + prior(prop);
                     const double diff = lnl_new - lnl_old;
-                    const bool acc = (a.ml_mode == DANGX_ML_OPTIMIZE) ? (diff > 0.0) : ((diff >= 0.0) || (exp(diff) > u3));
+                    const bool acc = (a.ml_mode == DANGX_ML_OPTIMIZE) ? (diff > 0.0) : ((diff >= 0.0) || (exp_nr(diff) > u3));
                     if (acc) { cur = prop; lnl_old = lnl_new; ++nacc; }
                 }
             }

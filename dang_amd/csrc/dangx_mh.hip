@@ -14,11 +14,11 @@ namespace {
 // Chain modes: the SED of the sampled component factorises into a part that is constant
 // along the chain (F_j, evaluated once) and a part that depends on the proposal, with the
 // reference's multiplication order kept, e.g. mbb (:947-948) = (A/B_j) * P_j:
-//   CH_POW       power-law beta     : exp(beta*lnr_j)
-//   CH_MBB_BETA  mbb beta (T fixed) : F_j = A/B_j ; sed = F_j * exp((beta+1)*lnr_j)
+//   CH_POW       power-law beta     : exp_nr(beta*lnr_j)
+//   CH_MBB_BETA  mbb beta (T fixed) : F_j = A/B_j ; sed = F_j * exp_nr((beta+1)*lnr_j)
 //   CH_MBB_T     mbb T (beta fixed) : F_j = P_j   ; sed = (A(T)/B_j(T)) * F_j
-//   CH_LOGN_NUP  lognormal nu_p     : sed = exp(-0.5*(log(nu_j/(nu_p*1e9))/w)^2) * cst_j
-//   CH_LOGN_W    lognormal w        : F_j = log(nu_j/(nu_p*1e9)) ; sed = exp(-0.5*(F_j/w)^2) * cst_j
+//   CH_LOGN_NUP  lognormal nu_p     : sed = exp_nr(-0.5*(log(nu_j/(nu_p*1e9))/w)^2) * cst_j
+//   CH_LOGN_W    lognormal w        : F_j = log(nu_j/(nu_p*1e9)) ; sed = exp_nr(-0.5*(F_j/w)^2) * cst_j
 //   CH_GENERIC   anything else (free-free T_e, bandpass-integrated bands): sed_prep + sed_eval
 struct ChainCtx {
     const Model& M;
@@ -46,7 +46,7 @@ __device__ __forceinline__ double chain_lnl(const ChainCtx& C, double th, int ln
     switch (C.a.mode) {
     case CH_POW: s0 = th; break;
     case CH_MBB_BETA: s0 = th + 1.0; break;
-    case CH_MBB_T: s0 = H_PLANCK / (K_B * th); s1 = exp(s0 * c.nu_ref) - 1.0; break;
+    case CH_MBB_T: s0 = H_PLANCK / (K_B * th); s1 = exp_nr(s0 * c.nu_ref) - 1.0; break;
     case CH_LOGN_NUP: s0 = log_pos(th); s1 = C.other; break;
     case CH_LOGN_W: s1 = th; break;
     default: pr = sed_prep(c, first ? th : C.other, first ? C.other : th); break;
@@ -55,11 +55,11 @@ __device__ __forceinline__ double chain_lnl(const ChainCtx& C, double th, int ln
     for (int j = 0; j < C.nb; ++j) {
         double s;
         switch (C.a.mode) {
-        case CH_POW: s = exp(s0 * c.lnr[j]); break;
-        case CH_MBB_BETA: s = C.F(j) * exp(s0 * c.lnr[j]); break;
-        case CH_MBB_T: s = s1 / (exp(s0 * M.band[j].nu_c) - 1.0) * C.F(j); break;
-        case CH_LOGN_NUP: { const double l = (c.lnu9[j] - s0) / s1; s = exp(-0.5 * (l * l)) * c.cst[j]; break; }
-        case CH_LOGN_W: { const double l = C.F(j) / s1; s = exp(-0.5 * (l * l)) * c.cst[j]; break; }
+        case CH_POW: s = exp_nr(s0 * c.lnr[j]); break;
+        case CH_MBB_BETA: s = C.F(j) * exp_nr(s0 * c.lnr[j]); break;
+        case CH_MBB_T: s = s1 / (exp_nr(s0 * M.band[j].nu_c) - 1.0) * C.F(j); break;
+        case CH_LOGN_NUP: { const double l = (c.lnu9[j] - s0) / s1; s = exp_nr(-0.5 * (l * l)) * c.cst[j]; break; }
+        case CH_LOGN_W: { const double l = C.F(j) / s1; s = exp_nr(-0.5 * (l * l)) * c.cst[j]; break; }
         default: s = (c.type == DANGX_HIFIT) ? 0.0 : sed_eval(M, c, j, pr); break;
         }
         // eval_signal (src/dang_component_mod.f90:754-776): amplitude(pix,map) * sed; T_cmb: the sed itself;
@@ -105,19 +105,19 @@ __device__ __forceinline__ double chain_lnl_tiled(const ChainCtx& C, double th, 
     double s0 = 0.0, s1 = 0.0;
     if (MODE == CH_POW) s0 = th;
     else if (MODE == CH_MBB_BETA) s0 = th + 1.0;
-    else { s0 = H_PLANCK / (K_B * th); s1 = exp(s0 * c.nu_ref) - 1.0; }
+    else { s0 = H_PLANCK / (K_B * th); s1 = exp_nr(s0 * c.nu_ref) - 1.0; }
     acc0 = 0.0; acc1 = 0.0;
     if (BP) {
         // chain-invariant scalars of the per-sample factor: mbb beta chain: z, A from the fixed temperature;
         // mbb T chain: the fixed beta + 1
         double bz = 0.0, bA = 0.0, bb1 = 0.0;
-        if (MODE == CH_MBB_BETA) { bz = H_PLANCK / (K_B * C.other); bA = exp(bz * c.nu_ref) - 1.0; }
+        if (MODE == CH_MBB_BETA) { bz = H_PLANCK / (K_B * C.other); bA = exp_nr(bz * c.nu_ref) - 1.0; }
         if (MODE == CH_MBB_T) bb1 = C.other + 1.0;
         for (int j = 0; j < C.nb; ++j) {
             const Band& b = M.band[j];
             double s;
             if (b.n == 0) {
-                const double e = exp((MODE == CH_MBB_T) ? s0 * b.nu_c : s0 * c.lnr[j]);
+                const double e = exp_nr((MODE == CH_MBB_T) ? s0 * b.nu_c : s0 * c.lnr[j]);
                 s = (MODE == CH_POW) ? e : (MODE == CH_MBB_BETA) ? C.F(j) * e : s1 / (e - 1.0) * C.F(j);
             } else {
                 const kptr nu = as_const(M.bp_nu0 + b.off);
@@ -126,9 +126,9 @@ __device__ __forceinline__ double chain_lnl_tiled(const ChainCtx& C, double th, 
                 s = 0.0;
 #pragma unroll 4
                 for (int q = 0; q < b.n; ++q) {
-                    if (MODE == CH_POW) s = s + tau[q] * exp(s0 * lnr[q]);
-                    else if (MODE == CH_MBB_BETA) s = s + tau[q] * bA / (exp(bz * nu[q]) - 1.0) * exp(s0 * lnr[q]);
-                    else s = s + tau[q] * s1 / (exp(s0 * nu[q]) - 1.0) * exp(bb1 * lnr[q]);
+                    if (MODE == CH_POW) s = s + tau[q] * exp_nr(s0 * lnr[q]);
+                    else if (MODE == CH_MBB_BETA) s = s + tau[q] * bA / (exp_nr(bz * nu[q]) - 1.0) * exp_nr(s0 * lnr[q]);
+                    else s = s + tau[q] * s1 / (exp_nr(s0 * nu[q]) - 1.0) * exp_nr(bb1 * lnr[q]);
                 }
             }
             const double r0 = (C.D(0, j) - C.amp0 * s) * C.IS(0, j);
@@ -152,7 +152,7 @@ __device__ __forceinline__ double chain_lnl_tiled(const ChainCtx& C, double th, 
         }
 #pragma unroll
         for (int t = 0; t < TB; ++t) {
-            const double e = exp(x[t]);
+            const double e = exp_nr(x[t]);
             if (MODE == CH_POW) s[t] = e;
             else if (MODE == CH_MBB_BETA) s[t] = f[t] * e;
             else s[t] = s1 / (e - 1.0) * f[t];
@@ -177,8 +177,8 @@ __device__ __forceinline__ double index_prior(const ChainCtx& C, double val) {
     const int t = c.prior_type[q];
     if (t == DANGX_PRIOR_GAUSSIAN) {
         // log(eval_normal_prior) (src/dang_util_mod.f90:112-121, src/dang_sample_mod.f90:395):
-        // log(exp(-(x-m)^2/(2 var))/(std*sqrt(2 pi))) = -(x-m)^2/(2 var) - log(std*sqrt(2 pi));
-        // the reference's exp() underflows to 0 (log -> -inf) beyond ~745
+        // log(exp_nr(-(x-m)^2/(2 var))/(std*sqrt(2 pi))) = -(x-m)^2/(2 var) - log(std*sqrt(2 pi));
+        // the reference's exp_nr() underflows to 0 (log -> -inf) beyond ~745
         const double mean = c.gauss[q][0], std = c.gauss[q][1];
         const double arg = ((val - mean) * (val - mean)) / (2 * (std * std));
         return (arg > 745.0) ? -INFINITY : -arg - c.lgden[q];
@@ -294,10 +294,10 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
     // --- chain-invariant SED factor
     if (a.mode == CH_MBB_BETA) {
         const double z = H_PLANCK / (K_B * sample1);
-        const double A = exp(z * c.nu_ref) - 1.0;
-        for (int j = 0; j < nb; ++j) C.F(j) = A / (exp(z * tab[(TROWS * M.ncomp) * nb + j]) - 1.0);
+        const double A = exp_nr(z * c.nu_ref) - 1.0;
+        for (int j = 0; j < nb; ++j) C.F(j) = A / (exp_nr(z * tab[(TROWS * M.ncomp) * nb + j]) - 1.0);
     } else if (a.mode == CH_MBB_T) {
-        for (int j = 0; j < nb; ++j) C.F(j) = exp((sample0 + 1.0) * tab[(TROWS * a.comp) * nb + j]);
+        for (int j = 0; j < nb; ++j) C.F(j) = exp_nr((sample0 + 1.0) * tab[(TROWS * a.comp) * nb + j]);
     } else if (a.mode == CH_LOGN_W) {
         {
             const double lp = log_pos(sample0);
@@ -344,8 +344,8 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
             if (a.ml_mode == DANGX_ML_OPTIMIZE) {
                 acc = diff > 0.0;  // :443-447
             } else {
-                // :448-454  diff > log(u)  <=>  diff >= 0 or exp(diff) > u   (u in (0,1))
-                acc = (diff >= 0.0) || (exp(diff) > u3);
+                // :448-454  diff > log(u)  <=>  diff >= 0 or exp_nr(diff) > u   (u in (0,1))
+                acc = (diff >= 0.0) || (exp_nr(diff) > u3);
             }
             if (acc) {
                 cur = prop;

@@ -7,7 +7,7 @@
 //   sed_prep()  -- everything that depends only on the pixel's spectral indices
 //                  (once per pixel, or once per Metropolis proposal);
 //   sed_eval()  -- the per-band part, using host-precomputed band scalars.
-// (nu/nu_ref)**beta is evaluated as exp(beta*log(nu/nu_ref)) with the logarithm
+// (nu/nu_ref)**beta is evaluated as exp_nr(beta*log(nu/nu_ref)) with the logarithm
 // precomputed on the host; this differs from pow() by a few ulp (|beta*ln r| * eps).
 #pragma once
 #include "dx_math.h"
@@ -20,18 +20,18 @@ struct Prep {
 };
 
 // src/dang_component_mod.f90:1024-1027 -- Gaunt-factor form, literal constants kept:
-//   log(exp(5.960 - sqrt(3)/pi * log(nu/1e9 * (T_e/1e4)**(-1.5))) + 2.71828)
+//   log(exp_nr(5.960 - sqrt(3)/pi * log(nu/1e9 * (T_e/1e4)**(-1.5))) + 2.71828)
 // with log(nu9*t15) = log(nu9) + log(t15): lnu9 is host-precomputed per band, lt15 = -1.5*log(T_e/1e4)
 // once per pixel (two transcendentals per band instead of three plus a pow per pixel).
 __device__ __forceinline__ double ff_gaunt(double lnu9, double lt15) {
     constexpr double S3PI = 1.7320508075688772 / PI;  // sqrt(3.d0)/pi
-    return log_pos(exp(5.960 - S3PI * (lnu9 + lt15)) + 2.71828);
+    return log_pos(exp_nr(5.960 - S3PI * (lnu9 + lt15)) + 2.71828);
 }
 
 // B_nu(nu,T)/compute_bnu_prime_RJ(nu)*1e6: evaluate_T_cmb / evaluate_hi_fit (src/dang_component_mod.f90:815-884,
 // B_nu :745-752, compute_bnu_prime_RJ src/dang_bp_mod.f90:160-168)
 __device__ __forceinline__ double planck_rj(double nu, double T) {
-    const double bnu = ((2.0 * H_PLANCK * (nu * nu * nu)) / (C_LIGHT * C_LIGHT)) * (1.0 / (exp((H_PLANCK * nu) / (K_B * T)) - 1));
+    const double bnu = ((2.0 * H_PLANCK * (nu * nu * nu)) / (C_LIGHT * C_LIGHT)) * (1.0 / (exp_nr((H_PLANCK * nu) / (K_B * T)) - 1));
     const double rj = 2.0 * K_B * (nu * nu) / (C_LIGHT * C_LIGHT);
     return bnu / rj;
 }
@@ -48,7 +48,7 @@ __device__ __forceinline__ Prep sed_prep(const Comp& c, double th0, double th1) 
         const double z = H_PLANCK / (K_B * th1);
         p.p0 = th0 + 1.0;
         p.p1 = z;
-        p.p2 = exp(z * c.nu_ref) - 1.0;
+        p.p2 = exp_nr(z * c.nu_ref) - 1.0;
         break;
     }
     case DANGX_FREEFREE: {  // :1017-1024
@@ -75,7 +75,7 @@ __device__ __forceinline__ Prep sed_prep(const Comp& c, double th0, double th1) 
 // bandpass-integrated forms (bp%id /= 'delta'): tau0-weighted sums in sample order, e.g. :909-913.  The reference
 // skips samples with nu0 == 0; the device copies carry tau = 0 and a harmless nu for those (s + 0*finite == s), so
 // the loops are branch-free, one loop per component type, four independent transcendental chains in flight.
-// (nu/nu_ref)**beta is exp(beta*log(nu/nu_ref)) with the log tabulated per (component, sample) on the host: the
+// (nu/nu_ref)**beta is exp_nr(beta*log(nu/nu_ref)) with the log tabulated per (component, sample) on the host: the
 // same identity the delta-bandpass path uses (20 fp64 ops instead of pow's ~150).
 // The sample tables are read-only for the whole launch and indexed wave-uniformly: viewed through the constant
 // address space they are fetched with scalar loads (s_load, scalar cache) instead of per-lane flat loads.
@@ -92,11 +92,11 @@ __device__ inline double sed_bandpass(const Model& M, const Comp& c, int j, cons
     switch (c.type) {
     case DANGX_POWERLAW:
 #pragma unroll 4
-        for (int i = 0; i < n; ++i) s = s + tau[i] * exp(p.p0 * lnr[i]);
+        for (int i = 0; i < n; ++i) s = s + tau[i] * exp_nr(p.p0 * lnr[i]);
         break;
     case DANGX_MBB:
 #pragma unroll 4
-        for (int i = 0; i < n; ++i) s = s + tau[i] * p.p2 / (exp(p.p1 * nu[i]) - 1.0) * exp(p.p0 * lnr[i]);
+        for (int i = 0; i < n; ++i) s = s + tau[i] * p.p2 / (exp_nr(p.p1 * nu[i]) - 1.0) * exp_nr(p.p0 * lnr[i]);
         break;
     case DANGX_FREEFREE:
 #pragma unroll 2
@@ -110,7 +110,7 @@ __device__ inline double sed_bandpass(const Model& M, const Comp& c, int j, cons
         for (int i = 0; i < n; ++i) {
             const double l = log_pos(nu[i] / p.p0) / p.p1;
             const double q = c.nu_ref / nu[i];
-            s = s + tau[i] * exp(-0.5 * (l * l)) * (q * q);
+            s = s + tau[i] * exp_nr(-0.5 * (l * l)) * (q * q);
         }
         break;
     case DANGX_TCMB:
@@ -129,14 +129,14 @@ __device__ __forceinline__ double sed_eval(const Model& M, const Comp& c, int j,
     if (M.band[j].n != 0) return sed_bandpass(M, c, j, p);
     switch (c.type) {
     case DANGX_POWERLAW:  // :908
-        return exp(p.p0 * c.lnr[j]);
+        return exp_nr(p.p0 * c.lnr[j]);
     case DANGX_MBB:  // :947-948
-        return p.p2 / (exp(p.p1 * M.band[j].nu_c) - 1.0) * exp(p.p0 * c.lnr[j]);
+        return p.p2 / (exp_nr(p.p1 * M.band[j].nu_c) - 1.0) * exp_nr(p.p0 * c.lnr[j]);
     case DANGX_FREEFREE:  // :1026-1027
         return ff_gaunt(c.lnu9[j], p.p0) / p.p1 * c.cst[j];
     case DANGX_LOGNORMAL: {  // :988
         const double l = (c.lnu9[j] - p.p2) / p.p1;
-        return exp(-0.5 * (l * l)) * c.cst[j];
+        return exp_nr(-0.5 * (l * l)) * c.cst[j];
     }
     case DANGX_TCMB:  // :836-846
         return planck_rj(M.band[j].nu_c, p.p0) * 1e6f;
@@ -175,12 +175,12 @@ __device__ __forceinline__ void sed_table_build(const Model& M, double* tab, int
 __device__ __forceinline__ double sed_eval_tab(int type, const double* tab, int nb, int ncomp, int l, int j, const Prep& p) {
     const double* tc = tab + (TROWS * l) * nb + j;
     switch (type) {
-    case DANGX_POWERLAW: return exp(p.p0 * tc[0]);
-    case DANGX_MBB: return p.p2 / (exp(p.p1 * tab[(TROWS * ncomp) * nb + j]) - 1.0) * exp(p.p0 * tc[0]);
+    case DANGX_POWERLAW: return exp_nr(p.p0 * tc[0]);
+    case DANGX_MBB: return p.p2 / (exp_nr(p.p1 * tab[(TROWS * ncomp) * nb + j]) - 1.0) * exp_nr(p.p0 * tc[0]);
     case DANGX_FREEFREE: return ff_gaunt(tc[2 * nb], p.p0) / p.p1 * tc[nb];
     case DANGX_LOGNORMAL: {
         const double l2 = (tab[(TROWS * l + 2) * nb + j] - p.p2) / p.p1;
-        return exp(-0.5 * (l2 * l2)) * tc[nb];
+        return exp_nr(-0.5 * (l2 * l2)) * tc[nb];
     }
     case DANGX_CMB: return tc[nb];
     default: return 0.0;
