@@ -147,3 +147,73 @@ def test_bad_arguments_fail_loudly(built):
         eng.index_sample(0, 0, 2, 10, "sample", 1, 2)                # map 2 with nmaps == 1
     with pytest.raises(da.DangxError):
         eng.sky_model_chisq(1, 3)
+
+
+def test_host_windows_into_full_sky_arrays(built):
+    """dangx_set_host_stride: a pixel-shard context reads and writes WINDOWS of the driver's full-sky arrays (plane q of
+    the shard starts plane_stride doubles after plane q-1) -- what fortran/dangx_multi_mod.f90 does for every GPU.  Upload,
+    put / get of amplitudes and indices and the sky / res / chi_map outputs through windows equal the packed path."""
+    import ctypes as C
+    from dang_amd import synth
+    full = synth.make_sky("C2", nside=4, start="truth")
+    dpar, ddata, bands, comps, meta = full
+    npix = meta["npix_global"]
+    shard = synth.make_sky("C2", nside=4, start="truth", rank=1, nranks=3)
+    p0, n = shard[4]["pix0"], shard[4]["npix"]
+    packed = da.Engine(shard[2], shard[3], shard[1], npix_global=npix, pix0=p0, device=0)
+    # the same shard fed from windows of the full-sky arrays
+    import copy
+    sh = copy.deepcopy(shard)
+    win = da.Engine(sh[2], sh[3], sh[1], npix_global=npix, pix0=p0, device=0)
+    lib, h = win.lib, win.h
+    assert lib.dangx_set_host_stride(h, npix) == 0
+
+    def at(a):                      # address of pixel p0 of plane 0 of a full-sky array [..., npix]
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        return a, a.ctypes.data + 8 * p0
+    keep = []
+    s, ps = at(ddata.sig_map); r, pr = at(ddata.rms_map); m, pm = at(ddata.masks)
+    keep += [s, r, m]
+    assert lib.dangx_upload_data(h, ps, pr, pm) == 0
+    for l, c in enumerate(comps):
+        a, pa = at(c.amplitude); keep.append(a)
+        assert lib.dangx_put_amplitude(h, l, pa) == 0
+        if c.nindices:
+            x, px = at(c.indices); keep.append(x)
+            assert lib.dangx_put_indices(h, l, px) == 0
+    for e in (packed, win):
+        e.amp_sample(1, L.FLAG_T, "sample", 3, 4)
+        e.index_sample(1, 0, 1, 5, "sample", 3, 5)
+    # read back through windows into full-sky arrays pre-filled with a sentinel: only the window changes
+    for l, c in enumerate(comps):
+        out = np.full((meta["nmaps"], npix), -7.0)
+        assert lib.dangx_get_amplitude(h, l, out.ctypes.data + 8 * p0) == 0
+        assert np.array_equal(out[:, p0:p0 + n], packed.get_amplitude(l))
+        assert np.all(out[:, :p0] == -7.0) and np.all(out[:, p0 + n:] == -7.0)
+        if c.nindices:
+            outx = np.full((c.nindices, meta["nmaps"], npix), -7.0)
+            assert lib.dangx_get_indices(h, l, outx.ctypes.data + 8 * p0) == 0
+            assert np.array_equal(outx[:, :, p0:p0 + n], packed.get_indices(l))
+            assert np.all(outx[:, :, :p0] == -7.0)
+    nb = meta["nbands"]
+    sky, res, chi = (np.full((nb, 3, npix), -7.0), np.full((nb, 3, npix), -7.0), np.full((3, npix), -7.0))
+    cs = C.c_double(0.0)
+    assert lib.dangx_sky_model_chisq(h, 1, 3, C.byref(cs), sky.ctypes.data + 8 * p0, res.ctypes.data + 8 * p0, chi.ctypes.data + 8 * p0) == 0
+    s2, sky2, res2, chi2 = packed.sky_model_chisq(1, 3, want_maps=True)
+    assert cs.value == s2 and np.array_equal(sky[:, :, p0:p0 + n], sky2, equal_nan=True) and np.array_equal(chi[:, p0:p0 + n], chi2)
+    assert np.all(sky[:, :, :p0] == -7.0) and np.all(res[:, :, p0 + n:] == -7.0)
+    assert lib.dangx_set_host_stride(h, n - 1) != 0          # a stride smaller than the shard is refused
+
+
+def test_convert_maps_scales_adopted_device_buffers_in_place(built):
+    import torch
+    from dang_amd import synth
+    dev = torch.device("cuda", 0)
+    dpar, ddata, bands, comps, meta = synth.make_sky("C2", nside=4, device=dev, as_numpy=False, start="truth")
+    sig0, rms0 = ddata.sig_map.clone(), ddata.rms_map.clone()
+    eng = da.initialize(bands, comps, ddata, npix_global=meta["npix_global"], device=0)
+    conv = da.convert_maps(ddata, ["uK_RJ", "uK_cmb", "MJy/sr", "uK_RJ", "uK_cmb"])
+    eng.synchronize()
+    for j in range(meta["nbands"]):
+        assert torch.equal(ddata.sig_map[j], sig0[j] * conv[j]) and torch.equal(ddata.rms_map[j], rms0[j] * conv[j])
+    assert conv[0] == 1.0 and conv[1] == 1.0 / eng.unit_conversion(1, "a2t") and conv[2] == 1.0 / eng.unit_conversion(2, "a2f")
