@@ -1,13 +1,18 @@
 // dangx_mhreg.hip -- Metropolis index kernels, register-resident form.  Compiled once per chain mode
 // (-DDX_REG_MODE=1..5) so the instantiations build in parallel, and once without it for the dispatcher.
+#ifndef DX_NO_VCOEF   // -DDX_NO_VCOEF: plain fma() in the once-per-proposal polynomials, for A/B timing
+#define DX_VCOEF 1   // dx_math.h: fma_vc
+#endif
 #include "dx_host.h"
 
 // the chain's exp: dx::exp_nr = the library routine minus its range selects (dx_math.h); -DDX_CHAIN_LIBEXP restores
 // the library call for A/B timing
 #ifdef DX_CHAIN_LIBEXP
 #define CEXP(x) exp(x)
+#define CEXP1(x) exp(x)
 #else
 #define CEXP(x) exp_nr(x)
+#define CEXP1(x) exp_nr_v(x)   // a call site that runs once per proposal (dx_math.h: fma_vc)
 #endif
 // reciprocals of the rms and inside the modified-blackbody SED: v_rcp_f64 + two Newton steps (<= 1 ulp, 6 vector
 // instructions) instead of the IEEE division sequence (11); -DDX_CHAIN_IEEEDIV restores a / b
@@ -15,6 +20,14 @@
 #define CDIV(a, b) ((a) / (b))
 #else
 #define CDIV(a, b) ((a) * fast_rcp(b))
+#endif
+
+// the chain's residual: with DX_CHAIN_SCALED (default) the staged planes hold d/sigma and a/sigma (the amplitude is fixed
+// during an index chain), so a band costs r = d' - a'*s; acc += r*r  (2 instructions per plane instead of 4) and the
+// factor -1/2 is applied to the band sum; -DDX_CHAIN_UNSCALED restores ((d - a*s)/sigma), acc -= r*r/2 for A/B timing.
+// Both forms carry the rounding of s scaled by the pixel's signal to noise; they differ in the last bits of lnL only.
+#ifndef DX_CHAIN_UNSCALED
+#define DX_CHAIN_SCALED 1
 #endif
 
 #ifdef DX_REG_MODE
@@ -29,7 +42,7 @@ namespace {
 // Arithmetic and operation order are identical to index_chain<MODE, SP, TB>.
 template <int MODE, int SP, int NB>
 struct RegChain {
-    double D[SP][NB], F[NB], ISr[SP][NB];  // cleaned data, chain-invariant SED factor, 1/rms
+    double D[SP][NB], F[NB], ISr[SP][NB];  // cleaned data, chain-invariant SED factor, 1/rms  (scaled form: d/rms, amp/rms)
     double amp[SP];
 
     __device__ __forceinline__ double is(int kk, int j) const { return ISr[kk][j]; }
@@ -67,15 +80,36 @@ struct RegChain {
 #pragma unroll
             for (int t = 0; t < TT; ++t) {
                 const int j = j0 + t;
+#ifdef DX_CHAIN_SCALED
+                const double r0 = fma(-is(0, j), s[t], D[0][j]);
+                acc0 = fma(r0, r0, acc0);
+                if (SP == 2) {
+                    const double r1 = fma(-is(SP - 1, j), s[t], D[SP - 1][j]);
+                    acc1 = fma(r1, r1, acc1);
+                }
+#else
                 const double r0 = (D[0][j] - amp[0] * s[t]) * is(0, j);
                 acc0 = acc0 - 0.5 * (r0 * r0);
                 if (SP == 2) {
                     const double r1 = (D[SP - 1][j] - amp[SP - 1] * s[t]) * is(SP - 1, j);
                     acc1 = acc1 - 0.5 * (r1 * r1);
                 }
+#endif
             }
         }
+#ifdef DX_CHAIN_SCALED
+        acc0 *= -0.5; acc1 *= -0.5;
+#endif
         return acc0 + acc1;
+    }
+    // after the other components are removed: d -> d/rms, 1/rms -> amp/rms
+    __device__ __forceinline__ void scale() {
+#ifdef DX_CHAIN_SCALED
+#pragma unroll
+        for (int kk = 0; kk < SP; ++kk)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) { D[kk][j] *= ISr[kk][j]; ISr[kk][j] *= amp[kk]; }
+#endif
     }
 };
 
@@ -220,6 +254,7 @@ __device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, co
             l = ln;
         }
     }
+    R.scale();
     // --- chain-invariant SED factor
     if (MODE == CH_MBB_BETA) {
         const double z = H_PLANCK / (K_B * sample1);
@@ -262,7 +297,7 @@ __device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, co
         lnl = R.lnl(M, c, prop, other, c0, c1);
         const double lnl_new = lnl + prior(prop);
         const double diff = lnl_new - lnl_old;
-        const bool acc = (a.ml_mode == DANGX_ML_OPTIMIZE) ? (diff > 0.0) : ((diff >= 0.0) || (CEXP(diff) > u3));  // :443-454
+        const bool acc = (a.ml_mode == DANGX_ML_OPTIMIZE) ? (diff > 0.0) : ((diff >= 0.0) || (CEXP1(diff) > u3));  // :443-454
         if (acc) { cur = prop; lnl_old = lnl_new; a0 = c0; a1 = c1; ++nacc; }
     }
 #pragma unroll

@@ -10,6 +10,22 @@
 
 namespace dx {
 
+// r*p + c with the coefficient in a VECTOR register and the three-address encoding.  For a polynomial that is evaluated
+// once per loop iteration the compiler keeps the coefficients in vector registers anyway (the scalar registers are taken
+// by the band constants) and then emits  v_mov_b64 tmp, c ; v_fmac_f64 tmp, r, p  -- two instructions per Horner step
+// (27 such copies in a Metropolis proposal); v_fma_f64 dst, r, p, c reads the same register without the copy.
+// Only translation units that define DX_VCOEF (the register-chain kernels) get it: elsewhere (amplitude kernels, one
+// normal deviate per tile) the longer live ranges cost spills and there is no loop to win in.
+__device__ __forceinline__ double fma_vc(double r, double p, double c) {
+#ifndef DX_VCOEF
+    return fma(r, p, c);
+#else
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(r), "v"(p), "v"(c));
+    return d;
+#endif
+}
+
 // 1/x for finite normal x, <= 1 ulp (v_rcp_f64 is good to 2^-23; each Newton step squares the error)
 __device__ __forceinline__ double fast_rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
@@ -59,8 +75,8 @@ __device__ __forceinline__ double log_pos(double x) {
     const double dk = (double)k;
     const double z = s * s;
     const double w = z * z;
-    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
-    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double t1 = w * fma_vc(w, fma_vc(w, Lg6, Lg4), Lg2);
+    const double t2 = z * fma_vc(w, fma_vc(w, fma_vc(w, Lg7, Lg5), Lg3), Lg1);
     const double R = t2 + t1;
     const double hfsq = 0.5 * f * f;
     return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
@@ -89,6 +105,24 @@ __device__ __forceinline__ double exp_nr(double x) {
     return ldexp(p, (int)dn);
 }
 
+// the same routine for a call site that runs once per loop iteration (the accept test): coefficients by fma_vc
+__device__ __forceinline__ double exp_nr_v(double x) {
+    const double dn = rint(x * 0x1.71547652b82fep+0);
+    const double r = fma(dn, -0x1.abc9e3b39803fp-56, fma(dn, -0x1.62e42fefa39efp-1, x));
+    double p = fma_vc(r, 0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22);
+    p = fma_vc(r, p, 0x1.71dee623fde64p-19);
+    p = fma_vc(r, p, 0x1.a01997c89e6b0p-16);
+    p = fma_vc(r, p, 0x1.a01a014761f6ep-13);
+    p = fma_vc(r, p, 0x1.6c16c1852b7b0p-10);
+    p = fma_vc(r, p, 0x1.1111111122322p-7);
+    p = fma_vc(r, p, 0x1.55555555502a1p-5);
+    p = fma_vc(r, p, 0x1.5555555555511p-3);
+    p = fma_vc(r, p, 0x1.000000000000bp-1);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    return ldexp(p, (int)dn);
+}
+
 // sin(2*pi*u) for u in [0,1): exact range reduction on u (t = 2u, k = rint(t) in {0,1,2}, r = t - k in [-1/2, 1/2] are
 // all exact; sin(pi t) = (-1)^k sin(pi r)) and ONE odd polynomial for sin(pi r) on [-1/2, 1/2] (Taylor to r^21, truncation
 // 1e-18; measured |error| <= 3.4e-16 against extended precision, libm's sin(2*pi*u) has 7e-16 from rounding 2*pi*u).
@@ -100,16 +134,16 @@ __device__ __forceinline__ double sin_2pi(double u) {
     double r = t - k;
     r = (k == 1.0) ? -r : r;
     const double z = r * r;
-    double p = fma(z, 0x1.2877020d52cf0p-31, -0x1.8a404211f9547p-26);
-    p = fma(z, p, 0x1.aaec32af93359p-21);
-    p = fma(z, p, -0x1.6fadb9f155744p-16);
-    p = fma(z, p, 0x1.e8f434d018d63p-12);
-    p = fma(z, p, -0x1.e3074fde8871fp-8);
-    p = fma(z, p, 0x1.50783487ee782p-4);
-    p = fma(z, p, -0x1.32d2cce62bd86p-1);
-    p = fma(z, p, 0x1.466bc6775aae2p+1);
-    p = fma(z, p, -0x1.4abbce625be53p+2);
-    p = fma(z, p, 0x1.921fb54442d18p+1);
+    double p = fma_vc(z, 0x1.2877020d52cf0p-31, -0x1.8a404211f9547p-26);
+    p = fma_vc(z, p, 0x1.aaec32af93359p-21);
+    p = fma_vc(z, p, -0x1.6fadb9f155744p-16);
+    p = fma_vc(z, p, 0x1.e8f434d018d63p-12);
+    p = fma_vc(z, p, -0x1.e3074fde8871fp-8);
+    p = fma_vc(z, p, 0x1.50783487ee782p-4);
+    p = fma_vc(z, p, -0x1.32d2cce62bd86p-1);
+    p = fma_vc(z, p, 0x1.466bc6775aae2p+1);
+    p = fma_vc(z, p, -0x1.4abbce625be53p+2);
+    p = fma_vc(z, p, 0x1.921fb54442d18p+1);
     return r * p;
 }
 
