@@ -90,32 +90,27 @@ __global__ __launch_bounds__(BLOCK, NG <= 4 ? 4 : 3) void k_amp_reg(const Model*
     double* tab = lds;
     double* prl = lds + (TROWS * NG + 3) * nb + tid;  // row (3*v + q): sed_prep value q of the v-th varying member
     double* col = prl + 3 * ra.nv * BLOCK;            // row (v*TB + t): its SED at band j0 + t
-    sed_table_build(M, tab, tid, BLOCK, a.gc, NG);
+    // grid = (pixel chunks, planes): no 64-bit division of a unit number by npix
     const long long u = (long long)blockIdx.x * BLOCK + tid;
-    const bool in_range = u < (long long)flag_nplanes(a.flag) * npix;
-    const int p = in_range ? (int)(u / npix) : 0;
-    const int i = in_range ? (int)(u - (long long)p * npix) : 0;
-    const int k = flag_map(a.flag, p);
-    const bool live = in_range && !is_masked(as_global(M.mask)[i]);  // masked rows/cols are zero: x keeps its value (:695)
-
-    // ---- per-pixel SED state of the varying members (ONE copy of the code: the loop over members is not unrolled, which
-    // keeps the scalar registers free for the polynomial coefficients of exp)
-    if (live) {
-#pragma unroll 1
-        for (int v = 0; v < ra.nv; ++v) {
+    const bool in_range = u < npix;
+    const int i = in_range ? (int)u : 0;
+    const int k = flag_map(a.flag, (int)blockIdx.y);
+    // ---- every load the prologue needs is issued NOW and unconditionally (a masked pixel's indices are read and dropped):
+    // the mask, then the indices behind an `if (live)`, then the first tile would be three HBM latencies in series for a
+    // wave that lives ~4 us; the table build and the random deviate below run under them
+    const double mk = as_global(M.mask)[i];
+    double th[NG][2];
+#pragma unroll
+    for (int v = 0; v < NG; ++v) {
+        th[v][0] = th[v][1] = 0.0;
+        if (v < ra.nv) {
             const Comp& c = M.comp[a.gc[ra.vcomp[v]]];
             const gcptr ix = as_global(c.idx) + (long long)(k - 1) * npix + i;   // c%indices(i,k,:), as load_theta
-            const double t0 = (c.nind > 0) ? ix[0] : 0.0;
-            const double t1 = (c.nind > 1) ? ix[(long long)M.nmaps * npix] : 0.0;
-            const Prep pr = sed_prep(c, t0, t1);
-            prl[(3 * v + 0) * BLOCK] = pr.p0;
-            prl[(3 * v + 1) * BLOCK] = pr.p1;
-            prl[(3 * v + 2) * BLOCK] = pr.p2;
+            if (c.nind > 0) th[v][0] = ix[0];
+            if (c.nind > 1) th[v][1] = ix[(long long)M.nmaps * npix];
         }
     }
-    __syncthreads();  // constant table complete (the only barrier; a thread only ever reads the columns it wrote)
-    if (!live) return;
-
+    sed_table_build(M, tab, tid, BLOCK, a.gc, NG);
     // ---- fluctuation term of the reference: ONE eta per unit (:258-260), no memory dependency
     const bool sample = (a.ml_mode == DANGX_ML_SAMPLE);
     const unsigned long long gpix = (unsigned long long)(M.pix0 + i);
@@ -125,6 +120,27 @@ __global__ __launch_bounds__(BLOCK, NG <= 4 ? 4 : 3) void k_amp_reg(const Model*
         uniform2(a.seed, a.stream, gpix, (uint32_t)k, u1, u2);
         eta = rand_normal(0.0, 1.0, u1, u2);
     }
+    const bool live = in_range && !is_masked(mk);  // masked rows/cols are zero: x keeps its value (:695)
+
+    // ---- per-pixel SED state of the varying members -> the thread's LDS rows (the indices pass through the rows so that
+    // ONE rolled copy of sed_prep serves every member: unrolled, its type switches cost the scalar registers the
+    // polynomial coefficients of exp live in)
+    if (live) {
+#pragma unroll
+        for (int v = 0; v < NG; ++v)
+            if (v < ra.nv) { prl[(3 * v + 0) * BLOCK] = th[v][0]; prl[(3 * v + 1) * BLOCK] = th[v][1]; }
+#pragma unroll 1
+        for (int v = 0; v < ra.nv; ++v) {
+            const Comp& c = M.comp[a.gc[ra.vcomp[v]]];
+            const Prep pr = sed_prep(c, prl[(3 * v + 0) * BLOCK], prl[(3 * v + 1) * BLOCK]);
+            prl[(3 * v + 0) * BLOCK] = pr.p0;
+            prl[(3 * v + 1) * BLOCK] = pr.p1;
+            prl[(3 * v + 2) * BLOCK] = pr.p2;
+        }
+    }
+    __syncthreads();  // constant table complete (the only barrier; a thread only ever reads the columns it wrote)
+    if (!live) return;
+
     double A[NG * (NG + 1) / 2], bv[NG];
 #pragma unroll
     for (int q = 0; q < NG * (NG + 1) / 2; ++q) A[q] = 0.0;
@@ -137,7 +153,8 @@ __global__ __launch_bounds__(BLOCK, NG <= 4 ? 4 : 3) void k_amp_reg(const Model*
 
 #pragma unroll 1
     for (int j0 = 0; j0 < nb; j0 += TB) {
-        // this tile's maps: issued now, consumed by phase B -- phase A below covers their latency
+        // this tile's maps: issued now, consumed by phase B -- phase A below covers their latency (requesting the first
+        // tile in the prologue as well was measured: no gain, 8 registers more)
         double dcur[TB], rcur[TB];
 #pragma unroll
         for (int t = 0; t < TB; ++t) {
@@ -227,7 +244,8 @@ template <int NG, int TB>
 int launch_tb(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, long long SN) {
     const size_t ldsz = amp_reg_lds<TB>(NG, ctx->hm.nbands, ra.nv);
     Timed t(ctx, DANGX_K_AMP_DIRECT);
-    hipLaunchKernelGGL((k_amp_reg<NG, TB>), dim3(nblocks(SN)), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, ctx->counters);
+    const int planes = flag_planes_h(a.flag);
+    hipLaunchKernelGGL((k_amp_reg<NG, TB>), dim3(nblocks(SN / planes), planes), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, ctx->counters);
     return 0;
 }
 
