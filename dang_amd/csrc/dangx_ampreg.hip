@@ -111,6 +111,10 @@ __global__ __launch_bounds__(BLOCK, NG <= 4 ? 4 : 3) void k_amp_reg(const Model*
         }
     }
     sed_table_build(M, tab, tid, BLOCK, a.gc, NG);
+#ifdef DX_AMP_TABLE_TWICE   // timing experiment: what one table build costs
+    __syncthreads();
+    sed_table_build(M, tab, tid, BLOCK, a.gc, NG);
+#endif
     // ---- fluctuation term of the reference: ONE eta per unit (:258-260), no memory dependency
     const bool sample = (a.ml_mode == DANGX_ML_SAMPLE);
     const unsigned long long gpix = (unsigned long long)(M.pix0 + i);

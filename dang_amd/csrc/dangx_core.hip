@@ -1741,7 +1741,7 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
     const bool reg_ok = !a.bp && d.lnl_type[nind] == DANGX_LNL_CHISQ && d.prior_type[nind] != DANGX_PRIOR_JEFFREYS &&
                         a.mode != CH_GENERIC && dx_mh_reg_supported(a.mode, ctx->hm.nbands);
     if (reg_ok) bs = BLOCK;  // register-resident form: no LDS columns
-    const unsigned nblk = nblocks(ctx->hm.npix, bs);
+    const unsigned nblk = nblocks((long long)ctx->hm.npix * (reg_ok ? dx_mh_reg_lanes(ctx->hm.nbands, Sp) : 1), bs);
     constexpr int RSTAGE = 128;  // blocks of the first reduction stage
     if (ensure_partial(ctx, 4ll * nblk + 4ll * RSTAGE)) return 1;
     if (accepted) HIPCHK(ctx, hipMemsetAsync(ctx->counters + 1, 0, sizeof(unsigned long long), ctx->stream));

@@ -40,13 +40,53 @@ namespace {
 // and the kernel uses no LDS and no barrier.  The CU's vector register file (512 KB) is three times its
 // LDS, so this form runs at 2-3 waves/SIMD where the LDS-column form is capped at 1-2.
 // Arithmetic and operation order are identical to index_chain<MODE, SP, TB>.
-template <int MODE, int SP, int NB>
+//
+// LP = 2 splits the bands of ONE pixel over two adjacent lanes (lane h of the pair owns bands [h*NB, (h+1)*NB) of the
+// 2*NB bands): each lane stages and evaluates its half, the two partial band sums of lnL are exchanged with one
+// cross-lane add per plane, and everything else (random numbers, prior, accept test) is computed by both lanes on
+// identical inputs, so the pair never diverges.  It halves the registers a lane needs -- two planes of 20 bands drop
+// from ~340 registers (one wave per SIMD) to the footprint of the 10-band kernel (two waves) -- at the price of the
+// duplicated per-proposal work; the per-band constants then differ between the lanes of a pair and live in vector
+// registers (K1, K2) instead of being scalar operands.
+template <int LP>
+struct BandPick {
+    int half;  // which half of the bands this lane owns (always 0 for LP == 1)
+    // per-band model constant for the lane's band j (j static): a scalar operand for LP == 1, else a select of two scalars
+    __device__ __forceinline__ double operator()(const double* arr, int j, int nbh) const {
+        if (LP == 1) return arr[j];
+        const double a = arr[j], b = arr[nbh + j];
+        return half ? b : a;
+    }
+    __device__ __forceinline__ double nu_c(const Model& M, int j, int nbh) const {
+        if (LP == 1) return M.band[j].nu_c;
+        const double a = M.band[j].nu_c, b = M.band[nbh + j].nu_c;
+        return half ? b : a;
+    }
+};
+
+template <int MODE, int SP, int NB, int LP>
 struct RegChain {
     double D[SP][NB], F[NB], ISr[SP][NB];  // cleaned data, chain-invariant SED factor, 1/rms  (scaled form: d/rms, amp/rms)
+    double K1[LP > 1 ? NB : 1], K2[LP > 1 ? NB : 1];  // LP > 1: the lane's per-band constants (see k1 / k2)
     double amp[SP];
 
     __device__ __forceinline__ double is(int kk, int j) const { return ISr[kk][j]; }
     __device__ __forceinline__ void set_is(int kk, int j, double v) { ISr[kk][j] = v; }
+    // the constant that multiplies / offsets the sampled parameter at band j, and the band's constant factor
+    __device__ __forceinline__ double k1(const Model& M, const Comp& c, int j) const {
+        if (LP > 1) return K1[j];
+        return (MODE == CH_MBB_T) ? M.band[j].nu_c : (MODE == CH_LOGN_NUP) ? c.lnu9[j] : c.lnr[j];
+    }
+    __device__ __forceinline__ double k2(const Comp& c, int j) const { return (LP > 1) ? K2[j] : c.cst[j]; }
+    __device__ __forceinline__ void set_k(const Model& M, const Comp& c, const BandPick<LP>& pick) {
+        if (LP > 1) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                K1[j] = (MODE == CH_MBB_T) ? pick.nu_c(M, j, NB) : (MODE == CH_LOGN_NUP) ? pick(c.lnu9, j, NB) : pick(c.lnr, j, NB);
+                K2[j] = (MODE == CH_LOGN_NUP || MODE == CH_LOGN_W) ? pick(c.cst, j, NB) : 0.0;
+            }
+        }
+    }
 
     __device__ __forceinline__ double lnl(const Model& M, const Comp& c, double th, double other, double& acc0, double& acc1) const {
         double s0 = 0.0, s1 = 0.0;
@@ -65,13 +105,13 @@ struct RegChain {
             for (int t = 0; t < TT; ++t) {
                 const int j = j0 + t;
                 if (MODE == CH_LOGN_NUP) {
-                    const double l = (c.lnu9[j] - s0) / s1;
-                    s[t] = CEXP(-0.5 * (l * l)) * c.cst[j];
+                    const double l = (k1(M, c, j) - s0) / s1;
+                    s[t] = CEXP(-0.5 * (l * l)) * k2(c, j);
                 } else if (MODE == CH_LOGN_W) {
                     const double l = F[j] / s1;
-                    s[t] = CEXP(-0.5 * (l * l)) * c.cst[j];
+                    s[t] = CEXP(-0.5 * (l * l)) * k2(c, j);
                 } else {
-                    const double e = CEXP((MODE == CH_MBB_T) ? s0 * M.band[j].nu_c : s0 * c.lnr[j]);
+                    const double e = CEXP(s0 * k1(M, c, j));
                     if (MODE == CH_POW) s[t] = e;
                     else if (MODE == CH_MBB_BETA) s[t] = F[j] * e;
                     else s[t] = CDIV(s1, e - 1.0) * F[j];
@@ -97,6 +137,10 @@ struct RegChain {
 #endif
             }
         }
+        if (LP > 1) {  // the other half's band sum: a + b on one lane, b + a on the other -- the same value
+            acc0 += __shfl_xor(acc0, 1, 64);
+            if (SP == 2) acc1 += __shfl_xor(acc1, 1, 64);
+        }
 #ifdef DX_CHAIN_SCALED
         acc0 *= -0.5; acc1 *= -0.5;
 #endif
@@ -114,90 +158,99 @@ struct RegChain {
 };
 
 // eval_sed of an "other" component for all NB bands of one plane, subtracted from D (static band index)
-template <int NB>
+template <int NB, int LP>
 __device__ __forceinline__ void subtract_other(const Model& M, const Comp& c2, int k, double amp2, double t0, double t1,
-                                               double (&Dk)[NB]) {
+                                               double (&Dk)[NB], const BandPick<LP>& pick) {
     if ((c2.const_planes >> (k - 1)) & 1) {  // spatially constant indices: host-evaluated SED
 #pragma unroll
-        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * c2.csed[k - 1][j];
+        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * pick(c2.csed[k - 1], j, NB);
         return;
     }
     const Prep pr = sed_prep(c2, t0, t1);
     switch (c2.type) {
     case DANGX_POWERLAW:
 #pragma unroll
-        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * CEXP(pr.p0 * c2.lnr[j]);
+        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * CEXP(pr.p0 * pick(c2.lnr, j, NB));
         break;
     case DANGX_MBB:
 #pragma unroll
-        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * (CDIV(pr.p2, CEXP(pr.p1 * M.band[j].nu_c) - 1.0) * CEXP(pr.p0 * c2.lnr[j]));
+        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * (CDIV(pr.p2, CEXP(pr.p1 * pick.nu_c(M, j, NB)) - 1.0) * CEXP(pr.p0 * pick(c2.lnr, j, NB)));
         break;
     case DANGX_FREEFREE:
 #pragma unroll
-        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * (ff_gaunt(c2.lnu9[j], pr.p0) / pr.p1 * c2.cst[j]);
+        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * (ff_gaunt(pick(c2.lnu9, j, NB), pr.p0) / pr.p1 * pick(c2.cst, j, NB));
         break;
     case DANGX_LOGNORMAL:
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const double l2 = (c2.lnu9[j] - pr.p2) / pr.p1;
-            Dk[j] -= amp2 * (CEXP(-0.5 * (l2 * l2)) * c2.cst[j]);
+            const double l2 = (pick(c2.lnu9, j, NB) - pr.p2) / pr.p1;
+            Dk[j] -= amp2 * (CEXP(-0.5 * (l2 * l2)) * pick(c2.cst, j, NB));
         }
         break;
     default:  // cmb
 #pragma unroll
-        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * c2.cst[j];
+        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * pick(c2.cst, j, NB);
         break;
     }
 }
 
 // Q and U planes of one pixel whose "other" component has the same indices on both (always the case once a Q+U
 // sweep has written them, :465): one SED evaluation per band serves both planes -- same values, same operations.
-template <int NB>
+template <int NB, int LP>
 __device__ __forceinline__ void subtract_other_pair(const Model& M, const Comp& c2, double ampa, double ampb, double t0, double t1,
-                                                    double (&Da)[NB], double (&Db)[NB]) {
+                                                    double (&Da)[NB], double (&Db)[NB], const BandPick<LP>& pick) {
     const Prep pr = sed_prep(c2, t0, t1);
     switch (c2.type) {
     case DANGX_POWERLAW:
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { const double s = CEXP(pr.p0 * c2.lnr[j]); Da[j] -= ampa * s; Db[j] -= ampb * s; }
+        for (int j = 0; j < NB; ++j) { const double s = CEXP(pr.p0 * pick(c2.lnr, j, NB)); Da[j] -= ampa * s; Db[j] -= ampb * s; }
         break;
     case DANGX_MBB:
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const double s = CDIV(pr.p2, CEXP(pr.p1 * M.band[j].nu_c) - 1.0) * CEXP(pr.p0 * c2.lnr[j]);
+            const double s = CDIV(pr.p2, CEXP(pr.p1 * pick.nu_c(M, j, NB)) - 1.0) * CEXP(pr.p0 * pick(c2.lnr, j, NB));
             Da[j] -= ampa * s; Db[j] -= ampb * s;
         }
         break;
     case DANGX_FREEFREE:
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { const double s = ff_gaunt(c2.lnu9[j], pr.p0) / pr.p1 * c2.cst[j]; Da[j] -= ampa * s; Db[j] -= ampb * s; }
+        for (int j = 0; j < NB; ++j) {
+            const double s = ff_gaunt(pick(c2.lnu9, j, NB), pr.p0) / pr.p1 * pick(c2.cst, j, NB);
+            Da[j] -= ampa * s; Db[j] -= ampb * s;
+        }
         break;
     case DANGX_LOGNORMAL:
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const double l2 = (c2.lnu9[j] - pr.p2) / pr.p1;
-            const double s = CEXP(-0.5 * (l2 * l2)) * c2.cst[j];
+            const double l2 = (pick(c2.lnu9, j, NB) - pr.p2) / pr.p1;
+            const double s = CEXP(-0.5 * (l2 * l2)) * pick(c2.cst, j, NB);
             Da[j] -= ampa * s; Db[j] -= ampb * s;
         }
         break;
     default:  // cmb
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { Da[j] -= ampa * c2.cst[j]; Db[j] -= ampb * c2.cst[j]; }
+        for (int j = 0; j < NB; ++j) { const double s = pick(c2.cst, j, NB); Da[j] -= ampa * s; Db[j] -= ampb * s; }
         break;
     }
 }
 
-template <int MODE, int SP, int NB>
-__device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, const IndexArgs& a, int i, double chi[4]) {
+// NB = bands per lane (all of them for LP == 1, half for LP == 2); half = which half this lane owns
+template <int MODE, int SP, int NB, int LP>
+__device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, const IndexArgs& a, int i, int half, double chi[4]) {
     const int npix = M.npix;
     const Comp& c = M.comp[a.comp];
     double* out = c.idx + ((long long)a.nind * M.nmaps) * npix + i;
     if (is_masked(M.mask[i])) {  // :362 cycle; index_map stays 0 (:223) and is copied back (:480-483)
+        if (half == 0) {
 #pragma unroll
-        for (int kk = 0; kk < SP; ++kk) out[(long long)(a.s1 + kk - 1) * npix] = 0.0;
+            for (int kk = 0; kk < SP; ++kk) out[(long long)(a.s1 + kk - 1) * npix] = 0.0;
+        }
         return 0ull;
     }
-    RegChain<MODE, SP, NB> R;
+    const BandPick<LP> pick = {half};
+    const int jb = half * NB;  // first band of this lane
+    RegChain<MODE, SP, NB, LP> R;
+    R.set_k(M, c, pick);
     double sample0, sample1;
     load_theta(M, c, i, a.s1, sample0, sample1);  // sample(l) = c%indices(i, map_inds(1), l), :372-377
     const bool first = (a.nind == 0);
@@ -212,12 +265,12 @@ __device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, co
         double rv[NB];
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            R.D[kk][j] = sigp[j * bstride];
-            rv[j] = rmsp[j * bstride];
+            R.D[kk][j] = sigp[(jb + j) * bstride];
+            rv[j] = rmsp[(jb + j) * bstride];
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            if (k == 1) R.D[kk][j] = (R.D[kk][j] - M.offset[j]) / M.gain[j];
+            if (k == 1) R.D[kk][j] = (R.D[kk][j] - pick(M.offset, j, NB)) / pick(M.gain, j, NB);
             R.set_is(kk, j, CDIV(1.0, rv[j]));
         }
     }
@@ -246,10 +299,10 @@ __device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, co
             if (ln >= 0) fetch(ln);
             const unsigned cp = (c2.const_planes >> (a.s1 - 1)) & 3u;
             if (SP == 2 && cp == 0 && ct0[0] == ct0[SP - 1] && ct1[0] == ct1[SP - 1]) {
-                subtract_other_pair<NB>(M, c2, ca[0], ca[SP - 1], ct0[0], ct1[0], R.D[0], R.D[SP - 1]);
+                subtract_other_pair<NB, LP>(M, c2, ca[0], ca[SP - 1], ct0[0], ct1[0], R.D[0], R.D[SP - 1], pick);
             } else {
 #pragma unroll
-                for (int kk = 0; kk < SP; ++kk) subtract_other<NB>(M, c2, a.s1 + kk, ca[kk], ct0[kk], ct1[kk], R.D[kk]);
+                for (int kk = 0; kk < SP; ++kk) subtract_other<NB, LP>(M, c2, a.s1 + kk, ca[kk], ct0[kk], ct1[kk], R.D[kk], pick);
             }
             l = ln;
         }
@@ -260,15 +313,15 @@ __device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, co
         const double z = H_PLANCK / (K_B * sample1);
         const double A = CEXP(z * c.nu_ref) - 1.0;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) R.F[j] = CDIV(A, CEXP(z * M.band[j].nu_c) - 1.0);
+        for (int j = 0; j < NB; ++j) R.F[j] = CDIV(A, CEXP(z * pick.nu_c(M, j, NB)) - 1.0);
     } else if (MODE == CH_MBB_T) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) R.F[j] = CEXP((sample0 + 1.0) * c.lnr[j]);
+        for (int j = 0; j < NB; ++j) R.F[j] = CEXP((sample0 + 1.0) * pick(c.lnr, j, NB));
     } else if (MODE == CH_LOGN_W) {
         {
             const double lp = log_pos(sample0);
 #pragma unroll
-            for (int j = 0; j < NB; ++j) R.F[j] = c.lnu9[j] - lp;
+            for (int j = 0; j < NB; ++j) R.F[j] = pick(c.lnu9, j, NB) - lp;
         }
     }
     const double other = first ? sample1 : sample0;  // the index that is not sampled
@@ -307,24 +360,30 @@ __device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, co
         const bool acc = (a.ml_mode == DANGX_ML_OPTIMIZE) ? (diff > 0.0) : ((diff >= 0.0) || (CEXP1(diff) > u3));  // :443-454
         if (acc) { cur = prop; lnl_old = lnl_new; a0 = c0; a1 = c1; ++nacc; }
     }
+    if (half != 0) {  // the pair's second lane carries the same chain: its sums and counts are the first lane's
+        chi[0] = chi[1] = 0.0;
+        return 0ull;
+    }
 #pragma unroll
     for (int kk = 0; kk < SP; ++kk) out[(long long)(a.s1 + kk - 1) * npix] = cur;  // :465, :483
     chi[2] = -2.0 * a0; chi[3] = -2.0 * a1;
     return nacc;
 }
 
-// Resident waves per SIMD follow the register need: 3 (<= 168 VGPRs) for one plane of <= 10 bands, 2 (<= 256) otherwise,
-// except two planes of 20 bands (C5), which need ~330 registers: one wave per SIMD with the overflow in AGPRs runs
-// 25 % faster than two waves spilling 70 registers to scratch (the chain has five independent exp chains in flight).
-template <int MODE, int SP, int NB>
-__global__ __launch_bounds__(BLOCK, (SP == 1 && NB <= 10) ? 3 : (SP == 2 && NB >= 20) ? 1 : 2) void k_index_mh_reg(const Model* __restrict__ Mp, IndexArgs a,
+// Resident waves per SIMD follow the register need: 3 (<= 168 VGPRs) for one plane of <= 10 bands, 2 (<= 256) otherwise.
+// Two planes of 20 bands (C5) need ~340 registers in one lane: they run as lane pairs (LP = 2, 10 bands per lane, two
+// waves per SIMD); the one-lane form (one wave per SIMD with the overflow in AGPRs) stays selectable with
+// DANGX_CHAIN_PAIR=0 for A/B timing.
+template <int MODE, int SP, int NB, int LP>
+__global__ __launch_bounds__(BLOCK, (SP == 1 && NB <= 10) ? 3 : (SP == 2 && NB >= 20 && LP == 1) ? 1 : 2) void k_index_mh_reg(const Model* __restrict__ Mp, IndexArgs a,
                                                         unsigned long long* __restrict__ accepted,
                                                         double* __restrict__ chi_partial) {
     const Model& M = *Mp;
     const int tid = threadIdx.x;
-    const int i = blockIdx.x * BLOCK + tid;
+    const long long t = (long long)blockIdx.x * BLOCK + tid;
+    const int i = (int)(t / LP), half = (int)(t % LP);
     double chi[4] = {0.0, 0.0, 0.0, 0.0};
-    unsigned long long nacc = (i < M.npix) ? index_chain_reg<MODE, SP, NB>(M, a, i, chi) : 0ull;
+    unsigned long long nacc = (i < M.npix) ? index_chain_reg<MODE, SP, NB / LP, LP>(M, a, i, half, chi) : 0ull;
     if (accepted) {
         for (int o = 32; o > 0; o >>= 1) nacc += __shfl_down(nacc, o, 64);
         if ((tid & 63) == 0 && nacc) atomicAdd(accepted, nacc);
@@ -352,8 +411,12 @@ __global__ __launch_bounds__(BLOCK, (SP == 1 && NB <= 10) ? 3 : (SP == 2 && NB >
 #define DX_CAT(a, b) DX_CAT2(a, b)
 bool DX_CAT(dx_launch_mh_reg_mode, DX_REG_MODE)(dangx_ctx* ctx, const IndexArgs& a, int Sp, unsigned nblk, unsigned long long* accp) {
     const int nb = ctx->hm.nbands;
+    if (dx_mh_reg_lanes(nb, Sp) == 2) {  // nblk counts blocks of BLOCK lanes = BLOCK / 2 pixels
+        hipLaunchKernelGGL((k_index_mh_reg<DX_REG_MODE, 2, 20, 2>), dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->dm, a, accp, ctx->partial);
+        return true;
+    }
 #define DX_LAUNCH_REG(SP_, NB_)                                                                                  \
-    hipLaunchKernelGGL((k_index_mh_reg<DX_REG_MODE, SP_, NB_>), dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->dm, a, accp, ctx->partial)
+    hipLaunchKernelGGL((k_index_mh_reg<DX_REG_MODE, SP_, NB_, 1>), dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->dm, a, accp, ctx->partial)
 #define DX_REG_NB(SP_)                                                                                           \
     do { if (nb == 10) DX_LAUNCH_REG(SP_, 10); else if (nb == 5) DX_LAUNCH_REG(SP_, 5);                          \
          else if (nb == 3) DX_LAUNCH_REG(SP_, 3); else if (nb == 6) DX_LAUNCH_REG(SP_, 6);                       \
@@ -371,6 +434,11 @@ bool dx_launch_mh_reg_mode3(dangx_ctx*, const IndexArgs&, int, unsigned, unsigne
 bool dx_launch_mh_reg_mode4(dangx_ctx*, const IndexArgs&, int, unsigned, unsigned long long*);
 bool dx_launch_mh_reg_mode5(dangx_ctx*, const IndexArgs&, int, unsigned, unsigned long long*);
 
+// lanes per pixel of the register chain: two planes of 20 bands run as lane pairs (DANGX_CHAIN_PAIR=0: one lane)
+int dx_mh_reg_lanes(int nb, int Sp) {
+    static const int pair = [] { const char* e = getenv("DANGX_CHAIN_PAIR"); return (e && e[0] == '0') ? 0 : 1; }();
+    return (pair && nb == 20 && Sp == 2) ? 2 : 1;
+}
 bool dx_mh_reg_supported(int mode, int nb) {
     return mode >= CH_POW && mode <= CH_LOGN_W && (nb == 3 || nb == 5 || nb == 6 || nb == 8 || nb == 10 || nb == 20);
 }

@@ -207,4 +207,5 @@ int dx_launch_sv_mixed(dangx_ctx* ctx, const GroupArgs& a, long long SN, const d
 void dx_launch_mh_lds(dangx_ctx* ctx, const IndexArgs& a, bool fast, int Sp, unsigned nblk, int bs, size_t lds, unsigned long long* accp);
 // register-resident Metropolis kernels; return false when (mode, nb) is not instantiated
 bool dx_mh_reg_supported(int mode, int nb);
+int dx_mh_reg_lanes(int nb, int Sp);  // lanes per pixel of the register chain (dangx_mhreg.hip)
 bool dx_launch_mh_reg(dangx_ctx* ctx, const IndexArgs& a, int Sp, unsigned nblk, unsigned long long* accp);
