@@ -13,6 +13,8 @@
 //     per component -- stride 1 into the constant table (a broadcast read) or stride BLOCK into the column;
 // so the HBM latency of the 2*nb map loads is covered by phase A of the same wave instead of by other waves, and
 // the kernel needs no barrier after the table is built (a thread only ever reads the column it wrote).
+// Measured and not kept: Q and U lanes of a pixel sharing one SED evaluation (lane pairs, -19 % vector instructions in the
+// Q+U launch: 1.47 -> 1.46 ms -- the kernel waits on memory, not on issue slots), requesting the first tile in the prologue.
 // Divisions by the rms, inside the mbb SED and in the Cholesky use v_rcp_f64 / v_rsq_f64 plus two Newton steps
 // (<= 1 ulp) instead of the IEEE division / sqrt sequences (12 / 18 fp64 instructions each).
 #include "dx_ampdata.h"

@@ -389,3 +389,30 @@ def test_index_means_for_write_data(built):
                     assert abs(got[(c.label, c.ind_label[j])] - want) <= 1e-13 * max(abs(want), 1.0)
     s, n = eng.index_masked_sum(1, 0, 1)
     assert n == int(m.sum())
+
+
+@pytest.mark.parametrize("config,nside", [("C2", 8), ("C5", 4)])
+@pytest.mark.parametrize("unequal", ["none", "some", "all"])
+def test_qu_amplitude_launch_with_equal_and_unequal_plane_indices(built, config, nside, unequal):
+    """The Q+U amplitude launch with the Q and U planes carrying the same spectral indices (what every Q+U index sweep
+    leaves), different ones on a few pixels, and different ones everywhere: the oracle's amplitudes in all three cases
+    (kernels that share SED evaluations between the two planes of a pixel must not assume the first case)."""
+    def tweak(dpar, ddata, bands, comps):
+        rng = np.random.default_rng(11)
+        for c in comps:
+            if c.nindices and c.cg_group == 2 and unequal != "none":
+                npix = c.indices.shape[-1]
+                pick = np.ones(npix, bool) if unequal == "all" else (rng.uniform(size=npix) < 0.02)
+                c.indices[0, 2, pick] *= 1.0 + 0.03 * rng.standard_normal(pick.sum())   # U plane only
+    case = make_case(config, nside=nside, start="truth", tweak=tweak)
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+    for ml in ("sample", "optimize"):
+        eng.amp_sample(2, L.FLAG_QU, ml, 9, 31)
+        orc.amp_sample_direct(2, L.FLAG_QU, ml, 9, 31, "reference")
+        assert_amps_close(eng, orc, len(comps), TOL_AMP, what="%s %s" % (unequal, ml))
+    # and plane by plane (the single-plane launches): same amplitudes as the oracle's single-plane solves
+    for flag in (L.FLAG_Q, L.FLAG_U):
+        eng.amp_sample(2, flag, "sample", 9, 40 + flag)
+        orc.amp_sample_direct(2, flag, "sample", 9, 40 + flag, "reference")
+    assert_amps_close(eng, orc, len(comps), TOL_AMP, what="single planes")
