@@ -16,7 +16,8 @@
 // Measured and not kept: Q and U lanes of a pixel sharing one SED evaluation (lane pairs, -19 % vector instructions in the
 // Q+U launch: 1.47 -> 1.46 ms -- the kernel waits on memory, not on issue slots), requesting the first tile in the prologue,
 // requesting the next tile band by band from phase B into the registers a band has just vacated (the map registers
-// then live across phase A: 22 spills, 0.78 -> 1.09 ms).
+// then live across phase A: 22 spills, 0.78 -> 1.09 ms), tiles of two bands at five waves per SIMD (93 registers: 0.79 ms,
+// no change).  tools/ubench/stream_planes.hip: the same loads and stores with no arithmetic take 0.48 ms (5.8 TB/s).
 // Divisions by the rms, inside the mbb SED and in the Cholesky use v_rcp_f64 / v_rsq_f64 plus two Newton steps
 // (<= 1 ulp) instead of the IEEE division / sqrt sequences (12 / 18 fp64 instructions each).
 #include "dx_ampdata.h"
