@@ -113,8 +113,25 @@ def check_reference_side():
     return True
 
 
+def build_ubench(force=False):
+    """hipcc -> dang_amd/lib/ub/{isa_rate,stream_planes}: the microbenchmarks behind profiles/r02_isa_rate.txt and
+    profiles/r02_stream_planes.txt (measurement tools, not part of the library)."""
+    out = os.path.join(LIBDIR, "ub")
+    os.makedirs(out, exist_ok=True)
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    built = []
+    for name in ("isa_rate", "stream_planes"):
+        src = os.path.join(ROOT, "tools", "ubench", name + ".hip")
+        exe = os.path.join(out, name)
+        if os.path.exists(src) and (force or _newer(exe, [src])):
+            _run([hipcc, "-O3", "--offload-arch=gfx950", "-o", exe, src])
+        built.append(exe)
+    return built
+
+
 def build_all(force=False):
     build_hip(force)
+    build_ubench(force)
     build_oracle(force)
     build_fortran(force)
     check_reference_side()
