@@ -80,6 +80,7 @@ def algorithmic_bytes(meta, comps, kernel, units):
       spectral indices (nidx_g) and the mask (1); write the group's nc amplitudes.
     index sweep, per unit: read d and sigma (2 nb), every amplitude that enters the model on that
       plane (nc_g), the group's indices (nidx_g) and the mask (1); write 1 index value.
+    fused solve + first sweep (k_amp_index), per unit: the solve's traffic plus the one index value written.
     """
     nb = meta["nbands"]
     nphys = len(meta["phys"])
@@ -88,6 +89,8 @@ def algorithmic_bytes(meta, comps, kernel, units):
         per_unit = 2 * nb + nidx + 1 + nphys
     elif kernel == "k_index_mh":
         per_unit = 2 * nb + nphys + nidx + 1 + 1
+    elif kernel == "k_amp_index":  # solve + first sweep in one launch: the maps once, amplitudes and one index written
+        per_unit = 2 * nb + nidx + 1 + nphys + 1
     else:  # k_sky_chisq: read d, sigma, amplitudes, indices, mask
         per_unit = 2 * nb + nphys + nidx + 1
     return 8.0 * per_unit * units
@@ -187,6 +190,8 @@ def main():
     ap.add_argument("--nside", type=int, default=None)
     ap.add_argument("--nsample", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fuse", action="store_true", help="diagnostic: amplitude solve and first index sweep of a plane set as "
+                    "two calls (two launches) instead of dangx_amp_index_sample")
     ap.add_argument("--bandpass", type=int, default=0, help="diagnostic (not a BASELINE config): integrate every second "
                     "band over an N-sample +-10%% top-hat bandpass instead of a delta (SURVEY 8f rank 3)")
     ap.add_argument("--streams", type=int, default=0, choices=[0, 1, 2], help="2: the temperature chain (group 1, T sweeps) and the "
@@ -255,18 +260,40 @@ def main():
         chisq_P = torch.zeros(2, dtype=torch.float64, device=dev)
     eng_of = (lambda f: engP if (two and f != 1) else eng)
 
+    # the first sampled (component, index) of every (CG group, flag): its sweep directly follows that group's solve on
+    # the same planes, and nothing else touches those planes in between -- the pair goes through ONE entry point
+    # (dangx_amp_index_sample: one kernel launch where the model allows it, bit for bit the two calls' result)
+    first_sweep = {}
+    if not args.no_fuse:
+        for g in dpar.cg_groups:
+            for f in g.pol_flag:
+                for l, c in enumerate(comps):
+                    hit = [j for j in range(c.nindices) if c.sample_index[j] and f in c.pol_flag[j]] if c.cg_group == g.cg_group else []
+                    if hit:
+                        first_sweep[(g.cg_group, f)] = (l, hit[0])
+                        break
+    fused_sweeps = set((l, j, f) for (grp, f), (l, j) in first_sweep.items())
+
     def gibbs_iteration(it):
         # sample_cg_groups (src/dang_cg_mod.f90:142-177)
         for g in dpar.cg_groups:
             for f in g.pol_flag:
-                eng_of(f).amp_sample(g.cg_group, f, dpar.ml_mode, dpar.seed, da.stream_id(it, 0, g.cg_group, 0, f),
-                                     solver="direct", fluct_mode=dpar.fluct_mode, want_counts=False)
+                if (g.cg_group, f) in first_sweep:
+                    l, j = first_sweep[(g.cg_group, f)]
+                    eng_of(f).amp_index_sample(g.cg_group, f, dpar.ml_mode, dpar.seed, da.stream_id(it, 0, g.cg_group, 0, f),
+                                               l, j, mapn[f], dpar.nsample, dpar.seed, da.stream_id(it, 1, l, j, f),
+                                               solver="direct", fluct_mode=dpar.fluct_mode, want_counts=False)
+                else:
+                    eng_of(f).amp_sample(g.cg_group, f, dpar.ml_mode, dpar.seed, da.stream_id(it, 0, g.cg_group, 0, f),
+                                         solver="direct", fluct_mode=dpar.fluct_mode, want_counts=False)
         # the chi^2 after the amplitude phase is captured by the first index sweep on each plane (fused);
         # sample_spectral_parameters (src/dang_sample_mod.f90:21-86)
         for l, c in enumerate(comps):
             for j in range(c.nindices):
                 if c.sample_index[j]:
                     for f in c.pol_flag[j]:
+                        if (l, j, f) in fused_sweeps:
+                            continue
                         eng_of(f).index_sample(l, j, mapn[f], dpar.nsample, dpar.ml_mode, dpar.seed,
                                                da.stream_id(it, 1, l, j, f), want_counts=False)
         # update_sky_model + compute_chisq after each phase (src/dang_cg_mod.f90:172-173,
@@ -329,9 +356,10 @@ def main():
     if rank == 0:
         # dominant kernel (largest total time on this rank) and its HBM roofline fraction
         dom = max(prof, key=lambda k: prof[k]["total_ms"])
-        units_per_step = {"k_amp_direct": meta["npix"] * nmaps,
-                          "k_index_mh": sum(meta["npix"] * (2 if f == 8 else 1) for c in comps for j in range(c.nindices)
-                                            if c.sample_index[j] for f in c.pol_flag[j]),
+        in_fused = fused_sweeps if "k_amp_index" in prof else set()
+        units_per_step = {"k_amp_direct": meta["npix"] * nmaps, "k_amp_index": meta["npix"] * nmaps,
+                          "k_index_mh": sum(meta["npix"] * (2 if f == 8 else 1) for l, c in enumerate(comps) for j in range(c.nindices)
+                                            if c.sample_index[j] for f in c.pol_flag[j] if (l, j, f) not in in_fused),
                           "k_sky_chisq": 2 * meta["npix"] * nmaps}
         launches_per_step = max(prof[dom]["launches"] // args.steps, 1)
         bytes_per_launch = algorithmic_bytes(meta, comps, dom, units_per_step.get(dom, meta["npix"] * nmaps)) / launches_per_step

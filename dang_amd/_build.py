@@ -40,7 +40,9 @@ def hip_sources():
 UNITS = [("dangx_core", "dangx_core.hip", []), ("dangx_amp", "dangx_amp.hip", []), ("dangx_ampreg", "dangx_ampreg.hip", []), ("dangx_mixed", "dangx_mixed.hip", []), ("dangx_schur", "dangx_schur.hip", []),
          ("dangx_mh", "dangx_mh.hip", []),
          ("dangx_mhreg", "dangx_mhreg.hip", [])] + \
-        [("dangx_mhreg_m%d" % m, "dangx_mhreg.hip", ["-DDX_REG_MODE=%d" % m]) for m in (1, 2, 3, 4, 5)]
+        [("dangx_mhreg_m%d" % m, "dangx_mhreg.hip", ["-DDX_REG_MODE=%d" % m]) for m in (1, 2, 3, 4, 5)] + \
+        [("dangx_fused", "dangx_fused.hip", [])] + \
+        [("dangx_fused_m%d" % m, "dangx_fused.hip", ["-DDX_REG_MODE=%d" % m]) for m in (1, 2, 3)]
 
 
 def build_hip(force=False, verbose=False):

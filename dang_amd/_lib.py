@@ -22,9 +22,9 @@ SOLVER_DIRECT, SOLVER_CG = 0, 1
 FLUCT_CORRECT, FLUCT_REFERENCE = 0, 1
 A2T, A2F, F2T = 0, 1, 2
 UNIT_CODES = {"uK_RJ": 0, "uK_cmb": 1, "MJy/sr": 2}
-K_AMP_DIRECT, K_INDEX_MH, K_SKY_CHISQ, K_REDUCE, K_CG_AX, K_CG_VEC = range(6)
+K_AMP_DIRECT, K_INDEX_MH, K_SKY_CHISQ, K_REDUCE, K_CG_AX, K_CG_VEC, K_AMP_INDEX = range(7)
 KERNEL_NAMES = {K_AMP_DIRECT: "k_amp_direct", K_INDEX_MH: "k_index_mh", K_SKY_CHISQ: "k_sky_chisq",
-                K_REDUCE: "k_reduce", K_CG_AX: "k_Ax", K_CG_VEC: "k_cg_vec"}
+                K_REDUCE: "k_reduce", K_CG_AX: "k_Ax", K_CG_VEC: "k_cg_vec", K_AMP_INDEX: "k_amp_index"}
 
 TYPE_CODES = {"power-law": POWERLAW, "mbb": MBB, "freefree": FREEFREE, "lognormal": LOGNORMAL, "cmb": CMB, "T_cmb": TCMB,
               "template": TEMPLATE, "monopole": MONOPOLE, "hi_fit": HIFIT}
@@ -95,6 +95,9 @@ SYMBOLS = {
     "dangx_amp_residual": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _D]),
     "dangx_index_sample": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
                                      C.POINTER(C.c_int64)]),
+    "dangx_amp_index_sample": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
+                                         C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "dangx_sky_model_chisq": (C.c_int, [_P, C.c_int, C.c_int, _D, _P, _P, _P]),
     "dangx_sky_model_chisq_dev": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "dangx_chisq_cached": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _D]),

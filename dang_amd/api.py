@@ -336,6 +336,19 @@ class Engine:
                                               C.byref(acc) if want_counts else None))
         return acc.value
 
+    def amp_index_sample(self, group, flag, ml_mode, seed_amp, stream_amp, comp, nind, map_n, nsample, seed_index,
+                         stream_index, solver="direct", fluct_mode="reference", want_counts=True):
+        """amp_sample(group, flag, ...) followed by index_sample(comp, nind, map_n, ...) on the same planes -- one kernel
+        launch when the model allows it, the two calls otherwise; bit for bit the same result either way.
+        Returns (units whose block was not positive definite, accepted proposals)."""
+        bad, acc = C.c_int64(0), C.c_int64(0)
+        self._chk(self.lib.dangx_amp_index_sample(
+            self.h, group, flag, L.ML_CODES[ml_mode], L.SOLVER_CG if solver == "cg" else L.SOLVER_DIRECT,
+            L.FLUCT_REFERENCE if fluct_mode == "reference" else L.FLUCT_CORRECT, seed_amp, stream_amp,
+            comp, nind, map_n, nsample, seed_index, stream_index,
+            C.byref(bad) if want_counts else None, C.byref(acc) if want_counts else None))
+        return bad.value, acc.value
+
     def sky_model_chisq(self, pol_lo, pol_hi, want_maps=False):
         s = C.c_double(0.0)
         if want_maps:

@@ -1618,6 +1618,10 @@ int dangx_amp_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solve
             return fail(ctx, "the CG solver reproduces the reference's fluctuation term only");
         return device_cg(ctx, a, i_max, converge, cg_iters);
     }
+    if (ctx->defer_amp) {  // dangx_amp_index_sample: the launch waits for the index sweep it is fused with
+        ctx->pending = a; ctx->pending_SN = SN; ctx->have_pending = true;
+        return 0;
+    }
     if (n_not_spd) HIPCHK(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));
     if (dx_launch_amp(ctx, a, SN)) return 1;
     HIPCHK(ctx, hipGetLastError());
@@ -1745,7 +1749,19 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
     constexpr int RSTAGE = 128;  // blocks of the first reduction stage
     if (ensure_partial(ctx, 4ll * nblk + 4ll * RSTAGE)) return 1;
     if (accepted) HIPCHK(ctx, hipMemsetAsync(ctx->counters + 1, 0, sizeof(unsigned long long), ctx->stream));
-    {
+    bool fused = false;
+    if (ctx->have_pending) {  // an amplitude solve on these planes is waiting: one launch for both, or the solve first
+        ctx->have_pending = false;
+        unsigned long long* accp = accepted ? ctx->counters + 1 : nullptr;
+        if (reg_ok && dx_mh_reg_lanes(ctx->hm.nbands, Sp) == 1) {
+            Timed t(ctx, DANGX_K_AMP_INDEX);
+            fused = dx_launch_fused(ctx, ctx->pending, a, Sp, nblk, accp);
+        }
+        if (!fused) {
+            if (dx_launch_amp(ctx, ctx->pending, ctx->pending_SN)) return 1;
+        }
+    }
+    if (!fused) {
         Timed t(ctx, DANGX_K_INDEX_MH);
         unsigned long long* accp = accepted ? ctx->counters + 1 : nullptr;
         const bool fast = d.lnl_type[nind] == DANGX_LNL_CHISQ &&
@@ -1771,6 +1787,64 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
         HIPCHK(ctx, hipMemcpyAsync(&v, ctx->counters + 1, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         *accepted = (int64_t)v;
+    }
+    return 0;
+}
+
+// dangx_amp_sample(group, flag, ...) followed by dangx_index_sample(comp, nind, map_n, ...) -- the amplitude solve of a CG
+// group and the first index sweep on the same planes, which is how sample_cg_groups / sample_spectral_parameters follow
+// each other plane set by plane set (src/dang.f90 main loop) -- with ONE kernel launch when the model allows it
+// (dangx_fused.hip: delta bands, diffuse members only, direct solver, reference fluctuation term, chisq likelihood,
+// gaussian / uniform prior, the sampled component a member of the group whose other members are the only other
+// components on these planes).  Results are those of the two calls, bit for bit; every other configuration IS the two calls.
+int dangx_amp_index_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed_amp,
+                           uint64_t stream_amp, int comp, int nind, int map_n, int nsample, uint64_t seed_index,
+                           uint64_t stream_index, int64_t* n_not_spd, int64_t* accepted) {
+    if (!ctx || check_comp(ctx, comp)) return 1;
+    static const bool enabled = [] { const char* e = getenv("DANGX_FUSE"); return !(e && e[0] == '0'); }();  // A/B switch
+    bool can = enabled && solver == DANGX_SOLVER_DIRECT && ctx->hm.all_delta != 0 &&
+               (ml_mode == DANGX_ML_OPTIMIZE || fluct_mode == DANGX_FLUCT_REFERENCE);
+    // the planes of the sweep are the planes of the solve
+    const int want = (flag == DANGX_FLAG_T) ? 1 : (flag == DANGX_FLAG_Q) ? 2 : (flag == DANGX_FLAG_U) ? 3 : (flag == DANGX_FLAG_QU) ? -1 : 0;
+    can = can && want != 0 && want == map_n;
+    if (can) {
+        const dangx_comp_desc& d = ctx->desc[comp];
+        const unsigned touched = (map_n == -1) ? 6u : 1u << (map_n - 1);
+        // a sweep that turns a spatially constant index map into a varying one changes which SED route the SOLVE takes
+        // (host-evaluated row against per-pixel evaluation) if it is launched after the descriptor update: first sweeps
+        // on constant maps go the two-call way
+        can = nind >= 0 && nind < d.nindices && !(ctx->idx_const[comp] & touched) && d.cg_group == group && d.sample_amplitude &&
+              d.lnl_type[nind] == DANGX_LNL_CHISQ && d.prior_type[nind] != DANGX_PRIOR_JEFFREYS &&
+              (d.type == DANGX_POWERLAW || d.type == DANGX_MBB);
+    }
+    if (can) {
+        GroupArgs g;
+        if (make_group(ctx, group, flag, g)) return 1;
+        can = g.nt == 0 && g.no == 0 && g.nuc == 0 &&
+              dx_fused_supported(ctx->desc[comp].type == DANGX_POWERLAW ? CH_POW : (nind == 0 ? CH_MBB_BETA : CH_MBB_T), ctx->hm.nbands, g.ng);
+        for (int l = 0; can && l < ctx->hm.ncomp; ++l)  // a T_cmb component is an "other" of every sweep and never a diffuse member
+            if (ctx->desc[l].type == DANGX_TCMB) can = false;
+    }
+    if (!can) {
+        const int rc = dangx_amp_sample(ctx, group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, 100, 1e-8, nullptr, n_not_spd);
+        return rc ? rc : dangx_index_sample(ctx, comp, nind, map_n, nsample, ml_mode, seed_index, stream_index, accepted);
+    }
+    if (n_not_spd) HIPCHK(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));
+    ctx->defer_amp = true;
+    int rc = dangx_amp_sample(ctx, group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, 100, 1e-8, nullptr, nullptr);
+    ctx->defer_amp = false;
+    if (rc) { ctx->have_pending = false; return rc; }
+    rc = dangx_index_sample(ctx, comp, nind, map_n, nsample, ml_mode, seed_index, stream_index, accepted);
+    if (ctx->have_pending) {  // the sweep failed before its launch site: the solve must not be lost
+        ctx->have_pending = false;
+        if (!rc && dx_launch_amp(ctx, ctx->pending, ctx->pending_SN)) return 1;
+    }
+    if (rc) return rc;
+    if (n_not_spd) {
+        unsigned long long v = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&v, ctx->counters, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        *n_not_spd = (int64_t)v;
     }
     return 0;
 }

@@ -3,372 +3,10 @@
 #ifndef DX_NO_VCOEF   // -DDX_NO_VCOEF: plain fma() in the once-per-proposal polynomials, for A/B timing
 #define DX_VCOEF 1   // dx_math.h: fma_vc
 #endif
-#include "dx_host.h"
-
-// the chain's exp: dx::exp_nr = the library routine minus its range selects (dx_math.h); -DDX_CHAIN_LIBEXP restores
-// the library call for A/B timing
-#ifdef DX_CHAIN_LIBEXP
-#define CEXP(x) exp(x)
-#define CEXP1(x) exp(x)
-#else
-#define CEXP(x) exp_nr(x)
-#define CEXP1(x) exp_nr_v(x)   // a call site that runs once per proposal (dx_math.h: fma_vc)
-#endif
-// reciprocals of the rms and inside the modified-blackbody SED: v_rcp_f64 + two Newton steps (<= 1 ulp, 6 vector
-// instructions) instead of the IEEE division sequence (11); -DDX_CHAIN_IEEEDIV restores a / b
-#ifdef DX_CHAIN_IEEEDIV
-#define CDIV(a, b) ((a) / (b))
-#else
-#define CDIV(a, b) ((a) * fast_rcp(b))
-#endif
-
-// the chain's residual: with DX_CHAIN_SCALED (default) the staged planes hold d/sigma and a/sigma (the amplitude is fixed
-// during an index chain), so a band costs r = d' - a'*s; acc += r*r  (2 instructions per plane instead of 4) and the
-// factor -1/2 is applied to the band sum; -DDX_CHAIN_UNSCALED restores ((d - a*s)/sigma), acc -= r*r/2 for A/B timing.
-// Both forms carry the rounding of s scaled by the pixel's signal to noise; they differ in the last bits of lnL only.
-#ifndef DX_CHAIN_UNSCALED
-#define DX_CHAIN_SCALED 1
-#endif
+#include "dx_chain.h"
 
 #ifdef DX_REG_MODE
 namespace {
-
-// ---------------------------------------------------------------------------
-// Register-resident form of the same chain (chisq likelihood, delta bandpasses, CH_POW / CH_MBB_BETA /
-// CH_MBB_T) for compile-time band count NB and plane count SP: the cleaned data, 1/rms and the chain-
-// invariant SED factor live in VGPRs (statically indexed, fully unrolled), per-band constants in SGPRs,
-// and the kernel uses no LDS and no barrier.  The CU's vector register file (512 KB) is three times its
-// LDS, so this form runs at 2-3 waves/SIMD where the LDS-column form is capped at 1-2.
-// Arithmetic and operation order are identical to index_chain<MODE, SP, TB>.
-//
-// LP = 2 splits the bands of ONE pixel over two adjacent lanes (lane h of the pair owns bands [h*NB, (h+1)*NB) of the
-// 2*NB bands): each lane stages and evaluates its half, the two partial band sums of lnL are exchanged with one
-// cross-lane add per plane, and everything else (random numbers, prior, accept test) is computed by both lanes on
-// identical inputs, so the pair never diverges.  It halves the registers a lane needs -- two planes of 20 bands drop
-// from ~340 registers (one wave per SIMD) to the footprint of the 10-band kernel (two waves) -- at the price of the
-// duplicated per-proposal work; the per-band constants then differ between the lanes of a pair and live in vector
-// registers (K1, K2) instead of being scalar operands.
-template <int LP>
-struct BandPick {
-    int half;  // which half of the bands this lane owns (always 0 for LP == 1)
-    // per-band model constant for the lane's band j (j static): a scalar operand for LP == 1, else a select of two scalars
-    __device__ __forceinline__ double operator()(const double* arr, int j, int nbh) const {
-        if (LP == 1) return arr[j];
-        const double a = arr[j], b = arr[nbh + j];
-        return half ? b : a;
-    }
-    __device__ __forceinline__ double nu_c(const Model& M, int j, int nbh) const {
-        if (LP == 1) return M.band[j].nu_c;
-        const double a = M.band[j].nu_c, b = M.band[nbh + j].nu_c;
-        return half ? b : a;
-    }
-};
-
-template <int MODE, int SP, int NB, int LP>
-struct RegChain {
-    double D[SP][NB], F[NB], ISr[SP][NB];  // cleaned data, chain-invariant SED factor, 1/rms  (scaled form: d/rms, amp/rms)
-    double K1[LP > 1 ? NB : 1], K2[LP > 1 ? NB : 1];  // LP > 1: the lane's per-band constants (see k1 / k2)
-    double amp[SP];
-
-    __device__ __forceinline__ double is(int kk, int j) const { return ISr[kk][j]; }
-    __device__ __forceinline__ void set_is(int kk, int j, double v) { ISr[kk][j] = v; }
-    // the constant that multiplies / offsets the sampled parameter at band j, and the band's constant factor
-    __device__ __forceinline__ double k1(const Model& M, const Comp& c, int j) const {
-        if (LP > 1) return K1[j];
-        return (MODE == CH_MBB_T) ? M.band[j].nu_c : (MODE == CH_LOGN_NUP) ? c.lnu9[j] : c.lnr[j];
-    }
-    __device__ __forceinline__ double k2(const Comp& c, int j) const { return (LP > 1) ? K2[j] : c.cst[j]; }
-    __device__ __forceinline__ void set_k(const Model& M, const Comp& c, const BandPick<LP>& pick) {
-        if (LP > 1) {
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                K1[j] = (MODE == CH_MBB_T) ? pick.nu_c(M, j, NB) : (MODE == CH_LOGN_NUP) ? pick(c.lnu9, j, NB) : pick(c.lnr, j, NB);
-                K2[j] = (MODE == CH_LOGN_NUP || MODE == CH_LOGN_W) ? pick(c.cst, j, NB) : 0.0;
-            }
-        }
-    }
-
-    __device__ __forceinline__ double lnl(const Model& M, const Comp& c, double th, double other, double& acc0, double& acc1) const {
-        double s0 = 0.0, s1 = 0.0;
-        if (MODE == CH_POW) s0 = th;
-        else if (MODE == CH_MBB_BETA) s0 = th + 1.0;
-        else if (MODE == CH_MBB_T) { s0 = H_PLANCK / (K_B * th); s1 = CEXP(s0 * c.nu_ref) - 1.0; }
-        else if (MODE == CH_LOGN_NUP) { s0 = log_pos(th); s1 = other; }  // log(nu/(nu_p*1e9)) = lnu9 - log(nu_p)
-        else s1 = th;  // CH_LOGN_W
-        acc0 = 0.0; acc1 = 0.0;
-        // bands in tiles of TT: TT independent exp chains interleave, then accumulate in band order
-        constexpr int TT = (NB % 5 == 0) ? 5 : (NB % 4 == 0) ? 4 : (NB % 3 == 0) ? 3 : 1;
-#pragma unroll
-        for (int j0 = 0; j0 < NB; j0 += TT) {
-            double s[TT];
-#pragma unroll
-            for (int t = 0; t < TT; ++t) {
-                const int j = j0 + t;
-                if (MODE == CH_LOGN_NUP) {
-                    const double l = (k1(M, c, j) - s0) / s1;
-                    s[t] = CEXP(-0.5 * (l * l)) * k2(c, j);
-                } else if (MODE == CH_LOGN_W) {
-                    const double l = F[j] / s1;
-                    s[t] = CEXP(-0.5 * (l * l)) * k2(c, j);
-                } else {
-                    const double e = CEXP(s0 * k1(M, c, j));
-                    if (MODE == CH_POW) s[t] = e;
-                    else if (MODE == CH_MBB_BETA) s[t] = F[j] * e;
-                    else s[t] = CDIV(s1, e - 1.0) * F[j];
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < TT; ++t) {
-                const int j = j0 + t;
-#ifdef DX_CHAIN_SCALED
-                const double r0 = fma(-is(0, j), s[t], D[0][j]);
-                acc0 = fma(r0, r0, acc0);
-                if (SP == 2) {
-                    const double r1 = fma(-is(SP - 1, j), s[t], D[SP - 1][j]);
-                    acc1 = fma(r1, r1, acc1);
-                }
-#else
-                const double r0 = (D[0][j] - amp[0] * s[t]) * is(0, j);
-                acc0 = acc0 - 0.5 * (r0 * r0);
-                if (SP == 2) {
-                    const double r1 = (D[SP - 1][j] - amp[SP - 1] * s[t]) * is(SP - 1, j);
-                    acc1 = acc1 - 0.5 * (r1 * r1);
-                }
-#endif
-            }
-        }
-        if (LP > 1) {  // the other half's band sum: a + b on one lane, b + a on the other -- the same value
-            acc0 += __shfl_xor(acc0, 1, 64);
-            if (SP == 2) acc1 += __shfl_xor(acc1, 1, 64);
-        }
-#ifdef DX_CHAIN_SCALED
-        acc0 *= -0.5; acc1 *= -0.5;
-#endif
-        return acc0 + acc1;
-    }
-    // after the other components are removed: d -> d/rms, 1/rms -> amp/rms
-    __device__ __forceinline__ void scale() {
-#ifdef DX_CHAIN_SCALED
-#pragma unroll
-        for (int kk = 0; kk < SP; ++kk)
-#pragma unroll
-            for (int j = 0; j < NB; ++j) { D[kk][j] *= ISr[kk][j]; ISr[kk][j] *= amp[kk]; }
-#endif
-    }
-};
-
-// eval_sed of an "other" component for all NB bands of one plane, subtracted from D (static band index)
-template <int NB, int LP>
-__device__ __forceinline__ void subtract_other(const Model& M, const Comp& c2, int k, double amp2, double t0, double t1,
-                                               double (&Dk)[NB], const BandPick<LP>& pick) {
-    if ((c2.const_planes >> (k - 1)) & 1) {  // spatially constant indices: host-evaluated SED
-#pragma unroll
-        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * pick(c2.csed[k - 1], j, NB);
-        return;
-    }
-    const Prep pr = sed_prep(c2, t0, t1);
-    switch (c2.type) {
-    case DANGX_POWERLAW:
-#pragma unroll
-        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * CEXP(pr.p0 * pick(c2.lnr, j, NB));
-        break;
-    case DANGX_MBB:
-#pragma unroll
-        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * (CDIV(pr.p2, CEXP(pr.p1 * pick.nu_c(M, j, NB)) - 1.0) * CEXP(pr.p0 * pick(c2.lnr, j, NB)));
-        break;
-    case DANGX_FREEFREE:
-#pragma unroll
-        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * (ff_gaunt(pick(c2.lnu9, j, NB), pr.p0) / pr.p1 * pick(c2.cst, j, NB));
-        break;
-    case DANGX_LOGNORMAL:
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const double l2 = (pick(c2.lnu9, j, NB) - pr.p2) / pr.p1;
-            Dk[j] -= amp2 * (CEXP(-0.5 * (l2 * l2)) * pick(c2.cst, j, NB));
-        }
-        break;
-    default:  // cmb
-#pragma unroll
-        for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * pick(c2.cst, j, NB);
-        break;
-    }
-}
-
-// Q and U planes of one pixel whose "other" component has the same indices on both (always the case once a Q+U
-// sweep has written them, :465): one SED evaluation per band serves both planes -- same values, same operations.
-template <int NB, int LP>
-__device__ __forceinline__ void subtract_other_pair(const Model& M, const Comp& c2, double ampa, double ampb, double t0, double t1,
-                                                    double (&Da)[NB], double (&Db)[NB], const BandPick<LP>& pick) {
-    const Prep pr = sed_prep(c2, t0, t1);
-    switch (c2.type) {
-    case DANGX_POWERLAW:
-#pragma unroll
-        for (int j = 0; j < NB; ++j) { const double s = CEXP(pr.p0 * pick(c2.lnr, j, NB)); Da[j] -= ampa * s; Db[j] -= ampb * s; }
-        break;
-    case DANGX_MBB:
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const double s = CDIV(pr.p2, CEXP(pr.p1 * pick.nu_c(M, j, NB)) - 1.0) * CEXP(pr.p0 * pick(c2.lnr, j, NB));
-            Da[j] -= ampa * s; Db[j] -= ampb * s;
-        }
-        break;
-    case DANGX_FREEFREE:
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const double s = ff_gaunt(pick(c2.lnu9, j, NB), pr.p0) / pr.p1 * pick(c2.cst, j, NB);
-            Da[j] -= ampa * s; Db[j] -= ampb * s;
-        }
-        break;
-    case DANGX_LOGNORMAL:
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const double l2 = (pick(c2.lnu9, j, NB) - pr.p2) / pr.p1;
-            const double s = CEXP(-0.5 * (l2 * l2)) * pick(c2.cst, j, NB);
-            Da[j] -= ampa * s; Db[j] -= ampb * s;
-        }
-        break;
-    default:  // cmb
-#pragma unroll
-        for (int j = 0; j < NB; ++j) { const double s = pick(c2.cst, j, NB); Da[j] -= ampa * s; Db[j] -= ampb * s; }
-        break;
-    }
-}
-
-// NB = bands per lane (all of them for LP == 1, half for LP == 2); half = which half this lane owns
-template <int MODE, int SP, int NB, int LP>
-__device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, const IndexArgs& a, int i, int half, double chi[4]) {
-    const int npix = M.npix;
-    const Comp& c = M.comp[a.comp];
-    double* out = c.idx + ((long long)a.nind * M.nmaps) * npix + i;
-    if (is_masked(M.mask[i])) {  // :362 cycle; index_map stays 0 (:223) and is copied back (:480-483)
-        if (half == 0) {
-#pragma unroll
-            for (int kk = 0; kk < SP; ++kk) out[(long long)(a.s1 + kk - 1) * npix] = 0.0;
-        }
-        return 0ull;
-    }
-    const BandPick<LP> pick = {half};
-    const int jb = half * NB;  // first band of this lane
-    RegChain<MODE, SP, NB, LP> R;
-    R.set_k(M, c, pick);
-    double sample0, sample1;
-    load_theta(M, c, i, a.s1, sample0, sample1);  // sample(l) = c%indices(i, map_inds(1), l), :372-377
-    const bool first = (a.nind == 0);
-    // --- stage data_raw (:173-177) and rms: every load issued before the first use
-    const long long bstride = (long long)M.nmaps * npix;
-#pragma unroll
-    for (int kk = 0; kk < SP; ++kk) {
-        const int k = a.s1 + kk;
-        R.amp[kk] = c.amp[(long long)(k - 1) * npix + i];
-        const double* sigp = M.sig + (long long)(k - 1) * npix + i;
-        const double* rmsp = M.rms + (long long)(k - 1) * npix + i;
-        double rv[NB];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            R.D[kk][j] = sigp[(jb + j) * bstride];
-            rv[j] = rmsp[(jb + j) * bstride];
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            if (k == 1) R.D[kk][j] = (R.D[kk][j] - pick(M.offset, j, NB)) / pick(M.gain, j, NB);
-            R.set_is(kk, j, CDIV(1.0, rv[j]));
-        }
-    }
-    // --- remove every OTHER component (:180-196) in component_list order, next one prefetched
-    {
-        unsigned om = a.others;
-        double na[SP], nt0[SP], nt1[SP];
-        auto fetch = [&](int l) {
-            const Comp& c2 = M.comp[l];
-#pragma unroll
-            for (int kk = 0; kk < SP; ++kk) {
-                na[kk] = c2.amp[(long long)(a.s1 + kk - 1) * npix + i];
-                nt0[kk] = nt1[kk] = 0.0;
-                if (!((c2.const_planes >> (a.s1 + kk - 1)) & 1)) load_theta(M, c2, i, a.s1 + kk, nt0[kk], nt1[kk]);
-            }
-        };
-        int l = om ? __builtin_ctz(om) : -1;
-        if (l >= 0) fetch(l);
-        while (l >= 0) {
-            const Comp& c2 = M.comp[l];
-            double ca[SP], ct0[SP], ct1[SP];
-#pragma unroll
-            for (int kk = 0; kk < SP; ++kk) { ca[kk] = na[kk]; ct0[kk] = nt0[kk]; ct1[kk] = nt1[kk]; }
-            om &= om - 1;
-            const int ln = om ? __builtin_ctz(om) : -1;
-            if (ln >= 0) fetch(ln);
-            const unsigned cp = (c2.const_planes >> (a.s1 - 1)) & 3u;
-            if (SP == 2 && cp == 0 && ct0[0] == ct0[SP - 1] && ct1[0] == ct1[SP - 1]) {
-                subtract_other_pair<NB, LP>(M, c2, ca[0], ca[SP - 1], ct0[0], ct1[0], R.D[0], R.D[SP - 1], pick);
-            } else {
-#pragma unroll
-                for (int kk = 0; kk < SP; ++kk) subtract_other<NB, LP>(M, c2, a.s1 + kk, ca[kk], ct0[kk], ct1[kk], R.D[kk], pick);
-            }
-            l = ln;
-        }
-    }
-    R.scale();
-    // --- chain-invariant SED factor
-    if (MODE == CH_MBB_BETA) {
-        const double z = H_PLANCK / (K_B * sample1);
-        const double A = CEXP(z * c.nu_ref) - 1.0;
-#pragma unroll
-        for (int j = 0; j < NB; ++j) R.F[j] = CDIV(A, CEXP(z * pick.nu_c(M, j, NB)) - 1.0);
-    } else if (MODE == CH_MBB_T) {
-#pragma unroll
-        for (int j = 0; j < NB; ++j) R.F[j] = CEXP((sample0 + 1.0) * pick(c.lnr, j, NB));
-    } else if (MODE == CH_LOGN_W) {
-        {
-            const double lp = log_pos(sample0);
-#pragma unroll
-            for (int j = 0; j < NB; ++j) R.F[j] = pick(c.lnu9, j, NB) - lp;
-        }
-    }
-    const double other = first ? sample1 : sample0;  // the index that is not sampled
-    // --- chain (gaussian / uniform prior inline; jeffreys falls back to the LDS form on the host side)
-    const unsigned long long gpix = (unsigned long long)(M.pix0 + i);
-    const int q = a.nind;
-    const bool gauss = c.prior_type[q] == DANGX_PRIOR_GAUSSIAN;
-    const double pmean = c.gauss[q][0], pstd = c.gauss[q][1], lgden = c.lgden[q];
-    // 1/(2 sigma^2) once per sweep; the proposal then multiplies ((x/d and x*(1/d) differ by <= 1 ulp of the prior term;
-    // -DDX_CHAIN_IEEEDIV restores the division: 15 instructions of a ~400-instruction proposal)
-    const double inv2v = 1.0 / (2 * (pstd * pstd));
-    auto prior = [&](double v) -> double {
-        if (!gauss) return 0.0;
-#ifdef DX_CHAIN_IEEEDIV
-        const double arg = ((v - pmean) * (v - pmean)) / (2 * (pstd * pstd));
-#else
-        const double arg = ((v - pmean) * (v - pmean)) * inv2v;
-#endif
-        return (arg > 745.0) ? -INFINITY : -arg - lgden;
-    };
-    unsigned long long nacc = 0;
-    double cur = first ? sample0 : sample1;
-    double a0, a1, c0, c1;
-    double lnl = R.lnl(M, c, cur, other, a0, a1);
-    chi[0] = -2.0 * a0; chi[1] = -2.0 * a1;
-    double lnl_old = lnl + prior(cur);
-    const double step = c.step[q], lo = c.uni[q][0], hi = c.uni[q][1];
-    for (int l = 1; l <= a.nsample; ++l) {
-        double u1, u2, u3;
-        uniform3(a.seed, a.stream, gpix, (uint32_t)l, u1, u2, u3);
-        const double prop = cur + rand_normal(0.0, step, u1, u2);  // :414
-        if (prop < lo || prop > hi) continue;                      // :415
-        lnl = R.lnl(M, c, prop, other, c0, c1);
-        const double lnl_new = lnl + prior(prop);
-        const double diff = lnl_new - lnl_old;
-        const bool acc = (a.ml_mode == DANGX_ML_OPTIMIZE) ? (diff > 0.0) : ((diff >= 0.0) || (CEXP1(diff) > u3));  // :443-454
-        if (acc) { cur = prop; lnl_old = lnl_new; a0 = c0; a1 = c1; ++nacc; }
-    }
-    if (half != 0) {  // the pair's second lane carries the same chain: its sums and counts are the first lane's
-        chi[0] = chi[1] = 0.0;
-        return 0ull;
-    }
-#pragma unroll
-    for (int kk = 0; kk < SP; ++kk) out[(long long)(a.s1 + kk - 1) * npix] = cur;  // :465, :483
-    chi[2] = -2.0 * a0; chi[3] = -2.0 * a1;
-    return nacc;
-}
 
 // Resident waves per SIMD follow the register need: 3 (<= 168 VGPRs) for one plane of <= 10 bands, 2 (<= 256) otherwise.
 // Two planes of 20 bands (C5) need ~340 registers in one lane: they run as lane pairs (LP = 2, 10 bands per lane, two

@@ -132,6 +132,14 @@ module dangx_mod
        integer(c_int64_t), value :: seed, stream
        integer(c_int64_t), intent(out), optional :: accepted
      end function
+     integer(c_int) function dangx_amp_index_sample(ctx, group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, &
+          comp, nind, map_n, nsample, seed_index, stream_index, n_not_spd, accepted) bind(C, name='dangx_amp_index_sample')
+       import :: c_int, c_ptr, c_int64_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: group, flag, ml_mode, solver, fluct_mode, comp, nind, map_n, nsample
+       integer(c_int64_t), value :: seed_amp, stream_amp, seed_index, stream_index
+       integer(c_int64_t), intent(out), optional :: n_not_spd, accepted
+     end function
      integer(c_int) function dangx_set_template(ctx, comp, tmpl, corr, nfit) bind(C, name='dangx_set_template')
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx, tmpl, corr        ! corr: integer(c_int32_t)(nbands), 1 = fitted band

@@ -69,7 +69,7 @@ enum { DANGX_FLUCT_CORRECT = 0, DANGX_FLUCT_REFERENCE = 1 };
 /* kernel ids for dangx_profile_get */
 enum {
     DANGX_K_AMP_DIRECT = 0, DANGX_K_INDEX_MH = 1, DANGX_K_SKY_CHISQ = 2, DANGX_K_REDUCE = 3,
-    DANGX_K_CG_AX = 4, DANGX_K_CG_VEC = 5, DANGX_K_COUNT = 8
+    DANGX_K_CG_AX = 4, DANGX_K_CG_VEC = 5, DANGX_K_AMP_INDEX = 6, DANGX_K_COUNT = 8
 };
 
 typedef struct dangx_ctx dangx_ctx;
@@ -207,6 +207,18 @@ int dangx_amp_residual(dangx_ctx *ctx, int group, int flag, int ml_mode, uint64_
  * accepted (nullable): number of accepted proposals over the shard. */
 int dangx_index_sample(dangx_ctx *ctx, int comp, int nind, int map_n, int nsample, int ml_mode,
                        uint64_t seed, uint64_t stream, int64_t *accepted);
+
+/* ---- the amplitude solve of a CG group and the FIRST index sweep on the same planes, in one call: exactly
+ * dangx_amp_sample(group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, 100, 1e-8, NULL, n_not_spd) followed by
+ * dangx_index_sample(comp, nind, map_n, nsample, ml_mode, seed_index, stream_index, accepted) -- the way sample_cg_groups
+ * (src/dang_cg_mod.f90:142-177) and sample_spectral_parameters (src/dang_sample_mod.f90:21-86) follow each other plane set by
+ * plane set in the main loop (src/dang.f90) -- and bit for bit their result.  When every step is independent per pixel
+ * (delta bands, diffuse members only, direct solver, reference fluctuation term, chisq likelihood with a gaussian / uniform
+ * prior, the sampled component a member of the group whose other members are the only other components on these planes)
+ * both run in ONE kernel launch: the maps are read once and the solve's arithmetic hides under the chain's. */
+int dangx_amp_index_sample(dangx_ctx *ctx, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed_amp,
+                           uint64_t stream_amp, int comp, int nind, int map_n, int nsample, uint64_t seed_index,
+                           uint64_t stream_index, int64_t *n_not_spd, int64_t *accepted);
 
 /* ---- sky model + chi^2: update_sky_model + compute_chisq
  * (src/dang_data_mod.f90:339-396, 494-526).  pol_lo..pol_hi = ddata%pol_type range.

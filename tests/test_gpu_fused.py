@@ -1,0 +1,124 @@
+"""dangx_amp_index_sample (the amplitude solve of a CG group and the first index sweep on the same planes in one kernel
+launch, dang_amd/csrc/dangx_fused.hip) against the two calls it stands for: bit for bit, in every state a Gibbs run
+passes through, and against the oracle like every other path."""
+import copy
+
+import numpy as np
+import pytest
+
+import dang_amd as da
+from dang_amd import _lib as L
+
+from util import MAPN, TOL_AMP, TOL_CHISQ, assert_amps_close, assert_indices_close, make_case, pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _engines(case):
+    dpar, ddata, bands, comps, meta = case
+    a = da.Engine(bands, copy.deepcopy(comps), ddata, npix_global=meta["npix_global"], pix0=meta["pix0"], device=0)
+    b = da.Engine(bands, copy.deepcopy(comps), ddata, npix_global=meta["npix_global"], pix0=meta["pix0"], device=0)
+    return a, b
+
+
+def _first_sweep(comps, group):
+    for l, c in enumerate(comps):
+        if c.cg_group == group:
+            for j in range(c.nindices):
+                if c.sample_index[j]:
+                    return l, j
+    raise AssertionError("no sampled index in group %d" % group)
+
+
+@pytest.mark.parametrize("ml_mode", ["sample", "optimize"])
+@pytest.mark.parametrize("start", ["truth", "prior"])
+def test_fused_equals_the_two_calls_bitwise(built, ml_mode, start):
+    """C3's model (10 bands, cmb + synch + dust + ff, IQU) at Nside 8: three Gibbs iterations, the fused entry point on
+    one context and amp_sample + index_sample on another; amplitudes, indices, chi^2 sums and both counters are equal bit
+    for bit after every iteration.  start='prior' begins with spatially constant index maps, i.e. passes through the
+    states in which the fused launch is not taken (first sweeps) and those in which it is."""
+    case = make_case("C3", nside=8, start=start)
+    dpar, ddata, bands, comps, meta = case
+    fus, two = _engines(case)
+    prof = []
+    for it in range(1, 4):
+        for eng in (fus, two):
+            eng.profile(True)
+            for g in dpar.cg_groups:
+                f = g.pol_flag[0]
+                l0, j0 = _first_sweep(comps, g.cg_group)
+                sa, si = da.stream_id(it, 0, g.cg_group, 0, f), da.stream_id(it, 1, l0, j0, f)
+                if eng is fus:
+                    bad, acc = eng.amp_index_sample(g.cg_group, f, ml_mode, 11, sa, l0, j0, MAPN[f], 10, 11, si)
+                else:
+                    _, bad = eng.amp_sample(g.cg_group, f, ml_mode, 11, sa)
+                    acc = eng.index_sample(l0, j0, MAPN[f], 10, ml_mode, 11, si)
+                prof.append((eng is fus, bad, acc))
+                for l, c in enumerate(comps):
+                    for j in range(c.nindices):
+                        if c.sample_index[j] and c.cg_group == g.cg_group and (l, j) != (l0, j0):
+                            eng.index_sample(l, j, MAPN[f], 10, ml_mode, 11, da.stream_id(it, 1, l, j, f))
+            eng.synchronize()
+        names = fus.profile_get()
+        if it > 1:   # from the second iteration on every index map varies: the fused kernel is the one that ran
+            assert "k_amp_index" in names and "k_amp_direct" not in names, names
+        assert "k_amp_index" not in two.profile_get()
+        for l, c in enumerate(comps):
+            assert np.array_equal(fus.get_amplitude(l), two.get_amplitude(l)), (it, l)
+            if c.nindices:
+                assert np.array_equal(fus.get_indices(l), two.get_indices(l)), (it, l)
+        for which in (0, 1):
+            assert fus.chisq_cached(which, 1, 3) == two.chisq_cached(which, 1, 3), (it, which)
+    counts_f = [p[1:] for p in prof if p[0]]
+    counts_t = [p[1:] for p in prof if not p[0]]
+    assert counts_f == counts_t and any(a > 0 for _, a in counts_f)
+
+
+def test_fused_against_the_oracle(built):
+    case = make_case("C3", nside=4, start="truth")
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+    for g in dpar.cg_groups:
+        f = g.pol_flag[0]
+        l0, j0 = _first_sweep(comps, g.cg_group)
+        bad, acc = eng.amp_index_sample(g.cg_group, f, "sample", 5, 21 + f, l0, j0, MAPN[f], 10, 5, 41 + f)
+        orc.amp_sample_direct(g.cg_group, f, "sample", 5, 21 + f, "reference")
+        oacc = orc.sample_index_mh(l0, j0, MAPN[f], 10, "sample", 5, 41 + f)
+        assert bad == 0 and acc == oacc
+    assert_amps_close(eng, orc, len(comps), TOL_AMP)
+    assert_indices_close(eng, orc, comps)
+    s, _ = orc.chisq(1, 3, ddata.nump)
+    assert abs(eng.chisq_cached(1, 1, 3) / meta["nbands"] / ddata.nump - s) <= TOL_CHISQ * s
+
+
+def test_configurations_the_fused_kernel_does_not_cover_take_the_two_calls(built):
+    """Unequal Q/U plane indices, a masked sky fraction, another band count, a Jeffreys prior, the textbook fluctuation
+    term: the entry point still returns what the two calls return (it IS the two calls there), bit for bit."""
+    def run(case, **kw):
+        dpar, ddata, bands, comps, meta = case
+        fus, two = _engines(case)
+        for g in dpar.cg_groups:
+            f = g.pol_flag[0]
+            l0, j0 = _first_sweep(comps, g.cg_group)
+            fus.amp_index_sample(g.cg_group, f, "sample", 3, 5, l0, j0, MAPN[f], 6, 3, 7, **kw)
+            two.amp_sample(g.cg_group, f, "sample", 3, 5, **kw)
+            two.index_sample(l0, j0, MAPN[f], 6, "sample", 3, 7)
+        for l, c in enumerate(comps):
+            assert np.array_equal(fus.get_amplitude(l), two.get_amplitude(l)), l
+            if c.nindices:
+                assert np.array_equal(fus.get_indices(l), two.get_indices(l)), l
+
+    def unequal(dpar, ddata, bands, comps):
+        rng = np.random.default_rng(2)
+        for c in comps:
+            if c.nindices and c.cg_group == 2:
+                c.indices[0, 2] *= 1.0 + 0.02 * rng.standard_normal(c.indices.shape[-1])
+
+    def jeffreys(dpar, ddata, bands, comps):
+        for c in comps:
+            c.prior_type = ["jeffreys"] * c.nindices
+
+    run(make_case("C3", nside=4, start="truth", tweak=unequal))            # fused, per-plane SED columns
+    run(make_case("C2", nside=4, start="truth"))                            # 5 bands: not instantiated
+    run(make_case("C3", nside=4, start="truth", tweak=jeffreys))            # LDS-form chain
+    run(make_case("C3", nside=4, start="truth"), fluct_mode="correct")      # k_amp_direct
