@@ -29,7 +29,7 @@ program dangx_fsmoke
   logical :: ok_amp, ok_idx
   type(dangx_sky) :: sky
   character(len=512) :: fin, fout, arg
-  integer :: i, j, k, l, f, it, u, map_n, nmeans
+  integer :: i, j, k, l, f, it, u, map_n, nmeans, lf, jf, fused_l(MAXC), fused_j(MAXC)
   integer, save :: ncalls = 0
 
   call get_command_argument(1, fin)
@@ -75,7 +75,47 @@ program dangx_fsmoke
   nacc_tot = 0
   chisq_amp = 0.d0; chisq_idx = 0.d0; ok_amp = .false.; ok_idx = .false.
   do it = 1, niter
+     fused_l = 0; fused_j = 0
      do i = 1, ngroups                                    ! sample_cg_groups, src/dang_cg_mod.f90:142-177
+        ! the first sampled index of the group's components on the group's planes: its sweep directly follows this solve
+        ! and nothing else touches those planes in between, so the pair goes through dangx_amp_index_sample (one launch
+        ! where the model allows it; the Python host of tests/test_fortran_gpu.py makes the two calls -- same bits)
+        lf = 0; jf = 0
+        if (it > 1) then
+           find: do l = 1, ncomp
+              if (desc(l)%cg_group /= grp(i)) cycle
+              do j = 1, desc(l)%nindices
+                 if (sample_index(j, l) /= 0 .and. pol_flag(j, l) == gflag(i)) then
+                    lf = l; jf = j
+                    exit find
+                 end if
+              end do
+           end do find
+        end if
+        if (lf > 0) then
+           if (iand(gflag(i), 1) /= 0) then
+              map_n = 1
+           else if (iand(gflag(i), 2) /= 0) then
+              map_n = 2
+           else if (iand(gflag(i), 4) /= 0) then
+              map_n = 3
+           else
+              map_n = -1
+           end if
+           fused_l(i) = lf; fused_j(i) = jf
+           if (it == niter) then
+              call dangx_sky_amp_index_sample(sky, grp(i), gflag(i), DANGX_ML_SAMPLE, DANGX_FLUCT_REFERENCE, seed, &
+                   dangx_stream_id(it, 0, grp(i), 0, gflag(i)), lf-1, jf-1, map_n, nsample, seed, &
+                   dangx_stream_id(it, 1, lf-1, jf-1, gflag(i)), nbad, nacc)
+              if (nbad /= 0) stop 3
+              nacc_tot = nacc_tot + nacc
+           else
+              call dangx_sky_amp_index_sample(sky, grp(i), gflag(i), DANGX_ML_SAMPLE, DANGX_FLUCT_REFERENCE, seed, &
+                   dangx_stream_id(it, 0, grp(i), 0, gflag(i)), lf-1, jf-1, map_n, nsample, seed, &
+                   dangx_stream_id(it, 1, lf-1, jf-1, gflag(i)))
+           end if
+           cycle
+        end if
         if (it == niter) then                             ! with the count: synchronises per context
            call dangx_sky_amp_sample(sky, grp(i), gflag(i), DANGX_ML_SAMPLE, DANGX_FLUCT_REFERENCE, seed, &
                 dangx_stream_id(it, 0, grp(i), 0, gflag(i)), nbad)
@@ -90,6 +130,7 @@ program dangx_fsmoke
            do j = 1, desc(l)%nindices
               if (sample_index(j, l) == 0) cycle
               f = pol_flag(j, l)
+              if (any(fused_l(1:ngroups) == l .and. fused_j(1:ngroups) == j .and. gflag(1:ngroups) == f)) cycle  ! done with its solve
               if (iand(f, 1) /= 0) then
                  map_n = 1
               else if (iand(f, 2) /= 0) then

@@ -233,6 +233,34 @@ contains
     end if
   end subroutine dangx_sky_index_sample
 
+  ! dangx_sky_amp_sample(group, flag, ...) directly followed by dangx_sky_index_sample(comp, nind, map_n, ...) on the same
+  ! planes, through dangx_amp_index_sample: one kernel launch per context where the model allows it, the two calls'
+  ! result bit for bit everywhere (the first sampled index of a CG group's components follows the group's solve this way)
+  subroutine dangx_sky_amp_index_sample(sky, group, flag, ml_mode, fluct_mode, seed_amp, stream_amp, &
+       comp, nind, map_n, nsample, seed_index, stream_index, n_not_spd, accepted)
+    type(dangx_sky), intent(in) :: sky
+    integer, intent(in) :: group, flag, ml_mode, fluct_mode, comp, nind, map_n, nsample
+    integer(c_int64_t), intent(in) :: seed_amp, stream_amp, seed_index, stream_index
+    integer(c_int64_t), intent(out), optional :: n_not_spd, accepted
+    integer(c_int64_t) :: nbad, nacc
+    integer :: r
+    if (present(n_not_spd) .or. present(accepted)) then
+       if (present(n_not_spd)) n_not_spd = 0
+       if (present(accepted)) accepted = 0
+       do r = 1, sky%nctx
+          call dangx_check(sky%ctx(r), dangx_amp_index_sample(sky%ctx(r), group, flag, ml_mode, DANGX_SOLVER_DIRECT, fluct_mode, &
+               seed_amp, stream_amp, comp, nind, map_n, nsample, seed_index, stream_index, nbad, nacc), 'dangx_amp_index_sample')
+          if (present(n_not_spd)) n_not_spd = n_not_spd + nbad
+          if (present(accepted)) accepted = accepted + nacc
+       end do
+    else
+       do r = 1, sky%nctx
+          call dangx_check(sky%ctx(r), dangx_amp_index_sample(sky%ctx(r), group, flag, ml_mode, DANGX_SOLVER_DIRECT, fluct_mode, &
+               seed_amp, stream_amp, comp, nind, map_n, nsample, seed_index, stream_index), 'dangx_amp_index_sample')
+       end do
+    end if
+  end subroutine dangx_sky_amp_index_sample
+
   ! sample_index_mh with sample_nside /= nside (src/dang_sample_mod.f90:199-217, 332-483) over the contexts: the three
   ! phases of dangx_index_sample_coarse, the shards' buffers added in shard order between them
   subroutine dangx_sky_index_sample_coarse(sky, comp, nind, map_n, nsample, ml_mode, seed, stream, nside, sample_nside, accepted)

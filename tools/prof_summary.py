@@ -105,7 +105,8 @@ def main():
         disp = collections.OrderedDict()          # one entry per dispatch
         for r in csv.DictReader(open(f)):
             s = short(r["Kernel_Name"])
-            k = "k_amp_direct" if s.startswith("k_amp_") else "k_index_mh" if s.startswith("k_index_mh") else None
+            k = ("k_amp_index" if s.startswith("k_amp_index") else "k_amp_direct" if s.startswith("k_amp_") else
+                     "k_index_mh" if s.startswith("k_index_mh") else None)
             if not k:
                 continue
             d = disp.setdefault((k, r["Dispatch_Id"]), {"meta": r})
@@ -138,7 +139,8 @@ def main():
                 if r["Counter_Name"] != cname:
                     continue
                 s = short(r["Kernel_Name"])
-                k = "k_amp_direct" if s.startswith("k_amp_") else "k_index_mh" if s.startswith("k_index_mh") else None
+                k = ("k_amp_index" if s.startswith("k_amp_index") else "k_amp_direct" if s.startswith("k_amp_") else
+                     "k_index_mh" if s.startswith("k_index_mh") else None)
                 if k:
                     fam.setdefault(k, {}).setdefault(cname, []).append(float(r["Counter_Value"]) * 1024.0)
         out = {"source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH corrected by the measured "
