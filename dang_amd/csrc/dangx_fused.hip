@@ -216,8 +216,14 @@ __global__ __launch_bounds__(BLOCK, DX_FUSED_WAVES(SP, NB)) void k_amp_index(con
                 if (g == fa.gself) { R.amp[kk] = bv[g]; continue; }
                 if (!((a.others >> ga.gc[g]) & 1u)) continue;
                 const double amp2 = bv[g];
+                // the stride goes through an opaque copy: otherwise the 4 x NB LDS addresses of the solve's band loop are
+                // kept in registers (one each) across the Cholesky just to be used again here
+                // (two planes only: 256 + 6 spilled -> 231 registers, 2.95 -> 2.86 ms; one plane has the room, and its schedule
+                // is better left alone: 2.17 against 2.25 ms)
+                int ms2 = ms[g];
+                if (SP == 2) asm volatile("" : "+s"(ms2));
 #pragma unroll
-                for (int j = 0; j < NB; ++j) R.D[kk][j] -= amp2 * mp[g][j * ms[g]];
+                for (int j = 0; j < NB; ++j) R.D[kk][j] -= amp2 * mp[g][j * ms2];
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
