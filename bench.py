@@ -375,9 +375,11 @@ def main():
             "n_gpus": world, "ranks_seen": ranks_seen, "backend": (args.backend if world > 1 else None), "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: Nside=%d, %d bands, %d components (%s), %s, NUMSAMPLE=%d, per-pixel indices, "
-                                   "direct block solve, reference fluctuation term; pixel-sharded over %d rank(s), %d stream(s) per rank%s"
+                                   "direct block solve, reference fluctuation term%s; pixel-sharded over %d rank(s), %d stream(s) per rank%s"
                                    % (args.config, meta["nside"], nb, len(meta["phys"]), "+".join(meta["phys"]),
-                                      "IQU" if nmaps == 3 else "I", args.nsample, world, 2 if two else 1,
+                                      "IQU" if nmaps == 3 else "I", args.nsample,
+                                      ", each group's solve and the first sweep on its planes in one launch" if "k_amp_index" in prof else "",
+                                      world, 2 if two else 1,
                                       ("; DIAGNOSTIC: every second band integrated over a %d-sample bandpass" % args.bandpass
                                        if args.bandpass else "") +
                                       ("; DIAGNOSTIC: ONE rank's shard of a %d-rank run" % shard_of if shard_of else "")),
