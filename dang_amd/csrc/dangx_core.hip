@@ -1835,9 +1835,9 @@ int dangx_amp_index_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int
     ctx->defer_amp = false;
     if (rc) { ctx->have_pending = false; return rc; }
     rc = dangx_index_sample(ctx, comp, nind, map_n, nsample, ml_mode, seed_index, stream_index, accepted);
-    if (ctx->have_pending) {  // the sweep failed before its launch site: the solve must not be lost
+    if (ctx->have_pending) {  // the sweep failed before its launch site: the solve still happens, as with the two calls
         ctx->have_pending = false;
-        if (!rc && dx_launch_amp(ctx, ctx->pending, ctx->pending_SN)) return 1;
+        if (dx_launch_amp(ctx, ctx->pending, ctx->pending_SN)) return 1;
     }
     if (rc) return rc;
     if (n_not_spd) {

@@ -122,3 +122,18 @@ def test_configurations_the_fused_kernel_does_not_cover_take_the_two_calls(built
     run(make_case("C2", nside=4, start="truth"))                            # 5 bands: not instantiated
     run(make_case("C3", nside=4, start="truth", tweak=jeffreys))            # LDS-form chain
     run(make_case("C3", nside=4, start="truth"), fluct_mode="correct")      # k_amp_direct
+
+
+def test_a_failing_sweep_still_leaves_the_solve_done(built):
+    """Error behaviour of the pair: when the index call is rejected (index number out of range) the amplitude solve has
+    happened all the same, exactly as with two separate calls."""
+    case = make_case("C3", nside=4, start="truth")
+    dpar, ddata, bands, comps, meta = case
+    fus, two = _engines(case)
+    for eng in (fus, two):   # make the index maps "varying" so that the fused route is the one that is tried
+        eng.index_sample(1, 0, 1, 2, "sample", 1, 1)
+    with pytest.raises(da.DangxError):
+        fus.amp_index_sample(1, L.FLAG_T, "sample", 3, 5, 1, 7, 1, 6, 3, 7)      # synch has no index 7
+    two.amp_sample(1, L.FLAG_T, "sample", 3, 5)
+    for l in range(len(comps)):
+        assert np.array_equal(fus.get_amplitude(l), two.get_amplitude(l)), l
