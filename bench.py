@@ -288,14 +288,28 @@ def main():
                                          solver="direct", fluct_mode=dpar.fluct_mode, want_counts=False)
         # the chi^2 after the amplitude phase is captured by the first index sweep on each plane (fused);
         # sample_spectral_parameters (src/dang_sample_mod.f90:21-86)
+        # consecutive sampled indices of one component on the same planes (dust beta, dust T) go through
+        # dangx_index_sample_pair: one launch and one staging of the maps where the chain covers both, the two sweeps otherwise
         for l, c in enumerate(comps):
-            for j in range(c.nindices):
-                if c.sample_index[j]:
-                    for f in c.pol_flag[j]:
-                        if (l, j, f) in fused_sweeps:
-                            continue
+            j = 0
+            while j < c.nindices:
+                if not c.sample_index[j]:
+                    j += 1
+                    continue
+                pair = (not args.no_fuse and j + 1 < c.nindices and c.sample_index[j + 1] and c.pol_flag[j] == c.pol_flag[j + 1])
+                for f in c.pol_flag[j]:
+                    if (l, j, f) in fused_sweeps:
+                        if pair:  # the first index went with the solve: the second alone
+                            eng_of(f).index_sample(l, j + 1, mapn[f], dpar.nsample, dpar.ml_mode, dpar.seed,
+                                                   da.stream_id(it, 1, l, j + 1, f), want_counts=False)
+                        continue
+                    if pair:
+                        eng_of(f).index_sample_pair(l, j, mapn[f], dpar.nsample, dpar.ml_mode, dpar.seed,
+                                                    da.stream_id(it, 1, l, j, f), da.stream_id(it, 1, l, j + 1, f), want_counts=False)
+                    else:
                         eng_of(f).index_sample(l, j, mapn[f], dpar.nsample, dpar.ml_mode, dpar.seed,
                                                da.stream_id(it, 1, l, j, f), want_counts=False)
+                j += 2 if pair else 1
         # update_sky_model + compute_chisq after each phase (src/dang_cg_mod.f90:172-173,
         # src/dang_sample_mod.f90:81-84): both values come out of the sweeps, no extra pass over the maps
         if two:  # T planes from the main context, Q/U planes from the side context; joined on the main stream

@@ -95,6 +95,8 @@ SYMBOLS = {
     "dangx_amp_residual": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _D]),
     "dangx_index_sample": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
                                      C.POINTER(C.c_int64)]),
+    "dangx_index_sample_pair": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64,
+                                          C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "dangx_amp_index_sample": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
                                          C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -336,6 +336,15 @@ class Engine:
                                               C.byref(acc) if want_counts else None))
         return acc.value
 
+    def index_sample_pair(self, comp, nind, map_n, nsample, ml_mode, seed, stream_first, stream_second, want_counts=True):
+        """index_sample(comp, nind, ...) followed by index_sample(comp, nind + 1, ...) on the same planes -- one kernel
+        launch where the register chain covers both indices; bit for bit the two calls.  Returns both accepted counts."""
+        a1, a2 = C.c_int64(0), C.c_int64(0)
+        self._chk(self.lib.dangx_index_sample_pair(self.h, comp, nind, map_n, nsample, L.ML_CODES[ml_mode], seed,
+                                                   stream_first, stream_second,
+                                                   C.byref(a1) if want_counts else None, C.byref(a2) if want_counts else None))
+        return a1.value, a2.value
+
     def amp_index_sample(self, group, flag, ml_mode, seed_amp, stream_amp, comp, nind, map_n, nsample, seed_index,
                          stream_index, solver="direct", fluct_mode="reference", want_counts=True):
         """amp_sample(group, flag, ...) followed by index_sample(comp, nind, map_n, ...) on the same planes -- one kernel

@@ -1748,7 +1748,7 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
     const unsigned nblk = nblocks((long long)ctx->hm.npix * (reg_ok ? dx_mh_reg_lanes(ctx->hm.nbands, Sp) : 1), bs);
     constexpr int RSTAGE = 128;  // blocks of the first reduction stage
     if (ensure_partial(ctx, 4ll * nblk + 4ll * RSTAGE)) return 1;
-    if (accepted) HIPCHK(ctx, hipMemsetAsync(ctx->counters + 1, 0, sizeof(unsigned long long), ctx->stream));
+    if (accepted) HIPCHK(ctx, hipMemsetAsync(ctx->counters + 1, 0, 2 * sizeof(unsigned long long), ctx->stream));
     bool fused = false;
     if (ctx->have_pending) {  // an amplitude solve on these planes is waiting: one launch for both, or the solve first
         ctx->have_pending = false;
@@ -1759,6 +1759,20 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
         }
         if (!fused) {
             if (dx_launch_amp(ctx, ctx->pending, ctx->pending_SN)) return 1;
+        }
+    }
+    if (!fused && ctx->pair_on) {  // dangx_index_sample_pair: this sweep and the sweep of index nind + 1 in one launch
+        ctx->pair_on = false;
+        if (reg_ok && dx_mh_reg_lanes(ctx->hm.nbands, Sp) == 1 && nind + 1 < d.nindices) {
+            IndexArgs b = a;
+            b.nind = nind + 1; b.stream = ctx->pair_stream;
+            b.mode = (d.type == DANGX_MBB) ? CH_MBB_T : (d.type == DANGX_LOGNORMAL && all_delta) ? CH_LOGN_W : CH_GENERIC;
+            const bool ok_b = d.lnl_type[nind + 1] == DANGX_LNL_CHISQ && d.prior_type[nind + 1] != DANGX_PRIOR_JEFFREYS;
+            unsigned long long* accp = accepted ? ctx->counters + 1 : nullptr;  // counters[1], counters[2]
+            if (ok_b) {
+                Timed t(ctx, DANGX_K_INDEX_MH);
+                fused = ctx->pair_done = dx_launch_mh_pair(ctx, a, b, Sp, nblk, accp);
+            }
         }
     }
     if (!fused) {
@@ -1787,6 +1801,33 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
         HIPCHK(ctx, hipMemcpyAsync(&v, ctx->counters + 1, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         *accepted = (int64_t)v;
+    }
+    return 0;
+}
+
+// dangx_index_sample(comp, nind, ...) followed by dangx_index_sample(comp, nind + 1, ...) on the same planes: two
+// consecutive indices of ONE component (the dust beta and dust T sweeps).  Nothing the second sweep removes from the data
+// has changed in between, so where the register chain covers both (chisq likelihood, gaussian / uniform priors, delta
+// bands; mbb beta -> T, log-normal nu_p -> w) they run in one launch on one staging of the maps -- bit for bit the two
+// calls, which everything else takes.
+int dangx_index_sample_pair(dangx_ctx* ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed,
+                            uint64_t stream_first, uint64_t stream_second, int64_t* accepted_first, int64_t* accepted_second) {
+    if (!ctx || check_comp(ctx, comp)) return 1;
+    static const bool enabled = [] { const char* e = getenv("DANGX_FUSE"); return !(e && e[0] == '0'); }();
+    const bool want_counts = accepted_first || accepted_second;
+    int64_t acc1 = 0;
+    ctx->pair_on = enabled; ctx->pair_done = false; ctx->pair_stream = stream_second;
+    int rc = dangx_index_sample(ctx, comp, nind, map_n, nsample, ml_mode, seed, stream_first, want_counts ? &acc1 : nullptr);
+    ctx->pair_on = false;
+    if (rc) return rc;
+    if (accepted_first) *accepted_first = acc1;
+    if (!ctx->pair_done) return dangx_index_sample(ctx, comp, nind + 1, map_n, nsample, ml_mode, seed, stream_second, accepted_second);
+    ctx->pair_done = false;
+    if (accepted_second) {
+        unsigned long long v = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&v, ctx->counters + 2, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        *accepted_second = (int64_t)v;
     }
     return 0;
 }

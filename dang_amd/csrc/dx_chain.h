@@ -234,14 +234,16 @@ __device__ __forceinline__ void subtract_other_pair(const Model& M, const Comp& 
 
 // Second half of a register chain, from staged planes to the written index map: R holds the cleaned data and 1/rms of
 // the lane's bands and the component's amplitudes; sample0/1 are its two current index values on the first plane.
-template <int MODE, int SP, int NB, int LP>
+// SCALE = false: the planes are already d/rms and amp/rms (a second chain of the same component on the same planes,
+// k_index_mh_pair); final_value (nullable) receives the value the chain ends at.
+template <int MODE, int SP, int NB, int LP, bool SCALE = true>
 __device__ __forceinline__ unsigned long long chain_finish(const Model& M, const IndexArgs& a, const Comp& c, RegChain<MODE, SP, NB, LP>& R,
                                                            const BandPick<LP>& pick, double sample0, double sample1, int i, int half,
-                                                           double chi[4]) {
+                                                           double chi[4], double* final_value = nullptr) {
     const int npix = M.npix;
     double* out = c.idx + ((long long)a.nind * M.nmaps) * npix + i;
     const bool first = (a.nind == 0);
-    R.scale();
+    if (SCALE) R.scale();
     // --- chain-invariant SED factor
     if (MODE == CH_MBB_BETA) {
         const double z = H_PLANCK / (K_B * sample1);
@@ -294,6 +296,7 @@ __device__ __forceinline__ unsigned long long chain_finish(const Model& M, const
         const bool acc = (a.ml_mode == DANGX_ML_OPTIMIZE) ? (diff > 0.0) : ((diff >= 0.0) || (CEXP1(diff) > u3));  // :443-454
         if (acc) { cur = prop; lnl_old = lnl_new; a0 = c0; a1 = c1; ++nacc; }
     }
+    if (final_value) *final_value = cur;
     if (half != 0) {  // the pair's second lane carries the same chain: its sums and counts are the first lane's
         chi[0] = chi[1] = 0.0;
         return 0ull;
@@ -304,26 +307,15 @@ __device__ __forceinline__ unsigned long long chain_finish(const Model& M, const
     return nacc;
 }
 
-// NB = bands per lane (all of them for LP == 1, half for LP == 2); half = which half this lane owns
+// Staging of a register chain: the component's index values, data_raw (:173-177) and 1/rms of the lane's bands, every
+// other component removed (:180-196).  The caller has dealt with masked pixels.
 template <int MODE, int SP, int NB, int LP>
-__device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, const IndexArgs& a, int i, int half, double chi[4]) {
+__device__ __forceinline__ void index_chain_stage(const Model& M, const IndexArgs& a, const Comp& c, RegChain<MODE, SP, NB, LP>& R,
+                                                  const BandPick<LP>& pick, int i, double& sample0, double& sample1) {
     const int npix = M.npix;
-    const Comp& c = M.comp[a.comp];
-    double* out = c.idx + ((long long)a.nind * M.nmaps) * npix + i;
-    if (is_masked(M.mask[i])) {  // :362 cycle; index_map stays 0 (:223) and is copied back (:480-483)
-        if (half == 0) {
-#pragma unroll
-            for (int kk = 0; kk < SP; ++kk) out[(long long)(a.s1 + kk - 1) * npix] = 0.0;
-        }
-        return 0ull;
-    }
-    const BandPick<LP> pick = {half};
-    const int jb = half * NB;  // first band of this lane
-    RegChain<MODE, SP, NB, LP> R;
+    const int jb = pick.half * NB;  // first band of this lane
     R.set_k(M, c, pick);
-    double sample0, sample1;
     load_theta(M, c, i, a.s1, sample0, sample1);  // sample(l) = c%indices(i, map_inds(1), l), :372-377
-    const bool first = (a.nind == 0);
     // --- stage data_raw (:173-177) and rms: every load issued before the first use
     const long long bstride = (long long)M.nmaps * npix;
 #pragma unroll
@@ -377,7 +369,62 @@ __device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, co
             l = ln;
         }
     }
+}
+
+// NB = bands per lane (all of them for LP == 1, half for LP == 2); half = which half this lane owns
+template <int MODE, int SP, int NB, int LP>
+__device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, const IndexArgs& a, int i, int half, double chi[4]) {
+    const int npix = M.npix;
+    const Comp& c = M.comp[a.comp];
+    double* out = c.idx + ((long long)a.nind * M.nmaps) * npix + i;
+    if (is_masked(M.mask[i])) {  // :362 cycle; index_map stays 0 (:223) and is copied back (:480-483)
+        if (half == 0) {
+#pragma unroll
+            for (int kk = 0; kk < SP; ++kk) out[(long long)(a.s1 + kk - 1) * npix] = 0.0;
+        }
+        return 0ull;
+    }
+    const BandPick<LP> pick = {half};
+    RegChain<MODE, SP, NB, LP> R;
+    double sample0, sample1;
+    index_chain_stage<MODE, SP, NB, LP>(M, a, c, R, pick, i, sample0, sample1);
     return chain_finish<MODE, SP, NB, LP>(M, a, c, R, pick, sample0, sample1, i, half, chi);
+}
+
+// Two consecutive sweeps of ONE component on the same planes -- index nind, then index nind + 1 (the dust beta and dust T
+// sweeps of every configuration) -- in one pass: nothing the second sweep removes from the data has changed (only the
+// component's own index did), so its staged planes ARE the first sweep's; it needs a new chain-invariant factor and its
+// own chain.  Same numbers as the two sweeps, bit for bit (the second sweep would have staged exactly these planes).
+template <int MODEA, int MODEB, int SP, int NB>
+__device__ __forceinline__ void index_chain_pair(const Model& M, const IndexArgs& a, const IndexArgs& b, int i, double chi[4],
+                                                 unsigned long long& nacc_a, unsigned long long& nacc_b) {
+    const int npix = M.npix;
+    const Comp& c = M.comp[a.comp];
+    nacc_a = nacc_b = 0ull;
+    if (is_masked(M.mask[i])) {
+#pragma unroll
+        for (int kk = 0; kk < SP; ++kk) {
+            c.idx[((long long)a.nind * M.nmaps + (a.s1 + kk - 1)) * npix + i] = 0.0;
+            c.idx[((long long)b.nind * M.nmaps + (a.s1 + kk - 1)) * npix + i] = 0.0;
+        }
+        return;
+    }
+    const BandPick<1> pick = {0};
+    RegChain<MODEA, SP, NB, 1> RA;
+    double sample0, sample1;
+    index_chain_stage<MODEA, SP, NB, 1>(M, a, c, RA, pick, i, sample0, sample1);
+    double chia[4] = {0.0, 0.0, 0.0, 0.0}, chib[4] = {0.0, 0.0, 0.0, 0.0}, va;
+    nacc_a = chain_finish<MODEA, SP, NB, 1>(M, a, c, RA, pick, sample0, sample1, i, 0, chia, &va);
+    RegChain<MODEB, SP, NB, 1> RB;
+#pragma unroll
+    for (int kk = 0; kk < SP; ++kk) {
+        RB.amp[kk] = RA.amp[kk];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { RB.D[kk][j] = RA.D[kk][j]; RB.ISr[kk][j] = RA.ISr[kk][j]; }
+    }
+    if (a.nind == 0) sample0 = va; else sample1 = va;
+    nacc_b = chain_finish<MODEB, SP, NB, 1, false>(M, b, c, RB, pick, sample0, sample1, i, 0, chib);
+    chi[0] = chia[0]; chi[1] = chia[1]; chi[2] = chib[2]; chi[3] = chib[3];
 }
 
 }  // namespace

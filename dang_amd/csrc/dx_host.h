@@ -117,6 +117,9 @@ struct dangx_ctx {
     double schur_resid = 0.0, schur_backward = 0.0;  // relative to the row of b / to the size of the row's terms
     // dangx_amp_index_sample: an amplitude solve whose launch waits for the index sweep it is fused with
     bool defer_amp = false, have_pending = false;
+    // dangx_index_sample_pair: the sweep of index nind is launched together with the sweep of index nind + 1
+    bool pair_on = false, pair_done = false;
+    unsigned long long pair_stream = 0;
     GroupArgs pending{};
     long long pending_SN = 0;
     int schur_refine = 0;
@@ -211,6 +214,8 @@ int dx_launch_sv_mixed(dangx_ctx* ctx, const GroupArgs& a, long long SN, const d
 void dx_launch_mh_lds(dangx_ctx* ctx, const IndexArgs& a, bool fast, int Sp, unsigned nblk, int bs, size_t lds, unsigned long long* accp);
 // register-resident Metropolis kernels; return false when (mode, nb) is not instantiated
 bool dx_mh_reg_supported(int mode, int nb);
+bool dx_mh_pair_supported(int mode_a, int mode_b, int nb, int Sp);
+bool dx_launch_mh_pair(dangx_ctx* ctx, const IndexArgs& a, const IndexArgs& b, int Sp, unsigned nblk, unsigned long long* accp);
 bool dx_fused_supported(int mode, int nb, int ng);
 bool dx_launch_fused(dangx_ctx* ctx, const GroupArgs& ga, const IndexArgs& a, int Sp, unsigned nblk, unsigned long long* accp);
 int dx_mh_reg_lanes(int nb, int Sp);  // lanes per pixel of the register chain (dangx_mhreg.hip)

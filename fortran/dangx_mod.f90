@@ -132,6 +132,14 @@ module dangx_mod
        integer(c_int64_t), value :: seed, stream
        integer(c_int64_t), intent(out), optional :: accepted
      end function
+     integer(c_int) function dangx_index_sample_pair(ctx, comp, nind, map_n, nsample, ml_mode, seed, stream_first, stream_second, &
+          accepted_first, accepted_second) bind(C, name='dangx_index_sample_pair')
+       import :: c_int, c_ptr, c_int64_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: comp, nind, map_n, nsample, ml_mode
+       integer(c_int64_t), value :: seed, stream_first, stream_second
+       integer(c_int64_t), intent(out), optional :: accepted_first, accepted_second
+     end function
      integer(c_int) function dangx_amp_index_sample(ctx, group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, &
           comp, nind, map_n, nsample, seed_index, stream_index, n_not_spd, accepted) bind(C, name='dangx_amp_index_sample')
        import :: c_int, c_ptr, c_int64_t

@@ -233,6 +233,33 @@ contains
     end if
   end subroutine dangx_sky_index_sample
 
+  ! two consecutive indices (nind, nind + 1) of one component on the same planes through dangx_index_sample_pair: one launch
+  ! per context where the register chain covers both, the two calls' result bit for bit everywhere
+  subroutine dangx_sky_index_sample_pair(sky, comp, nind, map_n, nsample, ml_mode, seed, stream_first, stream_second, &
+       accepted_first, accepted_second)
+    type(dangx_sky), intent(in) :: sky
+    integer, intent(in) :: comp, nind, map_n, nsample, ml_mode
+    integer(c_int64_t), intent(in) :: seed, stream_first, stream_second
+    integer(c_int64_t), intent(out), optional :: accepted_first, accepted_second
+    integer(c_int64_t) :: n1, n2
+    integer :: r
+    if (present(accepted_first) .or. present(accepted_second)) then
+       if (present(accepted_first)) accepted_first = 0
+       if (present(accepted_second)) accepted_second = 0
+       do r = 1, sky%nctx
+          call dangx_check(sky%ctx(r), dangx_index_sample_pair(sky%ctx(r), comp, nind, map_n, nsample, ml_mode, seed, &
+               stream_first, stream_second, n1, n2), 'dangx_index_sample_pair')
+          if (present(accepted_first)) accepted_first = accepted_first + n1
+          if (present(accepted_second)) accepted_second = accepted_second + n2
+       end do
+    else
+       do r = 1, sky%nctx
+          call dangx_check(sky%ctx(r), dangx_index_sample_pair(sky%ctx(r), comp, nind, map_n, nsample, ml_mode, seed, &
+               stream_first, stream_second), 'dangx_index_sample_pair')
+       end do
+    end if
+  end subroutine dangx_sky_index_sample_pair
+
   ! dangx_sky_amp_sample(group, flag, ...) directly followed by dangx_sky_index_sample(comp, nind, map_n, ...) on the same
   ! planes, through dangx_amp_index_sample: one kernel launch per context where the model allows it, the two calls'
   ! result bit for bit everywhere (the first sampled index of a CG group's components follows the group's solve this way)

@@ -208,6 +208,15 @@ int dangx_amp_residual(dangx_ctx *ctx, int group, int flag, int ml_mode, uint64_
 int dangx_index_sample(dangx_ctx *ctx, int comp, int nind, int map_n, int nsample, int ml_mode,
                        uint64_t seed, uint64_t stream, int64_t *accepted);
 
+/* ---- two consecutive indices of ONE component on the same planes, in one call: exactly
+ * dangx_index_sample(comp, nind, map_n, nsample, ml_mode, seed, stream_first, accepted_first) followed by
+ * dangx_index_sample(comp, nind + 1, map_n, nsample, ml_mode, seed, stream_second, accepted_second) -- consecutive passes of
+ * the loop over a component's indices in sample_spectral_parameters (src/dang_sample_mod.f90:40-75; dust beta, then dust T)
+ * -- and bit for bit their result.  Nothing the second sweep removes from the data has changed in between, so where the
+ * register chain covers both indices they run in ONE launch on one staging of the maps. */
+int dangx_index_sample_pair(dangx_ctx *ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed,
+                            uint64_t stream_first, uint64_t stream_second, int64_t *accepted_first, int64_t *accepted_second);
+
 /* ---- the amplitude solve of a CG group and the FIRST index sweep on the same planes, in one call: exactly
  * dangx_amp_sample(group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, 100, 1e-8, NULL, n_not_spd) followed by
  * dangx_index_sample(comp, nind, map_n, nsample, ml_mode, seed_index, stream_index, accepted) -- the way sample_cg_groups

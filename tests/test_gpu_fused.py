@@ -137,3 +137,31 @@ def test_a_failing_sweep_still_leaves_the_solve_done(built):
     two.amp_sample(1, L.FLAG_T, "sample", 3, 5)
     for l in range(len(comps)):
         assert np.array_equal(fus.get_amplitude(l), two.get_amplitude(l)), l
+
+
+@pytest.mark.parametrize("config,nside", [("C3", 8), ("C2", 8), ("C5", 4)])
+@pytest.mark.parametrize("ml_mode", ["sample", "optimize"])
+def test_index_sample_pair_equals_the_two_sweeps_bitwise(built, config, nside, ml_mode):
+    """dangx_index_sample_pair (two consecutive indices of one component in one launch) against the two sweeps: index maps,
+    chi^2 sums and both accepted counts bit for bit, for every two-index component of the configuration, on the T plane
+    and on Q+U (C5: 20 bands -- the T plane takes the pair kernel, Q+U the two lane-pair sweeps; its log-normal
+    component has one sampled index only and goes the two-call way too)."""
+    case = make_case(config, nside=nside, start="truth")
+    dpar, ddata, bands, comps, meta = case
+    one, two = _engines(case)
+    ran = 0
+    for it in (1, 2):
+        for l, c in enumerate(comps):
+            if c.nindices != 2:
+                continue
+            f = c.pol_flag[0][0]
+            s1, s2 = da.stream_id(it, 1, l, 0, f), da.stream_id(it, 1, l, 1, f)
+            a = one.index_sample_pair(l, 0, MAPN[f], 8, ml_mode, 17, s1, s2)
+            b = (two.index_sample(l, 0, MAPN[f], 8, ml_mode, 17, s1), two.index_sample(l, 1, MAPN[f], 8, ml_mode, 17, s2))
+            assert a == b, (l, a, b)
+            assert np.array_equal(one.get_indices(l), two.get_indices(l)), l
+            k = (1, 1) if f == L.FLAG_T else (2, 3)
+            for which in (0, 1):
+                assert one.chisq_cached(which, *k) == two.chisq_cached(which, *k), (l, which)
+            ran += 1
+    assert ran >= 4
