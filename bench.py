@@ -273,6 +273,25 @@ def main():
                         first_sweep[(g.cg_group, f)] = (l, hit[0])
                         break
     fused_sweeps = set((l, j, f) for (grp, f), (l, j) in first_sweep.items())
+    # what one iteration launches on the index side, for the byte accounting: (planes, index values written) per launch
+    index_launches = []
+    for l, c in enumerate(comps):
+        j = 0
+        while j < c.nindices:
+            if not c.sample_index[j]:
+                j += 1
+                continue
+            pair = (not args.no_fuse and j + 1 < c.nindices and c.sample_index[j + 1] and c.pol_flag[j] == c.pol_flag[j + 1])
+            for f in c.pol_flag[j]:
+                planes = 2 if f == 8 else 1
+                if (l, j, f) in fused_sweeps:
+                    if pair:
+                        index_launches.append((planes, 1))
+                elif pair:
+                    index_launches.append((planes, 2))
+                else:
+                    index_launches.append((planes, 1))
+            j += 2 if pair else 1
 
     def gibbs_iteration(it):
         # sample_cg_groups (src/dang_cg_mod.f90:142-177)
@@ -377,6 +396,11 @@ def main():
                           "k_sky_chisq": 2 * meta["npix"] * nmaps}
         launches_per_step = max(prof[dom]["launches"] // args.steps, 1)
         bytes_per_launch = algorithmic_bytes(meta, comps, dom, units_per_step.get(dom, meta["npix"] * nmaps)) / launches_per_step
+        if dom == "k_index_mh" and "k_amp_index" in prof:
+            # launches that sweep two consecutive indices of a component stage the maps once and write two index values:
+            # per launch 8 (2nb + nc + nidx + 1 + written) bytes per (pixel, plane) unit, averaged over this step's launches
+            nphys_, nidx_ = len(meta["phys"]), sum(c.nindices for c in comps[:len(meta["phys"])])
+            bytes_per_launch = sum(8.0 * (2 * nb + nphys_ + nidx_ + 1 + w) * meta["npix"] * pl for pl, w in index_launches) / max(len(index_launches), 1)
         achieved = bytes_per_launch / (prof[dom]["avg_ms"] * 1e-3) / 1e9
         standard = world == 1 and args.nside is None and not args.bandpass and not shard_of   # what the committed profiles are of
         # B_iter = 8 N_sp [(2nb + nidx + 1 + nc) + (2nb + nc + nidx + 1 + nidx_s)] over the WHOLE sky
@@ -392,7 +416,7 @@ def main():
                                    "direct block solve, reference fluctuation term%s; pixel-sharded over %d rank(s), %d stream(s) per rank%s"
                                    % (args.config, meta["nside"], nb, len(meta["phys"]), "+".join(meta["phys"]),
                                       "IQU" if nmaps == 3 else "I", args.nsample,
-                                      ", each group's solve and the first sweep on its planes in one launch" if "k_amp_index" in prof else "",
+                                      ", each group's solve and the first sweep on its planes in one launch, consecutive indices of a component in one launch" if "k_amp_index" in prof else "",
                                       world, 2 if two else 1,
                                       ("; DIAGNOSTIC: every second band integrated over a %d-sample bandpass" % args.bandpass
                                        if args.bandpass else "") +

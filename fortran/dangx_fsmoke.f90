@@ -15,7 +15,7 @@ program dangx_fsmoke
   implicit none
   integer, parameter :: MAXC = 16
   integer(c_int32_t) :: npix, nmaps, nbands, ncomp, nsample, niter, ngroups, nctx
-  integer(c_int64_t) :: seed, nbad, nacc, nacc_tot
+  integer(c_int64_t) :: seed, nbad, nacc, nacc2, nacc_tot
   integer(c_int) :: st, iters
   real(c_double), allocatable, target :: sig(:,:,:), rms(:,:,:), mask(:,:), freqs(:)
   real(c_double), allocatable, target :: sky_model(:,:,:), res_map(:,:,:), chi_map(:,:)
@@ -26,7 +26,7 @@ program dangx_fsmoke
   type(dangx_comp_desc) :: desc(MAXC)
   integer(c_int32_t) :: sample_index(2, MAXC), pol_flag(2, MAXC), grp(MAXC), gflag(MAXC)
   real(c_double) :: nump, chisq_explicit, chisq_amp, chisq_idx, means(2*MAXC)
-  logical :: ok_amp, ok_idx
+  logical :: ok_amp, ok_idx, paired
   type(dangx_sky) :: sky
   character(len=512) :: fin, fout, arg
   integer :: i, j, k, l, f, it, u, map_n, nmeans, lf, jf, fused_l(MAXC), fused_j(MAXC)
@@ -127,10 +127,20 @@ program dangx_fsmoke
      end do
      if (it > 1) then                                     ! sample_spectral_parameters, src/dang_sample_mod.f90:21-86
         do l = 1, ncomp
+           paired = .false.
            do j = 1, desc(l)%nindices
+              if (paired) then                            ! went with the index before it
+                 paired = .false.
+                 cycle
+              end if
               if (sample_index(j, l) == 0) cycle
               f = pol_flag(j, l)
               if (any(fused_l(1:ngroups) == l .and. fused_j(1:ngroups) == j .and. gflag(1:ngroups) == f)) cycle  ! done with its solve
+              ! two consecutive sampled indices of one component on the same planes: one entry point (one launch where the
+              ! register chain covers both); the Python host of the test makes the two calls -- same bits
+              if (j < desc(l)%nindices) then
+                 paired = sample_index(j+1, l) /= 0 .and. pol_flag(j+1, l) == f
+              end if
               if (iand(f, 1) /= 0) then
                  map_n = 1
               else if (iand(f, 2) /= 0) then
@@ -140,7 +150,16 @@ program dangx_fsmoke
               else
                  map_n = -1
               end if
-              if (it == niter) then
+              if (paired) then
+                 if (it == niter) then
+                    call dangx_sky_index_sample_pair(sky, l-1, j-1, map_n, nsample, DANGX_ML_SAMPLE, seed, &
+                         dangx_stream_id(it, 1, l-1, j-1, f), dangx_stream_id(it, 1, l-1, j, f), nacc, nacc2)
+                    nacc_tot = nacc_tot + nacc + nacc2
+                 else
+                    call dangx_sky_index_sample_pair(sky, l-1, j-1, map_n, nsample, DANGX_ML_SAMPLE, seed, &
+                         dangx_stream_id(it, 1, l-1, j-1, f), dangx_stream_id(it, 1, l-1, j, f))
+                 end if
+              else if (it == niter) then
                  call dangx_sky_index_sample(sky, l-1, j-1, map_n, nsample, DANGX_ML_SAMPLE, seed, &
                       dangx_stream_id(it, 1, l-1, j-1, f), nacc)
                  nacc_tot = nacc_tot + nacc
