@@ -1763,7 +1763,7 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
     }
     if (!fused && ctx->pair_on) {  // dangx_index_sample_pair: this sweep and the sweep of index nind + 1 in one launch
         ctx->pair_on = false;
-        if (reg_ok && dx_mh_reg_lanes(ctx->hm.nbands, Sp) == 1 && nind + 1 < d.nindices) {
+        if (reg_ok && nind + 1 < d.nindices) {
             IndexArgs b = a;
             b.nind = nind + 1; b.stream = ctx->pair_stream;
             b.mode = (d.type == DANGX_MBB) ? CH_MBB_T : (d.type == DANGX_LOGNORMAL && all_delta) ? CH_LOGN_W : CH_GENERIC;

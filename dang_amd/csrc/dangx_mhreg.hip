@@ -46,17 +46,17 @@ __global__ __launch_bounds__(BLOCK, (SP == 1 && NB <= 10) ? 3 : (SP == 2 && NB >
 #if DX_REG_MODE == 2 || DX_REG_MODE == 4
 // index nind and index nind + 1 of one component on the same planes in one launch (dx_chain.h: index_chain_pair); the
 // first chain has mode DX_REG_MODE, the second DX_REG_MODE + 1 (mbb: beta then T; log-normal: nu_p then w)
-template <int SP, int NB>
+template <int SP, int NB, int LP>
 __global__ __launch_bounds__(BLOCK, (SP == 1 && NB <= 10) ? 3 : 2) void k_index_mh_pair(const Model* __restrict__ Mp, IndexArgs a, IndexArgs b,
                                                         unsigned long long* __restrict__ accepted_a, unsigned long long* __restrict__ accepted_b,
                                                         double* __restrict__ chi_partial) {
     const Model& M = *Mp;
     const int tid = threadIdx.x;
     const long long t = (long long)blockIdx.x * BLOCK + tid;
-    const int i = (int)t;
+    const int i = (int)(t / LP), half = (int)(t % LP);   // LP = 2: the bands of a pixel over two adjacent lanes (dx_chain.h)
     double chi[4] = {0.0, 0.0, 0.0, 0.0};
     unsigned long long na = 0ull, nb_ = 0ull;
-    if (t < M.npix) index_chain_pair<DX_REG_MODE, DX_REG_MODE + 1, SP, NB>(M, a, b, i, chi, na, nb_);
+    if (i < M.npix) index_chain_pair<DX_REG_MODE, DX_REG_MODE + 1, SP, NB / LP, LP>(M, a, b, i, half, chi, na, nb_);
     if (accepted_a) {
         for (int o = 32; o > 0; o >>= 1) { na += __shfl_down(na, o, 64); nb_ += __shfl_down(nb_, o, 64); }
         if ((tid & 63) == 0) { if (na) atomicAdd(accepted_a, na); if (nb_) atomicAdd(accepted_b, nb_); }
@@ -88,10 +88,13 @@ __global__ __launch_bounds__(BLOCK, (SP == 1 && NB <= 10) ? 3 : 2) void k_index_
 bool DX_CATP(dx_launch_mh_pair_mode, DX_REG_MODE)(dangx_ctx* ctx, const IndexArgs& a, const IndexArgs& b, int Sp, unsigned nblk,
                                                  unsigned long long* accp) {
     const int nb = ctx->hm.nbands;
-#define DX_LAUNCH_PAIR(SP_, NB_)                                                                                  \
-    hipLaunchKernelGGL((k_index_mh_pair<SP_, NB_>), dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->dm, a, b, accp, accp ? accp + 1 : nullptr, ctx->partial)
-    if (Sp == 2) { if (nb == 10) DX_LAUNCH_PAIR(2, 10); else if (nb == 5) DX_LAUNCH_PAIR(2, 5); else return false; }
-    else { if (nb == 10) DX_LAUNCH_PAIR(1, 10); else if (nb == 5) DX_LAUNCH_PAIR(1, 5); else if (nb == 20) DX_LAUNCH_PAIR(1, 20); else return false; }
+#define DX_LAUNCH_PAIR(SP_, NB_, LP_)                                                                             \
+    hipLaunchKernelGGL((k_index_mh_pair<SP_, NB_, LP_>), dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->dm, a, b, accp, accp ? accp + 1 : nullptr, ctx->partial)
+    // nblk counts blocks of BLOCK lanes: BLOCK / 2 pixels for the lane-pair form (two planes of 20 bands)
+    if (Sp == 2) {
+        if (nb == 10) DX_LAUNCH_PAIR(2, 10, 1); else if (nb == 5) DX_LAUNCH_PAIR(2, 5, 1);
+        else if (nb == 20 && dx_mh_reg_lanes(nb, Sp) == 2) DX_LAUNCH_PAIR(2, 20, 2); else return false;
+    } else { if (nb == 10) DX_LAUNCH_PAIR(1, 10, 1); else if (nb == 5) DX_LAUNCH_PAIR(1, 5, 1); else if (nb == 20) DX_LAUNCH_PAIR(1, 20, 1); else return false; }
 #undef DX_LAUNCH_PAIR
     return true;
 }
@@ -134,7 +137,7 @@ bool dx_launch_mh_pair_mode4(dangx_ctx*, const IndexArgs&, const IndexArgs&, int
 // index a.nind and a.nind + 1 of one component in one launch; false: not covered (the caller makes the two launches)
 bool dx_mh_pair_supported(int mode_a, int mode_b, int nb, int Sp) {
     if (!((mode_a == CH_MBB_BETA && mode_b == CH_MBB_T) || (mode_a == CH_LOGN_NUP && mode_b == CH_LOGN_W))) return false;
-    return Sp == 2 ? (nb == 10 || nb == 5) : (nb == 10 || nb == 5 || nb == 20);
+    return Sp == 2 ? (nb == 10 || nb == 5 || (nb == 20 && dx_mh_reg_lanes(nb, Sp) == 2)) : (nb == 10 || nb == 5 || nb == 20);
 }
 bool dx_launch_mh_pair(dangx_ctx* ctx, const IndexArgs& a, const IndexArgs& b, int Sp, unsigned nblk, unsigned long long* accp) {
     if (!dx_mh_pair_supported(a.mode, b.mode, ctx->hm.nbands, Sp)) return false;

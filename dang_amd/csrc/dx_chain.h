@@ -395,27 +395,30 @@ __device__ __forceinline__ unsigned long long index_chain_reg(const Model& M, co
 // sweeps of every configuration) -- in one pass: nothing the second sweep removes from the data has changed (only the
 // component's own index did), so its staged planes ARE the first sweep's; it needs a new chain-invariant factor and its
 // own chain.  Same numbers as the two sweeps, bit for bit (the second sweep would have staged exactly these planes).
-template <int MODEA, int MODEB, int SP, int NB>
-__device__ __forceinline__ void index_chain_pair(const Model& M, const IndexArgs& a, const IndexArgs& b, int i, double chi[4],
+template <int MODEA, int MODEB, int SP, int NB, int LP>
+__device__ __forceinline__ void index_chain_pair(const Model& M, const IndexArgs& a, const IndexArgs& b, int i, int half, double chi[4],
                                                  unsigned long long& nacc_a, unsigned long long& nacc_b) {
     const int npix = M.npix;
     const Comp& c = M.comp[a.comp];
     nacc_a = nacc_b = 0ull;
     if (is_masked(M.mask[i])) {
+        if (half == 0) {
 #pragma unroll
-        for (int kk = 0; kk < SP; ++kk) {
-            c.idx[((long long)a.nind * M.nmaps + (a.s1 + kk - 1)) * npix + i] = 0.0;
-            c.idx[((long long)b.nind * M.nmaps + (a.s1 + kk - 1)) * npix + i] = 0.0;
+            for (int kk = 0; kk < SP; ++kk) {
+                c.idx[((long long)a.nind * M.nmaps + (a.s1 + kk - 1)) * npix + i] = 0.0;
+                c.idx[((long long)b.nind * M.nmaps + (a.s1 + kk - 1)) * npix + i] = 0.0;
+            }
         }
         return;
     }
-    const BandPick<1> pick = {0};
-    RegChain<MODEA, SP, NB, 1> RA;
+    const BandPick<LP> pick = {half};
+    RegChain<MODEA, SP, NB, LP> RA;
     double sample0, sample1;
-    index_chain_stage<MODEA, SP, NB, 1>(M, a, c, RA, pick, i, sample0, sample1);
+    index_chain_stage<MODEA, SP, NB, LP>(M, a, c, RA, pick, i, sample0, sample1);
     double chia[4] = {0.0, 0.0, 0.0, 0.0}, chib[4] = {0.0, 0.0, 0.0, 0.0}, va;
-    nacc_a = chain_finish<MODEA, SP, NB, 1>(M, a, c, RA, pick, sample0, sample1, i, 0, chia, &va);
-    RegChain<MODEB, SP, NB, 1> RB;
+    nacc_a = chain_finish<MODEA, SP, NB, LP>(M, a, c, RA, pick, sample0, sample1, i, half, chia, &va);
+    RegChain<MODEB, SP, NB, LP> RB;
+    RB.set_k(M, c, pick);
 #pragma unroll
     for (int kk = 0; kk < SP; ++kk) {
         RB.amp[kk] = RA.amp[kk];
@@ -423,7 +426,7 @@ __device__ __forceinline__ void index_chain_pair(const Model& M, const IndexArgs
         for (int j = 0; j < NB; ++j) { RB.D[kk][j] = RA.D[kk][j]; RB.ISr[kk][j] = RA.ISr[kk][j]; }
     }
     if (a.nind == 0) sample0 = va; else sample1 = va;
-    nacc_b = chain_finish<MODEB, SP, NB, 1, false>(M, b, c, RB, pick, sample0, sample1, i, 0, chib);
+    nacc_b = chain_finish<MODEB, SP, NB, LP, false>(M, b, c, RB, pick, sample0, sample1, i, half, chib);
     chi[0] = chia[0]; chi[1] = chia[1]; chi[2] = chib[2]; chi[3] = chib[3];
 }
 
