@@ -65,7 +65,8 @@ def measured_valu(config, kernel, avg_launch_s):
         if t.get("config") != config:
             return None
         k = t["kernels"][kernel]
-        rate = float(k["valu_lane_ops_per_launch"]) / avg_launch_s
+        # the profile's own rate (instruction counts of the SQ pass / durations of the trace pass) where it has one
+        rate = float(k["valu_lane_ops_per_s"]) if k.get("valu_lane_ops_per_s") else float(k["valu_lane_ops_per_launch"]) / avg_launch_s
         return {"busy": float(k["valu_issue_busy"]), "lane_ops_per_s": rate, "peak": VALU_PEAK_LANE_OPS,
                 "frac": rate / VALU_PEAK_LANE_OPS, "sustained_fp64_fma": VALU_SUSTAINED_FMA,
                 "source": os.path.relpath(_profile_json(config, "valu"), ROOT)}

@@ -111,21 +111,42 @@ def main():
                 continue
             d = disp.setdefault((k, r["Dispatch_Id"]), {"meta": r})
             d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-        fam = collections.OrderedDict()
+        # per kernel NAME: mean busy and mean lane-ops per dispatch (SQ pass); calls and mean duration (kernel-trace pass).
+        # A family's figures weight its kernels by the time they take in the traced run (a family mixes kernels of
+        # different length: single sweeps and two-index sweeps), and its lane-op RATE comes from the trace's durations.
+        byname = collections.OrderedDict()
         for (k, _), d in disp.items():
             r = d["meta"]
             vg = 2 * (int(r["VGPR_Count"]) + int(r["Accum_VGPR_Count"]))
             w = max(1, min(8, 512 // max(8 * ((vg + 7) // 8), 8)))
             busy = min(1.0, w * d.get("SQ_ACTIVE_INST_VALU", 0.0) / max(d.get("SQ_WAVE_CYCLES", 1.0), 1.0))
-            e = fam.setdefault(k, {"busy": [], "lane_ops": []})
+            e = byname.setdefault((k, short(r["Kernel_Name"])), {"busy": [], "lane_ops": []})
             e["busy"].append(busy)
             e["lane_ops"].append(64.0 * d.get("SQ_INSTS_VALU", 0.0))
+        trace = {}
+        if a.stats:
+            tf = glob.glob(os.path.join(a.stats, "**", "*kernel_stats.csv"), recursive=True)[0]
+            for r in csv.DictReader(open(tf)):
+                trace[short(r["Name"])] = (float(r["Calls"]), float(r["AverageNs"]) * 1e-9)
+        fam = collections.OrderedDict()
+        for (k, name), e in byname.items():
+            calls, dur = trace.get(name, (float(len(e["busy"])), 0.0))
+            wt = calls * dur if dur > 0 else float(len(e["busy"]))
+            f_ = fam.setdefault(k, {"busy": [], "lane_ops": [], "wt": [], "ops_total": 0.0, "time_total": 0.0, "n": 0})
+            f_["busy"].append(sum(e["busy"]) / len(e["busy"])); f_["lane_ops"].append(sum(e["lane_ops"]) / len(e["lane_ops"]))
+            f_["wt"].append(wt); f_["n"] += len(e["busy"])
+            if dur > 0:
+                f_["ops_total"] += calls * sum(e["lane_ops"]) / len(e["lane_ops"]); f_["time_total"] += calls * dur
         out = {"source": "%s (rocprofv3 --pmc SQ_* pass; busy = resident waves/SIMD x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per "
-                         "dispatch, lane-ops = 64 x SQ_INSTS_VALU)" % os.path.join("profiles", os.path.basename(a.out)),
+                         "dispatch, lane-ops = 64 x SQ_INSTS_VALU; per family the kernels are weighted by their time in the "
+                         "kernel-trace pass, whose durations also give the lane-op rate)" % os.path.join("profiles", os.path.basename(a.out)),
                "config": a.config, "kernels": {}}
         for k, e in fam.items():
-            out["kernels"][k] = {"valu_issue_busy": sum(e["busy"]) / len(e["busy"]),
-                                 "valu_lane_ops_per_launch": sum(e["lane_ops"]) / len(e["lane_ops"]), "dispatches": len(e["busy"])}
+            W = sum(e["wt"])
+            out["kernels"][k] = {"valu_issue_busy": sum(b * w for b, w in zip(e["busy"], e["wt"])) / W,
+                                 "valu_lane_ops_per_launch": sum(o * w for o, w in zip(e["lane_ops"], e["wt"])) / W,
+                                 "valu_lane_ops_per_s": (e["ops_total"] / e["time_total"]) if e["time_total"] > 0 else None,
+                                 "dispatches": e["n"]}
         json.dump(out, open(a.valu_json, "w"), indent=1)
     if a.traffic_json:
         import json
@@ -142,13 +163,27 @@ def main():
                 k = ("k_amp_index" if s.startswith("k_amp_index") else "k_amp_direct" if s.startswith("k_amp_") else
                      "k_index_mh" if s.startswith("k_index_mh") else None)
                 if k:
-                    fam.setdefault(k, {}).setdefault(cname, []).append(float(r["Counter_Value"]) * 1024.0)
+                    fam.setdefault(k, {}).setdefault(cname, {}).setdefault(s, []).append(float(r["Counter_Value"]) * 1024.0)
+        # a family's bytes per launch: its kernels' means weighted by their call counts in the kernel-trace pass (the
+        # run the bench line describes; the short PMC passes see a different mix of first-iteration kernels)
+        calls = {}
+        if a.stats:
+            tf = glob.glob(os.path.join(a.stats, "**", "*kernel_stats.csv"), recursive=True)[0]
+            for r in csv.DictReader(open(tf)):
+                calls[short(r["Name"])] = float(r["Calls"])
+
+        def wmean(per_name):
+            if not per_name:
+                return 0.0
+            num = sum(calls.get(n, 1.0) * sum(v) / len(v) for n, v in per_name.items())
+            return num / sum(calls.get(n, 1.0) for n in per_name)
         out = {"source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH corrected by the measured "
-                         "k_cg_vec calibration factor %.3f)" % (os.path.join("profiles", os.path.basename(a.out)), a.fetch_factor),
+                         "k_cg_vec calibration factor %.3f; kernels of a family weighted by their calls in the kernel-trace pass)"
+                         % (os.path.join("profiles", os.path.basename(a.out)), a.fetch_factor),
                "config": a.config, "fetch_correction": a.fetch_factor, "kernels": {}}
         for k, v in fam.items():
-            fr = sum(v.get("FETCH_SIZE", [0.0])) / max(len(v.get("FETCH_SIZE", [0.0])), 1)
-            wr = sum(v.get("WRITE_SIZE", [0.0])) / max(len(v.get("WRITE_SIZE", [0.0])), 1)
+            fr = wmean(v.get("FETCH_SIZE", {}))
+            wr = wmean(v.get("WRITE_SIZE", {}))
             out["kernels"][k] = {"fetch_raw_bytes": fr, "fetch_corrected_bytes": fr * a.fetch_factor, "write_bytes": wr,
                                  "hbm_bytes_per_launch": fr * a.fetch_factor + wr}
         json.dump(out, open(a.traffic_json, "w"), indent=1)
