@@ -660,11 +660,22 @@ def compute_chisq(ddata):
     return ddata.chisq
 
 
-def sample_cg_groups(dpar: DangParams, ddata: DangData, it=1, verbose=False, defer_chisq=False):
+def _plain_sweep(eng, c, j):
+    """index j of component c is an ordinary per-pixel sweep at the map resolution with nothing to tune first"""
+    coarse = c.sample_nside[j] if c.sample_nside else 0
+    return (c.sample_index[j] and not (c.index_mode and c.index_mode[j] == 1) and not (coarse and coarse != eng.nside)
+            and not (c.tuned and not c.tuned[j]))
+
+
+def sample_cg_groups(dpar: DangParams, ddata: DangData, it=1, verbose=False, defer_chisq=False, fuse_first=None, it_index=None):
     """sample_cg_groups(dpar, ddata), src/dang_cg_mod.f90:142-177.
 
     defer_chisq=True skips the chi^2 pass after the amplitude phase; sample_spectral_parameters then
-    reports it (ddata.chisq_after_amp) from the value its first sweeps compute as a by-product."""
+    reports it (ddata.chisq_after_amp) from the value its first sweeps compute as a by-product.
+    fuse_first: a set; every group's solve is then issued together with the first index sweep that
+    sample_spectral_parameters (iteration it_index) would run on the same planes (Engine.amp_index_sample: one kernel
+    launch where the model allows it, bit for bit the two calls) and (component, index, flag) of that sweep is added to
+    the set -- pass it to sample_spectral_parameters(skip=...).  See gibbs_iteration."""
     eng = ddata.engine
     info = []
     for g in dpar.cg_groups:
@@ -672,6 +683,22 @@ def sample_cg_groups(dpar: DangParams, ddata: DangData, it=1, verbose=False, def
             continue
         has_global = any(c.cg_group == g.cg_group and c.type in ("template", "monopole", "hi_fit") for c in eng.component_list)
         for f in g.pol_flag:
+            first = None
+            if fuse_first is not None and dpar.solver != "cg" and f in _MAPN:
+                for l, c in enumerate(eng.component_list):
+                    hit = [j for j in range(c.nindices) if c.sample_index[j] and f in c.pol_flag[j]] if c.cg_group == g.cg_group else []
+                    if hit:
+                        first = (l, hit[0]) if _plain_sweep(eng, c, hit[0]) else None
+                        break
+            if first is not None:
+                l, j = first
+                bad, acc = eng.amp_index_sample(g.cg_group, f, dpar.ml_mode, dpar.seed, stream_id(it, 0, g.cg_group, 0, f),
+                                                l, j, _MAPN[f], dpar.nsample, dpar.seed,
+                                                stream_id(it if it_index is None else it_index, 1, l, j, f),
+                                                solver=dpar.solver, fluct_mode=dpar.fluct_mode)
+                fuse_first.add((l, j, f))
+                info.append((g.cg_group, f, 0, bad))
+                continue
             cg_it, bad = eng.amp_sample(g.cg_group, f, dpar.ml_mode, dpar.seed, stream_id(it, 0, g.cg_group, 0, f),
                                         solver=dpar.solver, fluct_mode=dpar.fluct_mode,
                                         i_max=g.i_max, converge=g.converge)
@@ -690,8 +717,12 @@ def sample_cg_groups(dpar: DangParams, ddata: DangData, it=1, verbose=False, def
 _MAPN = {L.FLAG_T: 1, L.FLAG_Q: 2, L.FLAG_U: 3, L.FLAG_QU: -1}  # src/dang_sample_mod.f90:53-64
 
 
-def sample_spectral_parameters(dpar: DangParams, ddata: DangData, it=2, verbose=False):
-    """sample_spectral_parameters(dpar, ddata), src/dang_sample_mod.f90:21-86 (per-pixel index_mode)."""
+def sample_spectral_parameters(dpar: DangParams, ddata: DangData, it=2, verbose=False, skip=()):
+    """sample_spectral_parameters(dpar, ddata), src/dang_sample_mod.f90:21-86 (per-pixel index_mode).
+
+    Two consecutive plain sweeps of one component on the same planes (dust beta, dust T) go through
+    Engine.index_sample_pair (one launch, bit for bit the two sweeps).  skip: (component, index, flag) sweeps already done
+    together with their group's solve (sample_cg_groups(fuse_first=...))."""
     eng = ddata.engine
     sampled = False
     info = []
@@ -699,10 +730,20 @@ def sample_spectral_parameters(dpar: DangParams, ddata: DangData, it=2, verbose=
         if c.nindices == 0 or not any(c.sample_index):
             continue
         sampled = True
+        paired = set()
         for j in range(c.nindices):
             if not c.sample_index[j]:
                 continue
             for f in c.pol_flag[j]:
+                if (l, j, f) in skip or (j, f) in paired:
+                    continue
+                if (f in _MAPN and j + 1 < c.nindices and _plain_sweep(eng, c, j) and _plain_sweep(eng, c, j + 1)
+                        and f in c.pol_flag[j + 1] and (l, j + 1, f) not in skip):
+                    a1, a2 = eng.index_sample_pair(l, j, _MAPN[f], dpar.nsample, dpar.ml_mode, dpar.seed,
+                                                   stream_id(it, 1, l, j, f), stream_id(it, 1, l, j + 1, f))
+                    info.append((l, j, f, a1)); info.append((l, j + 1, f, a2))
+                    paired.add((j + 1, f))
+                    continue
                 if f not in _MAPN:
                     raise DangxError("There is something wrong with the poltype flag for component " + c.label)
                 coarse = c.sample_nside[j] if c.sample_nside else 0
@@ -735,6 +776,17 @@ def sample_spectral_parameters(dpar: DangParams, ddata: DangData, it=2, verbose=
         if verbose:
             print("%6d - Chisq: %16.5E" % (it, ddata.chisq))
     return info
+
+
+def gibbs_iteration(dpar: DangParams, ddata: DangData, it, verbose=False):
+    """sample_cg_groups followed by sample_spectral_parameters (one pass of the main loop, src/dang.f90:87-126, for
+    iterations in which both run) with every group's solve issued together with the first sweep on its planes: the same
+    state, bit for bit, as the two calls with the same `it`, in fewer kernel launches.  chi^2 after the amplitude phase
+    comes from the sweeps' by-product (ddata.chisq_after_amp)."""
+    done = set()
+    a = sample_cg_groups(dpar, ddata, it=it, verbose=False, defer_chisq=True, fuse_first=done, it_index=it)
+    b = sample_spectral_parameters(dpar, ddata, it=it, verbose=verbose, skip=done)
+    return a, b
 
 
 # --------------------------------------------------------------------------- full-sky mode, tuner, calibrators

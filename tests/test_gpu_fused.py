@@ -165,3 +165,31 @@ def test_index_sample_pair_equals_the_two_sweeps_bitwise(built, config, nside, m
                 assert one.chisq_cached(which, *k) == two.chisq_cached(which, *k), (l, which)
             ran += 1
     assert ran >= 4
+
+
+@pytest.mark.parametrize("config,nside", [("C3", 8), ("C2", 8)])
+def test_python_mirror_gibbs_iteration_equals_the_two_phases(built, config, nside):
+    """da.gibbs_iteration (solves issued with the first sweeps, consecutive indices paired) against da.sample_cg_groups +
+    a sample_spectral_parameters that makes every sweep on its own: same state and same chi^2 after each of three
+    iterations, bit for bit."""
+    case_a = make_case(config, nside=nside)
+    case_b = make_case(config, nside=nside)
+    for case in (case_a, case_b):
+        da.initialize(case[2], case[3], case[1], npix_global=case[4]["npix_global"], device=0)
+    (dpa, dda), (dpb, ddb) = (case_a[0], case_a[1]), (case_b[0], case_b[1])
+    comps = case_b[3]
+    for it in range(1, 4):
+        da.gibbs_iteration(dpa, dda, it)
+        da.sample_cg_groups(dpb, ddb, it=it, defer_chisq=True)
+        eng = ddb.engine
+        for l, c in enumerate(comps):                       # the index phase, one sweep per call
+            for j in range(c.nindices):
+                if c.sample_index[j]:
+                    for f in c.pol_flag[j]:
+                        eng.index_sample(l, j, MAPN[f], dpb.nsample, dpb.ml_mode, dpb.seed, da.stream_id(it, 1, l, j, f))
+        for l, c in enumerate(comps):
+            assert np.array_equal(dda.engine.get_amplitude(l), eng.get_amplitude(l)), (it, l)
+            if c.nindices:
+                assert np.array_equal(dda.engine.get_indices(l), eng.get_indices(l)), (it, l)
+        assert dda.engine.chisq_cached(1, 1, 3) == eng.chisq_cached(1, 1, 3)
+        assert dda.chisq == dda.engine.chisq_cached(1, 1, 3) / case_a[4]["nbands"] / dda.nump
