@@ -349,7 +349,7 @@ contains
     integer(c_int64_t) :: nacc
     real(c_double), target :: tpeek(2)
     type(dangx_comp_desc) :: d
-    logical(lgt) :: sampled
+    logical(lgt) :: sampled, pair_done, pairable
     sampled = .false.
     mode = merge(DANGX_ML_SAMPLE, DANGX_ML_OPTIMIZE, trim(dpar%ml_mode) == 'sample')
     do i = 1, ncomp
@@ -357,7 +357,12 @@ contains
        if (cc%nindices == 0) cycle
        if (.not. any(cc%sample_index)) cycle
        sampled = .true.
+       pair_done = .false.
        do j = 1, cc%nindices
+          if (pair_done) then                            ! this index went with the one before it (one launch)
+             pair_done = .false.
+             cycle
+          end if
           if (.not. cc%sample_index(j)) cycle
           do k = 1, cc%nflag(j)
              if (iand(cc%pol_flag(j,k),1) .ne. 0) then
@@ -397,8 +402,24 @@ contains
                    call fill_desc(cc, d)
                    call dangx_sky_set_component(gpu_sky, i-1, d)   ! the new step size
                 end if
-                call dangx_sky_index_sample(gpu_sky, i-1, j-1, map_n, nsample, mode, gpu_seed, &
-                     dangx_stream_id(iter, 1, i-1, j-1, cc%pol_flag(j,k)))
+                ! two consecutive plain per-pixel sweeps of this component on the same planes (dust beta, dust T): one entry
+                ! point, one kernel launch where the register chain covers both -- the same numbers as the two sweeps
+                pairable = .false.
+                if (j < cc%nindices .and. cc%nflag(j) == 1) then
+                   if (cc%sample_index(j+1) .and. cc%nflag(j+1) == 1) then
+                      pairable = cc%pol_flag(j+1,1) == cc%pol_flag(j,k) .and. cc%index_mode(j+1) /= 1 .and. &
+                           cc%sample_nside(j+1) == nside .and. cc%tuned(j+1)
+                   end if
+                end if
+                if (pairable) then
+                   write(*,fmt='(a,i4)') 'Sampling per-pixel at nside ', cc%sample_nside(j+1)
+                   call dangx_sky_index_sample_pair(gpu_sky, i-1, j-1, map_n, nsample, mode, gpu_seed, &
+                        dangx_stream_id(iter, 1, i-1, j-1, cc%pol_flag(j,k)), dangx_stream_id(iter, 1, i-1, j, cc%pol_flag(j,k)))
+                   pair_done = .true.
+                else
+                   call dangx_sky_index_sample(gpu_sky, i-1, j-1, map_n, nsample, mode, gpu_seed, &
+                        dangx_stream_id(iter, 1, i-1, j-1, cc%pol_flag(j,k)))
+                end if
              end if
           end do
        end do
