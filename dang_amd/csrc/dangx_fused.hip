@@ -269,8 +269,10 @@ bool DX_CAT(dx_launch_fused_mode, DX_REG_MODE)(dangx_ctx* ctx, const GroupArgs& 
                                               unsigned nblk, unsigned long long* accp) {
     const int nb = ctx->hm.nbands;
     // the instantiated (band count, group size) pairs: keep dx_fused_supported below in step
-    if (nb == 10 && ga.ng == 4) launch_fused_case<10, 4>(ctx, ga, fa, a, Sp, nblk, accp);
-    else if (nb == 5 && ga.ng == 3) launch_fused_case<5, 3>(ctx, ga, fa, a, Sp, nblk, accp);
+    if (nb == 10 && ga.ng == 4) launch_fused_case<10, 4>(ctx, ga, fa, a, Sp, nblk, accp);        // C3
+    else if (nb == 10 && ga.ng == 3) launch_fused_case<10, 3>(ctx, ga, fa, a, Sp, nblk, accp);
+    else if (nb == 5 && ga.ng == 3) launch_fused_case<5, 3>(ctx, ga, fa, a, Sp, nblk, accp);     // C2
+    else if (nb == 3 && ga.ng == 2) launch_fused_case<3, 2>(ctx, ga, fa, a, Sp, nblk, accp);     // C1
     else return false;
     return true;
 }
@@ -281,7 +283,7 @@ bool dx_launch_fused_mode3(dangx_ctx*, const GroupArgs&, const FusedArgs&, const
 
 // which (band count, group size) the fused kernel is instantiated for
 bool dx_fused_supported(int mode, int nb, int ng) {
-    return mode >= CH_POW && mode <= CH_MBB_T && ((nb == 10 && ng == 4) || (nb == 5 && ng == 3));
+    return mode >= CH_POW && mode <= CH_MBB_T && ((nb == 10 && (ng == 4 || ng == 3)) || (nb == 5 && ng == 3) || (nb == 3 && ng == 2));
 }
 
 // ga: the pending amplitude solve; a: the index sweep that follows it on the same planes.  false: not covered.

@@ -94,7 +94,10 @@ bool DX_CATP(dx_launch_mh_pair_mode, DX_REG_MODE)(dangx_ctx* ctx, const IndexArg
     if (Sp == 2) {
         if (nb == 10) DX_LAUNCH_PAIR(2, 10, 1); else if (nb == 5) DX_LAUNCH_PAIR(2, 5, 1);
         else if (nb == 20 && dx_mh_reg_lanes(nb, Sp) == 2) DX_LAUNCH_PAIR(2, 20, 2); else return false;
-    } else { if (nb == 10) DX_LAUNCH_PAIR(1, 10, 1); else if (nb == 5) DX_LAUNCH_PAIR(1, 5, 1); else if (nb == 20) DX_LAUNCH_PAIR(1, 20, 1); else return false; }
+    } else {
+        if (nb == 10) DX_LAUNCH_PAIR(1, 10, 1); else if (nb == 5) DX_LAUNCH_PAIR(1, 5, 1); else if (nb == 20) DX_LAUNCH_PAIR(1, 20, 1);
+        else if (nb == 3) DX_LAUNCH_PAIR(1, 3, 1); else return false;
+    }
 #undef DX_LAUNCH_PAIR
     return true;
 }
@@ -137,7 +140,7 @@ bool dx_launch_mh_pair_mode4(dangx_ctx*, const IndexArgs&, const IndexArgs&, int
 // index a.nind and a.nind + 1 of one component in one launch; false: not covered (the caller makes the two launches)
 bool dx_mh_pair_supported(int mode_a, int mode_b, int nb, int Sp) {
     if (!((mode_a == CH_MBB_BETA && mode_b == CH_MBB_T) || (mode_a == CH_LOGN_NUP && mode_b == CH_LOGN_W))) return false;
-    return Sp == 2 ? (nb == 10 || nb == 5 || (nb == 20 && dx_mh_reg_lanes(nb, Sp) == 2)) : (nb == 10 || nb == 5 || nb == 20);
+    return Sp == 2 ? (nb == 10 || nb == 5 || (nb == 20 && dx_mh_reg_lanes(nb, Sp) == 2)) : (nb == 10 || nb == 5 || nb == 20 || nb == 3);
 }
 bool dx_launch_mh_pair(dangx_ctx* ctx, const IndexArgs& a, const IndexArgs& b, int Sp, unsigned nblk, unsigned long long* accp) {
     if (!dx_mh_pair_supported(a.mode, b.mode, ctx->hm.nbands, Sp)) return false;

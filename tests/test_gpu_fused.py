@@ -31,13 +31,14 @@ def _first_sweep(comps, group):
 
 
 @pytest.mark.parametrize("ml_mode", ["sample", "optimize"])
-@pytest.mark.parametrize("start", ["truth", "prior"])
-def test_fused_equals_the_two_calls_bitwise(built, ml_mode, start):
-    """C3's model (10 bands, cmb + synch + dust + ff, IQU) at Nside 8: three Gibbs iterations, the fused entry point on
-    one context and amp_sample + index_sample on another; amplitudes, indices, chi^2 sums and both counters are equal bit
-    for bit after every iteration.  start='prior' begins with spatially constant index maps, i.e. passes through the
-    states in which the fused launch is not taken (first sweeps) and those in which it is."""
-    case = make_case("C3", nside=8, start=start)
+@pytest.mark.parametrize("config,start", [("C3", "truth"), ("C3", "prior"), ("C2", "prior"), ("C1", "prior")])
+def test_fused_equals_the_two_calls_bitwise(built, ml_mode, config, start):
+    """The BASELINE models (C3: 10 bands, cmb + synch + dust + ff, IQU; C2: 5 bands, 3 components, IQU; C1: 3 bands, 2
+    components, I) at Nside 8: three Gibbs iterations, the fused entry point on one context and amp_sample + index_sample
+    on another; amplitudes, indices, chi^2 sums and both counters are equal bit for bit after every iteration.
+    start='prior' begins with spatially constant index maps, i.e. passes through the states in which the fused launch is
+    not taken (first sweeps) and those in which it is."""
+    case = make_case(config, nside=8, start=start)
     dpar, ddata, bands, comps, meta = case
     fus, two = _engines(case)
     prof = []
@@ -68,7 +69,7 @@ def test_fused_equals_the_two_calls_bitwise(built, ml_mode, start):
             if c.nindices:
                 assert np.array_equal(fus.get_indices(l), two.get_indices(l)), (it, l)
         for which in (0, 1):
-            assert fus.chisq_cached(which, 1, 3) == two.chisq_cached(which, 1, 3), (it, which)
+            assert fus.chisq_cached(which, 1, meta["nmaps"]) == two.chisq_cached(which, 1, meta["nmaps"]), (it, which)
     counts_f = [p[1:] for p in prof if p[0]]
     counts_t = [p[1:] for p in prof if not p[0]]
     assert counts_f == counts_t and any(a > 0 for _, a in counts_f)
