@@ -73,7 +73,9 @@ __device__ __forceinline__ void uniform3(unsigned long long seed, unsigned long 
 // sin(2 pi u2) is evaluated as sinpi(2 u2) (no rounding of theta); log by log_pos (u1 is normal).
 __device__ __forceinline__ double rand_normal(double mean, double stdev, double u1, double u2) {
     const double r = fast_sqrt(-2.0 * log_pos(u1));  // u1 in (0,1): the argument is in [1e-16, 75]
-    return mean + stdev * r * sin_2pi(u2);
+    // one explicit fma: "x + (mean + a*b)" at a call site with mean = 0 could otherwise be contracted into fma(a, b, x) in
+    // one kernel and left as a rounded product plus an addition in another (see log_pos)
+    return fma(stdev * r, sin_2pi(u2), mean);
 }
 
 }  // namespace dx

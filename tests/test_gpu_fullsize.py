@@ -179,3 +179,33 @@ def test_fullsize_gibbs_chain_with_the_textbook_fluctuation_term(built):
         trace.append(ddata.chisq)
     assert np.all(np.isfinite(trace))
     assert trace[0] > 5.0 and abs(np.mean(trace[-20:]) - 1.0) < 0.03, (trace[0], trace[-1])
+
+
+@pytest.mark.parametrize("config", ["C3", "C5"])
+def test_fused_launches_fullsize_bitwise(built, config):
+    """The BASELINE skies at full size through the fused entry points (da.gibbs_iteration: each group's solve with the
+    first sweep on its planes, consecutive indices of a component in one launch) against one launch per step: the same
+    amplitude and index maps bit for bit after three iterations, the same chi^2 sums.  (C5: the solve is not fused -- its
+    log-normal member varies -- but the dust pairs are, on the T plane and, as lane pairs, on Q+U.)"""
+    _free_device_memory()
+    dev = torch.device("cuda", 0)
+    runs = []
+    for fused in (True, False):
+        dpar, ddata, bands, comps, meta = synth.make_sky(config, device=dev, as_numpy=False)
+        eng = da.initialize(bands, comps, ddata, npix_global=meta["npix_global"], device=0)
+        for it in range(1, 4):
+            if fused:
+                da.gibbs_iteration(dpar, ddata, it)
+            else:
+                for g in dpar.cg_groups:
+                    for f in g.pol_flag:
+                        eng.amp_sample(g.cg_group, f, dpar.ml_mode, dpar.seed, da.stream_id(it, 0, g.cg_group, 0, f))
+                _sweeps(eng, comps, dpar, it, dpar.ml_mode)
+        eng.synchronize()
+        runs.append((comps, eng.chisq_cached(0, 1, 3), eng.chisq_cached(1, 1, 3)))
+    (ca, b0, a0), (cb, b1, a1) = runs
+    for x, y in zip(ca, cb):
+        assert torch.equal(x.amplitude, y.amplitude), x.label
+        if x.nindices:
+            assert torch.equal(x.indices, y.indices), x.label
+    assert b0 == b1 and a0 == a1
