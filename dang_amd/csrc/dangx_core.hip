@@ -178,6 +178,58 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_chi(const double* __restrict__
     }
 }
 
+// the same two stages for up to CHI_RING sweeps at once, in launch order (identical sums: same chunks, same trees)
+struct ChiBatch {
+    const double* buf[dangx_ctx::CHI_RING];
+    long long nblk[dangx_ctx::CHI_RING];
+    int s1[dangx_ctx::CHI_RING], s2[dangx_ctx::CHI_RING], wb[dangx_ctx::CHI_RING];
+    int n;
+};
+__global__ __launch_bounds__(BLOCK) void k_reduce_rows_batch(ChiBatch b, double* __restrict__ stage) {
+    __shared__ double sh[BLOCK];
+    const int e = blockIdx.y;
+    const double* in = b.buf[e];
+    const long long n = b.nblk[e];
+    double* out = stage + (long long)e * 4 * gridDim.x;
+    const long long chunk = (n + gridDim.x - 1) / gridDim.x;
+    const long long lo = (long long)blockIdx.x * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+    for (int q = 0; q < 4; ++q) {
+        double s = 0.0;
+        for (long long t = lo + threadIdx.x; t < hi; t += BLOCK) s += in[(long long)q * n + t];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = BLOCK / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[(long long)q * gridDim.x + blockIdx.x] = sh[0];
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_reduce_chi_batch(ChiBatch b, const double* __restrict__ stage, long long n,
+                                                            double* __restrict__ cache) {
+    __shared__ double sh[BLOCK];
+    for (int e = 0; e < b.n; ++e) {
+        const double* partial = stage + (long long)e * 4 * n;
+        for (int q = 0; q < 4; ++q) {
+            double s = 0.0;
+            for (long long t = threadIdx.x; t < n; t += BLOCK) s += partial[(long long)q * n + t];
+            sh[threadIdx.x] = s;
+            __syncthreads();
+            for (int o = BLOCK / 2; o > 0; o >>= 1) {
+                if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                const int plane = (q & 1) ? b.s2[e] : b.s1[e];
+                const bool after = q >= 2;
+                if (!((q & 1) && b.s1[e] == b.s2[e]) && (after || b.wb[e])) cache[(after ? 3 : 0) + plane - 1] = sh[0];
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // out[0] = sum over planes pol_lo..pol_hi of cache[which*3 + plane-1]
 __global__ void k_chi_from_cache(const double* __restrict__ cache, int which, int pol_lo, int pol_hi, double* __restrict__ out) {
     double s = 0.0;
@@ -899,6 +951,41 @@ int ensure_work(dangx_ctx* ctx, long long n) {
 }
 
 
+constexpr int CHI_RSTAGE = 128;  // blocks of the first reduction stage of the sweeps' chi^2 partials
+
+// reduce every pending sweep's block partials into chi_cache (two launches for all of them, in launch order)
+int chi_flush(dangx_ctx* ctx) {
+    if (ctx->chi_npend == 0) return 0;
+    if (!ctx->chi_stage) HIPCHK(ctx, hipMalloc(&ctx->chi_stage, sizeof(double) * dangx_ctx::CHI_RING * 4 * CHI_RSTAGE));
+    ChiBatch b;
+    b.n = ctx->chi_npend;
+    for (int e = 0; e < b.n; ++e) {
+        const auto& p = ctx->chi_pend[e];
+        b.buf[e] = p.buf; b.nblk[e] = p.nblk; b.s1[e] = p.s1; b.s2[e] = p.s2; b.wb[e] = p.wb;
+    }
+    for (int e = b.n; e < dangx_ctx::CHI_RING; ++e) { b.buf[e] = nullptr; b.nblk[e] = 0; b.s1[e] = b.s2[e] = 1; b.wb[e] = 0; }
+    {
+        Timed t(ctx, DANGX_K_REDUCE);
+        hipLaunchKernelGGL(k_reduce_rows_batch, dim3(CHI_RSTAGE, b.n), dim3(BLOCK), 0, ctx->stream, b, ctx->chi_stage);
+        hipLaunchKernelGGL(k_reduce_chi_batch, dim3(1), dim3(BLOCK), 0, ctx->stream, b, ctx->chi_stage, (long long)CHI_RSTAGE, ctx->chi_cache);
+    }
+    ctx->chi_npend = 0;
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+// the buffer the next sweep writes its chi^2 block partials to ([4][nblk]); flushes first when the ring is full
+int chi_next(dangx_ctx* ctx, long long nblk, double** buf) {
+    if (ctx->chi_npend == dangx_ctx::CHI_RING && chi_flush(ctx)) return 1;
+    auto& p = ctx->chi_pend[ctx->chi_npend];
+    if (p.cap < 4 * nblk) {
+        if (p.buf) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(p.buf); p.buf = nullptr; p.cap = 0; }
+        HIPCHK(ctx, hipMalloc(&p.buf, sizeof(double) * (size_t)(4 * nblk)));
+        p.cap = 4 * nblk;
+    }
+    *buf = p.buf;
+    return 0;
+}
+
 int make_group(dangx_ctx* ctx, int group, int flag, GroupArgs& a) {
     if (flag != DANGX_FLAG_T && flag != DANGX_FLAG_Q && flag != DANGX_FLAG_U && flag != DANGX_FLAG_QU)
         return fail(ctx, "flag must be exactly one of T(1), Q(2), U(4), Q+U(8)");
@@ -1340,6 +1427,8 @@ int dangx_destroy(dangx_ctx* ctx) {
     ctx->hp_nside = ctx->hp_cnside = 0; ctx->cs_cap = 0;
     (void)hipFree(ctx->rows_out);
     (void)hipFree(ctx->dm); (void)hipFree(ctx->scalars); (void)hipFree(ctx->counters); (void)hipFree(ctx->chi_cache);
+    for (auto& p : ctx->chi_pend) if (p.buf) (void)hipFree(p.buf);
+    if (ctx->chi_stage) (void)hipFree(ctx->chi_stage);
     for (auto& e : ctx->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     delete ctx;
     return 0;
@@ -1747,7 +1836,16 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
     if (reg_ok) bs = BLOCK;  // register-resident form: no LDS columns
     const unsigned nblk = nblocks((long long)ctx->hm.npix * (reg_ok ? dx_mh_reg_lanes(ctx->hm.nbands, Sp) : 1), bs);
     constexpr int RSTAGE = 128;  // blocks of the first reduction stage
-    if (ensure_partial(ctx, 4ll * nblk + 4ll * RSTAGE)) return 1;
+    double* chi_buf = nullptr;
+    if (chi_next(ctx, nblk, &chi_buf)) return 1;
+    // the sweep kernels take their [4][nblk] chi^2 partial buffer from ctx->partial: lend them the ring's, give the
+    // context's own back on every way out of the launch section
+    struct Lend {
+        dangx_ctx* c; double* saved;
+        Lend(dangx_ctx* c_, double* b) : c(c_), saved(c_->partial) { c->partial = b; }
+        void back() { if (c) { c->partial = saved; c = nullptr; } }
+        ~Lend() { back(); }
+    } lend(ctx, chi_buf);
     if (accepted) HIPCHK(ctx, hipMemsetAsync(ctx->counters + 1, 0, 2 * sizeof(unsigned long long), ctx->stream));
     bool fused = false;
     if (ctx->have_pending) {  // an amplitude solve on these planes is waiting: one launch for both, or the solve first
@@ -1782,13 +1880,12 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
                           (a.mode == CH_POW || a.mode == CH_MBB_BETA || a.mode == CH_MBB_T);
         if (!(reg_ok && dx_launch_mh_reg(ctx, a, Sp, nblk, accp))) dx_launch_mh_lds(ctx, a, fast, Sp, nblk, bs, lds, accp);
     }
-    {   // fused chi^2 of the touched planes (before = state left by the amplitude phase, after = new state)
+    lend.back();
+    {   // fused chi^2 of the touched planes (before = state left by the amplitude phase, after = new state): the block
+        // partials wait in the ring (chi_flush) until a value is asked for
         const bool wb = !ctx->touched_since_amp[a.s1 - 1];
-        Timed t(ctx, DANGX_K_REDUCE);
-        double* stage = ctx->partial + 4ll * nblk;
-        hipLaunchKernelGGL(k_reduce_rows, dim3(RSTAGE), dim3(BLOCK), 0, ctx->stream, ctx->partial, (long long)nblk, 4, stage);
-        hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(BLOCK), 0, ctx->stream, stage, (long long)RSTAGE, a.s1, a.s2,
-                           wb ? 1 : 0, ctx->chi_cache);
+        auto& pend = ctx->chi_pend[ctx->chi_npend++];
+        pend.nblk = nblk; pend.s1 = a.s1; pend.s2 = a.s2; pend.wb = wb ? 1 : 0;
         for (int k = a.s1; k <= a.s2; ++k) {
             if (wb) ctx->chi_before_valid[k - 1] = true;
             ctx->chi_after_valid[k - 1] = true;
@@ -1901,6 +1998,7 @@ int dangx_chisq_cached_dev(dangx_ctx* ctx, int which, int pol_lo, int pol_hi, do
             ctx->err = "cached chi^2 not available for plane " + std::to_string(k);
             return 2;
         }
+    if (chi_flush(ctx)) return 1;
     hipLaunchKernelGGL(k_chi_from_cache, dim3(1), dim3(1), 0, ctx->stream, ctx->chi_cache, which, pol_lo, pol_hi, out_dev);
     HIPCHK(ctx, hipGetLastError());
     return 0;

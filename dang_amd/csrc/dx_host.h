@@ -92,6 +92,13 @@ struct dangx_ctx {
     long long partial_cap = 0;
     double* scalars = nullptr;              // device scalars [8]
     double* chi_cache = nullptr;            // device [6]: chi^2 before/after of planes 1..3 (fused in k_index_mh)
+    // block partials of the sweeps' chi^2 sums wait here until somebody asks for a value (dangx_chisq_cached) or the ring
+    // is full: ONE pair of reduction launches then serves every sweep since the last one (in launch order), instead of
+    // two small launches behind every sweep -- 6 % of a rank's iteration at the 8-rank shard size
+    static constexpr int CHI_RING = 8;
+    struct ChiPend { double* buf = nullptr; long long cap = 0, nblk = 0; int s1 = 0, s2 = 0, wb = 0; } chi_pend[CHI_RING];
+    int chi_npend = 0;
+    double* chi_stage = nullptr;
     bool chi_before_valid[3] = {}, chi_after_valid[3] = {}, touched_since_amp[3] = {};
     unsigned long long* counters = nullptr; // device counters [4]
     long long host_stride = 0;              // doubles between consecutive planes of host map arrays (0 = npix: packed)
