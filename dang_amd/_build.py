@@ -37,7 +37,7 @@ def hip_sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(ROOT, "include", "dangx.h")]
 
 
-UNITS = [("dangx_core", "dangx_core.hip", []), ("dangx_amp", "dangx_amp.hip", []), ("dangx_ampreg", "dangx_ampreg.hip", []), ("dangx_mixed", "dangx_mixed.hip", []), ("dangx_schur", "dangx_schur.hip", []),
+UNITS = [("dangx_core", "dangx_core.hip", []), ("dangx_sky", "dangx_sky.hip", []), ("dangx_amp", "dangx_amp.hip", []), ("dangx_ampreg", "dangx_ampreg.hip", []), ("dangx_mixed", "dangx_mixed.hip", []), ("dangx_schur", "dangx_schur.hip", []),
          ("dangx_mh", "dangx_mh.hip", []),
          ("dangx_mhreg", "dangx_mhreg.hip", [])] + \
         [("dangx_mhreg_m%d" % m, "dangx_mhreg.hip", ["-DDX_REG_MODE=%d" % m]) for m in (1, 2, 3, 4, 5)] + \
@@ -58,10 +58,19 @@ def build_hip(force=False, verbose=False):
     common = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
               "-Rpass-analysis=kernel-resource-usage"]
 
+    headers = [f for f in hip_sources() if f.endswith(".h")]
+
     def one(unit):
         name, srcfile, defs = unit
-        obj = os.path.join(objdir, name + ".o")
-        return obj, _run(common + defs + ["-c", "-o", obj, os.path.join(CSRC, srcfile)])
+        obj, log = os.path.join(objdir, name + ".o"), os.path.join(objdir, name + ".log")
+        src = os.path.join(CSRC, srcfile)
+        if not force and os.path.exists(log) and not _newer(obj, [src] + headers):   # this unit is up to date
+            with open(log) as f:
+                return obj, f.read()
+        out = _run(common + defs + ["-c", "-o", obj, src])
+        with open(log, "w") as f:
+            f.write(out)
+        return obj, out
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         results = list(ex.map(one, UNITS))
@@ -115,6 +124,24 @@ def check_reference_side():
     return True
 
 
+def build_reference_drive(force=False):
+    """flang -> fortran/reference_side/dang_gpu_drive: the reference-side wrapper (dang_gpu_mod.f90) compiled against the mock
+    modules of stubs/stubs.f90 and linked with libdangx.so, plus the driver that plays `program dang` for it -- so that the
+    wrapper RUNS on a GPU in the tests and in bench.py (`fortran_seam`).  Nothing of the reference is compiled."""
+    ref = os.path.join(FORTRAN_DIR, "reference_side")
+    if not os.path.exists(FLANG) or not os.path.isdir(ref):
+        return None
+    exe = os.path.join(ref, "dang_gpu_drive")
+    src = [os.path.join(FORTRAN_DIR, "dangx_mod.f90"), os.path.join(FORTRAN_DIR, "dangx_multi_mod.f90"),
+           os.path.join(ref, "stubs", "stubs.f90"), os.path.join(ref, "dang_gpu_mod.f90"), os.path.join(ref, "dang_gpu_drive.f90")]
+    if not force and not _newer(exe, src + [LIB]):
+        return exe
+    moddir = os.path.join(ref, "mod")
+    os.makedirs(moddir, exist_ok=True)
+    _run([FLANG, "-O2", "-J", moddir, "-o", exe] + src + ["-L" + LIBDIR, "-ldangx", "-Wl,-rpath," + LIBDIR])
+    return exe
+
+
 def build_ubench(force=False):
     """hipcc -> dang_amd/lib/ub/{isa_rate,stream_planes}: the microbenchmarks behind profiles/r02_isa_rate.txt and
     profiles/r02_stream_planes.txt (measurement tools, not part of the library)."""
@@ -137,6 +164,7 @@ def build_all(force=False):
     build_oracle(force)
     build_fortran(force)
     check_reference_side()
+    build_reference_drive(force)
 
 
 if __name__ == "__main__":

@@ -98,8 +98,8 @@ SYMBOLS = {
     "dangx_index_sample_pair": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64,
                                           C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "dangx_amp_index_sample": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
-                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
-                                         C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+                                         C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
+                                         C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "dangx_sky_model_chisq": (C.c_int, [_P, C.c_int, C.c_int, _D, _P, _P, _P]),
     "dangx_sky_model_chisq_dev": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "dangx_chisq_cached": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _D]),
@@ -110,6 +110,19 @@ SYMBOLS = {
     "dangx_fill_index": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_double]),
     "dangx_gain_sums": (C.c_int, [_P, C.c_int, _P]),
     "dangx_peek_indices": (C.c_int, [_P, C.c_int, C.c_int, C.c_longlong, _P]),
+    "dangx_fullsky_finish_coarse": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    # the sky-wide steps, chain included: (ctxs, nctx, ...) = the contexts of this process in shard order
+    "dangx_fullsky_sample": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
+                                       C.c_int, C.c_int, C.POINTER(C.c_int32), _D, _D, C.POINTER(C.c_int64)]),
+    "dangx_tune_step_size": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _D,
+                                       C.POINTER(C.c_uint32), C.POINTER(C.c_int32), _D]),
+    "dangx_tune_perpixel": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
+                                      C.POINTER(C.c_int32), _D]),
+    "dangx_fit_band_gain": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _D]),
+    "dangx_update_tcmb": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, _D]),
+    "dangx_plan_fusion": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
+    "dangx_sky_amp_sample": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
+                                       C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "dangx_group_size": (C.c_int64, [_P, C.c_int, C.c_int]),
     "dangx_compute_rhs": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "dangx_compute_Ax": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),

@@ -21,7 +21,6 @@ import math
 
 from . import _lib as L
 from . import dist as _dist
-from . import rng as _rng
 
 MISSVAL = -1.6375e30  # src/dang_util_mod.f90:19
 
@@ -346,16 +345,16 @@ class Engine:
         return a1.value, a2.value
 
     def amp_index_sample(self, group, flag, ml_mode, seed_amp, stream_amp, comp, nind, map_n, nsample, seed_index,
-                         stream_index, solver="direct", fluct_mode="reference", want_counts=True):
+                         stream_index, solver="direct", fluct_mode="reference", want_counts=True, i_max=100, converge=1e-8):
         """amp_sample(group, flag, ...) followed by index_sample(comp, nind, map_n, ...) on the same planes -- one kernel
         launch when the model allows it, the two calls otherwise; bit for bit the same result either way.
         Returns (units whose block was not positive definite, accepted proposals)."""
         bad, acc = C.c_int64(0), C.c_int64(0)
         self._chk(self.lib.dangx_amp_index_sample(
             self.h, group, flag, L.ML_CODES[ml_mode], L.SOLVER_CG if solver == "cg" else L.SOLVER_DIRECT,
-            L.FLUCT_REFERENCE if fluct_mode == "reference" else L.FLUCT_CORRECT, seed_amp, stream_amp,
+            L.FLUCT_REFERENCE if fluct_mode == "reference" else L.FLUCT_CORRECT, seed_amp, stream_amp, i_max, converge,
             comp, nind, map_n, nsample, seed_index, stream_index,
-            C.byref(bad) if want_counts else None, C.byref(acc) if want_counts else None))
+            None, C.byref(bad) if want_counts else None, C.byref(acc) if want_counts else None))
         return bad.value, acc.value
 
     def sky_model_chisq(self, pol_lo, pol_hi, want_maps=False):
@@ -651,6 +650,17 @@ def index_sample_coarse_multi(engines, comp, nind, map_n, nsample, ml_mode, seed
     return int(idx[-1])
 
 
+def sky_amp_sample(engines, group, flag, ml_mode, seed, stream, solver="direct", fluct_mode="reference", i_max=100, converge=1e-8):
+    """One (group, flag) pass of sample_cg_groups over several pixel-shard contexts of ONE process (dangx_sky_amp_sample): a
+    group with template / monopole / hi_fit members shares its Schur rows over the contexts.  Returns (cg_iters, n_not_spd)."""
+    arr, n = _ctx_array(engines)
+    it, bad = C.c_int(0), C.c_int64(0)
+    engines[0]._chk(engines[0].lib.dangx_sky_amp_sample(
+        arr, n, group, flag, L.ML_CODES[ml_mode], L.SOLVER_CG if solver == "cg" else L.SOLVER_DIRECT,
+        L.FLUCT_REFERENCE if fluct_mode == "reference" else L.FLUCT_CORRECT, seed, stream, i_max, converge, C.byref(it), C.byref(bad)))
+    return it.value, bad.value
+
+
 def compute_chisq(ddata):
     """update_sky_model + compute_chisq (src/dang_data_mod.f90:339-396, 494-526); all-reduced over shards."""
     eng = ddata.engine
@@ -667,35 +677,52 @@ def _plain_sweep(eng, c, j):
             and not (c.tuned and not c.tuned[j]))
 
 
+def fusable_first_sweeps(dpar, eng):
+    """{(cg_group, flag): (component, index)} -- the solves that may be issued TOGETHER with the first index sweep on their
+    planes without changing the result of the main loop (the reference runs every solve of sample_cg_groups before any sweep
+    of sample_spectral_parameters).  The rule lives behind the ABI, once for every host: dangx_plan_fusion
+    (dang_amd/csrc/dangx_sky.hip); here the two lists are put together in the reference's loop orders."""
+    comps = eng.component_list
+    pairs = [(g.cg_group, f) for g in dpar.cg_groups if g.sample for f in g.pol_flag]
+    sweeps = [(l, j, f, 1 if _plain_sweep(eng, c, j) else 0) for l, c in enumerate(comps) for j in range(c.nindices)
+              if c.sample_index[j] for f in c.pol_flag[j]]
+    if not pairs or not sweeps:
+        return {}
+    i32 = lambda v: np.ascontiguousarray(v, dtype=np.int32)
+    pg, pf = i32([p[0] for p in pairs]), i32([p[1] for p in pairs])
+    sc, sn, sf, sp = (i32([s[q] for s in sweeps]) for q in range(4))
+    first = np.full(len(pairs), -1, dtype=np.int32)
+    eng._chk(eng.lib.dangx_plan_fusion(eng.h, len(pairs), pg.ctypes.data, pf.ctypes.data, len(sweeps), sc.ctypes.data, sn.ctypes.data,
+                                       sf.ctypes.data, sp.ctypes.data, L.SOLVER_CG if dpar.solver == "cg" else L.SOLVER_DIRECT,
+                                       first.ctypes.data))
+    return {pairs[p]: sweeps[e][:2] for p, e in enumerate(first) if e >= 0}
+
+
 def sample_cg_groups(dpar: DangParams, ddata: DangData, it=1, verbose=False, defer_chisq=False, fuse_first=None, it_index=None):
     """sample_cg_groups(dpar, ddata), src/dang_cg_mod.f90:142-177.
 
     defer_chisq=True skips the chi^2 pass after the amplitude phase; sample_spectral_parameters then
     reports it (ddata.chisq_after_amp) from the value its first sweeps compute as a by-product.
-    fuse_first: a set; every group's solve is then issued together with the first index sweep that
-    sample_spectral_parameters (iteration it_index) would run on the same planes (Engine.amp_index_sample: one kernel
-    launch where the model allows it, bit for bit the two calls) and (component, index, flag) of that sweep is added to
-    the set -- pass it to sample_spectral_parameters(skip=...).  See gibbs_iteration."""
+    fuse_first: a set; a group's solve is then issued together with the first index sweep that
+    sample_spectral_parameters (iteration it_index) would run on the same planes -- where fusable_first_sweeps says the
+    main loop's result does not change (Engine.amp_index_sample: one kernel launch where the model allows it, bit for bit
+    the two calls) -- and (component, index, flag) of that sweep is added to the set: pass it to
+    sample_spectral_parameters(skip=...).  See gibbs_iteration."""
     eng = ddata.engine
     info = []
+    fusable = fusable_first_sweeps(dpar, eng) if fuse_first is not None else {}
     for g in dpar.cg_groups:
         if not g.sample:
             continue
         has_global = any(c.cg_group == g.cg_group and c.type in ("template", "monopole", "hi_fit") for c in eng.component_list)
         for f in g.pol_flag:
-            first = None
-            if fuse_first is not None and dpar.solver != "cg" and f in _MAPN:
-                for l, c in enumerate(eng.component_list):
-                    hit = [j for j in range(c.nindices) if c.sample_index[j] and f in c.pol_flag[j]] if c.cg_group == g.cg_group else []
-                    if hit:
-                        first = (l, hit[0]) if _plain_sweep(eng, c, hit[0]) else None
-                        break
+            first = fusable.get((g.cg_group, f))
             if first is not None:
                 l, j = first
                 bad, acc = eng.amp_index_sample(g.cg_group, f, dpar.ml_mode, dpar.seed, stream_id(it, 0, g.cg_group, 0, f),
                                                 l, j, _MAPN[f], dpar.nsample, dpar.seed,
                                                 stream_id(it if it_index is None else it_index, 1, l, j, f),
-                                                solver=dpar.solver, fluct_mode=dpar.fluct_mode)
+                                                solver=dpar.solver, fluct_mode=dpar.fluct_mode, i_max=g.i_max, converge=g.converge)
                 fuse_first.add((l, j, f))
                 info.append((g.cg_group, f, 0, bad))
                 continue
@@ -762,8 +789,8 @@ def sample_spectral_parameters(dpar: DangParams, ddata: DangData, it=2, verbose=
                                            stream_id(it, 1, l, j, f))
                 info.append((l, j, f, acc))
         if c.type == "T_cmb":  # "Update the global variable T_CMB": T_CMB = c%indices(0,1,1), :75-78 (it enters a2t of 'cmb')
-            t = eng.peek_indices(l, 1, 0)[0] if eng.pix0 == 0 else 0.0
-            eng.set_tcmb(_dist.bcast_from_rank0([t])[0])
+            arr, n = _ctx_array([eng])
+            eng._chk(eng.lib.dangx_update_tcmb(arr, n, l, None))
     if sampled:
         lo, hi = ddata.pol_type[0], ddata.pol_type[-1]
         before, after = eng.chisq_cached(0, lo, hi), eng.chisq_cached(1, lo, hi)
@@ -790,188 +817,65 @@ def gibbs_iteration(dpar: DangParams, ddata: DangData, it, verbose=False):
 
 
 # --------------------------------------------------------------------------- full-sky mode, tuner, calibrators
+# The chains themselves live behind the C ABI (dang_amd/csrc/dangx_sky.hip: dangx_fullsky_sample, dangx_tune_perpixel,
+# dangx_fit_band_gain, dangx_update_tcmb) -- one implementation for this mirror, the Fortran layers and any other host.
+# What is left here is marshalling: the component's `tuned` flags and step size travel through in/out arguments.
 
-def _fullsky_lnl(eng, c, nind, theta, nb, Sp):
-    """evaluate_lnL / evaluate_marginal_lnL over the whole sky (src/dang_lnl_mod.f90:126-182, 47-124); the device
-    returns this shard's sums, the all-reduce makes them global."""
-    lt = c.lnl_type[nind]
-    if lt == "chisq":
-        return _dist.allreduce_sum_float(eng.fullsky_sums(0, theta, 1)[0])
-    if lt == "marginal":
-        rows = eng.fullsky_sums(1, theta, 2 * nb * Sp)
-        rows = np.array([_dist.allreduce_sum_float(v) for v in rows])
-        lnl = 0.0
-        for q in range(nb * Sp):  # j outer, k inner (:113-122)
-            TNd, TNT = rows[2 * q], rows[2 * q + 1]
-            lnl = lnl - 0.5 * TNd * (1.0 / TNT) * TNd
-        return lnl
-    return 0.0
+def _ctx_array(engines):
+    arr = (C.c_void_p * len(engines))(*[e.h.value for e in engines])
+    return arr, len(engines)
 
 
-def _exp(x):
-    """exp with IEEE semantics (NaN stays NaN, overflow gives +inf) like the reference's `ratio = exp(diff)`."""
-    if x != x:
-        return x
-    return math.exp(x) if x < 709.0 else math.inf
+def _engines_of(ddata, engines=None):
+    return list(engines) if engines is not None else [ddata.engine]
 
 
-def _log_normal_prior(val, mean, std):
-    p = _rng.eval_normal_prior(val, mean, std)
-    return math.log(p) if p > 0.0 else -math.inf
-
-
-def _fullsky_prior(eng, c, nind, theta, val):
-    pt = c.prior_type[nind]
-    if pt == "gaussian":
-        return _log_normal_prior(val, c.gauss_prior[nind][0], c.gauss_prior[nind][1])
-    if pt == "jeffreys":
-        s = _dist.allreduce_sum_float(eng.fullsky_sums(2, [val, 0.0], 1)[0])
-        return math.log(math.sqrt(s)) if s > 0.0 else -math.inf
-    return 0.0
-
-
-def tune_spectral_parameter_length(dpar, eng, c, nind, theta_init, seed, stream, draw0=1, max_rounds=64):
-    """tune_spectral_parameter_length, src/dang_sample_mod.f90:623-717 (on data prepared by fullsky_prepare).
-    Adjusts c.step_size[nind] by +-50% until the acceptance over NUMSAMPLE steps is within [0.4, 0.6]; sets
-    c.tuned = True for ALL indices (:712).  Returns the next free draw counter."""
-    nb = eng.nbands
-    Sp = eng._fs_Sp
-    sample, theta = list(theta_init) + [0.0], list(theta_init) + [0.0]
-    sample, theta = sample[:2], theta[:2]
-    draw = draw0
-    lnl = lnl_new = lnl_old = 0.0
-    lt, pt = c.lnl_type[nind], c.prior_type[nind]
-    if lt in ("chisq", "marginal"):
-        lnl = _fullsky_lnl(eng, c, nind, sample, nb, Sp)
-    elif lt == "prior":
-        u1, u2 = _rng.uniform2(seed, stream, _rng.GLOBAL_PIX, draw)
-        draw += 1
-        sample[nind] = _rng.rand_normal(c.gauss_prior[nind][0], c.gauss_prior[nind][1], u1, u2)
-    if pt == "gaussian":
-        lnl_old = lnl + _log_normal_prior(sample[nind], c.gauss_prior[nind][0], c.gauss_prior[nind][1])
-    elif pt == "uniform":
-        lnl_old = lnl
-    rounds = 0
-    while not c.tuned[nind] and rounds < max_rounds:      # :663 do while (.not. c%tuned(nind)); bounded here
-        rounds += 1
-        accept = 0.0
-        for _ in range(dpar.nsample):
-            u1, u2, u3 = _rng.uniform3(seed, stream, _rng.GLOBAL_PIX, draw)
-            draw += 1
-            theta[nind] = sample[nind] + _rng.rand_normal(0.0, c.step_size[nind], u1, u2)
-            if theta[nind] < c.uni_prior[nind][0] or theta[nind] > c.uni_prior[nind][1]:
-                continue
-            if lt in ("chisq", "marginal"):
-                lnl = _fullsky_lnl(eng, c, nind, theta, nb, Sp)
-            if pt == "gaussian":
-                lnl_new = lnl + _log_normal_prior(theta[nind], c.gauss_prior[nind][0], c.gauss_prior[nind][1])
-            elif pt == "uniform":
-                lnl_new = lnl
-            diff = lnl_new - lnl_old
-            ratio = _exp(diff)
-            if (dpar.ml_mode == "optimize" and ratio > 1.0) or (dpar.ml_mode == "sample" and ratio > u3):
-                sample[nind] = theta[nind]
-                lnl_old = lnl_new
-                accept += 1
-            lnl = 0.0
-        l_after = dpar.nsample + 1                       # Fortran loop variable after the loop (:707)
-        if accept / l_after < float(np.float32(0.4)):
-            c.step_size[nind] = c.step_size[nind] - 0.5 * c.step_size[nind]
-        elif accept / l_after > float(np.float32(0.6)):
-            c.step_size[nind] = c.step_size[nind] + 0.5 * c.step_size[nind]
-        else:
-            c.tuned = [True] * max(c.nindices, 1)
-    return draw
-
-
-def tune_perpixel(dpar, ddata, l, nind, map_n, stream):
-    """The step-size tuning of the per-pixel branch, src/dang_sample_mod.f90:341-346: one pass of the tuner per index
-    of the component, each starting at sample(q) = sum(c%indices(:,map_inds(1),q)) / sum(mask(:,1)) with the entries
-    not yet reached still 0 (:337) -- literally as the reference runs it (the sums take every pixel and the mask's
-    VALUES; the tuner marks all indices tuned, so later passes only evaluate their starting likelihood).  The tuner's
-    sky-wide sums are device passes; the new step size reaches the device through dangx_set_component."""
-    eng = ddata.engine
-    c = eng.component_list[l]
-    s1 = 2 if map_n == -1 else map_n
-    eng._fs_Sp = 2 if map_n == -1 else 1
-    eng.fullsky_prepare(l, map_n)                          # data_raw minus every other component, :173-196
-    sample = [0.0, 0.0]
-    draw = 1
-    for q in range(c.nindices):
-        si, sm = eng.index_plain_sum(l, q, s1)
-        si, sm = _dist.allreduce_sum_float(si), _dist.allreduce_sum_float(sm)
-        sample[q] = si / sm
-        draw = tune_spectral_parameter_length(dpar, eng, c, nind, sample, dpar.seed, stream ^ 0x5555555555555555, draw0=draw)
-    eng._chk(eng.lib.dangx_set_component(eng.h, l, C.byref(comp_desc(c))))
-    return c.step_size[nind]
-
-
-def sample_index_mh_fullsky(dpar, ddata, l, nind, map_n, stream, sample_nside=None):
-    """sample_index_mh, index_mode == 1 (src/dang_sample_mod.f90:229-329): one spectral index for the whole sky.
-    sample_nside (/= nside): the chain's sums run over the degraded maps (:199-217); one whole-sky context."""
-    eng = ddata.engine
-    c = eng.component_list[l]
-    s1 = 2 if map_n == -1 else map_n
-    Sp = 2 if map_n == -1 else 1
-    eng._fs_Sp = Sp
-    nb = eng.nbands
+def _tuned_array(c):
+    n = max(c.nindices, 1)
     if not c.tuned:
-        c.tuned = [True] * max(c.nindices, 1)
-    if sample_nside:
-        eng.fullsky_prepare_coarse(l, map_n, sample_nside)  # :173-217
-    else:
-        eng.fullsky_prepare(l, map_n)                     # :173-196
-    first = _dist.bcast_from_rank0(eng.peek_indices(l, s1, 0))  # c%indices(0, map_inds(1), l), :240-242
-    sample = list(first) + [0.0] * (2 - c.nindices)
-    theta = list(sample)
-    lt = c.lnl_type[nind]
-    lnl, sample_it = 0.0, True
-    if lt in ("chisq", "marginal"):
-        lnl = _fullsky_lnl(eng, c, nind, sample, nb, Sp)
-    elif lt == "prior":                                   # :255-257
-        sample_it = False
-        u1, u2 = _rng.uniform2(dpar.seed, stream, _rng.GLOBAL_PIX, 0)
-        sample[nind] = _rng.rand_normal(c.gauss_prior[nind][0], c.gauss_prior[nind][1], u1, u2)
-    lnl_old = lnl + _fullsky_prior(eng, c, nind, sample, sample[nind])
-    accepted = 0
-    if sample_it:
-        if not c.tuned[nind]:                             # :272-275
-            tune_spectral_parameter_length(dpar, eng, c, nind, sample, dpar.seed, stream ^ 0x5555555555555555)
-            eng._chk(eng.lib.dangx_set_component(eng.h, l, C.byref(comp_desc(c))))   # the new step size
-        sample = list(first) + [0.0] * (2 - c.nindices)
-        theta = list(sample)
-        for step in range(1, dpar.nsample + 1):           # :282-324
-            u1, u2, u3 = _rng.uniform3(dpar.seed, stream, _rng.GLOBAL_PIX, step)
-            theta[nind] = sample[nind] + _rng.rand_normal(0.0, c.step_size[nind], u1, u2)
-            if theta[nind] < c.uni_prior[nind][0] or theta[nind] > c.uni_prior[nind][1]:
-                continue
-            lnl = _fullsky_lnl(eng, c, nind, theta, nb, Sp)
-            lnl_new = lnl + _fullsky_prior(eng, c, nind, theta, theta[nind])
-            diff = lnl_new - lnl_old
-            ratio = _exp(diff)
-            if (dpar.ml_mode == "optimize" and ratio > 1.0) or (dpar.ml_mode == "sample" and ratio > u3):
-                sample[nind] = theta[nind]
-                lnl_old = lnl_new
-                accepted += 1
-    eng.fill_index(l, nind, map_n, sample[nind])          # :329, :483
-    return accepted
+        c.tuned = [True] * n
+    return (C.c_int32 * n)(*[1 if t else 0 for t in c.tuned])
 
 
-def fit_band_gain(dpar, ddata, band, it=1):
-    """fit_band_gain(ddata, 1, band), src/dang_sample_mod.f90:570-621 (band 0-based here)."""
-    eng = ddata.engine
-    mu, sigma = eng.gain_sums(band)
-    mu, sigma = _dist.allreduce_sum_float(mu), _dist.allreduce_sum_float(sigma)
-    mu = mu / sigma
-    sigma = math.sqrt(1.0 / sigma)
-    if dpar.ml_mode == "optimize":
-        gain = mu
-    else:
-        u1, u2 = _rng.uniform2(dpar.seed, stream_id(it, 2, 0, 0, 0), _rng.GLOBAL_PIX, band)
-        gain = mu + sigma * _rng.rand_normal(0.0, 1.0, u1, u2)
-    ddata.gain[band] = gain
-    eng.set_calibration(ddata.gain, ddata.offset)
-    return gain
+def tune_perpixel(dpar, ddata, l, nind, map_n, stream, engines=None):
+    """The step-size tuning of the per-pixel branch, src/dang_sample_mod.f90:341-346 (dangx_tune_perpixel): updates
+    c.step_size[nind] and c.tuned; the contexts' descriptors follow inside the call."""
+    engs = _engines_of(ddata, engines)
+    c = engs[0].component_list[l]
+    arr, n = _ctx_array(engs)
+    tuned, step = _tuned_array(c), C.c_double(0.0)
+    engs[0]._chk(engs[0].lib.dangx_tune_perpixel(arr, n, l, nind, map_n, dpar.nsample, L.ML_CODES[dpar.ml_mode], dpar.seed, stream,
+                                                 tuned, C.byref(step)))
+    c.tuned = [bool(t) for t in tuned]
+    c.step_size[nind] = step.value
+    return step.value
+
+
+def sample_index_mh_fullsky(dpar, ddata, l, nind, map_n, stream, sample_nside=None, engines=None):
+    """sample_index_mh, index_mode == 1 (src/dang_sample_mod.f90:229-329): one spectral index for the whole sky, through
+    dangx_fullsky_sample (tuner included).  sample_nside (/= nside): the chain's sums run over the degraded maps (:199-217).
+    engines: the pixel-shard contexts of this process in shard order (default: ddata.engine).  Returns accepted proposals."""
+    engs = _engines_of(ddata, engines)
+    c = engs[0].component_list[l]
+    arr, n = _ctx_array(engs)
+    tuned, step, acc = _tuned_array(c), C.c_double(0.0), C.c_int64(0)
+    engs[0]._chk(engs[0].lib.dangx_fullsky_sample(arr, n, l, nind, map_n, dpar.nsample, L.ML_CODES[dpar.ml_mode], dpar.seed, stream,
+                                                  engs[0].nside if sample_nside else 0, int(sample_nside or 0), tuned,
+                                                  C.byref(step), None, C.byref(acc)))
+    c.tuned = [bool(t) for t in tuned]
+    if nind < len(c.step_size):
+        c.step_size[nind] = step.value
+    return acc.value
+
+
+def fit_band_gain(dpar, ddata, band, it=1, engines=None):
+    """fit_band_gain(ddata, 1, band), src/dang_sample_mod.f90:570-621 (band 0-based here), through dangx_fit_band_gain."""
+    engs = _engines_of(ddata, engines)
+    arr, n = _ctx_array(engs)
+    g = C.c_double(0.0)
+    engs[0]._chk(engs[0].lib.dangx_fit_band_gain(arr, n, band, L.ML_CODES[dpar.ml_mode], dpar.seed, stream_id(it, 2, 0, 0, 0), C.byref(g)))
+    ddata.gain[band] = g.value
+    return g.value
 
 
 def sample_calibrators(dpar, ddata, it=2, verbose=False):

@@ -343,12 +343,15 @@ __global__ __launch_bounds__(BLOCK) void k_fullsky_rows(const Model* __restrict_
     const bool coarse = crms != nullptr;
     const int npix = coarse ? (int)npix_c : M.npix;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
-    const bool in = i < npix;
+    // coarse: i is a coarse pixel number; the degraded maps are whole-sky on every shard, the amplitude of "pixel i" lives on
+    // the shard that holds full-resolution pixel i -- each coarse pixel is summed by exactly one shard
+    const long long il = coarse ? (long long)i - M.pix0 : i;
+    const bool in = i < npix && il >= 0 && il < M.npix;
     const bool msk = in ? is_masked(coarse ? cmask[i] : M.mask[i]) : true;
     const Prep pr = sed_prep(c, th0, th1);
     const int nrows = (what == 1) ? 2 * nb * Sp : 1;
     double amp[2] = {0.0, 0.0};
-    if (in) for (int kk = 0; kk < Sp; ++kk) amp[kk] = c.amp[(long long)(s1 + kk - 1) * M.npix + i];
+    if (in) for (int kk = 0; kk < Sp; ++kk) amp[kk] = c.amp[(long long)(s1 + kk - 1) * M.npix + il];
     auto rms_at = [&](int kk, int j) -> double {
         return coarse ? crms[((long long)kk * nb + j) * npix + i] : M.rms[((long long)j * M.nmaps + (s1 + kk - 1)) * npix + i];
     };
@@ -956,7 +959,7 @@ constexpr int CHI_RSTAGE = 128;  // blocks of the first reduction stage of the s
 // reduce every pending sweep's block partials into chi_cache (two launches for all of them, in launch order)
 int chi_flush(dangx_ctx* ctx) {
     if (ctx->chi_npend == 0) return 0;
-    if (!ctx->chi_stage) HIPCHK(ctx, hipMalloc(&ctx->chi_stage, sizeof(double) * dangx_ctx::CHI_RING * 4 * CHI_RSTAGE));
+    (void)hipSetDevice(ctx->device);  // the caller may have been working on another context's device
     ChiBatch b;
     b.n = ctx->chi_npend;
     for (int e = 0; e < b.n; ++e) {
@@ -1156,8 +1159,37 @@ int device_cg(dangx_ctx* ctx, const GroupArgs& a, int i_max, double converge, in
 // (pass 1), solve the nglob x nglob Schur system on the host, back-substitute per unit (pass 2).  The linear
 // system is the one cg_search iterates on (compute_rhs / compute_Ax / compute_sample_vector,
 // src/dang_cg_mod.f90:326-1096), quirks included; the answer is its exact solution instead of the iterate at i_max.
-int device_schur(dangx_ctx* ctx, const GroupArgs& a, long long SN, int64_t* n_not_spd, int* nullity) {
+// cs[0..nc): the contexts of this process that share the sky (shard order; nc = 1: dangx_amp_sample); as[r], SNs[r]: the
+// group as context r sees it.  Row sums are added over the contexts in shard order, then over the ranks (cs[0]'s callback);
+// the small system is solved once and every context gets the same global amplitudes.
+int device_schur(dangx_ctx* const* cs, int nc, const GroupArgs* as, const long long* SNs, int64_t* n_not_spd, int* nullity) {
+    dangx_ctx* ctx = cs[0];
+    const GroupArgs& a = as[0];
     const int R = a.nglob, nb = ctx->hm.nbands;
+    auto each = [&](auto&& fn) -> int {  // fn(context, its group, its SN) on every context; the first error is the call's
+        for (int r = 0; r < nc; ++r)
+            if (fn(cs[r], as[r], SNs[r])) { if (cs[r] != ctx) ctx->err = cs[r]->err; return 1; }
+        return 0;
+    };
+    // rows_dev of every context -> host, added in shard order, then over the ranks
+    auto gather = [&](std::vector<double>& rows, int n) -> int {
+        std::vector<double> part((size_t)n);
+        std::fill(rows.begin(), rows.end(), 0.0);
+        for (int r = 0; r < nc; ++r) {
+            (void)hipSetDevice(cs[r]->device);
+            HIPCHK(ctx, hipMemcpyAsync(part.data(), cs[r]->work[0], sizeof(double) * n, hipMemcpyDeviceToHost, cs[r]->stream));
+            HIPCHK(ctx, hipStreamSynchronize(cs[r]->stream));
+            for (int q = 0; q < n; ++q) rows[q] += part[q];
+        }
+        return rank_sum(ctx, rows.data(), n);
+    };
+    auto set_globals = [&](const std::vector<double>& g) -> int {  // new global amplitudes + back-substitution everywhere
+        return each([&](dangx_ctx* c, const GroupArgs& ga, long long SN) -> int {
+            (void)hipSetDevice(c->device);
+            x_to_globals(c, ga, g);
+            return sync_model(c) || dx_launch_schur_pass2(c, ga, SN);
+        });
+    };
     if (R > DX_MAX_ROWS) return fail(ctx, "more than 32 global amplitudes in one CG group: use DANGX_SOLVER_CG");
     SchurArgs sa;
     std::memset(&sa, 0, sizeof(sa));
@@ -1187,15 +1219,22 @@ int device_schur(dangx_ctx* ctx, const GroupArgs& a, long long SN, int64_t* n_no
             }
         }
     const int nrows = R * R + 3 * R;
-    if (ensure_work(ctx, std::max<long long>(nrows, 1))) return 1;
-    if (dx_launch_schur_pass1(ctx, a, sa, SN, ctx->work[0])) return 1;
+    if (each([&](dangx_ctx* c, const GroupArgs& ga, long long SN) -> int {  // enqueued on every device before any result is awaited
+            (void)hipSetDevice(c->device);
+            return ensure_work(c, std::max<long long>(nrows, 1)) || dx_launch_schur_pass1(c, ga, sa, SN, c->work[0]);
+        }))
+        return 1;
     std::vector<double> rows(nrows);
-    unsigned long long bad = 0;
-    HIPCHK(ctx, hipMemcpyAsync(rows.data(), ctx->work[0], sizeof(double) * nrows, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(&bad, ctx->counters, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (n_not_spd) *n_not_spd = (int64_t)bad;
-    if (rank_sum(ctx, rows.data(), nrows)) return 1;  // pixel-sharded run: every rank then solves the same small system
+    if (gather(rows, nrows)) return 1;  // every context / rank then solves the same small system
+    unsigned long long bad_all = 0;
+    for (int r = 0; r < nc; ++r) {
+        unsigned long long bad = 0;
+        (void)hipSetDevice(cs[r]->device);
+        HIPCHK(ctx, hipMemcpyAsync(&bad, cs[r]->counters, sizeof(bad), hipMemcpyDeviceToHost, cs[r]->stream));
+        HIPCHK(ctx, hipStreamSynchronize(cs[r]->stream));
+        bad_all += bad;
+    }
+    if (n_not_spd) *n_not_spd = (int64_t)bad_all;
     // S g = t (+ fluctuation sums).  S is not symmetric when a monopole is fitted (its row weight is 1, :857), so:
     // Gaussian elimination, on the system equilibrated by G's diagonal (row amplitudes span ~1e-6 for hi_fit to ~1e2),
     // for the CORRECTION to the current amplitudes, S d = t - S g0, with complete pivoting.  A remaining pivot at
@@ -1274,23 +1313,23 @@ int device_schur(dangx_ctx* ctx, const GroupArgs& a, long long SN, int64_t* n_no
     lu_solve(t, d);
     for (int r = 0; r < R; ++r) g[r] = g0[r] + d[r];
     if (nullity) *nullity = R - rank;
-    x_to_globals(ctx, a, g);
-    if (sync_model(ctx)) return 1;
-    if (dx_launch_schur_pass2(ctx, a, SN)) return 1;
+    if (set_globals(g)) return 1;
     // Residual check + iterative refinement.  Pass 1 forms S and t as sums of per-unit differences that cancel to the
     // part of a global row the diffuse members do NOT absorb; when they absorb nearly all of it (a fitted monopole
     // beside the CMB) S keeps only a few digits and S g = t is solved for a slightly wrong S.  The true residual of the
     // global rows, r = b - A x evaluated directly at the new state (k_schur_resid: no elimination, no cancellation),
     // drives the correction g += S^-1 r; the diffuse rows are re-solved exactly by pass 2.  The contraction factor is
     // cond(S) * (relative error of S); the loop stops at 1e-12 of the row of b, or when a step no longer helps.
-    ctx->schur_refine = 0;
-    double prev = INFINITY;
+    int refine = 0;
+    double prev = INFINITY, resid_b = 0.0, resid_bw = 0.0;
     std::vector<double> rr(3 * R), res(R);
     for (int step = 0; step <= 4; ++step) {
-        if (dx_launch_schur_resid(ctx, a, sa, SN, ctx->work[0])) return 1;
-        HIPCHK(ctx, hipMemcpyAsync(rr.data(), ctx->work[0], sizeof(double) * 3 * R, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        if (rank_sum(ctx, rr.data(), 3 * R)) return 1;
+        if (each([&](dangx_ctx* c, const GroupArgs& ga, long long SN) -> int {
+                (void)hipSetDevice(c->device);
+                return dx_launch_schur_resid(c, ga, sa, SN, c->work[0]);
+            }))
+            return 1;
+        if (gather(rr, 3 * R)) return 1;
         double worst = 0.0, worst_bw = 0.0;
         for (int r = 0; r < R; ++r) {
             res[r] = rr[r] + fl[r];
@@ -1302,20 +1341,19 @@ int device_schur(dangx_ctx* ctx, const GroupArgs& a, long long SN, int64_t* n_no
         }
         if (step > 0 && !(worst < prev)) {  // the last correction did not help: take it back
             for (int r = 0; r < R; ++r) g[r] -= d[r];
-            x_to_globals(ctx, a, g);
-            if (sync_model(ctx) || dx_launch_schur_pass2(ctx, a, SN)) return 1;
-            ctx->schur_refine -= 1;
+            if (set_globals(g)) return 1;
+            refine -= 1;
             break;
         }
-        ctx->schur_resid = prev = worst;
-        ctx->schur_backward = worst_bw;
+        resid_b = prev = worst;
+        resid_bw = worst_bw;
         if (worst <= 1e-12 || worst_bw <= 1e-15 || step == 4) break;
         lu_solve(res, d);
         for (int r = 0; r < R; ++r) g[r] += d[r];
-        x_to_globals(ctx, a, g);
-        if (sync_model(ctx) || dx_launch_schur_pass2(ctx, a, SN)) return 1;
-        ctx->schur_refine += 1;
+        if (set_globals(g)) return 1;
+        refine += 1;
     }
+    for (int r = 0; r < nc; ++r) { cs[r]->schur_resid = resid_b; cs[r]->schur_backward = resid_bw; cs[r]->schur_refine = refine; }
     return 0;
 }
 
@@ -1396,6 +1434,7 @@ int dangx_create(dangx_ctx** out, const dangx_dims* dims) {
     for (int j = 0; j < MAXB; ++j) { M.gain[j] = 1.0; M.offset[j] = 0.0; }  // src/dang_data_mod.f90:127-128
     if (hipMalloc(&ctx->dm, sizeof(Model)) != hipSuccess || hipMalloc(&ctx->scalars, 8 * sizeof(double)) != hipSuccess ||
         hipMalloc(&ctx->chi_cache, 6 * sizeof(double)) != hipSuccess ||
+        hipMalloc(&ctx->chi_stage, sizeof(double) * dangx_ctx::CHI_RING * 4 * CHI_RSTAGE) != hipSuccess ||
         hipMalloc(&ctx->rows_out, (4 * MAXB + 8) * sizeof(double)) != hipSuccess ||
         hipMalloc(&ctx->counters, 4 * sizeof(unsigned long long)) != hipSuccess) {
         delete ctx;
@@ -1438,6 +1477,13 @@ const char* dangx_last_error(const dangx_ctx* ctx) { return ctx ? ctx->err.c_str
 
 int dangx_set_stream(dangx_ctx* ctx, void* s) {
     if (!ctx) return 1;
+    if ((hipStream_t)s != ctx->stream) {
+        // chi^2 block partials of the sweeps launched so far wait in the ring: reduce them on the stream that produced
+        // them, and let everything enqueued there finish before the first launch on the new stream can overtake it
+        (void)hipSetDevice(ctx->device);
+        if (chi_flush(ctx)) return 1;
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     ctx->stream = (hipStream_t)s;
     return 0;
 }
@@ -1698,7 +1744,8 @@ int dangx_amp_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solve
         if (fluct_mode != DANGX_FLUCT_REFERENCE && ml_mode == DANGX_ML_SAMPLE)
             return fail(ctx, "groups with template / monopole / hi_fit members reproduce the reference's fluctuation term only");
         int nullity = 0;
-        if (device_schur(ctx, a, SN, n_not_spd, &nullity)) return 1;
+        dangx_ctx* one[1] = {ctx};
+        if (device_schur(one, 1, &a, &SN, n_not_spd, &nullity)) return 1;
         if (cg_iters) *cg_iters = -nullity;  // 0: regular system; -k: k directions of the global amplitudes left at their current value
         return 0;
     }
@@ -1720,6 +1767,60 @@ int dangx_amp_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solve
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         *n_not_spd = (int64_t)v;
     }
+    return 0;
+}
+
+// One (group, flag) pass of sample_cg_groups over several contexts of ONE process (include/dangx.h).  Independent per-pixel
+// work is enqueued on every device before the first result is awaited; a coupled group shares its Schur rows.
+int dangx_sky_amp_sample(dangx_ctx* const* ctxs, int nctx, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed,
+                         uint64_t stream, int i_max, double converge, int* cg_iters, int64_t* n_not_spd) {
+    if (!ctxs || nctx < 1) return 1;
+    for (int r = 0; r < nctx; ++r) if (!ctxs[r]) return 1;
+    dangx_ctx* c0 = ctxs[0];
+    if (nctx == 1) return dangx_amp_sample(c0, group, flag, ml_mode, solver, fluct_mode, seed, stream, i_max, converge, cg_iters, n_not_spd);
+    if (nctx > 64) return fail(c0, "too many contexts");
+    auto bubble = [&](dangx_ctx* who) { if (who != c0) c0->err = who->err; return 1; };
+    if (ml_mode != DANGX_ML_SAMPLE && ml_mode != DANGX_ML_OPTIMIZE) return fail(c0, "bad ml_mode");
+    GroupArgs probe;
+    if (make_group(c0, group, flag, probe)) return 1;
+    if (cg_iters) *cg_iters = 0;
+    if (n_not_spd) *n_not_spd = 0;
+    if (probe.nt == 0 && solver != DANGX_SOLVER_CG) {  // block diagonal: every shard on its own
+        for (int r = 0; r < nctx; ++r)
+            if (dangx_amp_sample(ctxs[r], group, flag, ml_mode, solver, fluct_mode, seed, stream, i_max, converge, nullptr, nullptr))
+                return bubble(ctxs[r]);
+        if (n_not_spd)   // the counters are read after every device has its launch
+            for (int r = 0; r < nctx; ++r) {
+                unsigned long long v = 0;
+                (void)hipSetDevice(ctxs[r]->device);
+                HIPCHK(c0, hipMemcpyAsync(&v, ctxs[r]->counters, sizeof(v), hipMemcpyDeviceToHost, ctxs[r]->stream));
+                HIPCHK(c0, hipStreamSynchronize(ctxs[r]->stream));
+                *n_not_spd += (int64_t)v;
+            }
+        return 0;
+    }
+    if (solver == DANGX_SOLVER_CG)
+        return fail(c0, "the device CG (DANGX_SOLVER_CG) iterates on ONE context per process: use DANGX_SOLVER_DIRECT, or one process per GPU with dangx_set_allreduce");
+    if (fluct_mode != DANGX_FLUCT_REFERENCE && ml_mode == DANGX_ML_SAMPLE)
+        return fail(c0, "groups with template / monopole / hi_fit members reproduce the reference's fluctuation term only");
+    std::vector<GroupArgs> as((size_t)nctx);
+    std::vector<long long> SNs((size_t)nctx);
+    for (int r = 0; r < nctx; ++r) {
+        dangx_ctx* c = ctxs[r];
+        (void)hipSetDevice(c->device);
+        if (make_group(c, group, flag, as[r]) || sync_model(c)) return bubble(c);
+        as[r].ml_mode = ml_mode; as[r].fluct = fluct_mode; as[r].seed = seed; as[r].stream = stream;
+        SNs[r] = (long long)flag_planes_h(flag) * c->hm.npix;
+        for (int pl = 0; pl < flag_planes_h(flag); ++pl) {
+            const int k = (flag & DANGX_FLAG_QU) ? 2 + pl : (flag & DANGX_FLAG_T) ? 1 : (flag & DANGX_FLAG_Q) ? 2 : 3;
+            c->chi_before_valid[k - 1] = c->chi_after_valid[k - 1] = c->touched_since_amp[k - 1] = false;
+            for (int g = 0; g < as[r].ng; ++g) c->plane_nz[as[r].gc[g]] |= 1u << (k - 1);
+        }
+        if (as[r].nglob != as[0].nglob || as[r].nt != as[0].nt) return fail(c0, "the contexts disagree on the group's global-amplitude members");
+    }
+    int nullity = 0;
+    if (device_schur(ctxs, nctx, as.data(), SNs.data(), n_not_spd, &nullity)) return 1;
+    if (cg_iters) *cg_iters = -nullity;
     return 0;
 }
 
@@ -1881,6 +1982,7 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
         if (!(reg_ok && dx_launch_mh_reg(ctx, a, Sp, nblk, accp))) dx_launch_mh_lds(ctx, a, fast, Sp, nblk, bs, lds, accp);
     }
     lend.back();
+    HIPCHK(ctx, hipGetLastError());  // a failed launch must not leave a pending entry over partials nobody wrote
     {   // fused chi^2 of the touched planes (before = state left by the amplitude phase, after = new state): the block
         // partials wait in the ring (chi_flush) until a value is asked for
         const bool wb = !ctx->touched_since_amp[a.s1 - 1];
@@ -1892,7 +1994,6 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
             ctx->touched_since_amp[k - 1] = true;
         }
     }
-    HIPCHK(ctx, hipGetLastError());
     if (accepted) {
         unsigned long long v = 0;
         HIPCHK(ctx, hipMemcpyAsync(&v, ctx->counters + 1, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
@@ -1936,9 +2037,10 @@ int dangx_index_sample_pair(dangx_ctx* ctx, int comp, int nind, int map_n, int n
 // gaussian / uniform prior, the sampled component a member of the group whose other members are the only other
 // components on these planes).  Results are those of the two calls, bit for bit; every other configuration IS the two calls.
 int dangx_amp_index_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed_amp,
-                           uint64_t stream_amp, int comp, int nind, int map_n, int nsample, uint64_t seed_index,
-                           uint64_t stream_index, int64_t* n_not_spd, int64_t* accepted) {
+                           uint64_t stream_amp, int i_max, double converge, int comp, int nind, int map_n, int nsample,
+                           uint64_t seed_index, uint64_t stream_index, int* cg_iters, int64_t* n_not_spd, int64_t* accepted) {
     if (!ctx || check_comp(ctx, comp)) return 1;
+    if (cg_iters) *cg_iters = 0;
     static const bool enabled = [] { const char* e = getenv("DANGX_FUSE"); return !(e && e[0] == '0'); }();  // A/B switch
     bool can = enabled && solver == DANGX_SOLVER_DIRECT && ctx->hm.all_delta != 0 &&
                (ml_mode == DANGX_ML_OPTIMIZE || fluct_mode == DANGX_FLUCT_REFERENCE);
@@ -1964,12 +2066,12 @@ int dangx_amp_index_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int
             if (ctx->desc[l].type == DANGX_TCMB) can = false;
     }
     if (!can) {
-        const int rc = dangx_amp_sample(ctx, group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, 100, 1e-8, nullptr, n_not_spd);
+        const int rc = dangx_amp_sample(ctx, group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, i_max, converge, cg_iters, n_not_spd);
         return rc ? rc : dangx_index_sample(ctx, comp, nind, map_n, nsample, ml_mode, seed_index, stream_index, accepted);
     }
     if (n_not_spd) HIPCHK(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));
     ctx->defer_amp = true;
-    int rc = dangx_amp_sample(ctx, group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, 100, 1e-8, nullptr, nullptr);
+    int rc = dangx_amp_sample(ctx, group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, i_max, converge, nullptr, nullptr);
     ctx->defer_amp = false;
     if (rc) { ctx->have_pending = false; return rc; }
     rc = dangx_index_sample(ctx, comp, nind, map_n, nsample, ml_mode, seed_index, stream_index, accepted);
@@ -1992,6 +2094,7 @@ int dangx_amp_index_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int
 // if some plane has not been covered by a sweep since its last amplitude update: use dangx_sky_model_chisq.
 int dangx_chisq_cached_dev(dangx_ctx* ctx, int which, int pol_lo, int pol_hi, double* out_dev) {
     if (!ctx || !out_dev || (which != 0 && which != 1)) return 1;
+    (void)hipSetDevice(ctx->device);
     if (pol_lo < 1 || pol_hi > ctx->dims.nmaps || pol_lo > pol_hi) return fail(ctx, "bad pol_type range");
     for (int k = pol_lo; k <= pol_hi; ++k)
         if (!(which ? ctx->chi_after_valid[k - 1] : ctx->chi_before_valid[k - 1])) {
@@ -2302,6 +2405,34 @@ int dangx_coarse_partials(dangx_ctx* ctx, int comp, int map_n, int nside, int sa
     return 0;
 }
 
+// finish the degraded data / rms / mask from the child sums of ALL shards (phase B's first half) -> cs_data / cs_rms / cs_mask
+static int coarse_finish(dangx_ctx* ctx, int Sp, long long npc, int nside, int sample_nside, const double* partials_sum) {
+    const long long nq = (long long)Sp * ctx->hm.nbands * npc;
+    if (coarse_alloc(ctx, Sp, npc)) return 1;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->cs_part, partials_sum, sizeof(double) * coarse_partials_len(ctx, Sp, npc), hipMemcpyHostToDevice, ctx->stream));
+    const double *dt = ctx->cs_part, *dc = dt + nq, *rt = dc + nq, *rc = rt + nq, *mt = rc + nq, *mc = mt + npc;
+    const double scale = (double)sample_nside * 1.0 / nside;
+    hipLaunchKernelGGL(k_udgrade_finish, dim3(nblocks(nq)), dim3(BLOCK), 0, ctx->stream, dt, dc, ctx->cs_data, nq, 0, scale);
+    hipLaunchKernelGGL(k_udgrade_finish, dim3(nblocks(nq)), dim3(BLOCK), 0, ctx->stream, rt, rc, ctx->cs_rms, nq, 1, scale);
+    hipLaunchKernelGGL(k_udgrade_finish, dim3(nblocks(npc)), dim3(BLOCK), 0, ctx->stream, mt, mc, ctx->cs_mask, npc, 2, scale);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+// full-sky index mode at a coarser Nside ON A PIXEL SHARD: dangx_coarse_partials of every shard, added, then this call on
+// every shard -- the degraded maps are then whole-sky on each of them and dangx_fullsky_sums adds, per shard, the coarse
+// pixels i whose full-resolution pixel i the shard holds
+int dangx_fullsky_finish_coarse(dangx_ctx* ctx, int comp, int map_n, int nside, int sample_nside, const double* partials_sum) {
+    if (!ctx || !partials_sum || coarse_check(ctx, comp, nside, sample_nside)) return 1;
+    (void)hipSetDevice(ctx->device);
+    int s1, s2;
+    if (map_planes(ctx, map_n, s1, s2) || sync_model(ctx)) return 1;
+    const long long npc = 12LL * sample_nside * sample_nside;
+    if (coarse_finish(ctx, s2 - s1 + 1, npc, nside, sample_nside, partials_sum)) return 1;
+    ctx->fs_comp = comp; ctx->fs_s1 = s1; ctx->fs_s2 = s2; ctx->fs_npc = npc;
+    return 0;
+}
+
 int dangx_coarse_chains(dangx_ctx* ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed, uint64_t stream,
                         int nside, int sample_nside, const double* partials_sum, double* index_out) {
     if (!ctx || !partials_sum || !index_out || coarse_check(ctx, comp, nside, sample_nside)) return 1;
@@ -2314,13 +2445,8 @@ int dangx_coarse_chains(dangx_ctx* ctx, int comp, int nind, int map_n, int nsamp
     if (map_planes(ctx, map_n, s1, s2) || sync_model(ctx)) return 1;
     const int Sp = s2 - s1 + 1, nb = ctx->hm.nbands;
     const long long npc = 12LL * sample_nside * sample_nside, nq = (long long)Sp * nb * npc;
-    if (coarse_alloc(ctx, Sp, npc)) return 1;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->cs_part, partials_sum, sizeof(double) * coarse_partials_len(ctx, Sp, npc), hipMemcpyHostToDevice, ctx->stream));
-    const double *dt = ctx->cs_part, *dc = dt + nq, *rt = dc + nq, *rc = rt + nq, *mt = rc + nq, *mc = mt + npc;
-    const double scale = (double)sample_nside * 1.0 / nside;
-    hipLaunchKernelGGL(k_udgrade_finish, dim3(nblocks(nq)), dim3(BLOCK), 0, ctx->stream, dt, dc, ctx->cs_data, nq, 0, scale);
-    hipLaunchKernelGGL(k_udgrade_finish, dim3(nblocks(nq)), dim3(BLOCK), 0, ctx->stream, rt, rc, ctx->cs_rms, nq, 1, scale);
-    hipLaunchKernelGGL(k_udgrade_finish, dim3(nblocks(npc)), dim3(BLOCK), 0, ctx->stream, mt, mc, ctx->cs_mask, npc, 2, scale);
+    if (coarse_finish(ctx, Sp, npc, nside, sample_nside, partials_sum)) return 1;
+    (void)nq;
     IndexArgs a{};
     a.comp = comp; a.nind = nind; a.nsample = nsample; a.ml_mode = ml_mode; a.seed = seed; a.stream = stream;
     a.s1 = s1; a.s2 = s2; a.mode = CH_GENERIC;

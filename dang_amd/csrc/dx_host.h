@@ -151,6 +151,7 @@ struct dangx_ctx {
 // model (T_CMB, calibration, host pushes of state, new data, new descriptors) calls this
 inline void invalidate_chi(dangx_ctx* ctx) {
     for (int k = 0; k < 3; ++k) ctx->chi_before_valid[k] = ctx->chi_after_valid[k] = false;
+    ctx->chi_npend = 0;  // block partials still waiting in the ring belong to that model too: nobody may read them
 }
 
 inline int fail(dangx_ctx* ctx, const std::string& msg) {

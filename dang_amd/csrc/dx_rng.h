@@ -72,7 +72,11 @@ __device__ __forceinline__ void uniform3(unsigned long long seed, unsigned long 
 //   r = (-2 log u1)**0.5 ; theta = 2 pi u2 ; c = mean + stdev*r*sin(theta)
 // sin(2 pi u2) is evaluated as sinpi(2 u2) (no rounding of theta); log by log_pos (u1 is normal).
 __device__ __forceinline__ double rand_normal(double mean, double stdev, double u1, double u2) {
-    const double r = fast_sqrt(-2.0 * log_pos(u1));  // u1 in (0,1): the argument is in [1e-16, 75]
+    // u1 in (0,1]: u53 rounds to exactly 1.0 for the one word pattern 2^53 - 1 (probability 2^-53 per draw); the argument
+    // is then -0.0, where the reciprocal-square-root seed is -inf and the Goldschmidt steps give NaN -- sqrt(-0) = -0 in
+    // the reference's arithmetic, i.e. a zero deviate: select it
+    const double arg = -2.0 * log_pos(u1);
+    const double r = (arg > 0.0) ? fast_sqrt(arg) : 0.0;
     // one explicit fma: "x + (mean + a*b)" at a call site with mean = 0 could otherwise be contracted into fma(a, b, x) in
     // one kernel and left as a rounded product plus an addition in another (see log_pos)
     return fma(stdev * r, sin_2pi(u2), mean);

@@ -141,11 +141,14 @@ module dangx_mod
        integer(c_int64_t), intent(out), optional :: accepted_first, accepted_second
      end function
      integer(c_int) function dangx_amp_index_sample(ctx, group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, &
-          comp, nind, map_n, nsample, seed_index, stream_index, n_not_spd, accepted) bind(C, name='dangx_amp_index_sample')
-       import :: c_int, c_ptr, c_int64_t
+          i_max, converge, comp, nind, map_n, nsample, seed_index, stream_index, cg_iters, n_not_spd, accepted) &
+          bind(C, name='dangx_amp_index_sample')
+       import :: c_int, c_ptr, c_int64_t, c_double
        type(c_ptr), value :: ctx
-       integer(c_int), value :: group, flag, ml_mode, solver, fluct_mode, comp, nind, map_n, nsample
+       integer(c_int), value :: group, flag, ml_mode, solver, fluct_mode, i_max, comp, nind, map_n, nsample
+       real(c_double), value :: converge
        integer(c_int64_t), value :: seed_amp, stream_amp, seed_index, stream_index
+       integer(c_int), intent(out), optional :: cg_iters
        integer(c_int64_t), intent(out), optional :: n_not_spd, accepted
      end function
      integer(c_int) function dangx_set_template(ctx, comp, tmpl, corr, nfit) bind(C, name='dangx_set_template')
@@ -290,6 +293,152 @@ module dangx_mod
        type(c_ptr), value :: ctx, user
        type(c_funptr), value :: fn
        integer(c_int), value :: is_root
+     end function
+     ! ---- the sky-wide steps, chain included (dang_amd/csrc/dangx_sky.hip): ctxs = the contexts of this process in shard order
+     integer(c_int) function dangx_fullsky_sample(ctxs, nctx, comp, nind, map_n, nsample, ml_mode, seed, stream, nside, &
+          sample_nside, tuned, step_size, value, accepted) bind(C, name='dangx_fullsky_sample')
+       import :: c_int, c_ptr, c_int32_t, c_int64_t, c_double
+       type(c_ptr), intent(in) :: ctxs(*)
+       integer(c_int), value :: nctx, comp, nind, map_n, nsample, ml_mode, nside, sample_nside
+       integer(c_int64_t), value :: seed, stream
+       integer(c_int32_t), intent(inout), optional :: tuned(*)       ! c%tuned(1:nindices), 1 = tuned
+       real(c_double), intent(out), optional :: step_size, value
+       integer(c_int64_t), intent(out), optional :: accepted
+     end function
+     integer(c_int) function dangx_tune_step_size(ctxs, nctx, comp, nind, nsample, ml_mode, seed, stream, theta_init, draw, &
+          tuned, step_size) bind(C, name='dangx_tune_step_size')
+       import :: c_int, c_ptr, c_int32_t, c_int64_t, c_double
+       type(c_ptr), intent(in) :: ctxs(*)
+       integer(c_int), value :: nctx, comp, nind, nsample, ml_mode
+       integer(c_int64_t), value :: seed, stream
+       real(c_double), intent(in) :: theta_init(2)
+       integer(c_int32_t), intent(inout) :: draw                    ! running draw counter (unsigned in C; small here)
+       integer(c_int32_t), intent(inout) :: tuned(*)
+       real(c_double), intent(out), optional :: step_size
+     end function
+     integer(c_int) function dangx_tune_perpixel(ctxs, nctx, comp, nind, map_n, nsample, ml_mode, seed, stream, tuned, step_size) &
+          bind(C, name='dangx_tune_perpixel')
+       import :: c_int, c_ptr, c_int32_t, c_int64_t, c_double
+       type(c_ptr), intent(in) :: ctxs(*)
+       integer(c_int), value :: nctx, comp, nind, map_n, nsample, ml_mode
+       integer(c_int64_t), value :: seed, stream
+       integer(c_int32_t), intent(inout) :: tuned(*)
+       real(c_double), intent(out), optional :: step_size
+     end function
+     integer(c_int) function dangx_fit_band_gain(ctxs, nctx, band, ml_mode, seed, stream, gain) bind(C, name='dangx_fit_band_gain')
+       import :: c_int, c_ptr, c_int64_t, c_double
+       type(c_ptr), intent(in) :: ctxs(*)
+       integer(c_int), value :: nctx, band, ml_mode
+       integer(c_int64_t), value :: seed, stream
+       real(c_double), intent(out), optional :: gain
+     end function
+     integer(c_int) function dangx_update_tcmb(ctxs, nctx, comp, tcmb) bind(C, name='dangx_update_tcmb')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), intent(in) :: ctxs(*)
+       integer(c_int), value :: nctx, comp
+       real(c_double), intent(out), optional :: tcmb
+     end function
+     integer(c_int) function dangx_sky_amp_sample_c(ctxs, nctx, group, flag, ml_mode, solver, fluct_mode, seed, stream, &
+          i_max, converge, cg_iters, n_not_spd) bind(C, name='dangx_sky_amp_sample')
+       import :: c_int, c_ptr, c_double, c_int64_t
+       type(c_ptr), intent(in) :: ctxs(*)
+       integer(c_int), value :: nctx, group, flag, ml_mode, solver, fluct_mode, i_max
+       integer(c_int64_t), value :: seed, stream
+       real(c_double), value :: converge
+       integer(c_int), intent(out), optional :: cg_iters
+       integer(c_int64_t), intent(out), optional :: n_not_spd
+     end function
+     integer(c_int) function dangx_plan_fusion(ctx, npairs, pair_group, pair_flag, nsweeps, sweep_comp, sweep_nind, sweep_flag, &
+          sweep_plain, solver, first_sweep) bind(C, name='dangx_plan_fusion')
+       import :: c_int, c_ptr, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: npairs, nsweeps, solver
+       integer(c_int32_t), intent(in) :: pair_group(*), pair_flag(*), sweep_comp(*), sweep_nind(*), sweep_flag(*), sweep_plain(*)
+       integer(c_int32_t), intent(out) :: first_sweep(*)    ! 0-based position in the sweep list, or -1
+     end function
+     integer(c_int) function dangx_fullsky_finish_coarse(ctx, comp, map_n, nside, sample_nside, partials_sum) &
+          bind(C, name='dangx_fullsky_finish_coarse')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, partials_sum
+       integer(c_int), value :: comp, map_n, nside, sample_nside
+     end function
+     ! ---- the rest of the ABI (device-resident buffers, secondary seams, profiling)
+     type(c_ptr) function dangx_version() bind(C, name='dangx_version')
+       import :: c_ptr
+     end function
+     integer(c_int) function dangx_set_stream(ctx, hip_stream) bind(C, name='dangx_set_stream')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, hip_stream
+     end function
+     integer(c_int) function dangx_adopt_device_data(ctx, sig_dev, rms_dev, mask_dev) bind(C, name='dangx_adopt_device_data')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, sig_dev, rms_dev, mask_dev
+     end function
+     integer(c_int) function dangx_adopt_device_state(ctx, comp, amp_dev, idx_dev) bind(C, name='dangx_adopt_device_state')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, amp_dev, idx_dev
+       integer(c_int), value :: comp
+     end function
+     type(c_ptr) function dangx_amplitude_devptr(ctx, comp) bind(C, name='dangx_amplitude_devptr')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: comp
+     end function
+     type(c_ptr) function dangx_indices_devptr(ctx, comp) bind(C, name='dangx_indices_devptr')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: comp
+     end function
+     integer(c_int) function dangx_sky_model_chisq_dev(ctx, pol_lo, pol_hi, chisq_sum_dev) bind(C, name='dangx_sky_model_chisq_dev')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, chisq_sum_dev
+       integer(c_int), value :: pol_lo, pol_hi
+     end function
+     integer(c_int) function dangx_chisq_cached_dev(ctx, which, pol_lo, pol_hi, chisq_sum_dev) bind(C, name='dangx_chisq_cached_dev')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, chisq_sum_dev
+       integer(c_int), value :: which, pol_lo, pol_hi
+     end function
+     integer(c_int64_t) function dangx_group_size(ctx, group, flag) bind(C, name='dangx_group_size')
+       import :: c_int, c_ptr, c_int64_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: group, flag
+     end function
+     integer(c_int) function dangx_compute_rhs(ctx, group, flag, b) bind(C, name='dangx_compute_rhs')      ! src/dang_cg_mod.f90:326
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, b
+       integer(c_int), value :: group, flag
+     end function
+     integer(c_int) function dangx_compute_Ax(ctx, group, flag, x, res) bind(C, name='dangx_compute_Ax')   ! :598
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, x, res
+       integer(c_int), value :: group, flag
+     end function
+     integer(c_int) function dangx_compute_sample_vector(ctx, group, flag, eta, res) bind(C, name='dangx_compute_sample_vector')  ! :913
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, eta, res
+       integer(c_int), value :: group, flag
+     end function
+     integer(c_int) function dangx_eval_sed(ctx, comp, band, map_n, out) bind(C, name='dangx_eval_sed')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, out
+       integer(c_int), value :: comp, band, map_n
+     end function
+     integer(c_int) function dangx_profile_enable(ctx, on) bind(C, name='dangx_profile_enable')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: on
+     end function
+     integer(c_int) function dangx_profile_reset(ctx) bind(C, name='dangx_profile_reset')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function
+     integer(c_int) function dangx_profile_get(ctx, kernel_id, total_ms, launches) bind(C, name='dangx_profile_get')
+       import :: c_int, c_ptr, c_double, c_int64_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: kernel_id
+       real(c_double), intent(out) :: total_ms
+       integer(c_int64_t), intent(out) :: launches
      end function
      integer(c_int) function dangx_sky_model_chisq(ctx, pol_lo, pol_hi, chisq_sum, sky, res, chi_map) &
           bind(C, name='dangx_sky_model_chisq')

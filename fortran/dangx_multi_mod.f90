@@ -183,30 +183,26 @@ contains
     end do
   end subroutine dangx_sky_wait
 
-  ! one (group, flag) pass of sample_cg_groups (src/dang_cg_mod.f90:166-171) with the direct block solve.  Groups with
-  ! template / monopole / hi_fit members couple all pixels: they need a sum over the contexts INSIDE the solve, which
-  ! one host thread cannot serve for several blocking calls -- run those with nctx = 1 or one process per GPU
-  ! (dangx_set_allreduce); diffuse groups, i.e. every BASELINE configuration, shard freely.
-  subroutine dangx_sky_amp_sample(sky, group, flag, ml_mode, fluct_mode, seed, stream, n_not_spd)
+  ! one (group, flag) pass of sample_cg_groups (src/dang_cg_mod.f90:166-171) through dangx_sky_amp_sample: diffuse groups
+  ! (every BASELINE configuration) are enqueued on every device; groups with template / monopole / hi_fit members share
+  ! their Schur rows over the contexts (pass 1 everywhere, one small solve, pass 2 everywhere).  Without n_not_spd a
+  ! diffuse group's call does not wait for any device.
+  subroutine dangx_sky_amp_sample(sky, group, flag, ml_mode, fluct_mode, seed, stream, n_not_spd, nullity)
     type(dangx_sky), intent(in) :: sky
     integer, intent(in) :: group, flag, ml_mode, fluct_mode
     integer(c_int64_t), intent(in) :: seed, stream
     integer(c_int64_t), intent(out), optional :: n_not_spd
+    integer, intent(out), optional :: nullity          ! directions of the global amplitudes left at their current value
     integer(c_int) :: iters
     integer(c_int64_t) :: nbad
-    integer :: r
-    if (present(n_not_spd)) then
-       n_not_spd = 0
-       do r = 1, sky%nctx
-          call dangx_check(sky%ctx(r), dangx_amp_sample(sky%ctx(r), group, flag, ml_mode, DANGX_SOLVER_DIRECT, fluct_mode, &
-               seed, stream, 0, 0.d0, iters, nbad), 'dangx_amp_sample')
-          n_not_spd = n_not_spd + nbad
-       end do
+    if (present(n_not_spd) .or. present(nullity)) then
+       call dangx_check(sky%ctx(1), dangx_sky_amp_sample_c(sky%ctx, sky%nctx, group, flag, ml_mode, DANGX_SOLVER_DIRECT, &
+            fluct_mode, seed, stream, 0, 0.d0, iters, nbad), 'dangx_sky_amp_sample')
+       if (present(n_not_spd)) n_not_spd = nbad
+       if (present(nullity)) nullity = -iters
     else
-       do r = 1, sky%nctx
-          call dangx_check(sky%ctx(r), dangx_amp_sample(sky%ctx(r), group, flag, ml_mode, DANGX_SOLVER_DIRECT, fluct_mode, &
-               seed, stream, 0, 0.d0), 'dangx_amp_sample')
-       end do
+       call dangx_check(sky%ctx(1), dangx_sky_amp_sample_c(sky%ctx, sky%nctx, group, flag, ml_mode, DANGX_SOLVER_DIRECT, &
+            fluct_mode, seed, stream, 0, 0.d0), 'dangx_sky_amp_sample')
     end if
   end subroutine dangx_sky_amp_sample
 
@@ -276,14 +272,15 @@ contains
        if (present(accepted)) accepted = 0
        do r = 1, sky%nctx
           call dangx_check(sky%ctx(r), dangx_amp_index_sample(sky%ctx(r), group, flag, ml_mode, DANGX_SOLVER_DIRECT, fluct_mode, &
-               seed_amp, stream_amp, comp, nind, map_n, nsample, seed_index, stream_index, nbad, nacc), 'dangx_amp_index_sample')
+               seed_amp, stream_amp, 0, 0.d0, comp, nind, map_n, nsample, seed_index, stream_index, n_not_spd=nbad, accepted=nacc), &
+               'dangx_amp_index_sample')
           if (present(n_not_spd)) n_not_spd = n_not_spd + nbad
           if (present(accepted)) accepted = accepted + nacc
        end do
     else
        do r = 1, sky%nctx
           call dangx_check(sky%ctx(r), dangx_amp_index_sample(sky%ctx(r), group, flag, ml_mode, DANGX_SOLVER_DIRECT, fluct_mode, &
-               seed_amp, stream_amp, comp, nind, map_n, nsample, seed_index, stream_index), 'dangx_amp_index_sample')
+               seed_amp, stream_amp, 0, 0.d0, comp, nind, map_n, nsample, seed_index, stream_index), 'dangx_amp_index_sample')
        end do
     end if
   end subroutine dangx_sky_amp_index_sample
@@ -385,75 +382,47 @@ contains
     avg = tot/ntot
   end function dangx_sky_index_mean
 
-  ! sum(c%indices(:,map_n,nind))/sum(mask(:,1)) over every pixel: the per-pixel tuner's start (src/dang_sample_mod.f90:344)
-  function dangx_sky_index_plain_mean(sky, comp, nind, map_n) result(avg)
+  ! ---- the sky-wide steps of the loop: the chains run behind the C ABI (dang_amd/csrc/dangx_sky.hip), over all contexts
+  ! sample_index_mh with index_mode == 1 (src/dang_sample_mod.f90:229-329), tuner included; comp / nind 0-based.
+  ! tuned(1:nindices) = c%tuned as 0 / 1, step_size = c%step_size(nind) after the call.
+  subroutine dangx_sky_fullsky_sample(sky, comp, nind, map_n, nsample, ml_mode, seed, stream, nside, sample_nside, tuned, &
+       step_size, value, accepted)
     type(dangx_sky), intent(in) :: sky
-    integer, intent(in) :: comp, nind, map_n
-    real(c_double) :: avg, s, m, st, mt
-    integer :: r
-    st = 0.d0; mt = 0.d0
-    do r = 1, sky%nctx
-       call dangx_check(sky%ctx(r), dangx_index_plain_sum(sky%ctx(r), comp, nind, map_n, s, m), 'dangx_index_plain_sum')
-       st = st + s; mt = mt + m
-    end do
-    avg = st/mt
-  end function dangx_sky_index_plain_mean
+    integer, intent(in) :: comp, nind, map_n, nsample, ml_mode, nside, sample_nside
+    integer(c_int64_t), intent(in) :: seed, stream
+    integer(c_int32_t), intent(inout) :: tuned(*)
+    real(c_double), intent(out) :: step_size, value
+    integer(c_int64_t), intent(out) :: accepted
+    call dangx_check(sky%ctx(1), dangx_fullsky_sample(sky%ctx, sky%nctx, comp, nind, map_n, nsample, ml_mode, seed, stream, &
+         nside, sample_nside, tuned, step_size, value, accepted), 'dangx_fullsky_sample')
+  end subroutine dangx_sky_fullsky_sample
 
-  ! the two sums of fit_band_gain (src/dang_sample_mod.f90:606-607), band 0-based
-  subroutine dangx_sky_gain_sums(sky, band, mu, sigma)
+  ! the 'Tuning!' block of the per-pixel branch (src/dang_sample_mod.f90:337-346)
+  subroutine dangx_sky_tune_perpixel(sky, comp, nind, map_n, nsample, ml_mode, seed, stream, tuned, step_size)
     type(dangx_sky), intent(in) :: sky
-    integer, intent(in) :: band
-    real(c_double), intent(out) :: mu, sigma
-    real(c_double), target :: o(2)
-    integer :: r
-    mu = 0.d0; sigma = 0.d0
-    do r = 1, sky%nctx
-       call dangx_check(sky%ctx(r), dangx_gain_sums(sky%ctx(r), band, c_loc(o)), 'dangx_gain_sums')
-       mu = mu + o(1); sigma = sigma + o(2)
-    end do
-  end subroutine dangx_sky_gain_sums
+    integer, intent(in) :: comp, nind, map_n, nsample, ml_mode
+    integer(c_int64_t), intent(in) :: seed, stream
+    integer(c_int32_t), intent(inout) :: tuned(*)
+    real(c_double), intent(out) :: step_size
+    call dangx_check(sky%ctx(1), dangx_tune_perpixel(sky%ctx, sky%nctx, comp, nind, map_n, nsample, ml_mode, seed, stream, &
+         tuned, step_size), 'dangx_tune_perpixel')
+  end subroutine dangx_sky_tune_perpixel
 
-  ! full-sky chain primitives (index_mode == 1 and the tuner): prepare once, then sums at a trial theta
-  subroutine dangx_sky_fullsky_prepare(sky, comp, map_n)
+  ! fit_band_gain(ddata, 1, band) (src/dang_sample_mod.f90:570-621), band 0-based; the new gain is on every context
+  function dangx_sky_fit_band_gain(sky, band, ml_mode, seed, stream) result(gain)
     type(dangx_sky), intent(in) :: sky
-    integer, intent(in) :: comp, map_n
-    integer :: r
-    do r = 1, sky%nctx
-       call dangx_check(sky%ctx(r), dangx_fullsky_prepare(sky%ctx(r), comp, map_n), 'dangx_fullsky_prepare')
-    end do
-  end subroutine dangx_sky_fullsky_prepare
+    integer, intent(in) :: band, ml_mode
+    integer(c_int64_t), intent(in) :: seed, stream
+    real(c_double) :: gain
+    call dangx_check(sky%ctx(1), dangx_fit_band_gain(sky%ctx, sky%nctx, band, ml_mode, seed, stream, gain), 'dangx_fit_band_gain')
+  end function dangx_sky_fit_band_gain
 
-  subroutine dangx_sky_fullsky_sums(sky, what, theta, rows, nrows)
+  ! "Update the global variable T_CMB" (src/dang_sample_mod.f90:75-78) from the 'T_cmb' component comp (0-based)
+  function dangx_sky_update_tcmb(sky, comp) result(T)
     type(dangx_sky), intent(in) :: sky
-    integer, intent(in) :: what, nrows
-    real(c_double), intent(in), target :: theta(2)
-    real(c_double), intent(out) :: rows(nrows)
-    real(c_double), target :: part(nrows)
-    integer :: r
-    rows = 0.d0
-    do r = 1, sky%nctx
-       call dangx_check(sky%ctx(r), dangx_fullsky_sums(sky%ctx(r), what, c_loc(theta), c_loc(part), nrows), 'dangx_fullsky_sums')
-       rows = rows + part
-    end do
-  end subroutine dangx_sky_fullsky_sums
-
-  subroutine dangx_sky_fill_index(sky, comp, nind, map_n, value)
-    type(dangx_sky), intent(in) :: sky
-    integer, intent(in) :: comp, nind, map_n
-    real(c_double), intent(in) :: value
-    integer :: r
-    do r = 1, sky%nctx
-       call dangx_check(sky%ctx(r), dangx_fill_index(sky%ctx(r), comp, nind, map_n, value), 'dangx_fill_index')
-    end do
-  end subroutine dangx_sky_fill_index
-
-  ! c%indices(0, map_n, :) -- pixel 0 lives on the first context (src/dang_sample_mod.f90:240-242)
-  subroutine dangx_sky_peek_first(sky, comp, map_n, out)
-    type(dangx_sky), intent(in) :: sky
-    integer, intent(in) :: comp, map_n
-    real(c_double), intent(out), target :: out(2)
-    out = 0.d0
-    call dangx_check(sky%ctx(1), dangx_peek_indices(sky%ctx(1), comp, map_n, 0_c_int64_t, c_loc(out)), 'dangx_peek_indices')
-  end subroutine dangx_sky_peek_first
+    integer, intent(in) :: comp
+    real(c_double) :: T
+    call dangx_check(sky%ctx(1), dangx_update_tcmb(sky%ctx, sky%nctx, comp, T), 'dangx_update_tcmb')
+  end function dangx_sky_update_tcmb
 
 end module dangx_multi_mod

@@ -121,15 +121,10 @@ contains
     integer(c_int) :: ndev
     integer(c_int64_t) :: p0, np
     integer :: i, j, nctx, r
-    integer, allocatable :: iseed(:)
 
     call dangx_check(c_null_ptr, dangx_device_count(ndev), 'dangx_device_count')
     nctx = ndev
     if (present(ngpu)) nctx = ngpu
-    do i = 1, ncomp                                  ! coupled groups cannot be split over contexts of ONE host thread
-       cc => component_list(i)%p
-       if (type_code(cc) >= DANGX_TEMPLATE .and. cc%sample_amplitude) nctx = 1
-    end do
     if (numprocs > 1) then
        ! one context on this rank's range [p0, p0+np) of the sky: a one-context sky whose window starts at p0
        call dangx_shard_range(int(npix, c_int64_t), rank, numprocs, p0, np)
@@ -141,12 +136,8 @@ contains
        call dangx_check(gpu_sky%ctx(1), dangx_set_host_stride(gpu_sky%ctx(1), int(npix, c_int64_t)), 'dangx_set_host_stride')
        call dangx_check(gpu_sky%ctx(1), dangx_set_allreduce(gpu_sky%ctx(1), c_funloc(dang_allreduce), c_null_ptr, &
             merge(1, 0, rank == master)), 'dangx_set_allreduce')
-       ! the sky-wide chains (full-sky index mode, tuner, gain draw) run on the host of EVERY rank: they must draw the
-       ! same numbers, so the intrinsic generator gets one seed on all ranks (the reference leaves it unseeded)
-       call random_seed(size=r)
-       allocate(iseed(r)); iseed = 20240601
-       call random_seed(put=iseed)
-       deallocate(iseed)
+       ! the sky-wide chains (full-sky index mode, tuner, gain draw) run behind the ABI on EVERY rank with keyed random
+       ! numbers: same draws everywhere, nothing to seed here
     else
        call dangx_sky_create(gpu_sky, int(npix, c_int64_t), nmaps, nbands, ncomp, nctx)
     end if
@@ -308,50 +299,99 @@ contains
     end if
   end function gpu_index_mean
 
-  subroutine sample_cg_groups_gpu(dpar, ddata)
-    ! same signature and effect as sample_cg_groups, src/dang_cg_mod.f90:142-177
+  integer(i4b) function map_of_flag(flag)
+    ! src/dang_sample_mod.f90:53-64: T -> 1, Q -> 2, U -> 3, Q+U -> -1; 0 = "something wrong with the poltype flag"
+    integer(i4b), intent(in) :: flag
+    if (iand(flag,1) .ne. 0) then
+       map_of_flag = 1
+    else if (iand(flag,2) .ne. 0) then
+       map_of_flag = 2
+    else if (iand(flag,4) .ne. 0) then
+       map_of_flag = 3
+    else if (iand(flag,8) .ne. 0) then
+       map_of_flag = -1
+    else
+       map_of_flag = 0
+    end if
+  end function map_of_flag
+
+  ! an ordinary per-pixel sweep at the map resolution with nothing to tune first
+  logical function plain_sweep(cc, j)
+    type(dang_comps), intent(in) :: cc
+    integer(i4b), intent(in)     :: j
+    plain_sweep = cc%index_mode(j) /= 1 .and. cc%sample_nside(j) == nside .and. cc%tuned(j)
+  end function plain_sweep
+
+  ! ---- the amplitude phase.  first_sweep(p) > 0: the p-th (group, flag) pass is issued together with sweep number
+  ! first_sweep(p) of the list (sw_*), through dangx_amp_index_sample -- one kernel launch where the model allows it.
+  subroutine run_solves(dpar, ddata, per_group_stats, first_sweep, sw_comp, sw_nind)
     type(dang_data)   :: ddata
     type(dang_params) :: dpar
-    integer(i4b) :: i, f, mode
+    logical, intent(in) :: per_group_stats
+    integer(c_int32_t), intent(in), optional :: first_sweep(:), sw_comp(:), sw_nind(:)
+    integer(i4b) :: i, f, mode, p, e, flag, nullity
     integer(c_int64_t) :: nbad
     integer(c_int) :: refinements
     real(c_double) :: resid(2)
     logical :: coupled
     mode = merge(DANGX_ML_SAMPLE, DANGX_ML_OPTIMIZE, trim(dpar%ml_mode) == 'sample')
+    p = 0
     do i = 1, ncg_groups
-       if (cg_groups(i)%p%sample) then
-          write(*,fmt='(a,i4)') "Computing a CG search of CG group ", i
-          coupled = cg_groups(i)%p%ntemp > 0
-          ! DIRECT: per-pixel block solve instead of the CG iteration; groups with template / monopole / hi_fit members:
-          ! Schur-complement solve with iterative refinement of the global rows.  (DANGX_SOLVER_CG through dangx_amp_sample
-          ! would run the reference's cg_search on the device instead.)
-          do f = 1, cg_groups(i)%p%nflag
-             call dangx_sky_amp_sample(gpu_sky, i, cg_groups(i)%p%pol_flag(f), mode, DANGX_FLUCT_REFERENCE, gpu_seed, &
-                  dangx_stream_id(iter, 0, i, 0, cg_groups(i)%p%pol_flag(f)), nbad)
+       if (.not. cg_groups(i)%p%sample) cycle
+       write(*,fmt='(a,i4)') "Computing a CG search of CG group ", i
+       coupled = cg_groups(i)%p%ntemp > 0
+       ! DIRECT: per-pixel block solve instead of the CG iteration; groups with template / monopole / hi_fit members:
+       ! Schur-complement solve over all contexts with iterative refinement of the global rows
+       do f = 1, cg_groups(i)%p%nflag
+          flag = cg_groups(i)%p%pol_flag(f)
+          p = p + 1
+          e = 0
+          if (present(first_sweep)) e = first_sweep(p) + 1
+          if (e > 0) then
+             call dangx_sky_amp_index_sample(gpu_sky, i, flag, mode, DANGX_FLUCT_REFERENCE, gpu_seed, &
+                  dangx_stream_id(iter, 0, i, 0, flag), int(sw_comp(e)), int(sw_nind(e)), map_of_flag(flag), nsample, gpu_seed, &
+                  dangx_stream_id(iter, 1, int(sw_comp(e)), int(sw_nind(e)), flag))
+          else if (coupled .or. per_group_stats) then     ! with the count: the chi^2 pass below waits for the device anyway
+             call dangx_sky_amp_sample(gpu_sky, i, flag, mode, DANGX_FLUCT_REFERENCE, gpu_seed, &
+                  dangx_stream_id(iter, 0, i, 0, flag), nbad, nullity)
              if (nbad > 0) write(*,*) 'warning: ', nbad, ' non-SPD pixel blocks left unchanged'
              if (coupled) then
                 call dangx_check(gpu_sky%ctx(1), dangx_schur_info(gpu_sky%ctx(1), resid, refinements), 'schur_info')
                 write(*,fmt='(a,es10.2,a,i2,a)') '  global rows: |b - A x| / |b| = ', resid(1), ' after ', refinements, ' refinement(s)'
              end if
-          end do
-          if (coupled) call refresh_offsets(ddata)       ! update_sky_model: offset <- monopole amplitudes
-          call gpu_chisq(ddata, .true.)                   ! update_sky_model + write_stats_to_term, :172-173
-       end if
+          else
+             call dangx_sky_amp_sample(gpu_sky, i, flag, mode, DANGX_FLUCT_REFERENCE, gpu_seed, dangx_stream_id(iter, 0, i, 0, flag))
+          end if
+       end do
+       if (coupled) call refresh_offsets(ddata)           ! update_sky_model: offset <- monopole amplitudes
+       if (per_group_stats) call gpu_chisq(ddata, .true.) ! update_sky_model + write_stats_to_term, :172-173
     end do
-  end subroutine sample_cg_groups_gpu
+  end subroutine run_solves
 
-  subroutine sample_spectral_parameters_gpu(dpar, ddata)
-    ! same signature and effect as sample_spectral_parameters, src/dang_sample_mod.f90:21-86
+  subroutine sample_cg_groups_gpu(dpar, ddata)
+    ! same signature and effect as sample_cg_groups, src/dang_cg_mod.f90:142-177 (chi^2 and the index means printed after
+    ! every group, which costs one pass over the maps per group: gibbs_iteration_gpu prints them once per iteration)
     type(dang_data)   :: ddata
     type(dang_params) :: dpar
+    call run_solves(dpar, ddata, .true.)
+  end subroutine sample_cg_groups_gpu
+
+  ! ---- the index phase: the loops of sample_spectral_parameters (src/dang_sample_mod.f90:32-79); sweep number e of the
+  ! iteration is skipped when skip(e) is set (it went with its group's solve)
+  subroutine run_sweeps(dpar, ddata, skip, sampled)
+    type(dang_data)   :: ddata
+    type(dang_params) :: dpar
+    logical, intent(in), optional :: skip(:)
+    logical(lgt), intent(out)     :: sampled
     type(dang_comps), pointer :: cc
-    integer(i4b) :: i, j, k, map_n, mode
-    integer(c_int64_t) :: nacc
-    real(c_double), target :: tpeek(2)
-    type(dangx_comp_desc) :: d
-    logical(lgt) :: sampled, pair_done, pairable
+    integer(i4b) :: i, j, k, e, map_n, mode, flag
+    integer(c_int64_t) :: nacc, stream
+    integer(c_int32_t) :: tuned(2)
+    real(c_double) :: step, val
+    logical(lgt) :: pair_done, pairable, skip_next
     sampled = .false.
     mode = merge(DANGX_ML_SAMPLE, DANGX_ML_OPTIMIZE, trim(dpar%ml_mode) == 'sample')
+    e = 0
     do i = 1, ncomp
        cc => component_list(i)%p
        if (cc%nindices == 0) cycle
@@ -359,276 +399,151 @@ contains
        sampled = .true.
        pair_done = .false.
        do j = 1, cc%nindices
-          if (pair_done) then                            ! this index went with the one before it (one launch)
-             pair_done = .false.
-             cycle
-          end if
           if (.not. cc%sample_index(j)) cycle
           do k = 1, cc%nflag(j)
-             if (iand(cc%pol_flag(j,k),1) .ne. 0) then
-                map_n = 1
-             else if (iand(cc%pol_flag(j,k),2) .ne. 0) then
-                map_n = 2
-             else if (iand(cc%pol_flag(j,k),4) .ne. 0) then
-                map_n = 3
-             else if (iand(cc%pol_flag(j,k),8) .ne. 0) then
-                map_n = -1
-             else
+             e = e + 1
+             if (pair_done) then                          ! this index went with the one before it (one launch)
+                pair_done = .false.
+                cycle
+             end if
+             if (present(skip)) then
+                if (skip(e)) cycle
+             end if
+             flag = cc%pol_flag(j,k)
+             map_n = map_of_flag(flag)
+             if (map_n == 0) then
                 write(*,*) "There is something wrong with the poltype flag"
                 cycle
              end if
-             if (cc%index_mode(j) == 1) then
+             stream = dangx_stream_id(iter, 1, i-1, j-1, flag)
+             tuned = 1
+             tuned(1:cc%nindices) = merge(1_c_int32_t, 0_c_int32_t, cc%tuned(1:cc%nindices))
+             if (cc%index_mode(j) == 1) then              ! one index for the whole sky: the chain runs behind the ABI
                 write(*,*) 'Sampling fullsky'
-                if (cc%sample_nside(j) /= nside .and. (gpu_sky%nctx > 1 .or. numprocs > 1)) then
-                   write(*,*) 'dang_gpu_mod: sample_nside /= nside needs the whole sky in one context (dangx_init(..., ngpu=1))'
-                   stop
-                end if
-                call sample_index_mh_fullsky_gpu(cc, i-1, j, map_n)
+                call dangx_sky_fullsky_sample(gpu_sky, i-1, j-1, map_n, nsample, mode, gpu_seed, stream, nside, &
+                     cc%sample_nside(j), tuned, step, val, nacc)
+                cc%tuned(1:cc%nindices) = tuned(1:cc%nindices) /= 0
+                cc%step_size(j) = step
              else if (cc%sample_nside(j) /= nside) then
                 write(*,fmt='(a,i4)') 'Sampling per-pixel at nside ', cc%sample_nside(j)
                 if (numprocs > 1) then      ! one context per process: the sums over the shards go through dang_allreduce
                    call dangx_check(gpu_sky%ctx(1), dangx_index_sample_coarse(gpu_sky%ctx(1), i-1, j-1, map_n, nsample, mode, &
-                        gpu_seed, dangx_stream_id(iter, 1, i-1, j-1, cc%pol_flag(j,k)), nside, cc%sample_nside(j), nacc), &
-                        'index_sample_coarse')
+                        gpu_seed, stream, nside, cc%sample_nside(j), nacc), 'index_sample_coarse')
                 else                        ! one process, one or several contexts
-                   call dangx_sky_index_sample_coarse(gpu_sky, i-1, j-1, map_n, nsample, mode, gpu_seed, &
-                        dangx_stream_id(iter, 1, i-1, j-1, cc%pol_flag(j,k)), nside, cc%sample_nside(j), nacc)
+                   call dangx_sky_index_sample_coarse(gpu_sky, i-1, j-1, map_n, nsample, mode, gpu_seed, stream, nside, &
+                        cc%sample_nside(j), nacc)
                 end if
              else
                 write(*,fmt='(a,i4)') 'Sampling per-pixel at nside ', cc%sample_nside(j)
-                if (.not. cc%tuned(j)) then              ! 'Tuning!', src/dang_sample_mod.f90:341-346
+                if (.not. cc%tuned(j)) then               ! 'Tuning!', src/dang_sample_mod.f90:341-346
                    write(*,*) 'Tuning!'
-                   call tune_perpixel_gpu(cc, i-1, j, map_n)
-                   call fill_desc(cc, d)
-                   call dangx_sky_set_component(gpu_sky, i-1, d)   ! the new step size
+                   call dangx_sky_tune_perpixel(gpu_sky, i-1, j-1, map_n, nsample, mode, gpu_seed, stream, tuned, step)
+                   cc%tuned(1:cc%nindices) = tuned(1:cc%nindices) /= 0
+                   cc%step_size(j) = step
                 end if
-                ! two consecutive plain per-pixel sweeps of this component on the same planes (dust beta, dust T): one entry
-                ! point, one kernel launch where the register chain covers both -- the same numbers as the two sweeps
+                ! two consecutive plain sweeps of this component on the same planes (dust beta, dust T): one entry point,
+                ! one kernel launch where the register chain covers both -- the same numbers as the two sweeps
                 pairable = .false.
                 if (j < cc%nindices .and. cc%nflag(j) == 1) then
                    if (cc%sample_index(j+1) .and. cc%nflag(j+1) == 1) then
-                      pairable = cc%pol_flag(j+1,1) == cc%pol_flag(j,k) .and. cc%index_mode(j+1) /= 1 .and. &
-                           cc%sample_nside(j+1) == nside .and. cc%tuned(j+1)
+                      skip_next = .false.
+                      if (present(skip)) skip_next = skip(e+1)
+                      pairable = cc%pol_flag(j+1,1) == flag .and. plain_sweep(cc, j+1) .and. .not. skip_next
                    end if
                 end if
                 if (pairable) then
                    write(*,fmt='(a,i4)') 'Sampling per-pixel at nside ', cc%sample_nside(j+1)
-                   call dangx_sky_index_sample_pair(gpu_sky, i-1, j-1, map_n, nsample, mode, gpu_seed, &
-                        dangx_stream_id(iter, 1, i-1, j-1, cc%pol_flag(j,k)), dangx_stream_id(iter, 1, i-1, j, cc%pol_flag(j,k)))
+                   call dangx_sky_index_sample_pair(gpu_sky, i-1, j-1, map_n, nsample, mode, gpu_seed, stream, &
+                        dangx_stream_id(iter, 1, i-1, j, flag))
                    pair_done = .true.
                 else
-                   call dangx_sky_index_sample(gpu_sky, i-1, j-1, map_n, nsample, mode, gpu_seed, &
-                        dangx_stream_id(iter, 1, i-1, j-1, cc%pol_flag(j,k)))
+                   call dangx_sky_index_sample(gpu_sky, i-1, j-1, map_n, nsample, mode, gpu_seed, stream)
                 end if
              end if
           end do
        end do
-       ! "Update the global variable T_CMB" (src/dang_sample_mod.f90:75-78): pixel 0 lives on the first shard
-       if (trim(cc%type) == 'T_cmb') then
-          tpeek = 0.d0
-          if (gpu_pix0 == 0) call dangx_sky_peek_first(gpu_sky, i-1, 1, tpeek)
-          T_CMB = rank_sum(tpeek(1))
-          call dangx_sky_set_tcmb(gpu_sky, T_CMB)
-       end if
+       ! "Update the global variable T_CMB" (src/dang_sample_mod.f90:75-78)
+       if (trim(cc%type) == 'T_cmb') T_CMB = dangx_sky_update_tcmb(gpu_sky, i-1)
     end do
+  end subroutine run_sweeps
+
+  subroutine sample_spectral_parameters_gpu(dpar, ddata)
+    ! same signature and effect as sample_spectral_parameters, src/dang_sample_mod.f90:21-86
+    type(dang_data)   :: ddata
+    type(dang_params) :: dpar
+    logical(lgt) :: sampled
+    call run_sweeps(dpar, ddata, sampled=sampled)
     if (sampled) call gpu_chisq(ddata, .true.)            ! update_sky_model + write_stats_to_term, :81-84
   end subroutine sample_spectral_parameters_gpu
 
-  ! ---- the sky-wide chain of index_mode == 1 and of the tuner: the reference's own statements with the three
-  ! evaluate_* / eval_jeffreys_prior calls replaced by device passes
-  function fullsky_lnl(cc, nind, sp, th) result(v)
+  ! One pass of the main loop for an iteration in which both phases run (src/dang.f90:101-106, iter > 1):
+  !     call sample_cg_groups_gpu(dpar, ddata); call sample_spectral_parameters_gpu(dpar, ddata)
+  ! with the same state at the end, bit for bit, in fewer passes over the maps: every group's solve is issued together with
+  ! the first sweep on its planes where dangx_plan_fusion says the loop's result does not change, consecutive sweeps of a
+  ! component go in pairs, no call waits for a count, and chi^2 comes from the sums the sweeps leave behind -- the statistics
+  ! are printed once, after the index phase.  (The two-call form prints them after every group, one more pass each.)
+  subroutine gibbs_iteration_gpu(dpar, ddata)
+    type(dang_data)   :: ddata
+    type(dang_params) :: dpar
     type(dang_comps), pointer :: cc
-    integer(i4b), intent(in)  :: nind, sp
-    real(c_double), intent(in) :: th(2)
-    real(dp) :: v
-    real(c_double) :: rows(4*nbands)
-    integer(i4b) :: q
-    v = 0.d0
-    if (trim(cc%lnl_type(nind)) == 'chisq') then                       ! evaluate_lnL, src/dang_lnl_mod.f90:126-182
-       call dangx_sky_fullsky_sums(gpu_sky, 0, th, rows, 1)
-       v = rank_sum(rows(1))
-    else if (trim(cc%lnl_type(nind)) == 'marginal') then              ! evaluate_marginal_lnL, :47-124: j outer, k inner
-       call dangx_sky_fullsky_sums(gpu_sky, 1, th, rows, 2*nbands*sp)
-       do q = 1, nbands*sp
-          v = v - 0.5d0*rank_sum(rows(2*q-1))*(1.d0/rank_sum(rows(2*q)))*rank_sum(rows(2*q-1))
-       end do
-    end if
-  end function fullsky_lnl
-
-  function fullsky_prior(cc, nind, val) result(v)
-    type(dang_comps), pointer :: cc
-    integer(i4b), intent(in)  :: nind
-    real(dp), intent(in)      :: val
-    real(dp) :: v
-    real(c_double) :: th(2), rows(1)
-    v = 0.d0
-    if (trim(cc%prior_type(nind)) == 'gaussian') then
-       v = log(eval_normal_prior(val, cc%gauss_prior(nind,1), cc%gauss_prior(nind,2)))
-    else if (trim(cc%prior_type(nind)) == 'jeffreys') then             ! eval_jeffreys_prior, src/dang_lnl_mod.f90:242-304
-       th = [val, 0.d0]
-       call dangx_sky_fullsky_sums(gpu_sky, 2, th, rows, 1)
-       v = log(sqrt(rank_sum(rows(1))))
-    end if
-  end function fullsky_prior
-
-  ! tune_spectral_parameter_length, src/dang_sample_mod.f90:623-717, on data prepared by dangx_sky_fullsky_prepare
-  subroutine tune_gpu(cc, nind, sp, theta_init)
-    type(dang_comps), pointer :: cc
-    integer(i4b), intent(in)  :: nind, sp
-    real(dp), intent(in)      :: theta_init(2)
-    real(c_double) :: theta(2), sample(2)
-    real(dp) :: accept, lnl, lnl_new, lnl_old, diff, ratio, num
-    integer(i4b) :: l
-    lnl = 0.d0; lnl_new = 0.d0; lnl_old = 0.d0
-    sample = theta_init; theta = theta_init
-    if (trim(cc%lnl_type(nind)) == 'prior') then
-       sample(nind) = rand_normal(cc%gauss_prior(nind,1), cc%gauss_prior(nind,2))
-    else
-       lnl = fullsky_lnl(cc, nind, sp, sample)
-    end if
-    if (trim(cc%prior_type(nind)) == 'gaussian') then
-       lnl_old = lnl + log(eval_normal_prior(sample(nind), cc%gauss_prior(nind,1), cc%gauss_prior(nind,2)))
-    else if (trim(cc%prior_type(nind)) == 'uniform') then
-       lnl_old = lnl
-    end if
-    do while (.not. cc%tuned(nind))
-       accept = 0.d0
-       do l = 1, nsample
-          theta(nind) = sample(nind) + rand_normal(0.d0, cc%step_size(nind))
-          if (theta(nind) .lt. cc%uni_prior(nind,1) .or. theta(nind) .gt. cc%uni_prior(nind,2)) cycle
-          if (trim(cc%lnl_type(nind)) == 'chisq' .or. trim(cc%lnl_type(nind)) == 'marginal') lnl = fullsky_lnl(cc, nind, sp, theta)
-          if (trim(cc%prior_type(nind)) == 'gaussian') then
-             lnl_new = lnl + log(eval_normal_prior(theta(nind), cc%gauss_prior(nind,1), cc%gauss_prior(nind,2)))
-          else if (trim(cc%prior_type(nind)) == 'uniform') then
-             lnl_new = lnl
-          end if
-          diff  = lnl_new - lnl_old
-          ratio = exp(diff)
-          if (trim(ml_mode) == 'optimize') then
-             if (ratio > 1.d0) then
-                sample(nind) = theta(nind); lnl_old = lnl_new; accept = accept + 1
-             end if
-          else if (trim(ml_mode) == 'sample') then
-             call RANDOM_NUMBER(num)
-             if (ratio > num) then
-                sample(nind) = theta(nind); lnl_old = lnl_new; accept = accept + 1
-             end if
-          end if
-          lnl = 0.d0
-       end do
-       if (accept/l .lt. 0.4) then
-          cc%step_size(nind) = cc%step_size(nind) - 0.5*cc%step_size(nind)
-       else if (accept/l .gt. 0.6) then
-          cc%step_size(nind) = cc%step_size(nind) + 0.5*cc%step_size(nind)
-       else
-          cc%tuned = .true.
-       end if
-       write(*,*) accept/l, cc%step_size(nind)
+    integer(c_int32_t), allocatable :: pg(:), pf(:), sc(:), sn(:), sf(:), sp(:), first(:)
+    logical, allocatable :: skip(:)
+    integer(i4b) :: i, j, k, f, np, ns
+    logical(lgt) :: sampled
+    np = 0; ns = 0
+    do i = 1, ncg_groups
+       if (cg_groups(i)%p%sample) np = np + cg_groups(i)%p%nflag
     end do
-  end subroutine tune_gpu
-
-  ! the 'Tuning!' block of the per-pixel branch, src/dang_sample_mod.f90:341-346 (comp0 0-based, nind 1-based)
-  subroutine tune_perpixel_gpu(cc, comp0, nind, map_n)
-    type(dang_comps), pointer :: cc
-    integer(i4b), intent(in)  :: comp0, nind, map_n
-    real(dp) :: sample(2)
-    integer(i4b) :: l, s1, sp
-    s1 = merge(2, map_n, map_n == -1); sp = merge(2, 1, map_n == -1)
-    call dangx_sky_fullsky_prepare(gpu_sky, comp0, map_n)             ! data_raw minus every other component, :173-196
-    sample = 0.d0
-    do l = 1, cc%nindices
-       ! sum(c%indices(:,map_inds(1),l))/sum(mask(:,1)): every pixel, the mask's values
-       sample(l) = dangx_sky_index_plain_mean(gpu_sky, comp0, l-1, s1)
-       call tune_gpu(cc, nind, sp, sample)
-    end do
-  end subroutine tune_perpixel_gpu
-
-  ! sample_index_mh, index_mode == 1 (src/dang_sample_mod.f90:229-329).  comp0 is 0-based, nind 1-based.
-  subroutine sample_index_mh_fullsky_gpu(cc, comp0, nind, map_n)
-    type(dang_comps), pointer  :: cc
-    integer(i4b), intent(in)   :: comp0, nind, map_n
-    real(c_double), target     :: sample(2), theta(2)
-    real(dp)                   :: lnl, lnl_old, lnl_new, diff, ratio, num
-    integer(i4b)               :: l, s1, sp
-    logical(lgt)               :: sample_it
-    type(dangx_comp_desc)      :: d
-
-    s1 = merge(2, map_n, map_n == -1); sp = merge(2, 1, map_n == -1)
-    if (cc%sample_nside(nind) /= nside) then                                                        ! :173-217, degraded maps
-       call dangx_check(gpu_sky%ctx(1), dangx_fullsky_prepare_coarse(gpu_sky%ctx(1), comp0, map_n, nside, cc%sample_nside(nind)), &
-            'fullsky_prepare_coarse')
-    else
-       call dangx_sky_fullsky_prepare(gpu_sky, comp0, map_n)                                       ! :173-196
-    end if
-    sample = 0.d0
-    if (gpu_pix0 == 0) call dangx_sky_peek_first(gpu_sky, comp0, s1, sample)                       ! :240-242
-    sample(1) = rank_sum(sample(1)); sample(2) = rank_sum(sample(2))
-    theta = sample
-    lnl = 0.d0; sample_it = .true.
-    if (trim(cc%lnl_type(nind)) == 'prior') then                                                    ! :255-257
-       sample_it = .false.
-       sample(nind) = rand_normal(cc%gauss_prior(nind,1), cc%gauss_prior(nind,2))
-    else
-       lnl = fullsky_lnl(cc, nind, sp, sample)
-    end if
-    lnl_old = lnl + fullsky_prior(cc, nind, sample(nind))
-    if (sample_it) then
-       if (.not. cc%tuned(nind)) then                                                               ! :272-275
-          call tune_gpu(cc, nind, sp, sample)
-          call fill_desc(cc, d)
-          call dangx_sky_set_component(gpu_sky, comp0, d)
-       end if
-       do l = 1, nsample                                                                            ! :282-324
-          theta(nind) = sample(nind) + rand_normal(0.d0, cc%step_size(nind))
-          if (theta(nind) < cc%uni_prior(nind,1) .or. theta(nind) > cc%uni_prior(nind,2)) cycle
-          lnl_new = fullsky_lnl(cc, nind, sp, theta) + fullsky_prior(cc, nind, theta(nind))
-          diff  = lnl_new - lnl_old
-          ratio = exp(diff)
-          if (trim(ml_mode) == 'optimize') then
-             if (ratio > 1.d0) then
-                sample(nind) = theta(nind); lnl_old = lnl_new
-             end if
-          else
-             call RANDOM_NUMBER(num)
-             if (ratio > num) then
-                sample(nind) = theta(nind); lnl_old = lnl_new
-             end if
-          end if
+    do i = 1, ncomp
+       cc => component_list(i)%p
+       do j = 1, cc%nindices
+          if (cc%sample_index(j)) ns = ns + cc%nflag(j)
        end do
-    end if
-    call dangx_sky_fill_index(gpu_sky, comp0, nind-1, map_n, sample(nind))                          ! :329, :483
-  end subroutine sample_index_mh_fullsky_gpu
+    end do
+    allocate(pg(np), pf(np), first(np), sc(ns), sn(ns), sf(ns), sp(ns), skip(ns))
+    np = 0; ns = 0
+    do i = 1, ncg_groups                                  ! the (group, flag) passes in sample_cg_groups' order
+       if (.not. cg_groups(i)%p%sample) cycle
+       do f = 1, cg_groups(i)%p%nflag
+          np = np + 1; pg(np) = i; pf(np) = cg_groups(i)%p%pol_flag(f)
+       end do
+    end do
+    do i = 1, ncomp                                       ! the sweeps in sample_spectral_parameters' order
+       cc => component_list(i)%p
+       do j = 1, cc%nindices
+          if (.not. cc%sample_index(j)) cycle
+          do k = 1, cc%nflag(j)
+             ns = ns + 1; sc(ns) = i-1; sn(ns) = j-1; sf(ns) = cc%pol_flag(j,k)
+             sp(ns) = merge(1, 0, plain_sweep(cc, j))
+          end do
+       end do
+    end do
+    first = -1
+    if (np > 0 .and. ns > 0) call dangx_check(gpu_sky%ctx(1), dangx_plan_fusion(gpu_sky%ctx(1), np, pg, pf, ns, sc, sn, sf, sp, &
+         DANGX_SOLVER_DIRECT, first), 'dangx_plan_fusion')
+    skip = .false.
+    do i = 1, np
+       if (first(i) >= 0) skip(first(i)+1) = .true.
+    end do
+    call run_solves(dpar, ddata, .false., first, sc, sn)
+    call run_sweeps(dpar, ddata, skip, sampled)
+    call gpu_chisq(ddata, .true.)
+  end subroutine gibbs_iteration_gpu
 
-  ! sample_calibrators + fit_band_gain (src/dang_sample_mod.f90:487-518, 570-621): the two sky-wide sums come from the
-  ! device, the draw stays here, the new gains go back with dangx_set_calibration
+  ! sample_calibrators + fit_band_gain (src/dang_sample_mod.f90:487-518, 570-621) through dangx_fit_band_gain: the sums, the
+  ! draw and ddata%gain(band) on every context behind the ABI
   subroutine sample_calibrators_gpu(ddata)
     type(dang_data), intent(inout) :: ddata
-    real(c_double), allocatable, target :: gain(:), offs(:)
-    real(dp) :: mu, sigma
-    integer(i4b) :: j
+    integer(i4b) :: j, mode
     logical(lgt) :: sampled
     sampled = .false.
     if (any(ddata%fit_gain(:))) then
        write(*,*) "Sampling band calibrators"
        sampled = .true.
     end if
+    mode = merge(DANGX_ML_SAMPLE, DANGX_ML_OPTIMIZE, trim(ml_mode) == 'sample')
     do j = 1, nbands
-       if (ddata%fit_gain(j)) then
-          call dangx_sky_gain_sums(gpu_sky, j-1, mu, sigma)
-          mu = rank_sum(mu); sigma = rank_sum(sigma)
-          mu = mu / sigma
-          sigma = sqrt(1.d0 / sigma)
-          if (trim(ml_mode) == 'optimize') then
-             ddata%gain(j) = mu
-          else
-             ddata%gain(j) = mu + sigma * rand_normal(0.d0, 1.d0)
-          end if
-          ! each band's fit sees the gains already drawn for the bands before it only through res_map of ITS OWN band,
-          ! so one upload after the loop would do; uploading per band keeps the device state equal to the host's
-          allocate(gain(nbands), offs(nbands)); gain = ddata%gain; offs = ddata%offset
-          call dangx_sky_set_calibration(gpu_sky, c_loc(gain), c_loc(offs))
-          deallocate(gain, offs)
-       end if
+       if (ddata%fit_gain(j)) ddata%gain(j) = dangx_sky_fit_band_gain(gpu_sky, j-1, mode, gpu_seed, dangx_stream_id(iter, 2, 0, 0, 0))
     end do
     if (sampled) call gpu_chisq(ddata, .true.)            ! update_sky_model + write_stats_to_term, :513-516
   end subroutine sample_calibrators_gpu
@@ -657,101 +572,80 @@ contains
     end if
   end subroutine dangx_refresh_host_state
 
-  ! write_data (src/dang_data_mod.f90:666-761) with the numbers taken from the device: same files, same formats.
-  ! Every iteration; moves no map.
+  ! a trace file of the run: opened for appending, created by the first iteration that writes to it
+  subroutine open_trace(unit, fname, created)
+    integer(i4b), intent(in)      :: unit
+    character(len=*), intent(in)  :: fname
+    logical, intent(out)          :: created
+    logical :: there
+    inquire(file=trim(fname), exist=there)
+    created = .not. there
+    if (there) then
+       open(unit, file=trim(fname), status='old', position='append', action='write')
+    else
+       open(unit, file=trim(fname), status='new', action='write')
+    end if
+  end subroutine open_trace
+
+  ! The per-iteration ASCII traces of write_data (src/dang_data_mod.f90:666-761) -- total_chisq_<S>.dat,
+  ! <comp>_<S>_amplitudes.dat, <comp>_<index>_mean_<S>.dat, band_gains_k<iter>.dat, band_offsets_k<iter>.dat, each with the
+  ! edit descriptors of the reference's statements (:695, :710-712, :719-729, :735-759) so that scripts/ keeps reading them --
+  ! with every number taken from the device: chi^2 from the sweeps' sums (or one pass), the index means from masked device
+  ! reductions, the template amplitudes from the context.  Runs every iteration and moves no map.
   subroutine write_data_gpu(ddata, dpar, map_n)
     type(dang_data)           :: ddata
     type(dang_params)         :: dpar
     integer(i4b), intent(in)  :: map_n
     type(dang_comps), pointer :: cc
-    integer(i4b)              :: j, n, unit
-    character(len=128)        :: fmt
-    character(len=512)        :: fname
-    character(len=1)          :: nmaps_str
-    character(len=4)          :: nband_str
-    character(len=5)          :: it_str
-    real(dp), allocatable     :: means(:,:)
+    real(dp), allocatable     :: avg(:,:)
+    character(len=512)        :: dir
+    character(len=80)         :: stokes
+    character(len=16)         :: nb_edit, it5
+    integer(i4b)              :: j, n, u
+    logical                   :: created
 
-    call gpu_chisq(ddata, .false.)                       ! write_data's compute_chisq(self), :694
+    call gpu_chisq(ddata, .false.)
     call pull_template_amplitudes(ddata_offset_only=.false.)
-    allocate(means(2, ncomp)); means = 0.d0              ! sky-wide sums: every rank takes part, the master writes
+    allocate(avg(2, ncomp)); avg = 0.d0                  ! sky-wide sums: every rank takes part, the master writes
     do n = 1, ncomp
        cc => component_list(n)%p
        do j = 1, cc%nindices
-          if (cc%sample_index(j)) means(j, n) = gpu_index_mean(n, j, map_n)   ! mask_avg(c%indices(:,map_n,j), self%masks(:,1))
+          if (cc%sample_index(j)) avg(j, n) = gpu_index_mean(n, j, map_n)
        end do
     end do
     if (rank /= master) return
     write(*,*) 'Output data files'
-    write(nband_str, '(i4)') nbands
-    write(it_str, '(i0.5)') iter
-    write(nmaps_str, '(i1)') nmaps
+    dir = dpar%outdir; stokes = tqu(map_n)
+    write(nb_edit, '(i4)') nbands
+    write(it5, '(i0.5)') iter
 
-    fname = trim(dpar%outdir) // 'total_chisq_' // trim(tqu(map_n)) // '.dat'
-    inquire(file=fname, exist=exist)
-    if (exist) then
-       open(33, file=fname, status="old", position="append", action="write")
-    else
-       open(33, file=fname, status="new", action="write")
-    end if
+    call open_trace(33, trim(dir)//'total_chisq_'//trim(stokes)//'.dat', created)
     write(33,*) ddata%chisq
     close(33)
 
     do n = 1, ncomp
        cc => component_list(n)%p
        if (trim(cc%type) == 'template' .or. trim(cc%type) == 'hi_fit') then
-          unit = getlun()
-          fname = trim(dpar%outdir) // trim(cc%label) // '_' // trim(tqu(map_n)) // '_amplitudes.dat'
-          inquire(file=fname, exist=exist)
-          if (exist) then
-             open(unit, file=fname, status="old", position="append", action="write")
-          else
-             open(unit, file=fname, status="new", action="write")
-             write(unit, fmt='('//trim(nband_str)//'(A17))') ddata%label
-          end if
-          write(unit, fmt='('//trim(nband_str)//'(E17.8))') cc%template_amplitudes(:,map_n)/cc%temp_norm(map_n)
-          close(unit)
+          u = getlun()
+          call open_trace(u, trim(dir)//trim(cc%label)//'_'//trim(stokes)//'_amplitudes.dat', created)
+          if (created) write(u, fmt='('//trim(nb_edit)//'(A17))') ddata%label
+          write(u, fmt='('//trim(nb_edit)//'(E17.8))') cc%template_amplitudes(:,map_n)/cc%temp_norm(map_n)
+          close(u)
        end if
        do j = 1, cc%nindices
-          if (cc%sample_index(j)) then
-             fmt = '('//nmaps_str//'(f12.8))'
-             unit = getlun()
-             fname = trim(dpar%outdir) // trim(cc%label) // '_' // trim(cc%ind_label(j)) // '_mean_' // trim(tqu(map_n)) // '.dat'
-             inquire(file=fname, exist=exist)
-             if (exist) then
-                open(unit, file=fname, status="old", position="append", action="write")
-             else
-                open(unit, file=fname, status="new", action="write")
-             end if
-             write(unit, fmt=fmt) means(j, n)
-             close(unit)
-          end if
+          if (.not. cc%sample_index(j)) cycle
+          u = getlun()
+          call open_trace(u, trim(dir)//trim(cc%label)//'_'//trim(cc%ind_label(j))//'_mean_'//trim(stokes)//'.dat', created)
+          write(u, fmt='('//achar(48+nmaps)//'(f12.8))') avg(j, n)
+          close(u)
        end do
     end do
 
-    fmt = '(a12,E16.8)'
-    fname = trim(dpar%outdir)//'band_gains_k'//it_str//'.dat'
-    inquire(file=fname, exist=exist)
-    if (exist) then
-       open(37, file=fname, status="old", position="append", action="write")
-    else
-       open(37, file=fname, status="new", action="write")
-    end if
-    do j = 1, nbands
-       write(37, fmt=fmt) trim(ddata%label(j)), ddata%gain(j)
-    end do
+    call open_trace(37, trim(dir)//'band_gains_k'//trim(it5)//'.dat', created)
+    write(37, fmt='(a12,E16.8)') (trim(ddata%label(j)), ddata%gain(j), j = 1, nbands)
     close(37)
-
-    fname = trim(dpar%outdir)//'band_offsets_k'//it_str//'.dat'
-    inquire(file=fname, exist=exist)
-    if (exist) then
-       open(38, file=fname, status="old", position="append", action="write")
-    else
-       open(38, file=fname, status="new", action="write")
-    end if
-    do j = 1, nbands
-       write(38, fmt=fmt) trim(ddata%label(j)), ddata%offset(j)/ddata%conversion(j)
-    end do
+    call open_trace(38, trim(dir)//'band_offsets_k'//trim(it5)//'.dat', created)
+    write(38, fmt='(a12,E16.8)') (trim(ddata%label(j)), ddata%offset(j)/ddata%conversion(j), j = 1, nbands)
     close(38)
   end subroutine write_data_gpu
 

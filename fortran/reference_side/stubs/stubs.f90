@@ -1,4 +1,6 @@
-! Type-check stubs for ../dang_gpu_mod.f90 (see README.md).  Declarations only.
+! Mock modules for ../dang_gpu_mod.f90 (see README.md): the NAMES of the reference's modules with just the declarations the
+! wrapper touches (types, globals, getlun).  Builder-owned test scaffolding for the wrapper -- no reference code, and nothing
+! of the reference is compiled with them: ../dang_gpu_drive.f90 fills these types from a problem file and RUNS the wrapper.
 module healpix_types                       ! HEALPix-F90 kinds
   integer, parameter :: i4b = selected_int_kind(9), i8b = selected_int_kind(16)
   integer, parameter :: sp = selected_real_kind(5,30), dp = selected_real_kind(12,200), lgt = kind(.true.)
@@ -24,17 +26,13 @@ module dang_util_mod                       ! src/dang_util_mod.f90:12-44, 100-13
   character(len=80), dimension(3) :: tqu
   character(len=10)  :: ml_mode
 contains
-  function rand_normal(mean, stdev) result(c)
-    double precision :: mean, stdev, c
-    c = mean + stdev
-  end function rand_normal
-  function eval_normal_prior(prop, mean, std) result(p)
-    real(dp) :: prop, mean, std, p
-    p = prop + mean + std
-  end function eval_normal_prior
   function getlun()
     integer(i4b) :: getlun
-    getlun = 9
+    logical :: busy
+    do getlun = 40, 99                      ! a free unit, as the reference's getlun hands out
+       inquire(unit=getlun, opened=busy)
+       if (.not. busy) return
+    end do
   end function getlun
 end module dang_util_mod
 

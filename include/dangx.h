@@ -218,7 +218,7 @@ int dangx_index_sample_pair(dangx_ctx *ctx, int comp, int nind, int map_n, int n
                             uint64_t stream_first, uint64_t stream_second, int64_t *accepted_first, int64_t *accepted_second);
 
 /* ---- the amplitude solve of a CG group and the FIRST index sweep on the same planes, in one call: exactly
- * dangx_amp_sample(group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, 100, 1e-8, NULL, n_not_spd) followed by
+ * dangx_amp_sample(group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, i_max, converge, cg_iters, n_not_spd) followed by
  * dangx_index_sample(comp, nind, map_n, nsample, ml_mode, seed_index, stream_index, accepted) -- the way sample_cg_groups
  * (src/dang_cg_mod.f90:142-177) and sample_spectral_parameters (src/dang_sample_mod.f90:21-86) follow each other plane set by
  * plane set in the main loop (src/dang.f90) -- and bit for bit their result.  When every step is independent per pixel
@@ -226,8 +226,8 @@ int dangx_index_sample_pair(dangx_ctx *ctx, int comp, int nind, int map_n, int n
  * prior, the sampled component a member of the group whose other members are the only other components on these planes)
  * both run in ONE kernel launch: the maps are read once and the solve's arithmetic hides under the chain's. */
 int dangx_amp_index_sample(dangx_ctx *ctx, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed_amp,
-                           uint64_t stream_amp, int comp, int nind, int map_n, int nsample, uint64_t seed_index,
-                           uint64_t stream_index, int64_t *n_not_spd, int64_t *accepted);
+                           uint64_t stream_amp, int i_max, double converge, int comp, int nind, int map_n, int nsample,
+                           uint64_t seed_index, uint64_t stream_index, int *cg_iters, int64_t *n_not_spd, int64_t *accepted);
 
 /* ---- sky model + chi^2: update_sky_model + compute_chisq
  * (src/dang_data_mod.f90:339-396, 494-526).  pol_lo..pol_hi = ddata%pol_type range.
@@ -315,6 +315,66 @@ int dangx_fill_index(dangx_ctx *ctx, int comp, int nind, int map_n, double value
 int dangx_gain_sums(dangx_ctx *ctx, int band, double *out);
 /* c%indices(pix, map_n, :) of one local pixel (the full-sky chain starts from pixel 0, :240-242) */
 int dangx_peek_indices(dangx_ctx *ctx, int comp, int map_n, long long pix, double *out);
+
+/* dangx_fullsky_prepare_coarse for a PIXEL SHARD: dangx_coarse_partials of every shard (map_n's planes), the buffers
+ * added over the shards, then this call on every shard with the sum.  The degraded data / rms / mask are then whole-sky
+ * on each shard, and dangx_fullsky_sums adds, per shard, the coarse pixels i whose full-resolution pixel i it holds
+ * (that is where the reference reads c%amplitude(i), src/dang_sample_mod.f90:548-563).  dangx_fullsky_sample does this. */
+int dangx_fullsky_finish_coarse(dangx_ctx *ctx, int comp, int map_n, int nside, int sample_nside, const double *partials_sum);
+
+/* ---- the SKY-WIDE steps of the Gibbs loop, chain included (dang_amd/csrc/dangx_sky.hip) --------------------------------
+ * One number describes the whole sky in these steps: a Metropolis step is a pass over the maps that leaves a few sums, plus
+ * a few scalar operations.  Each entry point runs the whole chain of the reference procedure it names, so the chain exists
+ * once for every host language.  ctxs[0..nctx) are the contexts of THIS process in shard order (nctx = 1: a whole-sky
+ * context, or one context per process); a sky-wide sum is the contexts' sums added in shard order, then summed over the
+ * ranks through ctxs[0]'s dangx_set_allreduce callback.  Random numbers: Philox4x32-10 keyed by (seed, stream, pixel label
+ * 2^40 - 1, running draw counter) -- the same on every rank.  Errors: dangx_last_error(ctxs[0]).
+ *
+ * dangx_fullsky_sample: sample_index_mh with index_mode == 1 (src/dang_sample_mod.f90:229-329) for index nind (0-based) of
+ *   component comp on map_n (1, 2, 3 or -1 = Q+U): data_raw minus the other components (:173-196; degraded when
+ *   sample_nside /= nside, :199-217; 0 or nside = full resolution), start at c%indices(0, map_inds(1), :) (:240-242), the
+ *   tuner when tuned[nind] == 0 (:272-275), nsample steps (:282-324), c%indices(:, s1:s2, nind) = result (:329, :483).
+ *   tuned[nindices] in/out = c%tuned (NULL: all tuned); step_size out (nullable) = c%step_size(nind) after the call (the
+ *   contexts' descriptors are updated); value out (nullable) = the sampled index; accepted out (nullable).
+ * dangx_tune_step_size: tune_spectral_parameter_length (:623-717) on data prepared by dangx_fullsky_prepare[_coarse] on every
+ *   context; theta_init[2]; *draw = running draw counter of the stream (in/out).  +-50 % until the acceptance over nsample
+ *   steps is within [0.4, 0.6]; then c%tuned = .true. for ALL indices (:712).  Bounded at 64 rounds (the reference's
+ *   `do while (.not. c%tuned(nind))` does not return when nothing is accepted any more).
+ * dangx_tune_perpixel: the 'Tuning!' block of the per-pixel branch (:337-346): one tuner pass per index l of the component,
+ *   starting at sample(l) = sum(c%indices(:,map_inds(1),l)) / sum(mask(:,1)) over EVERY pixel (mask VALUES summed).
+ * dangx_fit_band_gain: fit_band_gain(ddata, 1, band) (:570-621), band 0-based: gain = mu (optimize) or mu + sigma*N(0,1)
+ *   (draw slot = band); stored as ddata%gain(band) on every context (:619) and returned.
+ * dangx_update_tcmb: "Update the global variable T_CMB" (:75-78): T_CMB = c%indices(0,1,1) of a 'T_cmb' component, set on
+ *   every context (it enters a2t of the 'cmb' SED) and returned. */
+int dangx_fullsky_sample(dangx_ctx *const *ctxs, int nctx, int comp, int nind, int map_n, int nsample, int ml_mode,
+                         uint64_t seed, uint64_t stream, int nside, int sample_nside, int32_t *tuned, double *step_size,
+                         double *value, int64_t *accepted);
+int dangx_tune_step_size(dangx_ctx *const *ctxs, int nctx, int comp, int nind, int nsample, int ml_mode, uint64_t seed,
+                         uint64_t stream, const double *theta_init, uint32_t *draw, int32_t *tuned, double *step_size);
+int dangx_tune_perpixel(dangx_ctx *const *ctxs, int nctx, int comp, int nind, int map_n, int nsample, int ml_mode,
+                        uint64_t seed, uint64_t stream, int32_t *tuned, double *step_size);
+int dangx_fit_band_gain(dangx_ctx *const *ctxs, int nctx, int band, int ml_mode, uint64_t seed, uint64_t stream, double *gain);
+int dangx_update_tcmb(dangx_ctx *const *ctxs, int nctx, int comp, double *tcmb);
+
+/* ---- which solves may be issued together with the first index sweep on their planes (dangx_amp_index_sample) without changing
+ * the result of the main loop (src/dang.f90:101-106 runs every solve of sample_cg_groups before any sweep of
+ * sample_spectral_parameters).  pairs: the (group, flag) passes of the sampled CG groups in sample_cg_groups' order; sweeps: the
+ * (component, index, flag) sweeps in sample_spectral_parameters' order (component-major), sweep_plain = 1 for an ordinary
+ * per-pixel sweep at the map resolution with a tuned step.  first_sweep[npairs] out: position in the sweep list of the sweep
+ * to issue with that solve, or -1.  Pure host logic on the context's descriptors; the rule is stated at its definition
+ * (dang_amd/csrc/dangx_sky.hip). */
+int dangx_plan_fusion(dangx_ctx *ctx, int npairs, const int32_t *pair_group, const int32_t *pair_flag, int nsweeps,
+                      const int32_t *sweep_comp, const int32_t *sweep_nind, const int32_t *sweep_flag, const int32_t *sweep_plain,
+                      int solver, int32_t *first_sweep);
+
+/* ---- one (group, flag) pass of sample_cg_groups over SEVERAL contexts of one process (src/dang_cg_mod.f90:166-171).
+ * Diffuse groups: dangx_amp_sample on every context (enqueued on all before the first result is awaited).  Groups with
+ * template / monopole / hi_fit members couple all pixels through their global rows (:522-587, :833-893): with
+ * DANGX_SOLVER_DIRECT every context eliminates its per-pixel blocks (pass 1), the Schur rows are added over the contexts
+ * (shard order) and the ranks, the small system is solved once, every context back-substitutes (pass 2); the residual
+ * check and the refinement steps are shared the same way.  nctx = 1 IS dangx_amp_sample.  DANGX_SOLVER_CG needs nctx = 1. */
+int dangx_sky_amp_sample(dangx_ctx *const *ctxs, int nctx, int group, int flag, int ml_mode, int solver, int fluct_mode,
+                         uint64_t seed, uint64_t stream, int i_max, double converge, int *cg_iters, int64_t *n_not_spd);
 
 /* ---- secondary seams (type-bound procedures of dang_cg_group), host vectors in the
  * reference's packing [c1: plane1(npix), plane2(npix) | c2: ... ] -------------------- */

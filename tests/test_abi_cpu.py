@@ -23,6 +23,13 @@ def test_header_and_binding_agree(built):
     assert sorted(L.SYMBOLS) == names
 
 
+def test_fortran_module_binds_every_declared_symbol():
+    """fortran/dangx_mod.f90 (the ISO_C_BINDING layer of the drop-in) binds exactly the header's exports."""
+    f90 = open(os.path.join(ROOT, "fortran", "dangx_mod.f90")).read()
+    bound = sorted(set(re.findall(r"bind\(C,\s*name='(dangx_\w+)'\)", f90)))
+    assert bound == header_functions()
+
+
 def test_library_exports_every_declared_symbol(built):
     lib = ctypes.CDLL(L.LIB_PATH)
     for n in header_functions():
