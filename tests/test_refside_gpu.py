@@ -156,7 +156,7 @@ def test_wrapper_two_call_and_fused_forms_match_the_oracle_loop(built, tmp_path)
         for j in range(meta["nbands"]):
             assert lines[j][:12] == ("band%02d" % (j + 1)).rjust(12)           # (a12,E16.8): A12 right-justifies
             assert len(lines[j]) == 28 and "E" in lines[j][12:]
-            assert abs(float(lines[j][12:]) - trace[it - 1][2][j]) <= 1e-8 * trace[it - 1][2][j]
+            assert abs(float(lines[j][12:]) - trace[it - 1][2][j]) <= 1e-7 * trace[it - 1][2][j]   # E16.8: eight digits
         with open(os.path.join(outdir, "band_offsets_k%05d.dat" % it)) as f:
             assert len(f.read().splitlines()) == 3 * meta["nbands"]
 
