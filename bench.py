@@ -34,12 +34,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9
 VALU_SUSTAINED_FMA = 30.9e12
 # rocprofv3 --pmc summaries of the SAME command (tools/profile_round.sh): FETCH_SIZE / WRITE_SIZE and the SQ_* pass
-PROFILE_TAG = {"C3": "r02_z", "C5": "r02_c5z"}
+PROFILE_TAG = {"C3": ["r03_z", "r02_z"], "C5": ["r03_c5z", "r02_c5z"]}   # newest committed profile of the configuration first
 
 
 def _profile_json(config, kind):
-    tag = PROFILE_TAG.get(config)
-    return os.path.join(ROOT, "profiles", "%s_%s.json" % (tag, kind)) if tag else None
+    for tag in PROFILE_TAG.get(config, []):
+        path = os.path.join(ROOT, "profiles", "%s_%s.json" % (tag, kind))
+        if os.path.exists(path):
+            return path
+    return None
 
 
 def measured_traffic(config, kernel):
@@ -58,16 +61,16 @@ def measured_traffic(config, kernel):
 def measured_valu(config, kernel, avg_launch_s):
     """VALU-side roofline of `kernel` from the committed SQ-counter profile of the same command: share of the issue
     cycles of a SIMD in which a vector instruction issues (`busy`), and vector lane-operations per second = the
-    profile's lane-ops per launch / THIS run's average launch duration, against the issue peak.  None without a
-    committed profile of the configuration."""
+    profile's lane-ops per launch (64 x the instruction count of the SQ pass: a property of the code, not of the box) / THIS
+    run's average launch duration, against the issue peak.  None without a committed profile of the configuration."""
     try:
         t = json.load(open(_profile_json(config, "valu")))
         if t.get("config") != config:
             return None
         k = t["kernels"][kernel]
-        # the profile's own rate (instruction counts of the SQ pass / durations of the trace pass) where it has one
-        rate = float(k["valu_lane_ops_per_s"]) if k.get("valu_lane_ops_per_s") else float(k["valu_lane_ops_per_launch"]) / avg_launch_s
-        return {"busy": float(k["valu_issue_busy"]), "lane_ops_per_s": rate, "peak": VALU_PEAK_LANE_OPS,
+        rate = float(k["valu_lane_ops_per_launch"]) / avg_launch_s
+        return {"busy_in_profile": float(k["valu_issue_busy"]), "lane_ops_per_launch": float(k["valu_lane_ops_per_launch"]),
+                "lane_ops_per_s": rate, "peak": VALU_PEAK_LANE_OPS,
                 "frac": rate / VALU_PEAK_LANE_OPS, "sustained_fp64_fma": VALU_SUSTAINED_FMA,
                 "source": os.path.relpath(_profile_json(config, "valu"), ROOT)}
     except Exception:
@@ -134,11 +137,43 @@ def cpu_baseline(config_name, nsample, nside_sample=128):
     orc.chisq(1, meta["nmaps"], ddata.nump)
     dt = time.time() - t0
     scale = full_npix / meta["npix_global"]
-    return {"value": 1.0 / (dt * scale), "unit": "it/s", "cores": cores, "kind": "port",
+    # how the port relates to the reference itself: oracle seconds / the reference's own seconds per Gibbs iteration on the two
+    # configurations BASELINE.md section 2 holds reference timings for, both measured on the build container's 8 cores
+    # (tools/ref_ratio.py -> profiles/r03_ref_ratio.json).  < 1: the port is FASTER than the reference, i.e. the reference
+    # would post a lower it/s than `value` on the same cores.
+    try:
+        rr = json.load(open(os.path.join(ROOT, "profiles", "r03_ref_ratio.json")))
+        ref_ratio = {r["config"]: round(r["ratio_iteration"], 4) for r in rr["rows"]}
+        ref_ratio["source"] = "profiles/r03_ref_ratio.json (tools/ref_ratio.py, build container, 8 threads)"
+    except Exception:
+        ref_ratio = None
+    return {"value": 1.0 / (dt * scale), "unit": "it/s", "cores": cores, "kind": "port", "ref_ratio": ref_ratio,
             "sample": "1 Gibbs iteration of config %s at Nside=%d (%d px; CG iterations %s at i_max=100, converge=1e-8) "
                       "took %.2f s on %d OpenMP threads; scaled by pixel count x%d to Nside=%d"
                       % (config_name, nside_sample, meta["npix_global"], cg_iters, dt, cores, int(scale),
                          synth.CONFIGS[config_name]["nside"])}
+
+
+def fortran_seam(config_name, nsample, steps=10):
+    """Gibbs it/s through the REFERENCE-SIDE Fortran wrapper (fortran/reference_side/dang_gpu_mod.f90, run by dang_gpu_drive):
+    the two-call seam north_star names (`call sample_cg_groups_gpu` ; `call sample_spectral_parameters_gpu`, statistics after
+    every group as the reference prints them) beside `call gibbs_iteration_gpu` (solves fused with the first sweeps).  The
+    driver reads an Nside-8 problem of the same model and repeats its maps along the pixel axis up to the configuration's
+    pixel count (random streams are keyed by the global pixel); child processes, after this process's own timed region."""
+    import tempfile
+    from dang_amd import fdrive, synth
+    full_npix = 12 * synth.CONFIGS[config_name]["nside"] ** 2
+    dpar, ddata, bands, comps, meta = synth.make_sky(config_name, nside=8, nsample=nsample)
+    tile = full_npix // meta["npix_global"]
+    out = {"what": "it/s through the Fortran wrapper on %s tiled to %d pixels (%d timed iterations each)" % (config_name, full_npix, steps)}
+    with tempfile.TemporaryDirectory() as tmp:
+        fin = os.path.join(tmp, "in.bin")
+        fdrive.write_problem(fin, dpar, ddata, comps, meta, niter=steps + 2)
+        for mode in ("twocall", "fused"):
+            txt = fdrive.run(fin, os.path.join(tmp, "out_%s.bin" % mode), nctx=1, mode=mode, tile=tile)
+            secs = [float(l.split("=")[1].split()[0]) for l in txt.splitlines() if l.startswith("drive seconds per iteration")]
+            out["two_call_seam" if mode == "twocall" else "fused_gibbs_iteration_gpu"] = {"it_per_s": 1.0 / secs[0], "ms_per_step": 1e3 * secs[0]}
+    return out
 
 
 def launch_ranks(n, backend):
@@ -191,6 +226,8 @@ def main():
     ap.add_argument("--nside", type=int, default=None)
     ap.add_argument("--nsample", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fortran-seam", action="store_true", help="skip the it/s of the reference-side Fortran wrapper (two-call "
+                    "seam and gibbs_iteration_gpu), which bench.py otherwise reports beside the headline value at N=1")
     ap.add_argument("--no-fuse", action="store_true", help="diagnostic: amplitude solve and first index sweep of a plane set as "
                     "two calls (two launches) instead of dangx_amp_index_sample")
     ap.add_argument("--bandpass", type=int, default=0, help="diagnostic (not a BASELINE config): integrate every second "
@@ -423,17 +460,21 @@ def main():
                                        if args.bandpass else "") +
                                       ("; DIAGNOSTIC: ONE rank's shard of a %d-rank run" % shard_of if shard_of else "")),
                        "npix": meta["npix_global"], "chisq_after_amp": chisq[0], "chisq_after_index": chisq[1]},
-            # achieved / peak / frac: the HBM roofline (algorithmic bytes per launch / measured launch duration).  The
-            # dominant kernel is bound by fp64 vector issue, not by HBM: `valu` carries that roofline; `iter_frac` is
-            # SURVEY 8d's per-ITERATION figure (one amplitude pass + one fused index sweep) against the time of a step
-            "roofline": {"bound": "fp64-valu", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(args.config, dom) if standard else None,
-                         "avg_launch_ms": prof[dom]["avg_ms"], "bytes_per_launch": bytes_per_launch,
-                         "valu": measured_valu(args.config, dom, prof[dom]["avg_ms"] * 1e-3) if standard else None,
-                         "iter_bytes": iter_bytes, "iter_frac": iter_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS / world,
-                         "note": "fp64 VALU issue bound (valu.busy of the issue cycles carry a vector instruction); HBM "
-                                 "traffic <= algorithmic bytes, so the HBM fraction is what the arithmetic leaves"},
+            # The dominant kernel is bound by fp64 VECTOR ISSUE, not by HBM: achieved / peak / frac are that roofline -- vector
+            # lane-operations per second (the instruction count of the committed SQ-counter profile x 64, per launch, over
+            # THIS run's launch duration) against one vector instruction per SIMD every 4 cycles.  hbm_* = the HBM side
+            # (algorithmic bytes per launch / launch duration; traffic = counter-measured bytes); iter_frac = SURVEY 8d's
+            # per-ITERATION bytes against the time of a step.
+            "roofline": dict(
+                {"bound": "fp64-valu", "kernel": dom, "avg_launch_ms": prof[dom]["avg_ms"]},
+                **(lambda v: {"achieved": (v["lane_ops_per_s"] / 1e12 if v else None), "peak": VALU_PEAK_LANE_OPS / 1e12,
+                              "unit": "T lane-op/s", "frac": (v["frac"] if v else None), "valu": v})(
+                    measured_valu(args.config, dom, prof[dom]["avg_ms"] * 1e-3) if standard else None),
+                hbm_achieved=achieved, hbm_peak=HBM_PEAK_GBS, hbm_unit="GB/s", hbm_frac=achieved / HBM_PEAK_GBS,
+                bytes_per_launch=bytes_per_launch, traffic=measured_traffic(args.config, dom) if standard else None,
+                iter_bytes=iter_bytes, iter_frac=iter_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS / world,
+                note="fp64 VALU issue bound; HBM traffic <= algorithmic bytes, so hbm_frac is what the arithmetic leaves. "
+                     "frac is null when no SQ profile of this exact command is committed (non-standard flags)"),
             "kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"],
                             "ms_per_step": round(v["total_ms"] / args.steps, 4)} for k, v in prof.items()},
         }
@@ -445,6 +486,18 @@ def main():
             except Exception as e:  # the oracle is optional infrastructure; never let it break the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "it/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
+        if world == 1 and standard and not args.no_fortran_seam:
+            try:
+                log("timing the Fortran wrapper (fortran_seam)")
+                eng.close()
+                if two:
+                    engP.close()
+                del ddata.sig_map, ddata.rms_map
+                torch.cuda.empty_cache()
+                out["fortran_seam"] = fortran_seam(args.config, args.nsample)
+                log("fortran_seam done")
+            except Exception as e:  # flang absent / driver failed: say so in the line, never break it
+                out["fortran_seam"] = {"error": repr(e)[:500]}
         print(json.dumps(out))
     if world > 1:
         td.barrier()

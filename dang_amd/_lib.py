@@ -128,6 +128,8 @@ SYMBOLS = {
     "dangx_compute_Ax": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "dangx_compute_sample_vector": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "dangx_eval_sed": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
+    "dangx_rtc_kernels": (C.c_int, [_P, C.POINTER(C.c_int), C.c_char_p, C.c_int]),
+    "dangx_rtc_compile": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]),
     "dangx_profile_enable": (C.c_int, [_P, C.c_int]),
     "dangx_profile_reset": (C.c_int, [_P]),
     "dangx_profile_get": (C.c_int, [_P, C.c_int, _D, C.POINTER(C.c_int64)]),

@@ -527,6 +527,14 @@ class Engine:
         self._chk(self.lib.dangx_eval_sed(self.h, comp, band, map_n, out.ctypes.data))
         return out
 
+    def rtc_kernels(self):
+        """template-ids of the kernels this context obtained by run-time specialisation (csrc/dangx_rtc.hip)"""
+        n, buf = C.c_int(0), C.create_string_buffer(16384)
+        self._chk(self.lib.dangx_rtc_kernels(self.h, C.byref(n), buf, len(buf)))
+        names = [x for x in buf.value.decode().split("\n") if x]
+        assert len(names) == n.value or len(buf.value) >= len(buf) - 1
+        return names
+
     # -- profiling
     def profile(self, on=True):
         self._chk(self.lib.dangx_profile_enable(self.h, 1 if on else 0))

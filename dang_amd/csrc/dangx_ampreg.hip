@@ -268,6 +268,11 @@ int launch_ng(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, long lon
         if (nb % 5 == 0 && amp_reg_lds<5>(NG, nb, ra.nv) <= cap) return launch_tb<NG, 5>(ctx, a, ra, SN);
         if (nb % 4 == 0 && amp_reg_lds<4>(NG, nb, ra.nv) <= cap) return launch_tb<NG, 4>(ctx, a, ra, SN);
         if (nb % 3 == 0 && amp_reg_lds<3>(NG, nb, ra.nv) <= cap) return launch_tb<NG, 3>(ctx, a, ra, SN);
+        // band counts that 3, 4 and 5 do not divide (7, 11, 13, 14 ...): tiles of two bands, or of one
+        if (nb % 5 && nb % 4 && nb % 3) {
+            if (nb % 2 == 0 && amp_reg_lds<2>(NG, nb, ra.nv) <= cap) return launch_tb<NG, 2>(ctx, a, ra, SN);
+            if (nb % 2 && amp_reg_lds<1>(NG, nb, ra.nv) <= cap) return launch_tb<NG, 1>(ctx, a, ra, SN);
+        }
     }
     return -1;  // the LDS-column kernel is the better fit
 }

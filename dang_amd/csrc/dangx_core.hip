@@ -1469,6 +1469,7 @@ int dangx_destroy(dangx_ctx* ctx) {
     for (auto& p : ctx->chi_pend) if (p.buf) (void)hipFree(p.buf);
     if (ctx->chi_stage) (void)hipFree(ctx->chi_stage);
     for (auto& e : ctx->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    dx_rtc_release(ctx);
     delete ctx;
     return 0;
 }
@@ -1933,7 +1934,7 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
     while (bs > 64 && tabsz + per_thread * bs > 76 * 1024) bs >>= 1;
     const size_t lds = tabsz + per_thread * bs;
     const bool reg_ok = !a.bp && d.lnl_type[nind] == DANGX_LNL_CHISQ && d.prior_type[nind] != DANGX_PRIOR_JEFFREYS &&
-                        a.mode != CH_GENERIC && dx_mh_reg_supported(a.mode, ctx->hm.nbands);
+                        a.mode != CH_GENERIC && dx_mh_reg_supported(ctx, a.mode, ctx->hm.nbands, Sp);
     if (reg_ok) bs = BLOCK;  // register-resident form: no LDS columns
     const unsigned nblk = nblocks((long long)ctx->hm.npix * (reg_ok ? dx_mh_reg_lanes(ctx->hm.nbands, Sp) : 1), bs);
     constexpr int RSTAGE = 128;  // blocks of the first reduction stage

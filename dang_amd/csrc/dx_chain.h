@@ -1,6 +1,6 @@
 // dx_chain.h -- the register-resident Metropolis chain (device code shared by dangx_mhreg.hip and dangx_fused.hip).
 #pragma once
-#include "dx_host.h"
+#include "dx_args.h"
 
 
 // the chain's exp: dx::exp_nr = the library routine minus its range selects (dx_math.h); -DDX_CHAIN_LIBEXP restores

@@ -14,50 +14,7 @@
 #include <vector>
 
 #include "../../include/dangx.h"
-#include "dx_model.h"
-#include "dx_rng.h"
-#include "dx_sed.h"
-
-using namespace dx;
-
-constexpr int BLOCK = 256;
-
-struct GroupArgs {
-    int ng;          // sampled diffuse components of the group
-    int gc[MAXG];    // their component indices, in component_list order
-    int no;          // components NOT solved for (removed from the data)
-    int oc[MAXC];
-    int flag;        // one poltype bit
-    int ml_mode, fluct;
-    unsigned long long seed, stream;
-    // global-amplitude members of the group (template / monopole / hi_fit), after the diffuse ones in x:
-    // x = [diffuse: ng blocks of S*npix | global: nglob entries], component t owns rows trow[t] .. trow[t]+nfit-1
-    int nt, nglob;
-    int tc[MAXT], trow[MAXT];
-    // every template / monopole of the model (any group): bands with corr == false are removed from the data
-    // in compute_rhs (src/dang_cg_mod.f90:445-460)
-    int nuc, uc[MAXC];
-};
-
-__device__ __forceinline__ int flag_nplanes(int flag) { return (flag & DANGX_FLAG_QU) ? 2 : 1; }
-// src/dang_cg_mod.f90:357-363 and the flag-8 branches (:488-494): plane p -> map number
-__device__ __forceinline__ int flag_map(int flag, int p) {
-    if (flag & DANGX_FLAG_QU) return 2 + p;
-    if (flag & DANGX_FLAG_T) return 1;
-    if (flag & DANGX_FLAG_Q) return 2;
-    return 3;
-}
-
-// chain modes of the Metropolis kernels (see dangx_mh.hip)
-enum { CH_GENERIC = 0, CH_POW = 1, CH_MBB_BETA = 2, CH_MBB_T = 3, CH_LOGN_NUP = 4, CH_LOGN_W = 5 };
-
-struct IndexArgs {
-    int comp, nind, s1, s2, nsample, ml_mode, mode;
-    int bp;           // some band is bandpass-integrated or a non-diffuse component is present: the compile-time chain
-                      // modes then sum over the bandpass samples and remove the other components through comp_signal
-    unsigned others;  // bit l: component l (/= comp) may have a non-zero amplitude on planes s1..s2
-    unsigned long long seed, stream;
-};
+#include "dx_args.h"
 
 struct dangx_ctx {
     dangx_dims dims{};
@@ -130,6 +87,10 @@ struct dangx_ctx {
     GroupArgs pending{};
     long long pending_SN = 0;
     int schur_refine = 0;
+    // kernels specialised at run time for this context's model (dangx_rtc.hip)
+    std::vector<std::pair<std::string, hipFunction_t>> rtc_fns;
+    std::vector<hipModule_t> rtc_mods;
+    std::vector<std::string> rtc_failed;
     // profiling
     bool prof = false;
     struct Ev { hipEvent_t a, b; int kid; };
@@ -193,6 +154,12 @@ inline unsigned nblocks(long long n, int bs = BLOCK) { return (unsigned)((n + bs
 // out[row] = sum(partial[row][0..nblk)) for rows 0..rows-1 (deterministic; defined in dangx_core.hip)
 void dx_reduce_rows_to(dangx_ctx* ctx, const double* partial, unsigned nblk, int rows, double* out_dev);
 
+// run-time specialisation (dangx_rtc.hip): the kernel named by a template-id of `header`, or nullptr (+ ctx->err)
+bool dx_rtc_enabled();
+hipFunction_t dx_rtc_get(dangx_ctx* ctx, const char* header, const std::string& name_expr);
+int dx_rtc_launch(dangx_ctx* ctx, hipFunction_t fn, unsigned nblk, size_t lds, void** args);
+void dx_rtc_release(dangx_ctx* ctx);
+
 // launchers defined next to their kernels
 int dx_launch_amp(dangx_ctx* ctx, const GroupArgs& a, long long SN);
 // latency-hiding form of the direct solve (dangx_ampreg.hip): 0 = launched, -1 = case not covered
@@ -221,7 +188,7 @@ int dx_launch_sv_mixed(dangx_ctx* ctx, const GroupArgs& a, long long SN, const d
 // LDS-form Metropolis kernel (fast = chisq likelihood with CH_POW / CH_MBB_*; otherwise the generic chain)
 void dx_launch_mh_lds(dangx_ctx* ctx, const IndexArgs& a, bool fast, int Sp, unsigned nblk, int bs, size_t lds, unsigned long long* accp);
 // register-resident Metropolis kernels; return false when (mode, nb) is not instantiated
-bool dx_mh_reg_supported(int mode, int nb);
+bool dx_mh_reg_supported(dangx_ctx* ctx, int mode, int nb, int Sp);
 bool dx_mh_pair_supported(int mode_a, int mode_b, int nb, int Sp);
 bool dx_launch_mh_pair(dangx_ctx* ctx, const IndexArgs& a, const IndexArgs& b, int Sp, unsigned nblk, unsigned long long* accp);
 bool dx_fused_supported(int mode, int nb, int ng);

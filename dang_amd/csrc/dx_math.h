@@ -5,8 +5,7 @@
 // (measured in ISA instructions on gfx950: exp 19 f64 ops, log 76, sin 108, pow 148).
 // The helpers below are valid on the ranges the kernels use and keep <= 1-2 ulp accuracy.
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "dx_rtc_compat.h"
 
 namespace dx {
 

@@ -6,9 +6,12 @@
 // block in HBM that every kernel receives by pointer; all fields are
 // wave-uniform, so the compiler reads them through the scalar cache (s_load).
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "dx_rtc_compat.h"
+#ifdef __HIPCC_RTC__
+#include "dangx.h"   // the embedded copy (dangx_rtc.hip)
+#else
 #include "../../include/dangx.h"
+#endif
 
 namespace dx {
 

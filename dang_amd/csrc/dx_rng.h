@@ -17,8 +17,7 @@
 //        accept uniform u3 = word 3 [32 bits]  (each 32-bit word maps to (w + 0.5) * 2^-32)
 //   index phase, lnl_type=='prior' draw         : draw = 0 (uniform2)
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "dx_rtc_compat.h"
 #include "dx_math.h"
 #include "dx_model.h"
 

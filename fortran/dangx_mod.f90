@@ -424,6 +424,18 @@ module dangx_mod
        type(c_ptr), value :: ctx, out
        integer(c_int), value :: comp, band, map_n
      end function
+     integer(c_int) function dangx_rtc_kernels(ctx, n, names, names_len) bind(C, name='dangx_rtc_kernels')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, names                 ! names: character buffer or c_null_ptr
+       integer(c_int), intent(out) :: n
+       integer(c_int), value :: names_len
+     end function
+     integer(c_int) function dangx_rtc_compile(header, name_expr, log, log_len) bind(C, name='dangx_rtc_compile')
+       import :: c_int, c_char
+       character(kind=c_char), intent(in) :: header(*), name_expr(*)     ! null-terminated
+       character(kind=c_char), intent(out) :: log(*)
+       integer(c_int), value :: log_len
+     end function
      integer(c_int) function dangx_profile_enable(ctx, on) bind(C, name='dangx_profile_enable')
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx

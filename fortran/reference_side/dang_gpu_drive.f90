@@ -44,7 +44,8 @@ program dang_gpu_drive
   character(len=32), allocatable :: blabel(:)
   character(len=16) :: clabel, ilabel(2)
   character(len=512) :: fin, fout, arg, mode
-  integer :: u, i, j, l, k, npix0, niter, ngroups, nctx, tile, t, c0, c1, crate, it_first
+  integer :: u, i, j, l, k, npix0, niter, ngroups, nctx, tile, t, it_first
+  integer(i8b) :: c0, c1, crate
   real(dp) :: secs
 
   call get_command_argument(1, fin)

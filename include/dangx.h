@@ -385,6 +385,17 @@ int dangx_compute_sample_vector(dangx_ctx *ctx, int group, int flag, const doubl
 /* eval_sed(band, pix, map_n) for all local pixels of one component/band/map -> out[npix] (:778) */
 int dangx_eval_sed(dangx_ctx *ctx, int comp, int band, int map_n, double *out);
 
+/* ---- kernels specialised at run time (dang_amd/csrc/dangx_rtc.hip) -------------------------------------------------------
+ * The register-resident Metropolis kernels and the fused solve + first sweep are templates on the band count, the plane
+ * count and the group size; the library carries instantiations for 3 / 5 / 6 / 8 / 10 / 20 bands.  Any other model shape is
+ * compiled by hiprtc from the library's own (embedded) headers on the first sweep that needs it and cached on disk
+ * ($DANGX_CACHE_DIR, default ~/.cache/dangx); DANGX_RTC=0 disables this (such shapes then take the LDS-column kernels).
+ *   dangx_rtc_kernels: how many kernels this context obtained that way, and (names nullable) their template-ids, one per line.
+ *   dangx_rtc_compile: compile-only check (no device needed), e.g. ("dx_kern_chain.h", "dxk::k_index_mh_reg<1, 1, 9, 1>");
+ *                      0 on success; log receives the compiler's messages (or the kernel's symbol). */
+int dangx_rtc_kernels(dangx_ctx *ctx, int *n, char *names, int names_len);
+int dangx_rtc_compile(const char *header, const char *name_expr, char *log, int log_len);
+
 /* ---- per-kernel timing with HIP events on the context's stream ----------------- */
 int dangx_profile_enable(dangx_ctx *ctx, int on);
 int dangx_profile_reset(dangx_ctx *ctx);

@@ -38,6 +38,19 @@ def test_library_exports_every_declared_symbol(built):
     assert b"gfx950" in L.load().dangx_version()
 
 
+def test_run_time_specialisation_compiles_without_a_device(built):
+    """hiprtc builds the register chain / the fused kernel for a band count the library has no instantiation of, from the
+    headers embedded in the .so (compile only: no GPU needed)."""
+    lib = L.load()
+    for hdr, name in (("dx_kern_chain.h", "dxk::k_index_mh_reg<1, 1, 9, 1>"), ("dx_kern_chain.h", "dxk::k_index_mh_pair<2, 2, 7, 1>"),
+                      ("dx_kern_fused.h", "dxk::k_amp_index<1, 2, 9, 4>")):
+        log = ctypes.create_string_buffer(8192)
+        rc = lib.dangx_rtc_compile(hdr.encode(), name.encode(), log, len(log))
+        assert rc == 0 and log.value.startswith(b"_ZN3dxk"), (name, log.value.decode())
+    log = ctypes.create_string_buffer(8192)
+    assert lib.dangx_rtc_compile(b"dx_kern_chain.h", b"dxk::no_such_kernel<1>", log, len(log)) != 0 and log.value
+
+
 def test_struct_layouts_match_header():
     # dangx_dims: 4 x i32, 2 x i64, 2 x i32 ; dangx_comp_desc: 6 x i32, f64, 2x2 i32, 2x(2x2) f64, 2 f64
     assert ctypes.sizeof(L.Dims) == 4 * 4 + 2 * 8 + 2 * 4

@@ -1,0 +1,72 @@
+"""Model shapes without a built-in kernel instantiation (the library carries 3 / 5 / 6 / 8 / 10 / 20 bands): the register chain,
+the two-index sweep and the fused solve + first sweep are specialised at run time (csrc/dangx_rtc.hip) and must give the
+oracle's numbers like the built-in shapes do -- and it must be THOSE kernels that ran, not the LDS-column fallback."""
+import numpy as np
+import pytest
+
+import dang_amd as da
+from dang_amd import _lib as L
+
+from util import MAPN, make_case, pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_and_compare(case, niter=3):
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+    for it in range(1, niter + 1):
+        if it == 1:
+            da.sample_cg_groups(dpar, ddata, it=it)
+        else:
+            da.gibbs_iteration(dpar, ddata, it)
+        for g in dpar.cg_groups:
+            for f in g.pol_flag:
+                orc.amp_sample_direct(g.cg_group, f, dpar.ml_mode, dpar.seed, da.stream_id(it, 0, g.cg_group, 0, f), "reference")
+        if it > 1:
+            for l, c in enumerate(comps):
+                for j in range(c.nindices):
+                    if c.sample_index[j]:
+                        for f in c.pol_flag[j]:
+                            orc.sample_index_mh(l, j, MAPN[f], dpar.nsample, dpar.ml_mode, dpar.seed, da.stream_id(it, 1, l, j, f))
+    for l, c in enumerate(comps):
+        b = orc.amplitude(l)
+        assert np.abs(eng.get_amplitude(l) - b).max() <= 1e-9 * max(np.abs(b).max(), 1.0), l
+        if c.nindices:
+            assert np.abs(eng.get_indices(l) - orc.indices(l)).max() <= 1e-12, l
+    ochisq, _ = orc.chisq(1, meta["nmaps"], ddata.nump)
+    assert abs(ddata.chisq - ochisq) <= 1e-9 * ochisq
+    return eng
+
+
+@pytest.mark.parametrize("config,nbands,ng", [("C3", 9, 4), ("C2", 7, 3)])
+def test_unlisted_band_counts_run_the_specialised_kernels(built, config, nbands, ng):
+    eng = _run_and_compare(make_case(config, nside=8, nbands=nbands))
+    names = eng.rtc_kernels()
+    # both plane sets: the group's solve fused with the synchrotron sweep, the dust beta / T sweeps as one launch
+    for sp in (1, 2):
+        assert "dxk::k_amp_index<1, %d, %d, %d>" % (sp, nbands, ng) in names, names
+        assert "dxk::k_index_mh_pair<2, %d, %d, 1>" % (sp, nbands) in names, names
+    # nothing went through the LDS-column form: every sweep of the run was a register-chain launch
+    assert all(n.startswith("dxk::") for n in names)
+
+
+def test_fourteen_bands_polarisation_runs_as_lane_pairs(built):
+    """two planes of 14 bands do not fit one lane at two waves per SIMD: the chain is specialised in its lane-pair form"""
+    eng = _run_and_compare(make_case("C2", nside=8, nbands=14), niter=2)
+    names = eng.rtc_kernels()
+    assert any(n.startswith("dxk::k_index_mh_") and n.endswith(", 2, 14, 2>") for n in names), names
+
+
+def test_specialisation_can_be_switched_off(built, monkeypatch):
+    """DANGX_RTC=0: the same model through the LDS-column kernels -- same numbers (the parity bar does not depend on the form)"""
+    import subprocess, sys, os
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_shapes as t\n"
+            "from util import make_case\n"
+            "eng = t._run_and_compare(make_case('C2', nside=8, nbands=7), niter=2)\n"
+            "assert eng.rtc_kernels() == []\nprint('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                               os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DANGX_RTC="0"), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout
