@@ -225,6 +225,8 @@ def main():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--nside", type=int, default=None)
     ap.add_argument("--nsample", type=int, default=10)
+    ap.add_argument("--nbands", type=int, default=None, help="diagnostic (not a BASELINE config): the configuration's model on another "
+                    "number of bands -- a shape without a built-in kernel instantiation is specialised at run time (hiprtc)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fortran-seam", action="store_true", help="skip the it/s of the reference-side Fortran wrapper (two-call "
                     "seam and gibbs_iteration_gpu), which bench.py otherwise reports beside the headline value at N=1")
@@ -274,7 +276,7 @@ def main():
 
     log("building synthetic sky %s on %s" % (args.config, dev))
     shard_of = args.shard_of if (args.shard_of > 1 and world == 1) else 0
-    dpar, ddata, bands, comps, meta = synth.make_sky(args.config, nside=args.nside, device=dev, rank=rank,
+    dpar, ddata, bands, comps, meta = synth.make_sky(args.config, nside=args.nside, nbands=args.nbands, device=dev, rank=rank,
                                                      nranks=shard_of if shard_of else world, nsample=args.nsample, as_numpy=False)
     if args.bandpass > 0:
         import numpy as np
@@ -440,7 +442,8 @@ def main():
             nphys_, nidx_ = len(meta["phys"]), sum(c.nindices for c in comps[:len(meta["phys"])])
             bytes_per_launch = sum(8.0 * (2 * nb + nphys_ + nidx_ + 1 + w) * meta["npix"] * pl for pl, w in index_launches) / max(len(index_launches), 1)
         achieved = bytes_per_launch / (prof[dom]["avg_ms"] * 1e-3) / 1e9
-        standard = world == 1 and args.nside is None and not args.bandpass and not shard_of   # what the committed profiles are of
+        standard = (world == 1 and args.nside is None and args.nbands is None and args.nsample == 10 and not args.bandpass
+                    and not shard_of and not args.no_fuse)   # what the committed profiles are of
         # B_iter = 8 N_sp [(2nb + nidx + 1 + nc) + (2nb + nc + nidx + 1 + nidx_s)] over the WHOLE sky
         nphys = len(meta["phys"])
         nidx = sum(c.nindices for c in comps[:nphys])
@@ -458,6 +461,8 @@ def main():
                                       world, 2 if two else 1,
                                       ("; DIAGNOSTIC: every second band integrated over a %d-sample bandpass" % args.bandpass
                                        if args.bandpass else "") +
+                                      ("; DIAGNOSTIC: %d bands instead of the configuration's; kernels specialised at run time: %s"
+                                       % (args.nbands, ", ".join(eng.rtc_kernels()) or "none") if args.nbands else "") +
                                       ("; DIAGNOSTIC: ONE rank's shard of a %d-rank run" % shard_of if shard_of else "")),
                        "npix": meta["npix_global"], "chisq_after_amp": chisq[0], "chisq_after_index": chisq[1]},
             # The dominant kernel is bound by fp64 VECTOR ISSUE, not by HBM: achieved / peak / frac are that roofline -- vector
