@@ -49,3 +49,25 @@ def test_self_launched_ranks_report_their_count(built):
     assert one["n_gpus"] == 1 and one["ranks_seen"] == 1
     for k in ("chisq_after_amp", "chisq_after_index"):
         assert abs(two["config"][k] - one["config"][k]) <= 1e-12 * abs(one["config"][k])
+
+
+@pytest.mark.gpu
+def test_six_rank_rehearsal_of_the_sharded_path_on_one_gpu(built):
+    """The N-rank data path with what one GPU allows (no 8-GPU node has been available to any round; a box admits six
+    processes on its card): bench.py launches 6 gloo ranks on cuda:0 over the C3 model at Nside 256, each on its RING shard with
+    the two-stream form the 8-rank runs take (T chain and Q+U chain on separate HIP streams).  All ranks are seen by the
+    all-reduce, and chi^2 equals the one-rank value -- the sky does not depend on how it is sharded.  RCCL itself stays
+    unexercised."""
+    def run(*extra):
+        r = subprocess.run([sys.executable, BENCH, "--config", "C3", "--nside", "256", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                            "--no-fortran-seam"] + list(extra), env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        return json.loads(lines[0])
+    six = run("--gpus", "6", "--backend", "gloo", "--streams", "2")
+    one = run("--gpus", "1")
+    assert six["n_gpus"] == 6 and six["ranks_seen"] == 6 and six["backend"] == "gloo"
+    assert "6 rank(s), 2 stream(s) per rank" in six["config"]["workload"]
+    for k in ("chisq_after_amp", "chisq_after_index"):
+        assert abs(six["config"][k] - one["config"][k]) <= 1e-12 * abs(one["config"][k]), k
