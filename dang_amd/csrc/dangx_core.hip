@@ -1936,7 +1936,12 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
     const bool reg_ok = !a.bp && d.lnl_type[nind] == DANGX_LNL_CHISQ && d.prior_type[nind] != DANGX_PRIOR_JEFFREYS &&
                         a.mode != CH_GENERIC && dx_mh_reg_supported(ctx, a.mode, ctx->hm.nbands, Sp);
     if (reg_ok) bs = BLOCK;  // register-resident form: no LDS columns
-    const unsigned nblk = nblocks((long long)ctx->hm.npix * (reg_ok ? dx_mh_reg_lanes(ctx->hm.nbands, Sp) : 1), bs);
+    // lanes per pixel: of the chain's register form, or of the fused launch when a solve on these planes is waiting for this
+    // sweep and the model takes the one-launch form (decided now: the grid and the chi^2 buffers are sized by it)
+    int lanes = reg_ok ? dx_mh_reg_lanes(ctx->hm.nbands, Sp) : 1;
+    const int fused_lanes = (ctx->have_pending && reg_ok) ? dx_fused_lanes(ctx, ctx->pending, a, Sp) : 0;
+    if (fused_lanes) lanes = fused_lanes;
+    const unsigned nblk = nblocks((long long)ctx->hm.npix * lanes, bs);
     constexpr int RSTAGE = 128;  // blocks of the first reduction stage
     double* chi_buf = nullptr;
     if (chi_next(ctx, nblk, &chi_buf)) return 1;
@@ -1953,11 +1958,12 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
     if (ctx->have_pending) {  // an amplitude solve on these planes is waiting: one launch for both, or the solve first
         ctx->have_pending = false;
         unsigned long long* accp = accepted ? ctx->counters + 1 : nullptr;
-        if (reg_ok && dx_mh_reg_lanes(ctx->hm.nbands, Sp) == 1) {
+        if (fused_lanes) {
             Timed t(ctx, DANGX_K_AMP_INDEX);
-            fused = dx_launch_fused(ctx, ctx->pending, a, Sp, nblk, accp);
+            fused = dx_launch_fused(ctx, ctx->pending, a, Sp, fused_lanes, nblk, accp);
         }
         if (!fused) {
+            if (fused_lanes) return fail(ctx, "the fused solve + sweep launch failed after its kernel was prepared");
             if (dx_launch_amp(ctx, ctx->pending, ctx->pending_SN)) return 1;
         }
     }

@@ -21,44 +21,61 @@
 #include "dx_host.h"
 #include "dx_kern_fused.h"
 
+// LDS of one block: the constant table and, per lane, the SED columns of the varying members over the lane's bands plus
+// their two index values
+static size_t fused_lds(int ng, int nb, int nv, int lanes) {
+    return ((size_t)(TROWS * ng + 3) * nb + (size_t)nv * (nb / lanes + 2) * BLOCK) * sizeof(double);
+}
+
 #ifdef DX_REG_MODE
 #define DX_CAT2(a, b) a##b
 #define DX_CAT(a, b) DX_CAT2(a, b)
-template <int NB, int NG>
+template <int NB, int NG, int LP>
 static void launch_fused_case(dangx_ctx* ctx, const GroupArgs& ga, const FusedArgs& fa, const IndexArgs& a, int Sp, unsigned nblk,
                               unsigned long long* accp) {
-    const size_t ldsz = ((size_t)(TROWS * NG + 3) * NB + (size_t)fa.nv * (NB + 2) * BLOCK) * sizeof(double);
+    const size_t ldsz = fused_lds(NG, NB, fa.nv, LP);
     if (Sp == 2)
-        hipLaunchKernelGGL((dxk::k_amp_index<DX_REG_MODE, 2, NB, NG>), dim3(nblk), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, ga, fa, a, ctx->counters, accp, ctx->partial);
+        hipLaunchKernelGGL((dxk::k_amp_index<DX_REG_MODE, 2, NB, NG, LP>), dim3(nblk), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, ga, fa, a, ctx->counters, accp, ctx->partial);
     else
-        hipLaunchKernelGGL((dxk::k_amp_index<DX_REG_MODE, 1, NB, NG>), dim3(nblk), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, ga, fa, a, ctx->counters, accp, ctx->partial);
+        hipLaunchKernelGGL((dxk::k_amp_index<DX_REG_MODE, 1, NB, NG, LP>), dim3(nblk), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, ga, fa, a, ctx->counters, accp, ctx->partial);
 }
 bool DX_CAT(dx_launch_fused_mode, DX_REG_MODE)(dangx_ctx* ctx, const GroupArgs& ga, const FusedArgs& fa, const IndexArgs& a, int Sp,
-                                              unsigned nblk, unsigned long long* accp) {
+                                              int lanes, unsigned nblk, unsigned long long* accp) {
     const int nb = ctx->hm.nbands;
-    // the instantiated (band count, group size) pairs: keep dx_fused_supported below in step
-    if (nb == 10 && ga.ng == 4) launch_fused_case<10, 4>(ctx, ga, fa, a, Sp, nblk, accp);        // C3
-    else if (nb == 10 && ga.ng == 3) launch_fused_case<10, 3>(ctx, ga, fa, a, Sp, nblk, accp);
-    else if (nb == 5 && ga.ng == 3) launch_fused_case<5, 3>(ctx, ga, fa, a, Sp, nblk, accp);     // C2
-    else if (nb == 3 && ga.ng == 2) launch_fused_case<3, 2>(ctx, ga, fa, a, Sp, nblk, accp);     // C1
+    // the instantiated (band count, group size, lanes) triples: keep fused_builtin below in step
+    if (lanes == 1 && nb == 10 && ga.ng == 4) launch_fused_case<10, 4, 1>(ctx, ga, fa, a, Sp, nblk, accp);        // C3
+    else if (lanes == 1 && nb == 10 && ga.ng == 3) launch_fused_case<10, 3, 1>(ctx, ga, fa, a, Sp, nblk, accp);
+    else if (lanes == 1 && nb == 5 && ga.ng == 3) launch_fused_case<5, 3, 1>(ctx, ga, fa, a, Sp, nblk, accp);     // C2
+    else if (lanes == 1 && nb == 3 && ga.ng == 2) launch_fused_case<3, 2, 1>(ctx, ga, fa, a, Sp, nblk, accp);     // C1
+#if DX_REG_MODE == 1
+    else if (lanes == 2 && nb == 20 && ga.ng == 6) launch_fused_case<20, 6, 2>(ctx, ga, fa, a, Sp, nblk, accp);   // C5 (first sweep: synchrotron beta)
+#endif
     else return false;
     return true;
 }
 #else
-bool dx_launch_fused_mode1(dangx_ctx*, const GroupArgs&, const FusedArgs&, const IndexArgs&, int, unsigned, unsigned long long*);
-bool dx_launch_fused_mode2(dangx_ctx*, const GroupArgs&, const FusedArgs&, const IndexArgs&, int, unsigned, unsigned long long*);
-bool dx_launch_fused_mode3(dangx_ctx*, const GroupArgs&, const FusedArgs&, const IndexArgs&, int, unsigned, unsigned long long*);
+bool dx_launch_fused_mode1(dangx_ctx*, const GroupArgs&, const FusedArgs&, const IndexArgs&, int, int, unsigned, unsigned long long*);
+bool dx_launch_fused_mode2(dangx_ctx*, const GroupArgs&, const FusedArgs&, const IndexArgs&, int, int, unsigned, unsigned long long*);
+bool dx_launch_fused_mode3(dangx_ctx*, const GroupArgs&, const FusedArgs&, const IndexArgs&, int, int, unsigned, unsigned long long*);
 
-// which (band count, group size) the fused kernel is instantiated for
-bool dx_fused_supported(int mode, int nb, int ng) {
-    if (!(mode >= CH_POW && mode <= CH_MBB_T)) return false;
-    if ((nb == 10 && (ng == 4 || ng == 3)) || (nb == 5 && ng == 3) || (nb == 3 && ng == 2)) return true;
-    return dx_rtc_enabled() && nb <= 16 && ng >= 1 && ng <= 6;   // any other shape: specialised at run time (dx_launch_fused decides)
+static bool fused_builtin(int mode, int nb, int ng, int lanes) {
+    if (lanes == 1) return (nb == 10 && (ng == 4 || ng == 3)) || (nb == 5 && ng == 3) || (nb == 3 && ng == 2);
+    return mode == CH_POW && nb == 20 && ng == 6;
 }
 
-// ga: the pending amplitude solve; a: the index sweep that follows it on the same planes.  false: not covered.
-bool dx_launch_fused(dangx_ctx* ctx, const GroupArgs& ga, const IndexArgs& a, int Sp, unsigned nblk, unsigned long long* accp) {
-    FusedArgs fa;
+// could a fused launch exist for this (mode, bands, members)?  (dx_fused_lanes decides for the actual model and planes)
+bool dx_fused_supported(int mode, int nb, int ng) {
+    if (!(mode >= CH_POW && mode <= CH_MBB_T) || ng < 1 || ng > 6) return false;
+    return fused_builtin(mode, nb, ng, 1) || fused_builtin(mode, nb, ng, 2) || dx_rtc_enabled();
+}
+
+static std::string fused_name(int mode, int Sp, int nb, int ng, int lanes) {
+    return "dxk::k_amp_index<" + std::to_string(mode) + ", " + std::to_string(Sp) + ", " + std::to_string(nb) + ", " + std::to_string(ng) + ", " +
+           std::to_string(lanes) + ">";
+}
+
+// the members' roles in the fused kernel; false: this model does not take it
+static bool fused_args(dangx_ctx* ctx, const GroupArgs& ga, const IndexArgs& a, FusedArgs& fa) {
     fa.nv = 0; fa.gself = -1;
     unsigned planes = 0;
     for (int k = a.s1; k <= a.s2; ++k) planes |= 1u << (k - 1);
@@ -69,7 +86,7 @@ bool dx_launch_fused(dangx_ctx* ctx, const GroupArgs& ga, const IndexArgs& a, in
         const unsigned cm = (unsigned)c.const_planes & planes;
         if (cm != 0 && cm != planes) return false;  // constant on one plane only: the two kernels would take different routes
         if (cm != planes) {  // varies on the planes of the launch: evaluated per pixel
-            if (c.type != DANGX_POWERLAW && c.type != DANGX_MBB) return false;
+            if (c.type != DANGX_POWERLAW && c.type != DANGX_MBB && c.type != DANGX_FREEFREE && c.type != DANGX_LOGNORMAL) return false;
             fa.vcomp[fa.nv] = (signed char)g; fa.vtype[fa.nv] = (signed char)c.type;
             fa.vslot[g] = (signed char)fa.nv++;
         }
@@ -79,31 +96,48 @@ bool dx_launch_fused(dangx_ctx* ctx, const GroupArgs& ga, const IndexArgs& a, in
     // (d / gain) and by the chain ((d - offset) / gain); the kernel carries neither, such models take the two launches
     for (int j = 0; j < ctx->hm.nbands; ++j)
         if (ctx->hm.gain[j] != 1.0 || ctx->hm.offset[j] != 0.0) return false;
+    return true;
+}
+
+// Lanes per pixel of the fused launch for the pending solve `ga` and the sweep `a`, 0 when the pair takes the two launches.
+// One lane while the chain's planes and the solve's normal equations fit two waves per SIMD (one plane: up to 16 bands, two
+// planes: up to 10) and the members' SED columns two blocks per CU; else lane pairs (even band count, half the bands and
+// half the columns per lane: C5's 20 bands and 6 members).  A shape without a built-in instantiation is specialised HERE
+// (hiprtc or the disk cache), so that the launch that follows cannot fail: the caller sizes its grid by this answer.
+int dx_fused_lanes(dangx_ctx* ctx, const GroupArgs& ga, const IndexArgs& a, int Sp) {
+    if (!(a.mode >= CH_POW && a.mode <= CH_MBB_T) || ga.ng < 1 || ga.ng > 6) return 0;
+    FusedArgs fa;
+    if (!fused_args(ctx, ga, a, fa)) return 0;
+    const int nb = ctx->hm.nbands, ng = ga.ng, cap = (Sp == 2) ? 10 : 16;
+    int lanes = 0;
+    if (nb <= cap && fused_lds(ng, nb, fa.nv, 1) <= 80u * 1024u) lanes = 1;
+    else if (nb % 2 == 0 && nb / 2 <= cap && fused_lds(ng, nb, fa.nv, 2) <= 80u * 1024u) lanes = 2;
+    if (!lanes) return 0;
+    if (fused_builtin(a.mode, nb, ng, lanes)) return lanes;
+    return dx_rtc_get(ctx, "dx_kern_fused.h", fused_name(a.mode, Sp, nb, ng, lanes)) ? lanes : 0;
+}
+
+// ga: the pending amplitude solve; a: the index sweep that follows it on the same planes; lanes: dx_fused_lanes' answer
+bool dx_launch_fused(dangx_ctx* ctx, const GroupArgs& ga, const IndexArgs& a, int Sp, int lanes, unsigned nblk, unsigned long long* accp) {
+    FusedArgs fa;
+    if (lanes < 1 || !fused_args(ctx, ga, a, fa)) return false;
     bool done = false;
     switch (a.mode) {
-    case CH_POW: done = dx_launch_fused_mode1(ctx, ga, fa, a, Sp, nblk, accp); break;
-    case CH_MBB_BETA: done = dx_launch_fused_mode2(ctx, ga, fa, a, Sp, nblk, accp); break;
-    case CH_MBB_T: done = dx_launch_fused_mode3(ctx, ga, fa, a, Sp, nblk, accp); break;
+    case CH_POW: done = dx_launch_fused_mode1(ctx, ga, fa, a, Sp, lanes, nblk, accp); break;
+    case CH_MBB_BETA: done = dx_launch_fused_mode2(ctx, ga, fa, a, Sp, lanes, nblk, accp); break;
+    case CH_MBB_T: done = dx_launch_fused_mode3(ctx, ga, fa, a, Sp, lanes, nblk, accp); break;
     default: return false;
     }
     if (done) return true;
-    // No built-in instantiation for (bands, members): specialise the template now -- where the fused form pays: the chain's
-    // planes and the solve's normal equations must fit the registers of two waves per SIMD (one plane: up to 16 bands, two
-    // planes: up to 10), and the members' SED columns two blocks per CU.  Anything else takes the two launches.
     const int nb = ctx->hm.nbands, ng = ga.ng;
-    if (!dx_rtc_enabled() || ng < 1 || ng > 6 || nb > (Sp == 2 ? 10 : 16)) return false;
-    const size_t ldsz = ((size_t)(TROWS * ng + 3) * nb + (size_t)fa.nv * (nb + 2) * BLOCK) * sizeof(double);
-    if (ldsz > 80u * 1024u) return false;
-    hipFunction_t fn = dx_rtc_get(ctx, "dx_kern_fused.h", "dxk::k_amp_index<" + std::to_string(a.mode) + ", " + std::to_string(Sp) + ", " +
-                                                            std::to_string(nb) + ", " + std::to_string(ng) + ">");
+    hipFunction_t fn = dx_rtc_get(ctx, "dx_kern_fused.h", fused_name(a.mode, Sp, nb, ng, lanes));
     if (!fn) return false;
     const Model* dm = ctx->dm;
     GroupArgs gg = ga;
-    FusedArgs ff = fa;
     IndexArgs aa = a;
     unsigned long long* bad = ctx->counters;
     double* part = ctx->partial;
-    void* args[] = {&dm, &gg, &ff, &aa, &bad, &accp, &part};
-    return dx_rtc_launch(ctx, fn, nblk, ldsz, args) == 0;
+    void* args[] = {&dm, &gg, &fa, &aa, &bad, &accp, &part};
+    return dx_rtc_launch(ctx, fn, nblk, fused_lds(ng, nb, fa.nv, lanes), args) == 0;
 }
 #endif

@@ -94,6 +94,13 @@ struct RegChain {
         else if (MODE == CH_LOGN_NUP) { s0 = log_pos(th); s1 = other; }  // log(nu/(nu_p*1e9)) = lnu9 - log(nu_p)
         else s1 = th;  // CH_LOGN_W
         acc0 = 0.0; acc1 = 0.0;
+        // log-normal: ln(nu/nu_p)/w as a product with 1/w (v_rcp_f64 + two Newton steps, once per evaluation) instead of one
+        // IEEE division per band -- the expression the amplitude kernels use for the same SED (sed_tile), <= 1 ulp from it
+#ifdef DX_CHAIN_IEEEDIV
+        const double rs1 = 1.0 / s1;
+#else
+        const double rs1 = (MODE == CH_LOGN_NUP || MODE == CH_LOGN_W) ? fast_rcp(s1) : 0.0;
+#endif
         // bands in tiles of TT: TT independent exp chains interleave, then accumulate in band order
         constexpr int TT = (NB % 5 == 0) ? 5 : (NB % 4 == 0) ? 4 : (NB % 3 == 0) ? 3 : 1;
 #pragma unroll
@@ -103,10 +110,10 @@ struct RegChain {
             for (int t = 0; t < TT; ++t) {
                 const int j = j0 + t;
                 if (MODE == CH_LOGN_NUP) {
-                    const double l = (k1(M, c, j) - s0) / s1;
+                    const double l = (k1(M, c, j) - s0) * rs1;
                     s[t] = CEXP(-0.5 * (l * l)) * k2(c, j);
                 } else if (MODE == CH_LOGN_W) {
-                    const double l = F[j] / s1;
+                    const double l = F[j] * rs1;
                     s[t] = CEXP(-0.5 * (l * l)) * k2(c, j);
                 } else {
                     const double e = CEXP(s0 * k1(M, c, j));
@@ -178,13 +185,15 @@ __device__ __forceinline__ void subtract_other(const Model& M, const Comp& c2, i
 #pragma unroll
         for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * (ff_gaunt(pick(c2.lnu9, j, NB), pr.p0) / pr.p1 * pick(c2.cst, j, NB));
         break;
-    case DANGX_LOGNORMAL:
+    case DANGX_LOGNORMAL: {
+        const double rp1 = fast_rcp(pr.p1);  // as sed_tile (dangx_ampreg.hip) forms it
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const double l2 = (pick(c2.lnu9, j, NB) - pr.p2) / pr.p1;
+            const double l2 = (pick(c2.lnu9, j, NB) - pr.p2) * rp1;
             Dk[j] -= amp2 * (CEXP(-0.5 * (l2 * l2)) * pick(c2.cst, j, NB));
         }
         break;
+    }
     default:  // cmb
 #pragma unroll
         for (int j = 0; j < NB; ++j) Dk[j] -= amp2 * pick(c2.cst, j, NB);
@@ -217,14 +226,16 @@ __device__ __forceinline__ void subtract_other_pair(const Model& M, const Comp& 
             Da[j] -= ampa * s; Db[j] -= ampb * s;
         }
         break;
-    case DANGX_LOGNORMAL:
+    case DANGX_LOGNORMAL: {
+        const double rp1 = fast_rcp(pr.p1);
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const double l2 = (pick(c2.lnu9, j, NB) - pr.p2) / pr.p1;
+            const double l2 = (pick(c2.lnu9, j, NB) - pr.p2) * rp1;
             const double s = CEXP(-0.5 * (l2 * l2)) * pick(c2.cst, j, NB);
             Da[j] -= ampa * s; Db[j] -= ampb * s;
         }
         break;
+    }
     default:  // cmb
 #pragma unroll
         for (int j = 0; j < NB; ++j) { const double s = pick(c2.cst, j, NB); Da[j] -= ampa * s; Db[j] -= ampb * s; }

@@ -192,6 +192,7 @@ bool dx_mh_reg_supported(dangx_ctx* ctx, int mode, int nb, int Sp);
 bool dx_mh_pair_supported(int mode_a, int mode_b, int nb, int Sp);
 bool dx_launch_mh_pair(dangx_ctx* ctx, const IndexArgs& a, const IndexArgs& b, int Sp, unsigned nblk, unsigned long long* accp);
 bool dx_fused_supported(int mode, int nb, int ng);
-bool dx_launch_fused(dangx_ctx* ctx, const GroupArgs& ga, const IndexArgs& a, int Sp, unsigned nblk, unsigned long long* accp);
+int dx_fused_lanes(dangx_ctx* ctx, const GroupArgs& ga, const IndexArgs& a, int Sp);  // 0: the two launches
+bool dx_launch_fused(dangx_ctx* ctx, const GroupArgs& ga, const IndexArgs& a, int Sp, int lanes, unsigned nblk, unsigned long long* accp);
 int dx_mh_reg_lanes(int nb, int Sp);  // lanes per pixel of the register chain (dangx_mhreg.hip)
 bool dx_launch_mh_reg(dangx_ctx* ctx, const IndexArgs& a, int Sp, unsigned nblk, unsigned long long* accp);

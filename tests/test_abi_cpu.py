@@ -43,7 +43,7 @@ def test_run_time_specialisation_compiles_without_a_device(built):
     headers embedded in the .so (compile only: no GPU needed)."""
     lib = L.load()
     for hdr, name in (("dx_kern_chain.h", "dxk::k_index_mh_reg<1, 1, 9, 1>"), ("dx_kern_chain.h", "dxk::k_index_mh_pair<2, 2, 7, 1>"),
-                      ("dx_kern_fused.h", "dxk::k_amp_index<1, 2, 9, 4>")):
+                      ("dx_kern_fused.h", "dxk::k_amp_index<1, 2, 9, 4, 1>")):
         log = ctypes.create_string_buffer(8192)
         rc = lib.dangx_rtc_compile(hdr.encode(), name.encode(), log, len(log))
         assert rc == 0 and log.value.startswith(b"_ZN3dxk"), (name, log.value.decode())

@@ -184,9 +184,12 @@ def test_fullsize_gibbs_chain_with_the_textbook_fluctuation_term(built):
 @pytest.mark.parametrize("config", ["C3", "C5"])
 def test_fused_launches_fullsize_bitwise(built, config):
     """The BASELINE skies at full size through the fused entry points (da.gibbs_iteration: each group's solve with the
-    first sweep on its planes, consecutive indices of a component in one launch) against one launch per step: the same
-    amplitude and index maps bit for bit after three iterations, the same chi^2 sums.  (C5: the solve is not fused -- its
-    log-normal member varies -- but the dust pairs are, on the T plane and, as lane pairs, on Q+U.)"""
+    first sweep on its planes, consecutive indices of a component in one launch) against one launch per step.  C3: the same
+    amplitude and index maps bit for bit after three iterations, the same chi^2 sums.  C5 (20 bands, 6 members): the fused
+    solve runs as lane pairs, which adds the two halves of the band sums of the normal equations instead of band by band --
+    the amplitudes agree to the parity tolerance (1e-9 of the map's largest amplitude), and the chains, which then start from
+    amplitudes that differ in the last bits, end at the same index values except where an accept test was decided by those
+    bits (counted: fewer than one pixel in 10^5)."""
     _free_device_memory()
     dev = torch.device("cuda", 0)
     runs = []
@@ -204,8 +207,22 @@ def test_fused_launches_fullsize_bitwise(built, config):
         eng.synchronize()
         runs.append((comps, eng.chisq_cached(0, 1, 3), eng.chisq_cached(1, 1, 3)))
     (ca, b0, a0), (cb, b1, a1) = runs
+    if config == "C3":
+        for x, y in zip(ca, cb):
+            assert torch.equal(x.amplitude, y.amplitude), x.label
+            if x.nindices:
+                assert torch.equal(x.indices, y.indices), x.label
+        assert b0 == b1 and a0 == a1
+        return
+    npix = ca[0].amplitude.shape[-1]
     for x, y in zip(ca, cb):
-        assert torch.equal(x.amplitude, y.amplitude), x.label
         if x.nindices:
-            assert torch.equal(x.indices, y.indices), x.label
-    assert b0 == b1 and a0 == a1
+            same = (x.indices == y.indices).all(dim=0).all(dim=0)          # per pixel: every index map, every plane
+            flipped = int((~same).sum().item())
+            assert flipped <= npix * 1e-5, (x.label, flipped)
+    for x, y in zip(ca, cb):
+        scale = float(y.amplitude.abs().max().item())
+        d = (x.amplitude - y.amplitude).abs()
+        # pixels whose chains diverged carry different indices into the next solve: judge the amplitudes on the 99.99 % quantile
+        assert float(torch.quantile(d.flatten()[:: max(1, d.numel() // 4000000)], 0.9999).item()) <= 1e-9 * scale, x.label
+    assert abs(b0 - b1) <= 1e-9 * abs(b1) and abs(a0 - a1) <= 1e-6 * abs(a1)

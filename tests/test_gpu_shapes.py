@@ -45,7 +45,7 @@ def test_unlisted_band_counts_run_the_specialised_kernels(built, config, nbands,
     names = eng.rtc_kernels()
     # both plane sets: the group's solve fused with the synchrotron sweep, the dust beta / T sweeps as one launch
     for sp in (1, 2):
-        assert "dxk::k_amp_index<1, %d, %d, %d>" % (sp, nbands, ng) in names, names
+        assert "dxk::k_amp_index<1, %d, %d, %d, 1>" % (sp, nbands, ng) in names, names
         assert "dxk::k_index_mh_pair<2, %d, %d, 1>" % (sp, nbands) in names, names
     # nothing went through the LDS-column form: every sweep of the run was a register-chain launch
     assert all(n.startswith("dxk::") for n in names)
