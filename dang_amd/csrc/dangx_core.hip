@@ -2049,6 +2049,8 @@ int dangx_amp_index_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int
     if (!ctx || check_comp(ctx, comp)) return 1;
     if (cg_iters) *cg_iters = 0;
     static const bool enabled = [] { const char* e = getenv("DANGX_FUSE"); return !(e && e[0] == '0'); }();  // A/B switch
+    (void)hipSetDevice(ctx->device);
+    if (sync_model(ctx)) return 1;  // all_delta and the constant-plane flags the decision below reads are set there
     bool can = enabled && solver == DANGX_SOLVER_DIRECT && ctx->hm.all_delta != 0 &&
                (ml_mode == DANGX_ML_OPTIMIZE || fluct_mode == DANGX_FLUCT_REFERENCE);
     // the planes of the sweep are the planes of the solve

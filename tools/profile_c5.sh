@@ -7,9 +7,9 @@ R=$(pwd)
 out=$R/gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-B="python3 $R/bench.py --config C5 --no-cpu-baseline"
+B="python3 $R/bench.py --config C5 --no-cpu-baseline --no-fortran-seam"
 echo "[c5] plain bench"
-python3 $R/bench.py --config C5 --no-cpu-baseline --steps 5 --warmup 2 > "$out/${tag}_bench.json" 2> "$out/bench.err"
+python3 $R/bench.py --config C5 --no-cpu-baseline --no-fortran-seam --steps 5 --warmup 2 > "$out/${tag}_bench.json" 2> "$out/bench.err"
 echo "[c5] kernel trace"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o run -- $B --steps 5 --warmup 2 > "$out/${tag}_bench_under_rocprof.json" 2> "$out/trace.err"
 echo "[c5] SQ counters"

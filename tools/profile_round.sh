@@ -11,7 +11,7 @@ R=$(pwd)
 out=$R/gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline"
+B="python3 $R/bench.py --no-cpu-baseline --no-fortran-seam"
 echo "[profile] plain bench (the numbers the JSON line reports)"; 
 python3 $R/bench.py --steps 20 --warmup 3 > "$out/${tag}_bench.json" 2> "$out/bench.err"
 echo "[profile] kernel trace"
