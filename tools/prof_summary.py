@@ -18,6 +18,7 @@ import re
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
+    name = re.sub(r"^dxk::", "", name)   # the register-chain / fused kernel templates live in namespace dxk
     m = re.match(r"([A-Za-z_0-9:]+(<[^(]*>)?)", name)
     return (m.group(1) if m else name)[:70]
 
