@@ -111,7 +111,10 @@ int dx_fused_lanes(dangx_ctx* ctx, const GroupArgs& ga, const IndexArgs& a, int 
     const int nb = ctx->hm.nbands, ng = ga.ng, cap = (Sp == 2) ? 10 : 16;
     int lanes = 0;
     if (nb <= cap && fused_lds(ng, nb, fa.nv, 1) <= 80u * 1024u) lanes = 1;
-    else if (nb % 2 == 0 && nb / 2 <= cap && fused_lds(ng, nb, fa.nv, 2) <= 80u * 1024u) lanes = 2;
+    // lane pairs only where the chain itself runs as lane pairs (two planes of more than 12 bands): on one plane the chain's
+    // one-lane form does not repeat the per-proposal work on a second lane, and the two launches are faster than a paired
+    // fused one (C5, T plane: 7.4 + 12.5 ms against 21.1 ms)
+    else if (nb % 2 == 0 && nb / 2 <= cap && dx_mh_reg_lanes(nb, Sp) == 2 && fused_lds(ng, nb, fa.nv, 2) <= 80u * 1024u) lanes = 2;
     if (!lanes) return 0;
     if (fused_builtin(a.mode, nb, ng, lanes)) return lanes;
     return dx_rtc_get(ctx, "dx_kern_fused.h", fused_name(a.mode, Sp, nb, ng, lanes)) ? lanes : 0;

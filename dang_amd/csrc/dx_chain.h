@@ -27,6 +27,10 @@
 #ifndef DX_CHAIN_UNSCALED
 #define DX_CHAIN_SCALED 1
 #endif
+// lane-pair kernels: each lane draws the random numbers of every second step for both (1), or both draw all of them (0: A/B)
+#ifndef DX_CHAIN_PAIR_RNG
+#define DX_CHAIN_PAIR_RNG 1
+#endif
 
 namespace {
 
@@ -296,16 +300,34 @@ __device__ __forceinline__ unsigned long long chain_finish(const Model& M, const
     chi[0] = -2.0 * a0; chi[1] = -2.0 * a1;
     double lnl_old = lnl + prior(cur);
     const double step = c.step[q], lo = c.uni[q][0], hi = c.uni[q][1];
-    for (int l = 1; l <= a.nsample; ++l) {
-        double u1, u2, u3;
-        uniform3(a.seed, a.stream, gpix, (uint32_t)l, u1, u2, u3);
-        const double prop = cur + rand_normal(0.0, step, u1, u2);  // :414
-        if (prop < lo || prop > hi) continue;                      // :415
+    // one Metropolis step from the proposal deviate g = rand_normal(0, step) and the accept uniform u3
+    auto mh_step = [&](double g, double u3) {
+        const double prop = cur + g;                               // :414
+        if (prop < lo || prop > hi) return;                        // :415
         lnl = R.lnl(M, c, prop, other, c0, c1);
         const double lnl_new = lnl + prior(prop);
         const double diff = lnl_new - lnl_old;
         const bool acc = (a.ml_mode == DANGX_ML_OPTIMIZE) ? (diff > 0.0) : ((diff >= 0.0) || (CEXP1(diff) > u3));  // :443-454
         if (acc) { cur = prop; lnl_old = lnl_new; a0 = c0; a1 = c1; ++nacc; }
+    };
+    if (LP == 1 || DX_CHAIN_PAIR_RNG == 0) {
+        for (int l = 1; l <= a.nsample; ++l) {
+            double u1, u2, u3;
+            uniform3(a.seed, a.stream, gpix, (uint32_t)l, u1, u2, u3);
+            mh_step(rand_normal(0.0, step, u1, u2), u3);
+        }
+    } else {
+        // Lane pairs: both lanes of a pixel would draw the SAME numbers for every step (a third of a proposal's instructions).
+        // Instead lane h draws for step l + h, and the two steps take their numbers from the lane that made them: the random
+        // numbers of a pixel are computed once per TWO steps -- the same draws, the same arithmetic, half the instructions.
+        for (int l = 1; l <= a.nsample; l += 2) {
+            double u1, u2, u3;
+            uniform3(a.seed, a.stream, gpix, (uint32_t)(l + half), u1, u2, u3);
+            const double g = rand_normal(0.0, step, u1, u2);
+            const double go = __shfl_xor(g, 1, 64), uo = __shfl_xor(u3, 1, 64);
+            mh_step(half == 0 ? g : go, half == 0 ? u3 : uo);                          // step l: the even lane's numbers
+            if (l + 1 <= a.nsample) mh_step(half == 0 ? go : g, half == 0 ? uo : u3);  // step l + 1: the odd lane's
+        }
     }
     if (final_value) *final_value = cur;
     if (half != 0) {  // the pair's second lane carries the same chain: its sums and counts are the first lane's
