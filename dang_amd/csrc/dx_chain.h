@@ -300,26 +300,31 @@ __device__ __forceinline__ unsigned long long chain_finish(const Model& M, const
     chi[0] = -2.0 * a0; chi[1] = -2.0 * a1;
     double lnl_old = lnl + prior(cur);
     const double step = c.step[q], lo = c.uni[q][0], hi = c.uni[q][1];
-    // one Metropolis step from the proposal deviate g = rand_normal(0, step) and the accept uniform u3
-    auto mh_step = [&](double g, double u3) {
-        const double prop = cur + g;                               // :414
-        if (prop < lo || prop > hi) return;                        // :415
-        lnl = R.lnl(M, c, prop, other, c0, c1);
-        const double lnl_new = lnl + prior(prop);
-        const double diff = lnl_new - lnl_old;
-        const bool acc = (a.ml_mode == DANGX_ML_OPTIMIZE) ? (diff > 0.0) : ((diff >= 0.0) || (CEXP1(diff) > u3));  // :443-454
-        if (acc) { cur = prop; lnl_old = lnl_new; a0 = c0; a1 = c1; ++nacc; }
-    };
     if (LP == 1 || DX_CHAIN_PAIR_RNG == 0) {
         for (int l = 1; l <= a.nsample; ++l) {
             double u1, u2, u3;
             uniform3(a.seed, a.stream, gpix, (uint32_t)l, u1, u2, u3);
-            mh_step(rand_normal(0.0, step, u1, u2), u3);
+            const double prop = cur + rand_normal(0.0, step, u1, u2);  // :414
+            if (prop < lo || prop > hi) continue;                      // :415
+            lnl = R.lnl(M, c, prop, other, c0, c1);
+            const double lnl_new = lnl + prior(prop);
+            const double diff = lnl_new - lnl_old;
+            const bool acc = (a.ml_mode == DANGX_ML_OPTIMIZE) ? (diff > 0.0) : ((diff >= 0.0) || (CEXP1(diff) > u3));  // :443-454
+            if (acc) { cur = prop; lnl_old = lnl_new; a0 = c0; a1 = c1; ++nacc; }
         }
     } else {
         // Lane pairs: both lanes of a pixel would draw the SAME numbers for every step (a third of a proposal's instructions).
         // Instead lane h draws for step l + h, and the two steps take their numbers from the lane that made them: the random
         // numbers of a pixel are computed once per TWO steps -- the same draws, the same arithmetic, half the instructions.
+        auto mh_step = [&](double g, double u3) {   // one step from the proposal deviate g = rand_normal(0, step) and the accept uniform
+            const double prop = cur + g;                               // :414
+            if (prop < lo || prop > hi) return;                        // :415
+            lnl = R.lnl(M, c, prop, other, c0, c1);
+            const double lnl_new = lnl + prior(prop);
+            const double diff = lnl_new - lnl_old;
+            const bool acc = (a.ml_mode == DANGX_ML_OPTIMIZE) ? (diff > 0.0) : ((diff >= 0.0) || (CEXP1(diff) > u3));  // :443-454
+            if (acc) { cur = prop; lnl_old = lnl_new; a0 = c0; a1 = c1; ++nacc; }
+        };
         for (int l = 1; l <= a.nsample; l += 2) {
             double u1, u2, u3;
             uniform3(a.seed, a.stream, gpix, (uint32_t)(l + half), u1, u2, u3);
