@@ -313,6 +313,11 @@ def main():
                         first_sweep[(g.cg_group, f)] = (l, hit[0])
                         break
     fused_sweeps = set((l, j, f) for (grp, f), (l, j) in first_sweep.items())
+    # ... and EVERY sweep on the group's planes follows it through the same entry point (dangx_plane_set_sample: one launch for
+    # many-band, many-member models such as C5; for C3 it IS the fused solve + first sweep and the paired dust sweeps)
+    plane_sets = {(grp, f): [(l, j) for l, c in enumerate(comps) for j in range(c.nindices) if c.sample_index[j] and f in c.pol_flag[j]]
+                  for (grp, f) in first_sweep}
+    in_plane_set = set((l, j, f) for (grp, f), lst in plane_sets.items() for l, j in lst)
     # what one iteration launches on the index side, for the byte accounting: (planes, index values written) per launch
     index_launches = []
     for l, c in enumerate(comps):
@@ -337,11 +342,10 @@ def main():
         # sample_cg_groups (src/dang_cg_mod.f90:142-177)
         for g in dpar.cg_groups:
             for f in g.pol_flag:
-                if (g.cg_group, f) in first_sweep:
-                    l, j = first_sweep[(g.cg_group, f)]
-                    eng_of(f).amp_index_sample(g.cg_group, f, dpar.ml_mode, dpar.seed, da.stream_id(it, 0, g.cg_group, 0, f),
-                                               l, j, mapn[f], dpar.nsample, dpar.seed, da.stream_id(it, 1, l, j, f),
-                                               solver="direct", fluct_mode=dpar.fluct_mode, want_counts=False)
+                if (g.cg_group, f) in plane_sets:
+                    eng_of(f).plane_set_sample(g.cg_group, f, dpar.ml_mode, dpar.seed, da.stream_id(it, 0, g.cg_group, 0, f),
+                                               [(l, j, da.stream_id(it, 1, l, j, f)) for l, j in plane_sets[(g.cg_group, f)]],
+                                               dpar.nsample, dpar.seed, solver="direct", fluct_mode=dpar.fluct_mode, want_counts=False)
                 else:
                     eng_of(f).amp_sample(g.cg_group, f, dpar.ml_mode, dpar.seed, da.stream_id(it, 0, g.cg_group, 0, f),
                                          solver="direct", fluct_mode=dpar.fluct_mode, want_counts=False)
@@ -357,10 +361,7 @@ def main():
                     continue
                 pair = (not args.no_fuse and j + 1 < c.nindices and c.sample_index[j + 1] and c.pol_flag[j] == c.pol_flag[j + 1])
                 for f in c.pol_flag[j]:
-                    if (l, j, f) in fused_sweeps:
-                        if pair:  # the first index went with the solve: the second alone
-                            eng_of(f).index_sample(l, j + 1, mapn[f], dpar.nsample, dpar.ml_mode, dpar.seed,
-                                                   da.stream_id(it, 1, l, j + 1, f), want_counts=False)
+                    if (l, j, f) in in_plane_set:   # went with its group's solve
                         continue
                     if pair:
                         eng_of(f).index_sample_pair(l, j, mapn[f], dpar.nsample, dpar.ml_mode, dpar.seed,

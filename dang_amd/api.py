@@ -357,6 +357,24 @@ class Engine:
             None, C.byref(bad) if want_counts else None, C.byref(acc) if want_counts else None))
         return bad.value, acc.value
 
+    def plane_set_sample(self, group, flag, ml_mode, seed_amp, stream_amp, sweeps, nsample, seed_index, solver="direct",
+                         fluct_mode="reference", want_counts=True, i_max=100, converge=1e-8):
+        """amp_sample(group, flag, ...) followed by index_sample(comp, nind, map_n of the flag, ...) for every (comp, nind, stream)
+        of `sweeps` (the sweeps on the group's planes, in the reference's order) -- dangx_plane_set_sample: ONE launch for models
+        with many bands and members (the members' SED columns stay in LDS across the sweeps), otherwise those calls through the
+        two-step fusions.  Returns (units whose block was not positive definite, [accepted proposals per sweep])."""
+        n = len(sweeps)
+        comp = np.ascontiguousarray([s[0] for s in sweeps], dtype=np.int32)
+        nind = np.ascontiguousarray([s[1] for s in sweeps], dtype=np.int32)
+        strm = np.ascontiguousarray([s[2] for s in sweeps], dtype=np.uint64)
+        bad, acc = C.c_int64(0), np.zeros(n, dtype=np.int64)
+        self._chk(self.lib.dangx_plane_set_sample(
+            self.h, group, flag, L.ML_CODES[ml_mode], L.SOLVER_CG if solver == "cg" else L.SOLVER_DIRECT,
+            L.FLUCT_REFERENCE if fluct_mode == "reference" else L.FLUCT_CORRECT, seed_amp, stream_amp, i_max, converge,
+            n, comp.ctypes.data, nind.ctypes.data, strm.ctypes.data, nsample, seed_index, None,
+            C.byref(bad) if want_counts else None, acc.ctypes.data if want_counts else None))
+        return bad.value, [int(a) for a in acc]
+
     def sky_model_chisq(self, pol_lo, pol_hi, want_maps=False):
         s = C.c_double(0.0)
         if want_maps:
@@ -706,6 +724,10 @@ def fusable_first_sweeps(dpar, eng):
     return {pairs[p]: sweeps[e][:2] for p, e in enumerate(first) if e >= 0}
 
 
+def _planes(flag):
+    return {L.FLAG_T: 1, L.FLAG_Q: 2, L.FLAG_U: 4, L.FLAG_QU: 6}.get(flag, 7)
+
+
 def sample_cg_groups(dpar: DangParams, ddata: DangData, it=1, verbose=False, defer_chisq=False, fuse_first=None, it_index=None):
     """sample_cg_groups(dpar, ddata), src/dang_cg_mod.f90:142-177.
 
@@ -726,12 +748,21 @@ def sample_cg_groups(dpar: DangParams, ddata: DangData, it=1, verbose=False, def
         for f in g.pol_flag:
             first = fusable.get((g.cg_group, f))
             if first is not None:
-                l, j = first
-                bad, acc = eng.amp_index_sample(g.cg_group, f, dpar.ml_mode, dpar.seed, stream_id(it, 0, g.cg_group, 0, f),
-                                                l, j, _MAPN[f], dpar.nsample, dpar.seed,
-                                                stream_id(it if it_index is None else it_index, 1, l, j, f),
-                                                solver=dpar.solver, fluct_mode=dpar.fluct_mode, i_max=g.i_max, converge=g.converge)
-                fuse_first.add((l, j, f))
+                # the solve with EVERY sweep on its planes, in the reference's order (all of them are plain per-pixel sweeps and
+                # nothing else touches these planes, so pulling them forward leaves the loop's result unchanged): one entry
+                # point -- one launch for many-band, many-member models, the two-step fusions otherwise
+                iti = it if it_index is None else it_index
+                same = [(l, j) for l, c in enumerate(eng.component_list) for j in range(c.nindices)
+                        if c.sample_index[j] and f in c.pol_flag[j]]
+                foreign = any(c.sample_index[j] and f2 != f and (_planes(f2) & _planes(f))
+                              for c in eng.component_list for j in range(c.nindices) for f2 in c.pol_flag[j])
+                if foreign or same[0] != tuple(first):
+                    same = [tuple(first)]        # another flag shares a plane: only the first sweep goes with the solve
+                bad, accs = eng.plane_set_sample(g.cg_group, f, dpar.ml_mode, dpar.seed, stream_id(it, 0, g.cg_group, 0, f),
+                                                 [(l, j, stream_id(iti, 1, l, j, f)) for l, j in same], dpar.nsample, dpar.seed,
+                                                 solver=dpar.solver, fluct_mode=dpar.fluct_mode, i_max=g.i_max, converge=g.converge)
+                for l, j in same:
+                    fuse_first.add((l, j, f))
                 info.append((g.cg_group, f, 0, bad))
                 continue
             cg_it, bad = eng.amp_sample(g.cg_group, f, dpar.ml_mode, dpar.seed, stream_id(it, 0, g.cg_group, 0, f),

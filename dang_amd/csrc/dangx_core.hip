@@ -723,6 +723,17 @@ __global__ __launch_bounds__(BLOCK) void k_not_constant(const double* __restrict
         }
 }
 
+// flags bit q is set when index map q of an [nind][3][npix] array differs between the Q and the U plane somewhere
+__global__ __launch_bounds__(BLOCK) void k_qu_differ(const double* __restrict__ idx, long long npix, int nind, unsigned* __restrict__ flags) {
+    for (int q = 0; q < nind; ++q) {
+        const double* mq = idx + ((long long)q * 3 + 1) * npix;
+        bool diff = false;
+        for (long long t = (long long)blockIdx.x * BLOCK + threadIdx.x; t < npix; t += (long long)gridDim.x * BLOCK)
+            diff = diff || (mq[t] != mq[npix + t]);
+        if (__ballot(diff) && (threadIdx.x & 63) == 0) atomicOr(flags, 1u << q);
+    }
+}
+
 // eval_sed(band, pix, map_n) over the shard (src/dang_component_mod.f90:778-813)
 __global__ __launch_bounds__(BLOCK) void k_eval_sed(const Model* __restrict__ Mp, int comp, int band, int map_n,
                                                     double* __restrict__ out) {
@@ -1397,6 +1408,7 @@ int ensure_state(dangx_ctx* ctx, int comp) {
         HIPCHK(ctx, hipMalloc(&ctx->idx[comp], plane * nind));
         HIPCHK(ctx, hipMemset(ctx->idx[comp], 0, plane * nind));
         ctx->own_idx[comp] = true; ctx->dirty = true;
+        ctx->qu_equal[comp] = (1u << nind) - 1u;
     }
     return 0;
 }
@@ -1436,7 +1448,7 @@ int dangx_create(dangx_ctx** out, const dangx_dims* dims) {
         hipMalloc(&ctx->chi_cache, 6 * sizeof(double)) != hipSuccess ||
         hipMalloc(&ctx->chi_stage, sizeof(double) * dangx_ctx::CHI_RING * 4 * CHI_RSTAGE) != hipSuccess ||
         hipMalloc(&ctx->rows_out, (4 * MAXB + 8) * sizeof(double)) != hipSuccess ||
-        hipMalloc(&ctx->counters, 4 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc(&ctx->counters, 16 * sizeof(unsigned long long)) != hipSuccess) {
         delete ctx;
         return 5;
     }
@@ -1630,6 +1642,12 @@ int dangx_put_indices(dangx_ctx* ctx, int comp, const double* ind) {
             }
             if (cst) ctx->idx_const[comp] |= 1u << k;
         }
+        ctx->qu_equal[comp] = 0;
+        for (int q = 0; q < ctx->desc[comp].nindices && ctx->dims.nmaps == 3; ++q) {
+            bool eq = true;
+            for (long long t = 0; t < np && eq; ++t) eq = host_at(ctx, ind, (long long)q * 3 + 1, t) == host_at(ctx, ind, (long long)q * 3 + 2, t);
+            if (eq) ctx->qu_equal[comp] |= 1u << q;
+        }
         ctx->dirty = true;
     }
     return copy_planes(ctx, ctx->idx[comp], ind, (size_t)ctx->dims.nmaps * ctx->desc[comp].nindices, true);
@@ -1707,6 +1725,15 @@ int dangx_adopt_device_state(dangx_ctx* ctx, int comp, double* amp_dev, double* 
                 ctx->idx_val[comp][k][q] = first[q * 3 + k];
             }
             if (cst) ctx->idx_const[comp] |= 1u << k;
+        }
+        ctx->qu_equal[comp] = 0;
+        if (nmaps == 3) {
+            unsigned dq = 0;
+            HIPCHK(ctx, hipMemsetAsync(df, 0, sizeof(unsigned), ctx->stream));
+            hipLaunchKernelGGL(k_qu_differ, dim3(1024), dim3(BLOCK), 0, ctx->stream, idx_dev, (long long)ctx->dims.npix, nind, df);
+            HIPCHK(ctx, hipMemcpyAsync(&dq, df, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->qu_equal[comp] = ~dq & ((1u << nind) - 1u);
         }
     }
     ctx->dirty = true;
@@ -1899,6 +1926,10 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
         unsigned touched = 0;
         if (map_n == -1) touched = 6u; else if (map_n >= 1 && map_n <= 3) touched = 1u << (map_n - 1);
         if (ctx->idx_const[comp] & touched) { ctx->idx_const[comp] &= ~touched; ctx->dirty = true; }
+        if (nind >= 0 && nind < DANGX_MAX_IND) {  // a Q+U sweep writes one value to both planes (:465); a Q or U sweep to one
+            if (map_n == -1) ctx->qu_equal[comp] |= 1u << nind;
+            else if (map_n == 2 || map_n == 3) ctx->qu_equal[comp] &= ~(1u << nind);
+        }
     }
     if (sync_model(ctx)) return 1;
     const dangx_comp_desc& d = ctx->desc[comp];
@@ -2028,6 +2059,10 @@ int dangx_index_sample_pair(dangx_ctx* ctx, int comp, int nind, int map_n, int n
     if (accepted_first) *accepted_first = acc1;
     if (!ctx->pair_done) return dangx_index_sample(ctx, comp, nind + 1, map_n, nsample, ml_mode, seed, stream_second, accepted_second);
     ctx->pair_done = false;
+    if (nind + 1 < DANGX_MAX_IND) {
+        if (map_n == -1) ctx->qu_equal[comp] |= 1u << (nind + 1);
+        else if (map_n == 2 || map_n == 3) ctx->qu_equal[comp] &= ~(1u << (nind + 1));
+    }
     if (accepted_second) {
         unsigned long long v = 0;
         HIPCHK(ctx, hipMemcpyAsync(&v, ctx->counters + 2, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
@@ -2094,6 +2129,134 @@ int dangx_amp_index_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int
         HIPCHK(ctx, hipMemcpyAsync(&v, ctx->counters, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         *n_not_spd = (int64_t)v;
+    }
+    return 0;
+}
+
+// dangx_amp_sample(group, flag, ...) followed by dangx_index_sample(comp[s], nind[s], map_n of the flag, ...) for s = 0 ..
+// nsweeps-1 -- everything one iteration of the main loop does on ONE plane set of a CG group: the solve of sample_cg_groups
+// (src/dang_cg_mod.f90:166-171) and the passes of sample_spectral_parameters that touch these planes (src/dang_sample_mod.f90:
+// 40-75), in the reference's order.  Where k_plane_set covers the model (dx_kern_planeset.h: many bands and members, every swept
+// component a member of the group) all of it is ONE launch with the members' SED columns kept in LDS; everything else IS those
+// calls (through dangx_amp_index_sample / dangx_index_sample_pair where they apply).
+int dangx_plane_set_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed_amp, uint64_t stream_amp,
+                           int i_max, double converge, int nsweeps, const int32_t* comp, const int32_t* nind, const uint64_t* stream,
+                           int nsample, uint64_t seed_index, int* cg_iters, int64_t* n_not_spd, int64_t* accepted) {
+    if (!ctx || nsweeps < 1 || !comp || !nind || !stream) return 1;
+    (void)hipSetDevice(ctx->device);
+    if (sync_model(ctx)) return 1;
+    const int map_n = (flag == DANGX_FLAG_T) ? 1 : (flag == DANGX_FLAG_Q) ? 2 : (flag == DANGX_FLAG_U) ? 3 : (flag == DANGX_FLAG_QU) ? -1 : 0;
+    if (map_n == 0) return fail(ctx, "flag must be exactly one of T(1), Q(2), U(4), Q+U(8)");
+    for (int s = 0; s < nsweeps; ++s)
+        if (check_comp(ctx, comp[s]) || nind[s] < 0 || nind[s] >= ctx->desc[comp[s]].nindices) return fail(ctx, "sweep list: component / index out of range");
+    if (cg_iters) *cg_iters = 0;
+    if (n_not_spd) *n_not_spd = 0;
+    static const bool enabled = [] { const char* e = getenv("DANGX_FUSE"); return !(e && e[0] == '0'); }();
+    // ---- does the one-launch form cover this?  (the conditions of dangx_amp_index_sample, for every sweep of the list)
+    const unsigned touched = (map_n == -1) ? 6u : 1u << (map_n - 1);
+    bool can = enabled && nsweeps <= 2 * DX_MAX_SWEEPS && solver == DANGX_SOLVER_DIRECT && ctx->hm.all_delta != 0 &&
+               (ml_mode == DANGX_ML_OPTIMIZE || fluct_mode == DANGX_FLUCT_REFERENCE) &&
+               (ml_mode == DANGX_ML_SAMPLE || ml_mode == DANGX_ML_OPTIMIZE);
+    GroupArgs g;
+    SweepList sl;
+    std::memset(&sl, 0, sizeof(sl));
+    if (can) {
+        if (make_group(ctx, group, flag, g)) return 1;
+        can = g.nt == 0 && g.no == 0 && g.nuc == 0;
+        for (int l = 0; can && l < ctx->hm.ncomp; ++l)
+            if (ctx->desc[l].type == DANGX_TCMB) can = false;
+    }
+    for (int s = 0; can && s < nsweeps; ++s) {
+        const dangx_comp_desc& d = ctx->desc[comp[s]];
+        int gm = -1;
+        for (int q = 0; q < g.ng; ++q) if (g.gc[q] == comp[s]) gm = q;
+        can = gm >= 0 && !(ctx->idx_const[comp[s]] & touched) && d.lnl_type[nind[s]] == DANGX_LNL_CHISQ &&
+              d.prior_type[nind[s]] != DANGX_PRIOR_JEFFREYS && (d.type == DANGX_POWERLAW || d.type == DANGX_MBB || d.type == DANGX_LOGNORMAL);
+        if (!can) break;
+        const int mode = (d.type == DANGX_POWERLAW) ? CH_POW : (d.type == DANGX_MBB) ? (nind[s] == 0 ? CH_MBB_BETA : CH_MBB_T) : (nind[s] == 0 ? CH_LOGN_NUP : CH_LOGN_W);
+        if (sl.n > 0 && sl.s[sl.n - 1].comp == comp[s] && !sl.s[sl.n - 1].pair && sl.s[sl.n - 1].nind + 1 == nind[s] &&
+            (sl.s[sl.n - 1].mode == CH_MBB_BETA || sl.s[sl.n - 1].mode == CH_LOGN_NUP)) {
+            sl.s[sl.n - 1].pair = 1; sl.s[sl.n - 1].stream2 = stream[s];   // index nind + 1 of the same component: one item
+            continue;
+        }
+        for (int q = 0; q < sl.n; ++q) if (sl.s[q].comp == comp[s]) can = false;  // a component's sweeps must be consecutive
+        if (!can || sl.n == DX_MAX_SWEEPS) { can = false; break; }
+        SweepItem& it = sl.s[sl.n++];
+        it.comp = comp[s]; it.nind = nind[s]; it.mode = mode; it.pair = 0; it.gmember = gm; it.stream = stream[s]; it.stream2 = 0;
+    }
+    int lanes = 0;
+    if (can) {
+        sl.nsample = nsample; sl.ml_mode = ml_mode; sl.seed = seed_index;
+        sl.s1 = (map_n == -1) ? 2 : map_n; sl.s2 = (map_n == -1) ? 3 : map_n;
+        g.ml_mode = ml_mode; g.fluct = fluct_mode; g.seed = seed_amp; g.stream = stream_amp;
+        lanes = dx_planeset_lanes(ctx, g, sl);
+    }
+    if (!lanes) {  // the calls this entry point stands for, through the two-step fusions where they apply
+        int s = 0;
+        int64_t acc = 0, acc2 = 0;
+        int rc = dangx_amp_index_sample(ctx, group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, i_max, converge, comp[0], nind[0],
+                                        map_n, nsample, seed_index, stream[0], cg_iters, n_not_spd, accepted ? &acc : nullptr);
+        if (rc) return rc;
+        if (accepted) accepted[0] = acc;
+        for (s = 1; s < nsweeps; ++s) {
+            if (s + 1 < nsweeps && comp[s + 1] == comp[s] && nind[s + 1] == nind[s] + 1) {
+                rc = dangx_index_sample_pair(ctx, comp[s], nind[s], map_n, nsample, ml_mode, seed_index, stream[s], stream[s + 1],
+                                             accepted ? &acc : nullptr, accepted ? &acc2 : nullptr);
+                if (rc) return rc;
+                if (accepted) { accepted[s] = acc; accepted[s + 1] = acc2; }
+                ++s;
+            } else {
+                rc = dangx_index_sample(ctx, comp[s], nind[s], map_n, nsample, ml_mode, seed_index, stream[s], accepted ? &acc : nullptr);
+                if (rc) return rc;
+                if (accepted) accepted[s] = acc;
+            }
+        }
+        return 0;
+    }
+    // ---- one launch.  Bookkeeping of dangx_amp_sample (the planes' cached chi^2 is stale, the members' amplitudes are about to
+    // be written) and of the sweeps (their chi^2 by-product: before = the state the solve leaves, after = the last sweep's)
+    const int Sp = sl.s2 - sl.s1 + 1;
+    for (int k = sl.s1; k <= sl.s2; ++k) {
+        ctx->chi_before_valid[k - 1] = ctx->chi_after_valid[k - 1] = ctx->touched_since_amp[k - 1] = false;
+        for (int q = 0; q < g.ng; ++q) ctx->plane_nz[g.gc[q]] |= 1u << (k - 1);
+    }
+    for (int q = 0; q < sl.n; ++q)
+        for (int e = 0; e <= sl.s[q].pair; ++e) {
+            if (map_n == -1) ctx->qu_equal[sl.s[q].comp] |= 1u << (sl.s[q].nind + e);
+            else if (map_n == 2 || map_n == 3) ctx->qu_equal[sl.s[q].comp] &= ~(1u << (sl.s[q].nind + e));
+        }
+    const unsigned nblk = nblocks((long long)ctx->hm.npix * lanes, BLOCK);
+    double* chi_buf = nullptr;
+    if (chi_next(ctx, nblk, &chi_buf)) return 1;
+    HIPCHK(ctx, hipMemsetAsync(ctx->counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
+    {
+        double* saved = ctx->partial;
+        ctx->partial = chi_buf;
+        bool ok;
+        {
+            Timed t(ctx, DANGX_K_AMP_INDEX);
+            ok = dx_launch_planeset(ctx, g, sl, lanes, nblk, accepted ? ctx->counters + 4 : nullptr);
+        }
+        ctx->partial = saved;
+        if (!ok) return fail(ctx, "the plane-set launch failed after its kernel was prepared");
+    }
+    HIPCHK(ctx, hipGetLastError());
+    {
+        auto& pend = ctx->chi_pend[ctx->chi_npend++];
+        pend.nblk = nblk; pend.s1 = sl.s1; pend.s2 = sl.s2; pend.wb = 1;
+        for (int k = sl.s1; k <= sl.s2; ++k) ctx->chi_before_valid[k - 1] = ctx->chi_after_valid[k - 1] = ctx->touched_since_amp[k - 1] = true;
+    }
+    (void)Sp;
+    if (n_not_spd || accepted) {
+        unsigned long long v[16];
+        HIPCHK(ctx, hipMemcpyAsync(v, ctx->counters, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (n_not_spd) *n_not_spd = (int64_t)v[0];
+        if (accepted) {   // the kernel counts per item (1 + pair entries each); the items follow the list's order
+            int slot = 4, s = 0;
+            for (int q = 0; q < sl.n; ++q)
+                for (int e = 0; e <= sl.s[q].pair; ++e) accepted[s++] = (int64_t)v[slot++];
+        }
     }
     return 0;
 }
@@ -2493,6 +2656,8 @@ int dangx_coarse_writeback(dangx_ctx* ctx, int comp, int nind, int map_n, int ns
         ctx->touched_since_amp[k - 1] = true;
         ctx->idx_const[comp] &= ~(1u << (k - 1));
     }
+    if (map_n == -1) ctx->qu_equal[comp] |= 1u << nind;
+    else if (map_n == 2 || map_n == 3) ctx->qu_equal[comp] &= ~(1u << nind);
     ctx->dirty = true;
     return 0;
 }
@@ -2560,6 +2725,8 @@ int dangx_index_sample_coarse(dangx_ctx* ctx, int comp, int nind, int map_n, int
         ctx->touched_since_amp[k - 1] = true;
         ctx->idx_const[comp] &= ~(1u << (k - 1));
     }
+    if (map_n == -1) ctx->qu_equal[comp] |= 1u << nind;
+    else if (map_n == 2 || map_n == 3) ctx->qu_equal[comp] &= ~(1u << nind);
     ctx->dirty = true;
     if (accepted) {
         unsigned long long v = 0;
@@ -2678,6 +2845,8 @@ int dangx_fill_index(dangx_ctx* ctx, int comp, int nind, int map_n, double value
         else if (ctx->idx_const[comp] & (1u << (k - 1))) ctx->idx_val[comp][k - 1][nind] = value;
         ctx->chi_before_valid[k - 1] = ctx->chi_after_valid[k - 1] = false;
     }
+    if (map_n == -1) ctx->qu_equal[comp] |= 1u << nind;
+    else if (map_n == 2 || map_n == 3) ctx->qu_equal[comp] &= ~(1u << nind);
     ctx->dirty = true;
     return 0;
 }

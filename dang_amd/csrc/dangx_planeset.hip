@@ -1,0 +1,101 @@
+// dangx_planeset.hip -- launcher of k_plane_set (dx_kern_planeset.h): a CG group's solve and EVERY index sweep on its planes in
+// one launch, with the members' SED columns kept in LDS across the sweeps.  Built-in instantiation: C5's shape (20 bands, 6
+// members, lane pairs); other shapes are specialised at run time (dangx_rtc.hip).
+#ifndef DX_NO_VCOEF
+#define DX_VCOEF 1   // dx_math.h: fma_vc
+#endif
+#include "dx_host.h"
+#include "dx_kern_planeset.h"
+
+static size_t planeset_lds(int ng, int nb, int nv, int lanes) {
+    return ((size_t)(TROWS * ng + 3) * nb + (size_t)nv * (nb / lanes) * BLOCK) * sizeof(double);
+}
+
+// the sweep items as template arguments: chain mode + 8 for an item that carries the component's next index too, 0 = none
+static void item_codes(const SweepList& sl, int code[4]) {
+    for (int q = 0; q < 4; ++q) code[q] = (q < sl.n) ? sl.s[q].mode + 8 * sl.s[q].pair : 0;
+}
+static std::string planeset_name(int Sp, int nb, int ng, int lanes, const SweepList& sl) {
+    int c[4];
+    item_codes(sl, c);
+    std::string s = "dxk::k_plane_set<" + std::to_string(Sp) + ", " + std::to_string(nb) + ", " + std::to_string(ng) + ", " + std::to_string(lanes);
+    for (int q = 0; q < 4; ++q) s += ", " + std::to_string(c[q]);
+    return s + ">";
+}
+
+// C5: 20 bands, 6 members, sweeps synchrotron beta | dust beta + T | AME nu_p
+static bool planeset_builtin(int nb, int ng, int lanes, const SweepList& sl) {
+    int c[4];
+    item_codes(sl, c);
+    return nb == 20 && ng == 6 && lanes == 2 && c[0] == CH_POW && c[1] == CH_MBB_BETA + 8 && c[2] == CH_LOGN_NUP && c[3] == 0;
+}
+
+// members' roles (as the fused kernel's), and the conditions the kernel relies on
+static bool planeset_args(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl, FusedArgs& fa) {
+    fa.nv = 0; fa.gself = -1;
+    unsigned planes = 0;
+    for (int k = sl.s1; k <= sl.s2; ++k) planes |= 1u << (k - 1);
+    for (int g = 0; g < MAXG; ++g) { fa.vslot[g] = -1; fa.vcomp[g] = 0; fa.vtype[g] = 0; }
+    for (int g = 0; g < ga.ng; ++g) {
+        const int l = ga.gc[g];
+        const Comp& c = ctx->hm.comp[l];
+        const unsigned cm = (unsigned)c.const_planes & planes;
+        if (cm != 0 && cm != planes) return false;
+        if (cm != planes) {
+            if (c.type != DANGX_POWERLAW && c.type != DANGX_MBB && c.type != DANGX_FREEFREE && c.type != DANGX_LOGNORMAL) return false;
+            // Q+U: the SED columns are evaluated once for both planes, so every index map of a varying member must be equal on
+            // them (as it is once a Q+U sweep has written it; dangx_core.hip keeps track)
+            if (sl.s2 > sl.s1 && (ctx->qu_equal[l] & ((1u << c.nind) - 1u)) != ((1u << c.nind) - 1u)) return false;
+            fa.vcomp[fa.nv] = (signed char)g; fa.vtype[fa.nv] = (signed char)c.type;
+            fa.vslot[g] = (signed char)fa.nv++;
+        }
+    }
+    for (int j = 0; j < ctx->hm.nbands; ++j)
+        if (ctx->hm.gain[j] != 1.0 || ctx->hm.offset[j] != 0.0) return false;
+    return true;
+}
+
+// Lanes per pixel of the plane-set launch, 0 when this (group, sweeps) takes the separate launches.  Where it pays: models whose
+// sweeps spend a good part of their time re-staging -- many members on many bands; the shapes that run as lane pairs (more
+// than 12 bands).  Up to 12 bands the two-launch form (fused solve + first sweep, then the paired sweeps, the T-plane ones at
+// three waves per SIMD) is at least as fast and stays.  Specialises the kernel when there is no built-in instantiation.
+int dx_planeset_lanes(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl) {
+    static const bool enabled = [] { const char* e = getenv("DANGX_PLANESET"); return !(e && e[0] == '0'); }();
+    if (!enabled || sl.n < 1 || sl.n > 4 || ga.ng < 1 || ga.ng > 6) return 0;
+    const int nb = ctx->hm.nbands, Sp = sl.s2 - sl.s1 + 1;
+    if (nb <= 12 || nb % 2 != 0 || nb / 2 > (Sp == 2 ? 10 : 16)) return 0;
+    for (int q = 0; q < sl.n; ++q) {
+        const int m = sl.s[q].mode;
+        if (m < CH_POW || m > CH_LOGN_W) return 0;
+        if (sl.s[q].pair && !(m == CH_MBB_BETA || m == CH_LOGN_NUP)) return 0;
+    }
+    FusedArgs fa;
+    if (!planeset_args(ctx, ga, sl, fa)) return 0;
+    if (planeset_lds(ga.ng, nb, fa.nv, 2) > 80u * 1024u) return 0;
+    if (planeset_builtin(nb, ga.ng, 2, sl)) return 2;
+    return dx_rtc_get(ctx, "dx_kern_planeset.h", planeset_name(Sp, nb, ga.ng, 2, sl)) ? 2 : 0;
+}
+
+// accp: per-sweep counters (sum over items of 1 + pair entries) or null
+bool dx_launch_planeset(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl, int lanes, unsigned nblk, unsigned long long* accp) {
+    FusedArgs fa;
+    if (lanes != 2 || !planeset_args(ctx, ga, sl, fa)) return false;
+    const int nb = ctx->hm.nbands, ng = ga.ng, Sp = sl.s2 - sl.s1 + 1;
+    const size_t ldsz = planeset_lds(ng, nb, fa.nv, lanes);
+    if (planeset_builtin(nb, ng, lanes, sl)) {
+        if (Sp == 2)
+            hipLaunchKernelGGL((dxk::k_plane_set<2, 20, 6, 2, CH_POW, CH_MBB_BETA + 8, CH_LOGN_NUP, 0>), dim3(nblk), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, ga, fa, sl, ctx->counters, accp, ctx->partial);
+        else
+            hipLaunchKernelGGL((dxk::k_plane_set<1, 20, 6, 2, CH_POW, CH_MBB_BETA + 8, CH_LOGN_NUP, 0>), dim3(nblk), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, ga, fa, sl, ctx->counters, accp, ctx->partial);
+        return true;
+    }
+    hipFunction_t fn = dx_rtc_get(ctx, "dx_kern_planeset.h", planeset_name(Sp, nb, ng, lanes, sl));
+    if (!fn) return false;
+    const Model* dm = ctx->dm;
+    GroupArgs gg = ga;
+    SweepList ss = sl;
+    unsigned long long* bad = ctx->counters;
+    double* part = ctx->partial;
+    void* args[] = {&dm, &gg, &fa, &ss, &bad, &accp, &part};
+    return dx_rtc_launch(ctx, fn, nblk, ldsz, args) == 0;
+}

@@ -46,3 +46,19 @@ struct IndexArgs {
     unsigned long long seed, stream;
 };
 
+// dangx_plane_set_sample: the index sweeps that follow a group's solve on its planes, in the reference's order (dx_kern_planeset.h)
+struct SweepItem {
+    int comp, nind;   // component and index (0-based) of the sweep
+    int mode;         // chain mode of the sweep (CH_POW ... CH_LOGN_W)
+    int pair;         // 1: index nind + 1 of the same component follows in the same item (mode + 1)
+    int gmember;      // the component's position among the group's members
+    int pad;
+    unsigned long long stream, stream2;  // random streams of the sweep (and of the paired one)
+};
+constexpr int DX_MAX_SWEEPS = 6;
+struct SweepList {
+    int n, nsample, ml_mode, s1, s2, pad;
+    unsigned long long seed;
+    SweepItem s[DX_MAX_SWEEPS];
+};
+

@@ -66,22 +66,31 @@ struct BandPick {
     }
 };
 
-template <int MODE, int SP, int NB, int LP>
+// KT: a lane pair's per-band constants are read from a table in LDS (kt1 / kt2 point at the lane's first band) instead of being
+// held in 2*NB registers -- for kernels that have the block's constant table anyway (k_plane_set)
+template <int MODE, int SP, int NB, int LP, bool KT = false>
 struct RegChain {
     double D[SP][NB], F[NB], ISr[SP][NB];  // cleaned data, chain-invariant SED factor, 1/rms  (scaled form: d/rms, amp/rms)
-    double K1[LP > 1 ? NB : 1], K2[LP > 1 ? NB : 1];  // LP > 1: the lane's per-band constants (see k1 / k2)
+    double K1[(LP > 1 && !KT) ? NB : 1], K2[(LP > 1 && !KT) ? NB : 1];  // LP > 1: the lane's per-band constants (see k1 / k2)
+    const double *kt1, *kt2;
     double amp[SP];
 
     __device__ __forceinline__ double is(int kk, int j) const { return ISr[kk][j]; }
     __device__ __forceinline__ void set_is(int kk, int j, double v) { ISr[kk][j] = v; }
     // the constant that multiplies / offsets the sampled parameter at band j, and the band's constant factor
     __device__ __forceinline__ double k1(const Model& M, const Comp& c, int j) const {
+        if (KT) return kt1[j];
         if (LP > 1) return K1[j];
         return (MODE == CH_MBB_T) ? M.band[j].nu_c : (MODE == CH_LOGN_NUP) ? c.lnu9[j] : c.lnr[j];
     }
-    __device__ __forceinline__ double k2(const Comp& c, int j) const { return (LP > 1) ? K2[j] : c.cst[j]; }
+    __device__ __forceinline__ double k2(const Comp& c, int j) const { return KT ? kt2[j] : (LP > 1) ? K2[j] : c.cst[j]; }
+    // KT: rows of the block's table (dx_sed.h: sed_table_build with `ng` row blocks) for group member g, from the lane's band jb
+    __device__ __forceinline__ void set_kt(const double* tab, int nbands, int ng, int g, int jb) {
+        kt1 = tab + ((MODE == CH_MBB_T) ? TROWS * ng : (MODE == CH_LOGN_NUP) ? TROWS * g + 2 : TROWS * g) * nbands + jb;
+        kt2 = tab + (TROWS * g + 1) * nbands + jb;
+    }
     __device__ __forceinline__ void set_k(const Model& M, const Comp& c, const BandPick<LP>& pick) {
-        if (LP > 1) {
+        if (LP > 1 && !KT) {
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 K1[j] = (MODE == CH_MBB_T) ? pick.nu_c(M, j, NB) : (MODE == CH_LOGN_NUP) ? pick(c.lnu9, j, NB) : pick(c.lnr, j, NB);
@@ -251,8 +260,8 @@ __device__ __forceinline__ void subtract_other_pair(const Model& M, const Comp& 
 // the lane's bands and the component's amplitudes; sample0/1 are its two current index values on the first plane.
 // SCALE = false: the planes are already d/rms and amp/rms (a second chain of the same component on the same planes,
 // k_index_mh_pair); final_value (nullable) receives the value the chain ends at.
-template <int MODE, int SP, int NB, int LP, bool SCALE = true>
-__device__ __forceinline__ unsigned long long chain_finish(const Model& M, const IndexArgs& a, const Comp& c, RegChain<MODE, SP, NB, LP>& R,
+template <int MODE, int SP, int NB, int LP, bool SCALE = true, class RC>
+__device__ __forceinline__ unsigned long long chain_finish(const Model& M, const IndexArgs& a, const Comp& c, RC& R,
                                                            const BandPick<LP>& pick, double sample0, double sample1, int i, int half,
                                                            double chi[4], double* final_value = nullptr) {
     const int npix = M.npix;

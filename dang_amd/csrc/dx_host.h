@@ -40,6 +40,7 @@ struct dangx_ctx {
     int corr_mask[MAXC] = {}, nfit[MAXC] = {};
     double tamp[MAXC][3][MAXB] = {};  // c%template_amplitudes, host mirror [map][band]
     unsigned idx_const[MAXC] = {}; // bit k-1: every index of the component is spatially constant on plane k
+    unsigned qu_equal[MAXC] = {};  // bit q: index map q of the component is equal on the Q and U planes for every pixel
     double idx_val[MAXC][3][MAXI] = {};
     std::vector<double> bp_nu0, bp_tau0;
     double *d_bp_nu0 = nullptr, *d_bp_tau0 = nullptr, *d_bp_lnr = nullptr;  // lnr: [ncomp][samples]
@@ -195,4 +196,7 @@ bool dx_fused_supported(int mode, int nb, int ng);
 int dx_fused_lanes(dangx_ctx* ctx, const GroupArgs& ga, const IndexArgs& a, int Sp);  // 0: the two launches
 bool dx_launch_fused(dangx_ctx* ctx, const GroupArgs& ga, const IndexArgs& a, int Sp, int lanes, unsigned nblk, unsigned long long* accp);
 int dx_mh_reg_lanes(int nb, int Sp);  // lanes per pixel of the register chain (dangx_mhreg.hip)
+// a group's solve and every sweep on its planes in one launch (dangx_planeset.hip): lanes per pixel, 0 = the separate launches
+int dx_planeset_lanes(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl);
+bool dx_launch_planeset(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl, int lanes, unsigned nblk, unsigned long long* accp);
 bool dx_launch_mh_reg(dangx_ctx* ctx, const IndexArgs& a, int Sp, unsigned nblk, unsigned long long* accp);

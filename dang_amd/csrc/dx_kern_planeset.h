@@ -1,0 +1,305 @@
+// dx_kern_planeset.h -- k_plane_set (template): ONE launch for everything a Gibbs iteration does on one plane set (T, or Q+U) of
+// a CG group without global-amplitude members: the group's amplitude solve, then every index sweep on these planes in the
+// reference's order (sample_cg_groups, src/dang_cg_mod.f90:166-171, followed by the passes of sample_spectral_parameters that
+// touch these planes, src/dang_sample_mod.f90:40-75).
+//
+// Why: every sweep of a plane set stages the plane set again -- 2*nb map planes and, to remove "every other component"
+// (src/dang_sample_mod.f90:180-196), the SEDs of all the other members at all bands.  For a model with many members and many
+// bands (C5: 6 members, 20 bands) that is 100 SED evaluations per pixel and plane per sweep, a fifth to a third of the sweep,
+// and between two sweeps only ONE member's SED changes.  Here the members' SED columns stay in LDS across the sweeps (k_amp_index
+// already builds them for the solve); a sweep forms its cleaned data d - sum_{g /= c} a_g s_g from the columns, in component
+// order, with the products the separate sweep would form (same values, same order: the index maps are what the separate
+// launches give, lane association of the band sums aside), and after its chain only the column of the member that moved is
+// evaluated again.  The maps are re-read per sweep (that is cheap: the kernels are bound by vector issue, not by HBM).
+//
+// Requirements checked by the launcher (dangx_planeset.hip): delta bands, unit gains / zero offsets, direct solver with the
+// reference fluctuation term, every swept component an amplitude-sampled member of the group with a register-chain mode (chisq
+// likelihood, gaussian / uniform prior), no other component on the planes, and -- for Q+U -- index maps that are equal on the
+// two planes for every member that varies (true once a Q+U sweep has written them, :465; tracked on the host).
+#pragma once
+#include "dx_kern_fused.h"
+
+namespace dxk {
+
+template <int V> struct ItemCode { static constexpr int value = V; };
+template <bool V> struct ItemFirst { static constexpr bool value = V; };
+
+// the cleaned data of a sweep of member `gself` from the members' SED columns: data_raw (:173-177) minus every other member in
+// component_list order (:180-196).  FIRST: R already holds this plane set's d and 1/sigma (the solve just used them).
+template <int MODE, int SP, int NBL, int LP, int NG, bool FIRST>
+__device__ __forceinline__ void ps_stage(const Model& M, RegChain<MODE, SP, NBL, LP, true>& R, const FusedArgs& fa, int gself, int s1, int i,
+                                         int jb, int NB, const double* __restrict__ tab, const double* __restrict__ col,
+                                         const GroupArgs& ga) {
+    const int npix = M.npix;
+    const long long bstride = (long long)M.nmaps * npix;
+#pragma unroll
+    for (int kk = 0; kk < SP; ++kk) {
+        const int k = s1 + kk;
+        if (!FIRST) {
+            const double* sigp = M.sig + (long long)(k - 1) * npix + i;
+            const double* rmsp = M.rms + (long long)(k - 1) * npix + i;
+            double rv[NBL];
+#pragma unroll
+            for (int j = 0; j < NBL; ++j) { R.D[kk][j] = sigp[(jb + j) * bstride]; rv[j] = rmsp[(jb + j) * bstride]; }
+#pragma unroll
+            for (int j = 0; j < NBL; ++j) R.set_is(kk, j, fast_rcp(rv[j]));
+        }
+        // the members' amplitudes on this plane: what THIS lane stored after the solve (both lanes of a pair store the same
+        // values, so that neither reads memory its partner wrote)
+        double av[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) av[g] = M.comp[ga.gc[g]].amp[(long long)(k - 1) * npix + i];
+        R.amp[kk] = av[0];
+#pragma unroll
+        for (int g = 1; g < NG; ++g) R.amp[kk] = (g == gself) ? av[g] : R.amp[kk];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g == gself) continue;
+            const double amp2 = av[g];
+            const bool var = fa.vslot[g] >= 0;
+            const double* mp = var ? col + (fa.vslot[g] * NBL) * BLOCK : tab + (TROWS * g + 2 + k) * NB + jb;  // else csed of plane k
+            int ms = var ? BLOCK : 1;
+            asm volatile("" : "+s"(ms));  // keeps the NBL addresses of a member out of registers between members (k_amp_index)
+#pragma unroll
+            for (int j = 0; j < NBL; ++j) R.D[kk][j] -= amp2 * mp[j * ms];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// one item of the sweep list for member gself: stage, chain (and the paired chain of index nind + 1 on the same staged planes,
+// as index_chain_pair does), count; leaves the member's two index values in sample0 / sample1
+template <int MODE, int PAIR, int SP, int NBL, int LP, int NG, bool FIRST, typename RFirst>
+__device__ __forceinline__ void ps_item(const Model& M, const SweepList& sl, const SweepItem& it, const FusedArgs& fa, RFirst& R0, int i, int half,
+                                        int jb, int NB, const double* __restrict__ tab, const double* __restrict__ col,
+                                        const GroupArgs& ga, double& sample0, double& sample1, double chi_first[4],
+                                        double chi_last[4], unsigned long long* __restrict__ accepted, int slot) {
+    const Comp& c = M.comp[it.comp];
+    const BandPick<LP> pick = {half};
+    IndexArgs a;
+    a.comp = it.comp; a.nind = it.nind; a.s1 = sl.s1; a.s2 = sl.s2; a.nsample = sl.nsample; a.ml_mode = sl.ml_mode; a.mode = MODE;
+    a.bp = 0; a.others = 0u; a.seed = sl.seed; a.stream = it.stream;
+    RegChain<MODE, SP, NBL, LP, true> R;   // per-band constants from the block's table in LDS
+    R.set_kt(tab, NB, NG, it.gmember, jb);
+    if (FIRST) {  // the solve's registers: d and 1/sigma of this plane set
+#pragma unroll
+        for (int kk = 0; kk < SP; ++kk)
+#pragma unroll
+            for (int j = 0; j < NBL; ++j) { R.D[kk][j] = R0.D[kk][j]; R.ISr[kk][j] = R0.ISr[kk][j]; }
+    }
+    ps_stage<MODE, SP, NBL, LP, NG, FIRST>(M, R, fa, it.gmember, sl.s1, i, jb, NB, tab, col, ga);
+    double chia[4] = {0.0, 0.0, 0.0, 0.0}, va;
+    unsigned long long na = chain_finish<MODE, SP, NBL, LP>(M, a, c, R, pick, sample0, sample1, i, half, chia, &va);
+    if (it.nind == 0) sample0 = va; else sample1 = va;
+    if (FIRST) { chi_first[0] = chia[0]; chi_first[1] = chia[1]; }
+    chi_last[2] = chia[2]; chi_last[3] = chia[3];
+    unsigned long long nb_ = 0ull;
+    if (PAIR) {
+        constexpr int MODEB = (MODE == CH_MBB_BETA || MODE == CH_LOGN_NUP) ? MODE + 1 : MODE;  // only those two modes have a pair
+        RegChain<MODEB, SP, NBL, LP, true> RB;
+        RB.set_kt(tab, NB, NG, it.gmember, jb);
+#pragma unroll
+        for (int kk = 0; kk < SP; ++kk) {
+            RB.amp[kk] = R.amp[kk];
+#pragma unroll
+            for (int j = 0; j < NBL; ++j) { RB.D[kk][j] = R.D[kk][j]; RB.ISr[kk][j] = R.ISr[kk][j]; }
+        }
+        IndexArgs b = a;
+        b.nind = it.nind + 1; b.stream = it.stream2; b.mode = MODEB;
+        double chib[4] = {0.0, 0.0, 0.0, 0.0}, vb;
+        nb_ = chain_finish<MODEB, SP, NBL, LP, false>(M, b, c, RB, pick, sample0, sample1, i, half, chib, &vb);
+        if (b.nind == 0) sample0 = vb; else sample1 = vb;
+        chi_last[2] = chib[2]; chi_last[3] = chib[3];
+    }
+    if (accepted) {  // per-sweep counters ([slot], [slot + 1] for the paired sweep): a diagnostic output, so one atomic per lane that
+        // accepted something (this code runs inside the pixel's live branch: no cross-lane reduction here)
+        if (na) atomicAdd(accepted + slot, na);
+        if (nb_) atomicAdd(accepted + slot + 1, nb_);
+    }
+}
+
+// C0 .. C3: the sweep items of the launch, compile-time: chain mode (CH_POW, CH_MBB_BETA, CH_LOGN_NUP ...) + 8 when index nind + 1 of
+// the same component follows in the same item (mbb: beta then T; log-normal: nu_p then w), 0 = no item.  A run-time switch over
+// the modes inside one kernel costs the register allocator ~200 spills (three inlined chains share one frame); a model's
+// sweep sequence is fixed for a run, so it is part of the specialisation: C5 = <POW, MBB_BETA + 8, LOGN_NUP> is built in, any
+// other sequence is compiled on first use (dangx_rtc.hip).
+template <int SP, int NB, int NG, int LP, int C0, int C1, int C2, int C3>
+__global__ __launch_bounds__(BLOCK, 2) void k_plane_set(const Model* __restrict__ Mp, GroupArgs ga, FusedArgs fa, SweepList sl,
+                                                        unsigned long long* __restrict__ not_spd, unsigned long long* __restrict__ accepted,
+                                                        double* __restrict__ chi_partial) {
+    constexpr int NBL = NB / LP;
+    extern __shared__ double lds[];  // [constant table | per-lane columns: nv*NBL rows of SEDs]
+    const Model& M = *Mp;
+    const int npix = M.npix, tid = threadIdx.x;
+    double* tab = lds;
+    double* col = lds + (TROWS * NG + 3) * NB + tid;
+    const long long t0 = (long long)blockIdx.x * BLOCK + tid;
+    const long long u = t0 / LP;
+    const int half = (int)(t0 % LP), jb = half * NBL;
+    const bool in_range = u < npix;
+    const int i = in_range ? (int)u : 0;
+    const double mk = M.mask[i];
+    sed_table_build(M, tab, tid, BLOCK, ga.gc, NG);
+    __syncthreads();
+    double chi[4] = {0.0, 0.0, 0.0, 0.0};
+    const bool live = in_range && !is_masked(mk);
+    if (in_range && !live && half == 0) {  // masked: x stays (:695); every swept index map gets a zero (:223, :480-483)
+        for (int q = 0; q < sl.n; ++q) {
+            const Comp& c = M.comp[sl.s[q].comp];
+            for (int e = 0; e <= sl.s[q].pair; ++e) {
+                double* out = c.idx + ((long long)(sl.s[q].nind + e) * M.nmaps) * npix + i;
+#pragma unroll
+                for (int kk = 0; kk < SP; ++kk) out[(long long)(sl.s1 + kk - 1) * npix] = 0.0;
+            }
+        }
+    }
+    if (live) {
+        const long long bstride = (long long)M.nmaps * npix;
+        const unsigned long long gpix = (unsigned long long)(M.pix0 + i);
+        const bool sample = (ga.ml_mode == DANGX_ML_SAMPLE);
+        // ---- SED columns of the varying members, once: their indices are equal on the planes of the launch (launcher)
+#pragma unroll 1
+        for (int v = 0; v < fa.nv; ++v) {
+            const Comp& c2 = M.comp[ga.gc[fa.vcomp[v]]];
+            double t0v, t1v;
+            load_theta(M, c2, i, sl.s1, t0v, t1v);
+            sed_column<NBL>(fa.vtype[v], tab, NB, NG, fa.vcomp[v], jb, sed_prep(c2, t0v, t1v), col + (v * NBL) * BLOCK);
+        }
+        // ---- the block solves of the plane set (k_amp_index's), amplitudes kept for the sweeps
+        RegChain<CH_POW, SP, NBL, LP> R0;  // storage for the maps of the plane set: d and 1/sigma
+#pragma unroll
+        for (int kk = 0; kk < SP; ++kk) {
+            const int k = sl.s1 + kk;
+            {
+                const double* sigp = M.sig + (long long)(k - 1) * npix + i;
+                const double* rmsp = M.rms + (long long)(k - 1) * npix + i;
+#pragma unroll
+                for (int j = 0; j < NBL; ++j) { R0.D[kk][j] = sigp[(jb + j) * bstride]; R0.ISr[kk][j] = rmsp[(jb + j) * bstride]; }
+            }
+            double eta = 0.0, f0 = 0.0;
+            if (sample) {
+                double u1, u2;
+                uniform2(ga.seed, ga.stream, gpix, (uint32_t)k, u1, u2);
+                eta = rand_normal(0.0, 1.0, u1, u2);
+            }
+            double A[NG * (NG + 1) / 2], bv[NG];
+#pragma unroll
+            for (int q = 0; q < NG * (NG + 1) / 2; ++q) A[q] = 0.0;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) bv[g] = 0.0;
+            const double* mp[NG];
+            int ms[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const bool var = fa.vslot[g] >= 0;
+                mp[g] = var ? col + (fa.vslot[g] * NBL) * BLOCK : tab + (TROWS * g + 2 + k) * NB + jb;
+                ms[g] = var ? BLOCK : 1;
+            }
+#pragma unroll
+            for (int j = 0; j < NBL; ++j) {
+                const double d = R0.D[kk][j];
+                const double is = fast_rcp(R0.ISr[kk][j]);
+                R0.set_is(kk, j, is);
+                const double inv = is * is;
+                double mrow[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) mrow[g] = mp[g][j * ms[g]];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const double t2 = mrow[g] * inv;
+                    bv[g] += d * t2;
+#pragma unroll
+                    for (int h = 0; h <= g; ++h) A[g * (g + 1) / 2 + h] += t2 * mrow[h];
+                }
+                f0 += (eta * is) * mrow[NG - 1];
+                if (j % DX_FUSED_GRP == DX_FUSED_GRP - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            if (LP > 1) {
+#pragma unroll
+                for (int q = 0; q < NG * (NG + 1) / 2; ++q) A[q] += __shfl_xor(A[q], 1, 64);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) bv[g] += __shfl_xor(bv[g], 1, 64);
+                f0 += __shfl_xor(f0, 1, 64);
+            }
+            bv[0] += f0;
+            bool ok = true;
+            double ri[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+#pragma unroll
+                for (int h = 0; h <= g; ++h) {
+                    double s = A[g * (g + 1) / 2 + h];
+#pragma unroll
+                    for (int t = 0; t < h; ++t) s -= A[g * (g + 1) / 2 + t] * A[h * (h + 1) / 2 + t];
+                    if (h == g) {
+                        if (!(s > 0.0) || !(s < 1.0e300)) ok = false;
+                        ri[g] = fast_rsqrt(s);
+                    } else {
+                        A[g * (g + 1) / 2 + h] = s * ri[h];
+                    }
+                }
+            }
+            if (ok) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    double s = bv[g];
+#pragma unroll
+                    for (int t = 0; t < g; ++t) s -= A[g * (g + 1) / 2 + t] * bv[t];
+                    bv[g] = s * ri[g];
+                }
+#pragma unroll
+                for (int g = NG - 1; g >= 0; --g) {
+                    double s = bv[g];
+#pragma unroll
+                    for (int t = g + 1; t < NG; ++t) s -= A[t * (t + 1) / 2 + g] * bv[t];
+                    bv[g] = s * ri[g];
+                }
+                // both lanes of a pair store (the same values): each lane later re-reads only what it wrote itself
+#pragma unroll
+                for (int g = 0; g < NG; ++g) M.comp[ga.gc[g]].amp[(long long)(k - 1) * npix + i] = bv[g];
+            } else {
+                if (half == 0) atomicAdd(not_spd, 1ull);  // x keeps its value: the sweeps run on the old amplitudes
+            }
+        }
+        // ---- the sweeps of the plane set, in the reference's order.  The first one reuses the solve's map registers (R0).
+        int slot = 0;
+        auto run = [&](auto code_tag, auto first_tag, int q) {
+            constexpr int CODE = decltype(code_tag)::value;
+            constexpr bool FIRST = decltype(first_tag)::value;
+            if constexpr (CODE != 0) {
+                const SweepItem it = sl.s[q];
+                const Comp& c = M.comp[it.comp];
+                double sample0, sample1, unused[4];
+                // a component's sweeps are consecutive and travel in ONE item: no lane reads here what its partner wrote
+                load_theta(M, c, i, sl.s1, sample0, sample1);
+                ps_item<(CODE & 7), (CODE >> 3), SP, NBL, LP, NG, FIRST>(M, sl, it, fa, R0, i, half, jb, NB, tab, col, ga, sample0, sample1,
+                                                                        FIRST ? chi : unused, chi, accepted, slot);
+                slot += 1 + (CODE >> 3);
+                // the member that moved: its SED column at the new indices (both lanes hold the same values)
+                if (q + 1 < sl.n && fa.vslot[it.gmember] >= 0)
+                    sed_column<NBL>(c.type, tab, NB, NG, it.gmember, jb, sed_prep(c, sample0, sample1), col + (fa.vslot[it.gmember] * NBL) * BLOCK);
+            }
+        };
+        run(ItemCode<C0>{}, ItemFirst<true>{}, 0);
+        run(ItemCode<C1>{}, ItemFirst<false>{}, 1);
+        run(ItemCode<C2>{}, ItemFirst<false>{}, 2);
+        run(ItemCode<C3>{}, ItemFirst<false>{}, 3);
+    }
+    if (chi_partial) {
+        __shared__ double sh[4][BLOCK / 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double v = chi[q];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            if ((tid & 63) == 0) sh[q][tid >> 6] = v;
+        }
+        __syncthreads();
+        if (tid < 4) {
+            double s = 0.0;
+            for (int w = 0; w < BLOCK / 64; ++w) s += sh[tid][w];
+            chi_partial[(long long)tid * gridDim.x + blockIdx.x] = s;
+        }
+    }
+}
+
+}  // namespace dxk

@@ -151,6 +151,19 @@ module dangx_mod
        integer(c_int), intent(out), optional :: cg_iters
        integer(c_int64_t), intent(out), optional :: n_not_spd, accepted
      end function
+     integer(c_int) function dangx_plane_set_sample(ctx, group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, i_max, converge, &
+          nsweeps, comp, nind, stream, nsample, seed_index, cg_iters, n_not_spd, accepted) bind(C, name='dangx_plane_set_sample')
+       import :: c_int, c_ptr, c_int32_t, c_int64_t, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: group, flag, ml_mode, solver, fluct_mode, i_max, nsweeps, nsample
+       real(c_double), value :: converge
+       integer(c_int64_t), value :: seed_amp, stream_amp, seed_index
+       integer(c_int32_t), intent(in) :: comp(*), nind(*)          ! 0-based, in sample_spectral_parameters' order
+       integer(c_int64_t), intent(in) :: stream(*)
+       integer(c_int), intent(out), optional :: cg_iters
+       integer(c_int64_t), intent(out), optional :: n_not_spd
+       integer(c_int64_t), intent(out), optional :: accepted(*)
+     end function
      integer(c_int) function dangx_set_template(ctx, comp, tmpl, corr, nfit) bind(C, name='dangx_set_template')
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx, tmpl, corr        ! corr: integer(c_int32_t)(nbands), 1 = fitted band

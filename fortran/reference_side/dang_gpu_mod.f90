@@ -315,6 +315,15 @@ contains
     end if
   end function map_of_flag
 
+  integer(i4b) function planes_of_flag(flag)
+    integer(i4b), intent(in) :: flag                       ! bit set of the map planes a poltype flag works on
+    planes_of_flag = 7
+    if (flag == 1) planes_of_flag = 1
+    if (flag == 2) planes_of_flag = 2
+    if (flag == 4) planes_of_flag = 4
+    if (flag == 8) planes_of_flag = 6
+  end function planes_of_flag
+
   ! an ordinary per-pixel sweep at the map resolution with nothing to tune first
   logical function plain_sweep(cc, j)
     type(dang_comps), intent(in) :: cc
@@ -322,14 +331,16 @@ contains
     plain_sweep = cc%index_mode(j) /= 1 .and. cc%sample_nside(j) == nside .and. cc%tuned(j)
   end function plain_sweep
 
-  ! ---- the amplitude phase.  first_sweep(p) > 0: the p-th (group, flag) pass is issued together with sweep number
-  ! first_sweep(p) of the list (sw_*), through dangx_amp_index_sample -- one kernel launch where the model allows it.
-  subroutine run_solves(dpar, ddata, per_group_stats, first_sweep, sw_comp, sw_nind)
+  ! ---- the amplitude phase.  owner(e) = p: sweep number e of the list (sw_*) is issued together with the p-th (group, flag)
+  ! pass, through dangx_plane_set_sample -- the solve and the sweeps on its planes in one launch where the model allows it.
+  subroutine run_solves(dpar, ddata, per_group_stats, owner, sw_comp, sw_nind)
     type(dang_data)   :: ddata
     type(dang_params) :: dpar
     logical, intent(in) :: per_group_stats
-    integer(c_int32_t), intent(in), optional :: first_sweep(:), sw_comp(:), sw_nind(:)
-    integer(i4b) :: i, f, mode, p, e, flag, nullity
+    integer(c_int32_t), intent(in), optional :: owner(:), sw_comp(:), sw_nind(:)
+    integer(c_int32_t), allocatable :: lc(:), ln(:)
+    integer(c_int64_t), allocatable :: ls(:)
+    integer(i4b) :: i, f, mode, p, e, q, nl, flag, nullity
     integer(c_int64_t) :: nbad
     integer(c_int) :: refinements
     real(c_double) :: resid(2)
@@ -345,12 +356,20 @@ contains
        do f = 1, cg_groups(i)%p%nflag
           flag = cg_groups(i)%p%pol_flag(f)
           p = p + 1
-          e = 0
-          if (present(first_sweep)) e = first_sweep(p) + 1
-          if (e > 0) then
-             call dangx_sky_amp_index_sample(gpu_sky, i, flag, mode, DANGX_FLUCT_REFERENCE, gpu_seed, &
-                  dangx_stream_id(iter, 0, i, 0, flag), int(sw_comp(e)), int(sw_nind(e)), map_of_flag(flag), nsample, gpu_seed, &
-                  dangx_stream_id(iter, 1, int(sw_comp(e)), int(sw_nind(e)), flag))
+          nl = 0
+          if (present(owner)) nl = count(owner == p)
+          if (nl > 0) then
+             allocate(lc(nl), ln(nl), ls(nl))
+             q = 0
+             do e = 1, size(owner)
+                if (owner(e) /= p) cycle
+                q = q + 1
+                lc(q) = sw_comp(e); ln(q) = sw_nind(e)
+                ls(q) = dangx_stream_id(iter, 1, int(sw_comp(e)), int(sw_nind(e)), flag)
+             end do
+             call dangx_sky_plane_set_sample(gpu_sky, i, flag, mode, DANGX_FLUCT_REFERENCE, gpu_seed, dangx_stream_id(iter, 0, i, 0, flag), &
+                  nl, lc, ln, ls, nsample, gpu_seed)
+             deallocate(lc, ln, ls)
           else if (coupled .or. per_group_stats) then     ! with the count: the chi^2 pass below waits for the device anyway
              call dangx_sky_amp_sample(gpu_sky, i, flag, mode, DANGX_FLUCT_REFERENCE, gpu_seed, &
                   dangx_stream_id(iter, 0, i, 0, flag), nbad, nullity)
@@ -486,9 +505,10 @@ contains
     type(dang_data)   :: ddata
     type(dang_params) :: dpar
     type(dang_comps), pointer :: cc
-    integer(c_int32_t), allocatable :: pg(:), pf(:), sc(:), sn(:), sf(:), sp(:), first(:)
+    integer(c_int32_t), allocatable :: pg(:), pf(:), sc(:), sn(:), sf(:), sp(:), first(:), owner(:)
     logical, allocatable :: skip(:)
-    integer(i4b) :: i, j, k, f, np, ns
+    logical :: foreign
+    integer(i4b) :: i, j, k, f, e, np, ns
     logical(lgt) :: sampled
     np = 0; ns = 0
     do i = 1, ncg_groups
@@ -500,7 +520,7 @@ contains
           if (cc%sample_index(j)) ns = ns + cc%nflag(j)
        end do
     end do
-    allocate(pg(np), pf(np), first(np), sc(ns), sn(ns), sf(ns), sp(ns), skip(ns))
+    allocate(pg(np), pf(np), first(np), sc(ns), sn(ns), sf(ns), sp(ns), skip(ns), owner(ns))
     np = 0; ns = 0
     do i = 1, ncg_groups                                  ! the (group, flag) passes in sample_cg_groups' order
        if (.not. cg_groups(i)%p%sample) cycle
@@ -521,11 +541,23 @@ contains
     first = -1
     if (np > 0 .and. ns > 0) call dangx_check(gpu_sky%ctx(1), dangx_plan_fusion(gpu_sky%ctx(1), np, pg, pf, ns, sc, sn, sf, sp, &
          DANGX_SOLVER_DIRECT, first), 'dangx_plan_fusion')
-    skip = .false.
+    ! a solve that may take its first sweep along takes EVERY sweep on its planes (they are plain per-pixel sweeps and nothing
+    ! else touches these planes); if a sweep with another flag shares a plane, only the first one goes with the solve
+    owner = 0
     do i = 1, np
-       if (first(i) >= 0) skip(first(i)+1) = .true.
+       if (first(i) < 0) cycle
+       foreign = .false.
+       do e = 1, ns
+          if (sf(e) /= pf(i) .and. iand(planes_of_flag(int(sf(e))), planes_of_flag(int(pf(i)))) /= 0) foreign = .true.
+       end do
+       if (foreign) then
+          owner(first(i)+1) = i
+       else
+          where (sf == pf(i)) owner = i
+       end if
     end do
-    call run_solves(dpar, ddata, .false., first, sc, sn)
+    skip = owner > 0
+    call run_solves(dpar, ddata, .false., owner, sc, sn)
     call run_sweeps(dpar, ddata, skip, sampled)
     call gpu_chisq(ddata, .true.)
   end subroutine gibbs_iteration_gpu

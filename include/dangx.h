@@ -229,6 +229,20 @@ int dangx_amp_index_sample(dangx_ctx *ctx, int group, int flag, int ml_mode, int
                            uint64_t stream_amp, int i_max, double converge, int comp, int nind, int map_n, int nsample,
                            uint64_t seed_index, uint64_t stream_index, int *cg_iters, int64_t *n_not_spd, int64_t *accepted);
 
+/* ---- everything one iteration does on ONE plane set of a CG group, in one call: exactly
+ * dangx_amp_sample(group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, i_max, converge, cg_iters, n_not_spd) followed by
+ * dangx_index_sample(comp[s], nind[s], map_n(flag), nsample, ml_mode, seed_index, stream[s], &accepted[s]) for s = 0 .. nsweeps-1 --
+ * the solve of sample_cg_groups (src/dang_cg_mod.f90:166-171) and the passes of sample_spectral_parameters on these planes
+ * (src/dang_sample_mod.f90:40-75) in the reference's order (the caller passes them in that order; dangx_plan_fusion says when the
+ * grouping leaves the main loop's result unchanged).  For models with many bands and members whose swept components are all
+ * members of the group (C5) this is ONE kernel launch that keeps the members' SED columns in LDS across the sweeps instead of
+ * evaluating every other member's SED again in every sweep; every other case IS the calls above (through dangx_amp_index_sample
+ * and dangx_index_sample_pair where they apply).  accepted[nsweeps] nullable. */
+int dangx_plane_set_sample(dangx_ctx *ctx, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed_amp,
+                           uint64_t stream_amp, int i_max, double converge, int nsweeps, const int32_t *comp, const int32_t *nind,
+                           const uint64_t *stream, int nsample, uint64_t seed_index, int *cg_iters, int64_t *n_not_spd,
+                           int64_t *accepted);
+
 /* ---- sky model + chi^2: update_sky_model + compute_chisq
  * (src/dang_data_mod.f90:339-396, 494-526).  pol_lo..pol_hi = ddata%pol_type range.
  * chisq_sum receives the LOCAL sum over unmasked pixels and planes of

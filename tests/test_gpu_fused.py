@@ -246,3 +246,91 @@ def test_c5_fused_lane_pairs_against_the_oracle(built):
         assert np.abs(a - b).max() <= 1e-11 * max(np.abs(b).max(), 1.0), l
         if c.nindices:
             assert np.abs(eng.get_indices(l) - two.get_indices(l)).max() <= 1e-12, l
+
+
+def _plane_sweeps(comps, group, f):
+    return [(l, j) for l, c in enumerate(comps) if c.cg_group == group for j in range(c.nindices) if c.sample_index[j] and f in c.pol_flag[j]]
+
+
+@pytest.mark.parametrize("nbands", [20, 16])
+def test_plane_set_launch_against_the_oracle(built, nbands):
+    """dangx_plane_set_sample on the C5 model (6 members; 20 bands: the built-in kernel, 16 bands: specialised at run time): a
+    group's solve and EVERY sweep on its planes -- synchrotron beta, dust beta + T, AME nu_p -- in ONE launch per plane set, the
+    members' SED columns kept in LDS across the sweeps.  Against the oracle's solve followed by its sweeps in the same order
+    (amplitudes, indices, accepted counts per sweep), and against the separate launches to the parity tolerance."""
+    case = make_case("C5", nside=4, nbands=nbands, start="truth")
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+    two = da.Engine(bands, copy.deepcopy(comps), ddata, npix_global=meta["npix_global"], pix0=meta["pix0"], device=0)
+    for it in (1, 2):
+        for g in dpar.cg_groups:
+            f = g.pol_flag[0]
+            sw = _plane_sweeps(comps, g.cg_group, f)
+            assert len(sw) == 4
+            sa = da.stream_id(it, 0, g.cg_group, 0, f)
+            eng.profile(True)
+            bad, accs = eng.plane_set_sample(g.cg_group, f, "sample", 5, sa, [(l, j, da.stream_id(it, 1, l, j, f)) for l, j in sw], 10, 5)
+            prof = eng.profile_get()
+            assert prof["k_amp_index"]["launches"] == 1 and "k_amp_direct" not in prof and "k_index_mh" not in prof, prof
+            two.amp_sample(g.cg_group, f, "sample", 5, sa)
+            orc.amp_sample_direct(g.cg_group, f, "sample", 5, sa, "reference")
+            for q, (l, j) in enumerate(sw):
+                s = da.stream_id(it, 1, l, j, f)
+                oacc = orc.sample_index_mh(l, j, MAPN[f], 10, "sample", 5, s)
+                tacc = two.index_sample(l, j, MAPN[f], 10, "sample", 5, s)
+                assert accs[q] == oacc == tacc, (it, l, j, accs[q], oacc, tacc)
+            assert bad == 0
+        assert_amps_close(eng, orc, len(comps), TOL_AMP)
+        assert_indices_close(eng, orc, comps)
+        for l, c in enumerate(comps):
+            a, b = eng.get_amplitude(l), two.get_amplitude(l)
+            assert np.abs(a - b).max() <= 1e-11 * max(np.abs(b).max(), 1.0), l
+            if c.nindices:
+                assert np.abs(eng.get_indices(l) - two.get_indices(l)).max() <= 1e-12, l
+        # the chi^2 by-product: before = the state the solve left, after = the state the last sweep left
+        o_after, _ = orc.chisq(1, 3, ddata.nump)
+        assert abs(eng.chisq_cached(1, 1, 3) / meta["nbands"] / ddata.nump - o_after) <= TOL_CHISQ * o_after
+    if nbands != 20:
+        assert any(n.startswith("dxk::k_plane_set<") for n in eng.rtc_kernels()), eng.rtc_kernels()
+
+
+def test_plane_set_entry_is_the_separate_calls_where_the_kernel_does_not_apply(built):
+    """C3 (10 bands): dangx_plane_set_sample IS dangx_amp_index_sample + dangx_index_sample_pair -- bit for bit the separate calls"""
+    case = make_case("C3", nside=8, start="truth")
+    dpar, ddata, bands, comps, meta = case
+    one, two = _engines(case)
+    for it in (1, 2):
+        for g in dpar.cg_groups:
+            f = g.pol_flag[0]
+            sw = _plane_sweeps(comps, g.cg_group, f)
+            sa = da.stream_id(it, 0, g.cg_group, 0, f)
+            bad, accs = one.plane_set_sample(g.cg_group, f, "sample", 5, sa, [(l, j, da.stream_id(it, 1, l, j, f)) for l, j in sw], 10, 5)
+            two.amp_sample(g.cg_group, f, "sample", 5, sa)
+            for q, (l, j) in enumerate(sw):
+                assert accs[q] == two.index_sample(l, j, MAPN[f], 10, "sample", 5, da.stream_id(it, 1, l, j, f))
+        for l, c in enumerate(comps):
+            assert np.array_equal(one.get_amplitude(l), two.get_amplitude(l)), l
+            if c.nindices:
+                assert np.array_equal(one.get_indices(l), two.get_indices(l)), l
+        for which in (0, 1):
+            assert one.chisq_cached(which, 1, 3) == two.chisq_cached(which, 1, 3)
+
+
+def test_c5_gibbs_iteration_matches_the_oracle_loop(built):
+    """da.gibbs_iteration on C5 (plane-set launches) against the oracle's loop in the reference's order: all solves, then all sweeps"""
+    case = make_case("C5", nside=4, start="truth")
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+    for it in (2, 3):
+        da.gibbs_iteration(dpar, ddata, it)
+        for g in dpar.cg_groups:
+            orc.amp_sample_direct(g.cg_group, g.pol_flag[0], "sample", dpar.seed, da.stream_id(it, 0, g.cg_group, 0, g.pol_flag[0]), "reference")
+        for l, c in enumerate(comps):
+            for j in range(c.nindices):
+                if c.sample_index[j]:
+                    f = c.pol_flag[j][0]
+                    orc.sample_index_mh(l, j, MAPN[f], dpar.nsample, "sample", dpar.seed, da.stream_id(it, 1, l, j, f))
+    assert_amps_close(eng, orc, len(comps), TOL_AMP)
+    assert_indices_close(eng, orc, comps)
+    ochisq, _ = orc.chisq(1, 3, ddata.nump)
+    assert abs(ddata.chisq - ochisq) <= 1e-9 * ochisq
