@@ -61,9 +61,14 @@ static bool planeset_args(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& 
 // three waves per SIMD) is at least as fast and stays.  Specialises the kernel when there is no built-in instantiation.
 int dx_planeset_lanes(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl) {
     static const bool enabled = [] { const char* e = getenv("DANGX_PLANESET"); return !(e && e[0] == '0'); }();
+    // DANGX_PLANESET=all: also for the shapes that run one lane per pixel (<= 12 bands; measured slower or equal there: A/B switch)
+    static const bool small_too = [] { const char* e = getenv("DANGX_PLANESET"); return e && e[0] == 'a'; }();
     if (!enabled || sl.n < 1 || sl.n > 4 || ga.ng < 1 || ga.ng > 6) return 0;
-    const int nb = ctx->hm.nbands, Sp = sl.s2 - sl.s1 + 1;
-    if (nb <= 12 || nb % 2 != 0 || nb / 2 > (Sp == 2 ? 10 : 16)) return 0;
+    const int nb = ctx->hm.nbands, Sp = sl.s2 - sl.s1 + 1, cap = (Sp == 2) ? 10 : 16;
+    int lanes = 0;
+    if (nb > 12 && nb % 2 == 0 && nb / 2 <= cap) lanes = 2;
+    else if (small_too && nb <= cap) lanes = 1;
+    if (!lanes) return 0;
     for (int q = 0; q < sl.n; ++q) {
         const int m = sl.s[q].mode;
         if (m < CH_POW || m > CH_LOGN_W) return 0;
@@ -71,15 +76,15 @@ int dx_planeset_lanes(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl) 
     }
     FusedArgs fa;
     if (!planeset_args(ctx, ga, sl, fa)) return 0;
-    if (planeset_lds(ga.ng, nb, fa.nv, 2) > 80u * 1024u) return 0;
-    if (planeset_builtin(nb, ga.ng, 2, sl)) return 2;
-    return dx_rtc_get(ctx, "dx_kern_planeset.h", planeset_name(Sp, nb, ga.ng, 2, sl)) ? 2 : 0;
+    if (planeset_lds(ga.ng, nb, fa.nv, lanes) > 80u * 1024u) return 0;
+    if (planeset_builtin(nb, ga.ng, lanes, sl)) return lanes;
+    return dx_rtc_get(ctx, "dx_kern_planeset.h", planeset_name(Sp, nb, ga.ng, lanes, sl)) ? lanes : 0;
 }
 
 // accp: per-sweep counters (sum over items of 1 + pair entries) or null
 bool dx_launch_planeset(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl, int lanes, unsigned nblk, unsigned long long* accp) {
     FusedArgs fa;
-    if (lanes != 2 || !planeset_args(ctx, ga, sl, fa)) return false;
+    if (lanes < 1 || lanes > 2 || !planeset_args(ctx, ga, sl, fa)) return false;
     const int nb = ctx->hm.nbands, ng = ga.ng, Sp = sl.s2 - sl.s1 + 1;
     const size_t ldsz = planeset_lds(ng, nb, fa.nv, lanes);
     if (planeset_builtin(nb, ng, lanes, sl)) {
