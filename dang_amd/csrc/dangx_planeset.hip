@@ -23,11 +23,24 @@ static std::string planeset_name(int Sp, int nb, int ng, int lanes, const SweepL
     return s + ">";
 }
 
-// C5: 20 bands, 6 members, sweeps synchrotron beta | dust beta + T | AME nu_p
+// the BASELINE shapes: C5 (20 bands, 6 members, lane pairs; sweeps synchrotron beta | dust beta + T | AME nu_p) and C3 / C2 / C1
+// (10 bands x 4 members, 5 x 3, 3 x 2; one lane per pixel; sweeps synchrotron beta | dust beta + T)
 static bool planeset_builtin(int nb, int ng, int lanes, const SweepList& sl) {
     int c[4];
     item_codes(sl, c);
-    return nb == 20 && ng == 6 && lanes == 2 && c[0] == CH_POW && c[1] == CH_MBB_BETA + 8 && c[2] == CH_LOGN_NUP && c[3] == 0;
+    if (nb == 20 && ng == 6 && lanes == 2) return c[0] == CH_POW && c[1] == CH_MBB_BETA + 8 && c[2] == CH_LOGN_NUP && c[3] == 0;
+    if (lanes == 1 && ((nb == 10 && ng == 4) || (nb == 5 && ng == 3) || (nb == 3 && ng == 2)))
+        return c[0] == CH_POW && c[1] == CH_MBB_BETA + 8 && c[2] == 0 && c[3] == 0;
+    return false;
+}
+
+template <int NB, int NG, int LP, int C0, int C1, int C2>
+static void launch_builtin(dangx_ctx* ctx, const GroupArgs& ga, const FusedArgs& fa, const SweepList& sl, int Sp, unsigned nblk, size_t ldsz,
+                           unsigned long long* accp) {
+    if (Sp == 2)
+        hipLaunchKernelGGL((dxk::k_plane_set<2, NB, NG, LP, C0, C1, C2, 0>), dim3(nblk), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, ga, fa, sl, ctx->counters, accp, ctx->partial);
+    else
+        hipLaunchKernelGGL((dxk::k_plane_set<1, NB, NG, LP, C0, C1, C2, 0>), dim3(nblk), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, ga, fa, sl, ctx->counters, accp, ctx->partial);
 }
 
 // members' roles (as the fused kernel's), and the conditions the kernel relies on
@@ -55,14 +68,14 @@ static bool planeset_args(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& 
     return true;
 }
 
-// Lanes per pixel of the plane-set launch, 0 when this (group, sweeps) takes the separate launches.  Where it pays: models whose
-// sweeps spend a good part of their time re-staging -- many members on many bands; the shapes that run as lane pairs (more
-// than 12 bands).  Up to 12 bands the two-launch form (fused solve + first sweep, then the paired sweeps, the T-plane ones at
-// three waves per SIMD) is at least as fast and stays.  Specialises the kernel when there is no built-in instantiation.
+// Lanes per pixel of the plane-set launch, 0 when this (group, sweeps) takes the separate launches.  One lane while chain and
+// normal equations fit two waves per SIMD (<= 16 bands on one plane, <= 10 on two), lane pairs above 12 bands (even counts).
+// Measured against the two-launch form on one box (bench.py, DANGX_PLANESET=pairs for the old path): C5 +19 %, C3 +3.7 %, 7 bands
+// +8.6 %, C1 +17 % (launch bound), the 8-rank shard of C3 +3 %, C2 -1 %.  Specialises the kernel when there is no built-in instantiation.
 int dx_planeset_lanes(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl) {
     static const bool enabled = [] { const char* e = getenv("DANGX_PLANESET"); return !(e && e[0] == '0'); }();
-    // DANGX_PLANESET=all: also for the shapes that run one lane per pixel (<= 12 bands; measured slower or equal there: A/B switch)
-    static const bool small_too = [] { const char* e = getenv("DANGX_PLANESET"); return e && e[0] == 'a'; }();
+    // DANGX_PLANESET=pairs: only for the shapes that run as lane pairs (A/B switch)
+    static const bool small_too = [] { const char* e = getenv("DANGX_PLANESET"); return !(e && e[0] == 'p'); }();
     if (!enabled || sl.n < 1 || sl.n > 4 || ga.ng < 1 || ga.ng > 6) return 0;
     const int nb = ctx->hm.nbands, Sp = sl.s2 - sl.s1 + 1, cap = (Sp == 2) ? 10 : 16;
     int lanes = 0;
@@ -88,10 +101,10 @@ bool dx_launch_planeset(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl
     const int nb = ctx->hm.nbands, ng = ga.ng, Sp = sl.s2 - sl.s1 + 1;
     const size_t ldsz = planeset_lds(ng, nb, fa.nv, lanes);
     if (planeset_builtin(nb, ng, lanes, sl)) {
-        if (Sp == 2)
-            hipLaunchKernelGGL((dxk::k_plane_set<2, 20, 6, 2, CH_POW, CH_MBB_BETA + 8, CH_LOGN_NUP, 0>), dim3(nblk), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, ga, fa, sl, ctx->counters, accp, ctx->partial);
-        else
-            hipLaunchKernelGGL((dxk::k_plane_set<1, 20, 6, 2, CH_POW, CH_MBB_BETA + 8, CH_LOGN_NUP, 0>), dim3(nblk), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, ga, fa, sl, ctx->counters, accp, ctx->partial);
+        if (nb == 20) launch_builtin<20, 6, 2, CH_POW, CH_MBB_BETA + 8, CH_LOGN_NUP>(ctx, ga, fa, sl, Sp, nblk, ldsz, accp);
+        else if (nb == 10) launch_builtin<10, 4, 1, CH_POW, CH_MBB_BETA + 8, 0>(ctx, ga, fa, sl, Sp, nblk, ldsz, accp);
+        else if (nb == 5) launch_builtin<5, 3, 1, CH_POW, CH_MBB_BETA + 8, 0>(ctx, ga, fa, sl, Sp, nblk, ldsz, accp);
+        else launch_builtin<3, 2, 1, CH_POW, CH_MBB_BETA + 8, 0>(ctx, ga, fa, sl, Sp, nblk, ldsz, accp);
         return true;
     }
     hipFunction_t fn = dx_rtc_get(ctx, "dx_kern_planeset.h", planeset_name(Sp, nb, ng, lanes, sl));

@@ -124,7 +124,7 @@ __device__ __forceinline__ void ps_item(const Model& M, const SweepList& sl, con
 // sweep sequence is fixed for a run, so it is part of the specialisation: C5 = <POW, MBB_BETA + 8, LOGN_NUP> is built in, any
 // other sequence is compiled on first use (dangx_rtc.hip).
 template <int SP, int NB, int NG, int LP, int C0, int C1, int C2, int C3>
-__global__ __launch_bounds__(BLOCK, 2) void k_plane_set(const Model* __restrict__ Mp, GroupArgs ga, FusedArgs fa, SweepList sl,
+__global__ __launch_bounds__(BLOCK, (NB / LP <= 5) ? 3 : 2) void k_plane_set(const Model* __restrict__ Mp, GroupArgs ga, FusedArgs fa, SweepList sl,
                                                         unsigned long long* __restrict__ not_spd, unsigned long long* __restrict__ accepted,
                                                         double* __restrict__ chi_partial) {
     constexpr int NBL = NB / LP;
