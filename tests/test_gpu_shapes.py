@@ -43,10 +43,10 @@ def _run_and_compare(case, niter=3):
 def test_unlisted_band_counts_run_the_specialised_kernels(built, config, nbands, ng):
     eng = _run_and_compare(make_case(config, nside=8, nbands=nbands))
     names = eng.rtc_kernels()
-    # both plane sets: the group's solve fused with the synchrotron sweep, the dust beta / T sweeps as one launch
+    # both plane sets: the group's solve and every sweep on its planes (synchrotron beta | dust beta + T) in one launch; the first
+    # iteration's stand-alone sweeps (no solve to go with) are register-chain launches, specialised too
     for sp in (1, 2):
-        assert "dxk::k_amp_index<1, %d, %d, %d, 1>" % (sp, nbands, ng) in names, names
-        assert "dxk::k_index_mh_pair<2, %d, %d, 1>" % (sp, nbands) in names, names
+        assert "dxk::k_plane_set<%d, %d, %d, 1, 1, 10, 0, 0>" % (sp, nbands, ng) in names, names
     # nothing went through the LDS-column form: every sweep of the run was a register-chain launch
     assert all(n.startswith("dxk::") for n in names)
 
