@@ -442,6 +442,12 @@ def main():
             # per launch 8 (2nb + nc + nidx + 1 + written) bytes per (pixel, plane) unit, averaged over this step's launches
             nphys_, nidx_ = len(meta["phys"]), sum(c.nindices for c in comps[:len(meta["phys"])])
             bytes_per_launch = sum(8.0 * (2 * nb + nphys_ + nidx_ + 1 + w) * meta["npix"] * pl for pl, w in index_launches) / max(len(index_launches), 1)
+        if dom == "k_amp_index" and "k_index_mh" not in prof:
+            # plane-set launches (dangx_plane_set_sample): a launch IS a plane set's share of the iteration -- the solve and every
+            # sweep on those planes; SURVEY 8d's per-iteration bytes of this rank's shard over the launches of a step
+            nphys_, nidx_ = len(meta["phys"]), sum(c.nindices for c in comps[:len(meta["phys"])])
+            nidx_s_ = sum(1 for c in comps[:nphys_] for j in range(c.nindices) if c.sample_index[j])
+            bytes_per_launch = 8.0 * meta["npix"] * nmaps * ((2 * nb + nidx_ + 1 + nphys_) + (2 * nb + nphys_ + nidx_ + 1 + nidx_s_)) / launches_per_step
         achieved = bytes_per_launch / (prof[dom]["avg_ms"] * 1e-3) / 1e9
         standard = (world == 1 and args.nside is None and args.nbands is None and args.nsample == 10 and not args.bandpass
                     and not shard_of and not args.no_fuse)   # what the committed profiles are of
@@ -458,7 +464,9 @@ def main():
                                    "direct block solve, reference fluctuation term%s; pixel-sharded over %d rank(s), %d stream(s) per rank%s"
                                    % (args.config, meta["nside"], nb, len(meta["phys"]), "+".join(meta["phys"]),
                                       "IQU" if nmaps == 3 else "I", args.nsample,
-                                      ", each group's solve and the first sweep on its planes in one launch, consecutive indices of a component in one launch" if "k_amp_index" in prof else "",
+                                      (", each group's solve and every sweep on its planes in ONE launch (dangx_plane_set_sample)" if "k_index_mh" not in prof else
+                                       ", each group's solve and the first sweep on its planes in one launch, consecutive indices of a component in one launch")
+                                      if "k_amp_index" in prof else "",
                                       world, 2 if two else 1,
                                       ("; DIAGNOSTIC: every second band integrated over a %d-sample bandpass" % args.bandpass
                                        if args.bandpass else "") +

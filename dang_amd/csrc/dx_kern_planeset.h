@@ -19,6 +19,11 @@
 #pragma once
 #include "dx_kern_fused.h"
 
+// resident waves per SIMD the register allocation aims at: three for small shapes (<= 5 bands per lane), two otherwise
+#ifndef DX_PS_WAVES
+#define DX_PS_WAVES(SP, NB, LP) (((NB) / (LP) <= 5) ? 3 : 2)
+#endif
+
 namespace dxk {
 
 template <int V> struct ItemCode { static constexpr int value = V; };
@@ -124,7 +129,7 @@ __device__ __forceinline__ void ps_item(const Model& M, const SweepList& sl, con
 // sweep sequence is fixed for a run, so it is part of the specialisation: C5 = <POW, MBB_BETA + 8, LOGN_NUP> is built in, any
 // other sequence is compiled on first use (dangx_rtc.hip).
 template <int SP, int NB, int NG, int LP, int C0, int C1, int C2, int C3>
-__global__ __launch_bounds__(BLOCK, (NB / LP <= 5) ? 3 : 2) void k_plane_set(const Model* __restrict__ Mp, GroupArgs ga, FusedArgs fa, SweepList sl,
+__global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP)) void k_plane_set(const Model* __restrict__ Mp, GroupArgs ga, FusedArgs fa, SweepList sl,
                                                         unsigned long long* __restrict__ not_spd, unsigned long long* __restrict__ accepted,
                                                         double* __restrict__ chi_partial) {
     constexpr int NBL = NB / LP;

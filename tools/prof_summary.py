@@ -106,7 +106,7 @@ def main():
         disp = collections.OrderedDict()          # one entry per dispatch
         for r in csv.DictReader(open(f)):
             s = short(r["Kernel_Name"])
-            k = ("k_amp_index" if s.startswith("k_amp_index") else "k_amp_direct" if s.startswith("k_amp_") else
+            k = ("k_amp_index" if s.startswith(("k_amp_index", "k_plane_set")) else "k_amp_direct" if s.startswith("k_amp_") else
                      "k_index_mh" if s.startswith("k_index_mh") else None)
             if not k:
                 continue
@@ -161,7 +161,7 @@ def main():
                 if r["Counter_Name"] != cname:
                     continue
                 s = short(r["Kernel_Name"])
-                k = ("k_amp_index" if s.startswith("k_amp_index") else "k_amp_direct" if s.startswith("k_amp_") else
+                k = ("k_amp_index" if s.startswith(("k_amp_index", "k_plane_set")) else "k_amp_direct" if s.startswith("k_amp_") else
                      "k_index_mh" if s.startswith("k_index_mh") else None)
                 if k:
                     fam.setdefault(k, {}).setdefault(cname, {}).setdefault(s, []).append(float(r["Counter_Value"]) * 1024.0)
