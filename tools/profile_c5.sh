@@ -13,12 +13,12 @@ python3 $R/bench.py --config C5 --no-cpu-baseline --no-fortran-seam --steps 5 --
 echo "[c5] kernel trace"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o run -- $B --steps 5 --warmup 2 > "$out/${tag}_bench_under_rocprof.json" 2> "$out/trace.err"
 echo "[c5] SQ counters"
-rocprofv3 --kernel-include-regex "k_(amp|index|schur|sky|cg|Ax|rhs|reduce)" --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES \
+rocprofv3 --kernel-include-regex "k_(amp|index|plane|schur|sky|cg|Ax|rhs|reduce)" --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES \
     -d "$out/sq" -o run -- $B --steps 1 --warmup 1 > /dev/null 2> "$out/sq.err"
 echo "[c5] FETCH_SIZE"
-rocprofv3 --kernel-include-regex "k_(amp|index|schur|sky|cg|Ax|rhs|reduce)" --output-format csv --pmc FETCH_SIZE -d "$out/pmc_fetch" -o run -- $B --steps 1 --warmup 1 > /dev/null 2> "$out/fetch.err"
+rocprofv3 --kernel-include-regex "k_(amp|index|plane|schur|sky|cg|Ax|rhs|reduce)" --output-format csv --pmc FETCH_SIZE -d "$out/pmc_fetch" -o run -- $B --steps 1 --warmup 1 > /dev/null 2> "$out/fetch.err"
 echo "[c5] WRITE_SIZE"
-rocprofv3 --kernel-include-regex "k_(amp|index|schur|sky|cg|Ax|rhs|reduce)" --output-format csv --pmc WRITE_SIZE -d "$out/pmc_write" -o run -- $B --steps 1 --warmup 1 > /dev/null 2> "$out/write.err"
+rocprofv3 --kernel-include-regex "k_(amp|index|plane|schur|sky|cg|Ax|rhs|reduce)" --output-format csv --pmc WRITE_SIZE -d "$out/pmc_write" -o run -- $B --steps 1 --warmup 1 > /dev/null 2> "$out/write.err"
 python3 $R/tools/prof_summary.py --stats "$out/trace" --pmc FETCH_SIZE="$out/pmc_fetch" --pmc WRITE_SIZE="$out/pmc_write" --sq "$out/sq" \
     --config C5 --traffic-json "$out/${tag}_traffic.json" --valu-json "$out/${tag}_valu.json" -o "$out/${tag}_profile.md" \
     --title "$tag: python3 bench.py --config C5 --steps 5 --warmup 2 (Nside 2048, 20 bands, 6 components, IQU, 1x MI355X); PMC passes: --steps 1 --warmup 1" > /dev/null

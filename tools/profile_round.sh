@@ -17,15 +17,15 @@ python3 $R/bench.py --steps 20 --warmup 3 > "$out/${tag}_bench.json" 2> "$out/be
 echo "[profile] kernel trace"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o run -- $B --steps 20 --warmup 3 > "$out/${tag}_bench_under_rocprof.json" 2> "$out/trace.err"
 echo "[profile] FETCH_SIZE"
-rocprofv3 --kernel-include-regex "k_(amp|index|schur|sky|cg|Ax|rhs|reduce)" --output-format csv --pmc FETCH_SIZE -d "$out/pmc_fetch" -o run -- $B --steps 2 --warmup 1 > /dev/null 2> "$out/fetch.err"
+rocprofv3 --kernel-include-regex "k_(amp|index|plane|schur|sky|cg|Ax|rhs|reduce)" --output-format csv --pmc FETCH_SIZE -d "$out/pmc_fetch" -o run -- $B --steps 2 --warmup 1 > /dev/null 2> "$out/fetch.err"
 echo "[profile] WRITE_SIZE"
-rocprofv3 --kernel-include-regex "k_(amp|index|schur|sky|cg|Ax|rhs|reduce)" --output-format csv --pmc WRITE_SIZE -d "$out/pmc_write" -o run -- $B --steps 2 --warmup 1 > /dev/null 2> "$out/write.err"
+rocprofv3 --kernel-include-regex "k_(amp|index|plane|schur|sky|cg|Ax|rhs|reduce)" --output-format csv --pmc WRITE_SIZE -d "$out/pmc_write" -o run -- $B --steps 2 --warmup 1 > /dev/null 2> "$out/write.err"
 echo "[profile] SQ counters"
-rocprofv3 --kernel-include-regex "k_(amp|index|schur|sky|cg|Ax|rhs|reduce)" --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES \
+rocprofv3 --kernel-include-regex "k_(amp|index|plane|schur|sky|cg|Ax|rhs|reduce)" --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES \
     -d "$out/sq" -o run -- $B --steps 2 --warmup 1 > /dev/null 2> "$out/sq.err"
 echo "[profile] FETCH/WRITE calibration on kernels of known byte count"
-rocprofv3 --kernel-include-regex "k_(amp|index|schur|sky|cg|Ax|rhs|reduce)" --output-format csv --pmc FETCH_SIZE -d "$out/cal_fetch" -o run -- python3 $R/tools/pmc_calib.py > "$out/cal.log" 2> "$out/cal_fetch.err"
-rocprofv3 --kernel-include-regex "k_(amp|index|schur|sky|cg|Ax|rhs|reduce)" --output-format csv --pmc WRITE_SIZE -d "$out/cal_write" -o run -- python3 $R/tools/pmc_calib.py >> "$out/cal.log" 2> "$out/cal_write.err"
+rocprofv3 --kernel-include-regex "k_(amp|index|plane|schur|sky|cg|Ax|rhs|reduce)" --output-format csv --pmc FETCH_SIZE -d "$out/cal_fetch" -o run -- python3 $R/tools/pmc_calib.py > "$out/cal.log" 2> "$out/cal_fetch.err"
+rocprofv3 --kernel-include-regex "k_(amp|index|plane|schur|sky|cg|Ax|rhs|reduce)" --output-format csv --pmc WRITE_SIZE -d "$out/cal_write" -o run -- python3 $R/tools/pmc_calib.py >> "$out/cal.log" 2> "$out/cal_write.err"
 python3 $R/tools/prof_summary.py --stats "$out/trace" --pmc FETCH_SIZE="$out/pmc_fetch" --pmc WRITE_SIZE="$out/pmc_write" \
     --sq "$out/sq" --traffic-json "$out/${tag}_traffic.json" --valu-json "$out/${tag}_valu.json" -o "$out/${tag}_profile.md" \
     --title "$tag: python3 bench.py --steps 20 --warmup 3 (C3, 1x MI355X); PMC passes: --steps 2 --warmup 1" > /dev/null
