@@ -61,31 +61,17 @@ end module dang_bp_mod
 module dang_component_mod                  ! src/dang_component_mod.f90:12-65
   use healpix_types
   implicit none
-  type :: dang_comps
-     integer(i4b)                                     :: cg_group
-     character(len=16)                                :: label, type
-     integer(i4b)                                     :: nfit
-     integer(i4b)                                     :: nindices
-     real(dp)                                         :: nu_ref
-     logical(lgt)                                     :: sample_amplitude
-     logical(lgt),      allocatable, dimension(:)     :: corr
-     character(len=16), allocatable, dimension(:)     :: ind_label
-     logical(lgt),      allocatable, dimension(:)     :: sample_index
-     logical(lgt),      allocatable, dimension(:)     :: tuned
-     integer(i4b),      allocatable, dimension(:)     :: sample_nside
-     real(dp),          allocatable, dimension(:)     :: step_size
-     real(dp),          allocatable, dimension(:,:)   :: amplitude
-     real(dp),          allocatable, dimension(:,:)   :: template
-     real(dp),          allocatable, dimension(:)     :: temp_norm
-     real(dp),          allocatable, dimension(:,:)   :: template_amplitudes
-     integer(i4b),      allocatable, dimension(:)     :: index_mode
-     real(dp),          allocatable, dimension(:,:,:) :: indices
-     character(len=16), allocatable, dimension(:)     :: lnl_type
-     character(len=16), allocatable, dimension(:)     :: prior_type
-     real(dp),          allocatable, dimension(:,:)   :: gauss_prior
-     real(dp),          allocatable, dimension(:,:)   :: uni_prior
-     integer(i4b),      allocatable, dimension(:)     :: nflag
-     integer(i4b),      allocatable, dimension(:,:)   :: pol_flag
+  type :: dang_comps                       ! the fields of the reference's type that dang_gpu_mod.f90 reads or writes, by kind
+     character(len=16) :: label, type
+     integer(i4b)      :: cg_group, nfit, nindices
+     real(dp)          :: nu_ref
+     logical(lgt)      :: sample_amplitude
+     logical(lgt),      allocatable :: corr(:), sample_index(:), tuned(:)
+     character(len=16), allocatable :: ind_label(:), lnl_type(:), prior_type(:)
+     integer(i4b),      allocatable :: sample_nside(:), index_mode(:), nflag(:), pol_flag(:,:)
+     real(dp),          allocatable :: step_size(:), temp_norm(:)
+     real(dp),          allocatable :: amplitude(:,:), template(:,:), template_amplitudes(:,:), gauss_prior(:,:), uni_prior(:,:)
+     real(dp),          allocatable :: indices(:,:,:)
   end type dang_comps
   type component_pointer
      type(dang_comps), pointer :: p => null()
