@@ -105,6 +105,8 @@ SYMBOLS = {
     "dangx_sky_model_chisq": (C.c_int, [_P, C.c_int, C.c_int, _D, _P, _P, _P]),
     "dangx_sky_model_chisq_dev": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "dangx_chisq_cached": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _D]),
+    "dangx_chisq_current": (C.c_int, [_P, C.c_int, C.c_int, _D]),
+    "dangx_index_masked_sums": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P]),
     "dangx_chisq_cached_dev": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "dangx_fullsky_prepare": (C.c_int, [_P, C.c_int, C.c_int]),
     "dangx_fullsky_prepare_coarse": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),

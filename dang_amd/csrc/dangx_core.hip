@@ -659,6 +659,28 @@ __global__ __launch_bounds__(BLOCK) void k_index_masked_sum(const Model* __restr
     }
 }
 
+// the same for several (component, index, map) triples in one launch: blockIdx.y = entry e, rows 2e (sum) and 2e + 1 (count)
+struct MeanList { int n; int comp[16], nind[16], k[16]; };
+__global__ __launch_bounds__(BLOCK) void k_index_masked_sums(const Model* __restrict__ Mp, MeanList ml, double* __restrict__ partial) {
+    __shared__ double sh[2][BLOCK / 64];
+    const Model& M = *Mp;
+    const int e = blockIdx.y;
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    double v = 0.0, n = 0.0;
+    if (i < M.npix && !is_masked(M.mask[i])) {
+        v = M.comp[ml.comp[e]].idx[((long long)ml.nind[e] * M.nmaps + (ml.k[e] - 1)) * M.npix + i];
+        n = 1.0;
+    }
+    for (int o = 32; o > 0; o >>= 1) { v += __shfl_down(v, o, 64); n += __shfl_down(n, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = v; sh[1][threadIdx.x >> 6] = n; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double t = 0.0;
+        for (int w = 0; w < BLOCK / 64; ++w) t += sh[threadIdx.x][w];
+        partial[(long long)(2 * e + threadIdx.x) * gridDim.x + blockIdx.x] = t;
+    }
+}
+
 // plain sums over EVERY local pixel: rows 0: sum(c%indices(:, k, nind)), 1: sum(masks(:,1)) -- the starting point of the
 // step-size tuner in the per-pixel branch, sample(l) = sum(c%indices(:,map_inds(1),l))/sum(mask(:,1))
 // (src/dang_sample_mod.f90:344: no mask test on the indices, the mask VALUES are summed)
@@ -2288,6 +2310,30 @@ int dangx_chisq_cached(dangx_ctx* ctx, int which, int pol_lo, int pol_hi, double
     return 0;
 }
 
+static int sky_chisq_launch(dangx_ctx* ctx, int pol_lo, int pol_hi, double* sky_d, double* res_d, double* chi_d, double* out_dev);
+
+// ddata%chisq's sum for the CURRENT state at the least cost: planes whose sum the last sweeps left behind come from the cache,
+// every other plane gets one explicit update_sky_model + compute_chisq pass over THAT plane, whose result is cached too (the
+// two-call form of the main loop asks after every CG group: only the group's own planes have changed since the last answer)
+int dangx_chisq_current(dangx_ctx* ctx, int pol_lo, int pol_hi, double* chisq_sum) {
+    if (!ctx || !chisq_sum) return 1;
+    (void)hipSetDevice(ctx->device);
+    if (pol_lo < 1 || pol_hi > ctx->dims.nmaps || pol_lo > pol_hi) return fail(ctx, "bad pol_type range");
+    if (sync_model(ctx) || chi_flush(ctx)) return 1;
+    for (int k = pol_lo; k <= pol_hi; ++k)
+        if (!ctx->chi_after_valid[k - 1]) {
+            if (sky_chisq_launch(ctx, k, k, nullptr, nullptr, nullptr, ctx->chi_cache + 3 + (k - 1))) return 1;
+            ctx->chi_after_valid[k - 1] = true;
+        }
+    double v[3] = {0.0, 0.0, 0.0};
+    HIPCHK(ctx, hipMemcpyAsync(v, ctx->chi_cache + 3, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    double s = 0.0;
+    for (int k = pol_lo; k <= pol_hi; ++k) s += v[k - 1];
+    *chisq_sum = s;
+    return 0;
+}
+
 static int sky_chisq_launch(dangx_ctx* ctx, int pol_lo, int pol_hi, double* sky_d, double* res_d, double* chi_d, double* out_dev) {
     if (pol_lo < 1 || pol_hi > ctx->dims.nmaps || pol_lo > pol_hi) return fail(ctx, "bad pol_type range");
     int bs = 256;
@@ -2755,6 +2801,34 @@ int dangx_index_masked_sum(dangx_ctx* ctx, int comp, int nind, int map_n, double
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     *sum = out[0];
     *count = (int64_t)out[1];
+    return 0;
+}
+
+// the masked sums of up to 16 index maps in ONE launch and ONE wait (write_stats_to_term prints them all after every phase,
+// src/dang_data_mod.f90:540-567; write_data every iteration, :716-731)
+int dangx_index_masked_sums(dangx_ctx* ctx, int n, const int32_t* comp, const int32_t* nind, const int32_t* map_n, double* sums, int64_t* counts) {
+    if (!ctx || n < 1 || n > 16 || !comp || !nind || !map_n || !sums || !counts) return 1;
+    (void)hipSetDevice(ctx->device);
+    MeanList ml;
+    ml.n = n;
+    for (int e = 0; e < 16; ++e) { ml.comp[e] = 0; ml.nind[e] = 0; ml.k[e] = 1; }
+    for (int e = 0; e < n; ++e) {
+        if (check_comp(ctx, comp[e])) return 1;
+        if (nind[e] < 0 || nind[e] >= ctx->desc[comp[e]].nindices) return fail(ctx, "index number out of range");
+        if (map_n[e] < 1 || map_n[e] > ctx->dims.nmaps) return fail(ctx, "map_n must be a map number (1..nmaps)");
+        ml.comp[e] = comp[e]; ml.nind[e] = nind[e]; ml.k[e] = map_n[e];
+    }
+    if (sync_model(ctx)) return 1;
+    const unsigned nblk = nblocks(ctx->hm.npix);
+    if (ensure_partial(ctx, 2ll * n * nblk)) return 1;
+    if (ensure_work(ctx, 64)) return 1;
+    hipLaunchKernelGGL(k_index_masked_sums, dim3(nblk, n), dim3(BLOCK), 0, ctx->stream, ctx->dm, ml, ctx->partial);
+    hipLaunchKernelGGL(k_reduce_rows_final, dim3(2 * n), dim3(BLOCK), 0, ctx->stream, ctx->partial, (long long)nblk, 2 * n, ctx->work[0]);
+    HIPCHK(ctx, hipGetLastError());
+    double out[32];
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->work[0], sizeof(double) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int e = 0; e < n; ++e) { sums[e] = out[2 * e]; counts[e] = (int64_t)out[2 * e + 1]; }
     return 0;
 }
 

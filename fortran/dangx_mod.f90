@@ -185,6 +185,20 @@ module dangx_mod
        integer(c_int), value :: which, pol_lo, pol_hi
        real(c_double), intent(out) :: chisq_sum
      end function
+     integer(c_int) function dangx_chisq_current(ctx, pol_lo, pol_hi, chisq_sum) bind(C, name='dangx_chisq_current')
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: pol_lo, pol_hi
+       real(c_double), intent(out) :: chisq_sum
+     end function
+     integer(c_int) function dangx_index_masked_sums(ctx, n, comp, nind, map_n, sums, counts) bind(C, name='dangx_index_masked_sums')
+       import :: c_int, c_ptr, c_int32_t, c_int64_t, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: n
+       integer(c_int32_t), intent(in) :: comp(*), nind(*), map_n(*)      ! comp / nind 0-based, map_n = 1..nmaps
+       real(c_double), intent(out) :: sums(*)
+       integer(c_int64_t), intent(out) :: counts(*)
+     end function
      integer(c_int) function dangx_fullsky_prepare(ctx, comp, map_n) bind(C, name='dangx_fullsky_prepare')
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx

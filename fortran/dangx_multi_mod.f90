@@ -396,6 +396,39 @@ contains
     chisq = chisq/sky%nbands/nump
   end function dangx_sky_chisq_cached
 
+  ! ddata%chisq for the current state at the least cost (dangx_chisq_current on every context): cached plane sums where the
+  ! last sweeps left them, an explicit pass over the other planes only
+  function dangx_sky_chisq_current(sky, pol_lo, pol_hi, nump) result(chisq)
+    type(dangx_sky), intent(in) :: sky
+    integer, intent(in) :: pol_lo, pol_hi
+    real(c_double), intent(in) :: nump
+    real(c_double) :: chisq, s
+    integer :: r
+    chisq = 0.d0
+    do r = 1, sky%nctx
+       call dangx_check(sky%ctx(r), dangx_chisq_current(sky%ctx(r), pol_lo, pol_hi, s), 'dangx_chisq_current')
+       chisq = chisq + s
+    end do
+    chisq = chisq/sky%nbands/nump
+  end function dangx_sky_chisq_current
+
+  ! n masked index means at once (one launch and one wait per context): comp / nind 0-based, map_n = 1..nmaps
+  subroutine dangx_sky_index_means(sky, n, comp, nind, map_n, avg)
+    type(dangx_sky), intent(in) :: sky
+    integer, intent(in) :: n
+    integer(c_int32_t), intent(in) :: comp(n), nind(n), map_n(n)
+    real(c_double), intent(out) :: avg(n)
+    real(c_double) :: s(n), tot(n)
+    integer(c_int64_t) :: cnt(n), ntot(n)
+    integer :: r
+    tot = 0.d0; ntot = 0
+    do r = 1, sky%nctx
+       call dangx_check(sky%ctx(r), dangx_index_masked_sums(sky%ctx(r), n, comp, nind, map_n, s, cnt), 'dangx_index_masked_sums')
+       tot = tot + s; ntot = ntot + cnt
+    end do
+    avg = tot/ntot
+  end subroutine dangx_sky_index_means
+
   ! mask_avg(c%indices(:,map_n,nind), masks(:,1)) (src/dang_util_mod.f90:186-206) without moving a map
   function dangx_sky_index_mean(sky, comp, nind, map_n) result(avg)
     type(dangx_sky), intent(in) :: sky

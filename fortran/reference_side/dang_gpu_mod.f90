@@ -238,66 +238,75 @@ contains
     end do
   end subroutine refresh_offsets
 
-  ! ddata%chisq as update_sky_model + compute_chisq leave it (src/dang_data_mod.f90:339-396, 494-526): from the sums the
-  ! index sweeps produced as a by-product when every plane was swept since its last change, otherwise one explicit pass
+  ! ddata%chisq as update_sky_model + compute_chisq leave it (src/dang_data_mod.f90:339-396, 494-526): plane by plane from the
+  ! sums the index sweeps left behind, or from one explicit pass over a plane that has changed since (dangx_chisq_current)
   subroutine gpu_chisq(ddata, announce)
     type(dang_data) :: ddata
     logical, intent(in) :: announce
-    logical :: ok
     integer :: lo, hi
     lo = ddata%pol_type(1); hi = ddata%pol_type(size(ddata%pol_type))
-    ddata%chisq = dangx_sky_chisq_cached(gpu_sky, 1, lo, hi, real(nump, c_double), ok)
-    if (.not. ok) ddata%chisq = dangx_sky_chisq(gpu_sky, lo, hi, real(nump, c_double))
-    ddata%chisq = rank_sum(ddata%chisq)
+    ddata%chisq = rank_sum(dangx_sky_chisq_current(gpu_sky, lo, hi, real(nump, c_double)))
     if (announce .and. rank == master) call write_stats_gpu(ddata)
   end subroutine gpu_chisq
 
-  ! write_stats_to_term (src/dang_data_mod.f90:528-570): the chi^2 line and the masked index means, from the device
+  ! write_stats_to_term (src/dang_data_mod.f90:528-570): the chi^2 line and the masked index means -- every mean of the list
+  ! from ONE device reduction
   subroutine write_stats_gpu(ddata)
     type(dang_data) :: ddata
     type(dang_comps), pointer :: cc
-    integer :: i, j, k
-    write(*,fmt='(a)') '---------------------------------------------'
-    write(*,fmt='(i6,a,E16.5)') iter, " - Chisq: ", ddata%chisq
+    integer(c_int32_t) :: lc(16), ln(16), lk(16)
+    character(len=48)  :: what(16)
+    real(c_double)     :: avg(16)
+    integer :: i, j, k, n, f
+    n = 0
     do i = 1, ncomp
        cc => component_list(i)%p
        do j = 1, cc%nindices
           if (.not. cc%sample_index(j)) cycle
           do k = 1, cc%nflag(j)
-             if (iand(cc%pol_flag(j,k),1) .ne. 0) then
-                write(*,fmt='(a,a,a,a,a,f12.5)') '     ', trim(cc%label), ' ', trim(cc%ind_label(j)), ' I mean:   ', gpu_index_mean(i, j, 1)
-             else if (iand(cc%pol_flag(j,k),2) .ne. 0) then
-                write(*,fmt='(a,a,a,a,a,f12.5)') '     ', trim(cc%label), ' ', trim(cc%ind_label(j)), ' Q mean:   ', gpu_index_mean(i, j, 2)
-             else if (iand(cc%pol_flag(j,k),4) .ne. 0) then
-                write(*,fmt='(a,a,a,a,a,f12.5)') '     ', trim(cc%label), ' ', trim(cc%ind_label(j)), ' U mean:   ', gpu_index_mean(i, j, 3)
-             else if (iand(cc%pol_flag(j,k),8) .ne. 0) then
-                write(*,fmt='(a,a,a,a,a,f12.5)') '     ', trim(cc%label), ' ', trim(cc%ind_label(j)), ' Q+U mean:   ', gpu_index_mean(i, j, 2)
+             f = cc%pol_flag(j,k)
+             if (iand(f, 15) == 0 .or. n == 16) cycle
+             n = n + 1
+             lc(n) = i-1; ln(n) = j-1
+             if (iand(f,1) .ne. 0) then
+                lk(n) = 1; what(n) = trim(cc%label)//' '//trim(cc%ind_label(j))//' I mean:   '
+             else if (iand(f,2) .ne. 0) then
+                lk(n) = 2; what(n) = trim(cc%label)//' '//trim(cc%ind_label(j))//' Q mean:   '
+             else if (iand(f,4) .ne. 0) then
+                lk(n) = 3; what(n) = trim(cc%label)//' '//trim(cc%ind_label(j))//' U mean:   '
+             else
+                lk(n) = 2; what(n) = trim(cc%label)//' '//trim(cc%ind_label(j))//' Q+U mean:   '
              end if
           end do
        end do
     end do
+    if (n > 0) call gpu_index_means(n, lc, ln, lk, avg)
+    write(*,fmt='(a)') '---------------------------------------------'
+    write(*,fmt='(i6,a,E16.5)') iter, " - Chisq: ", ddata%chisq
+    do i = 1, n
+       write(*,fmt='(a,a,f12.5)') '     ', what(i)(1:len_trim(what(i))+3), avg(i)
+    end do
     write(*,fmt='(a)') '---------------------------------------------'
   end subroutine write_stats_gpu
 
-  ! mask_avg(c%indices(:,map_n,j), ddata%masks(:,1)) (src/dang_util_mod.f90:186-206) without pulling the map;
-  ! comp and j are 1-based as in the reference
-  function gpu_index_mean(comp, j, map_n) result(avg)
-    integer(i4b), intent(in) :: comp, j, map_n
-    real(dp) :: avg, s, stot
-    integer(c_int64_t) :: n
-    real(dp) :: ntot
-    integer :: r
+  ! mask_avg(c%indices(:,map_n,j), ddata%masks(:,1)) (src/dang_util_mod.f90:186-206) for a LIST of index maps without pulling a
+  ! map: comp0 / nind0 0-based.  One launch and one wait per context; under MPI the sums and counts are added over the ranks.
+  subroutine gpu_index_means(n, comp0, nind0, map_n, avg)
+    integer, intent(in) :: n
+    integer(c_int32_t), intent(in) :: comp0(n), nind0(n), map_n(n)
+    real(c_double), intent(out) :: avg(n)
+    real(c_double) :: s(n)
+    integer(c_int64_t) :: cnt(n)
+    integer :: e
     if (numprocs == 1) then
-       avg = dangx_sky_index_mean(gpu_sky, comp-1, j-1, map_n)
+       call dangx_sky_index_means(gpu_sky, n, comp0, nind0, map_n, avg)
     else
-       stot = 0.d0; ntot = 0.d0
-       do r = 1, gpu_sky%nctx
-          call dangx_check(gpu_sky%ctx(r), dangx_index_masked_sum(gpu_sky%ctx(r), comp-1, j-1, map_n, s, n), 'index_masked_sum')
-          stot = stot + s; ntot = ntot + n
+       call dangx_check(gpu_sky%ctx(1), dangx_index_masked_sums(gpu_sky%ctx(1), n, comp0, nind0, map_n, s, cnt), 'index_masked_sums')
+       do e = 1, n
+          avg(e) = rank_sum(s(e))/rank_sum(real(cnt(e), dp))
        end do
-       avg = rank_sum(stot)/rank_sum(ntot)
     end if
-  end function gpu_index_mean
+  end subroutine gpu_index_means
 
   integer(i4b) function map_of_flag(flag)
     ! src/dang_sample_mod.f90:53-64: T -> 1, Q -> 2, U -> 3, Q+U -> -1; 0 = "something wrong with the poltype flag"
@@ -633,17 +642,26 @@ contains
     character(len=512)        :: dir
     character(len=80)         :: stokes
     character(len=16)         :: nb_edit, it5
-    integer(i4b)              :: j, n, u
+    integer(i4b)              :: j, n, u, nl
+    integer(c_int32_t)        :: lc(16), ln(16), lk(16)
+    real(c_double)            :: la(16)
     logical                   :: created
 
     call gpu_chisq(ddata, .false.)
     call pull_template_amplitudes(ddata_offset_only=.false.)
     allocate(avg(2, ncomp)); avg = 0.d0                  ! sky-wide sums: every rank takes part, the master writes
+    nl = 0
     do n = 1, ncomp
        cc => component_list(n)%p
        do j = 1, cc%nindices
-          if (cc%sample_index(j)) avg(j, n) = gpu_index_mean(n, j, map_n)
+          if (cc%sample_index(j) .and. nl < 16) then
+             nl = nl + 1; lc(nl) = n-1; ln(nl) = j-1; lk(nl) = map_n
+          end if
        end do
+    end do
+    if (nl > 0) call gpu_index_means(nl, lc, ln, lk, la)     ! mask_avg(c%indices(:,map_n,j), self%masks(:,1)) for all of them
+    do j = 1, nl
+       avg(ln(j)+1, lc(j)+1) = la(j)
     end do
     if (rank /= master) return
     write(*,*) 'Output data files'

@@ -261,6 +261,11 @@ int dangx_sky_model_chisq_dev(dangx_ctx *ctx, int pol_lo, int pol_hi, double *ch
 int dangx_chisq_cached(dangx_ctx *ctx, int which, int pol_lo, int pol_hi, double *chisq_sum);
 int dangx_chisq_cached_dev(dangx_ctx *ctx, int which, int pol_lo, int pol_hi, double *chisq_sum_dev);
 
+/* the same number for the CURRENT state at the least cost: cached sums where the last sweeps left them, one explicit pass over
+ * each remaining plane (whose sum is then cached too).  What gpu_chisq of the reference-side wrapper calls after every CG group
+ * and every phase (write_stats_to_term, src/dang_data_mod.f90:528-570). */
+int dangx_chisq_current(dangx_ctx *ctx, int pol_lo, int pol_hi, double *chisq_sum);
+
 /* ---- index phase with sample_nside /= nside (src/dang_sample_mod.f90:199-217, 332-483) --------------------------
  * One whole-sky context (npix = 12*nside^2, pix0 = 0), or a pixel shard with an all-reduce (see below).  As in the reference: the data minus every other component is
  * formed at full resolution, then degraded with HEALPix's udgrade_ring (RING -> NEST, mean of the good children,
@@ -301,6 +306,10 @@ int dangx_udgrade(dangx_ctx *ctx, int mode, const double *map_in, int nside_in, 
  * write_data every Gibbs iteration (src/dang_data_mod.f90:716-731, src/dang_util_mod.f90:186-206).  Returns this
  * shard's sum over unmasked pixels and their number; mask_avg = (all-reduced sum) / (all-reduced count). */
 int dangx_index_masked_sum(dangx_ctx *ctx, int comp, int nind, int map_n, double *sum, int64_t *count);
+
+/* n <= 16 such sums in one launch and one wait: (comp[e], nind[e], map_n[e]) -> sums[e], counts[e] */
+int dangx_index_masked_sums(dangx_ctx *ctx, int n, const int32_t *comp, const int32_t *nind, const int32_t *map_n, double *sums,
+                            int64_t *counts);
 
 /* Step-size tuning in the per-pixel branch (src/dang_sample_mod.f90:341-346) starts the tuner's sky-wide chain at
  * sample(l) = sum(c%indices(:,map_inds(1),l)) / sum(mask(:,1)): both sums run over EVERY pixel and the mask VALUES are
