@@ -70,3 +70,25 @@ def test_specialisation_can_be_switched_off(built, monkeypatch):
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DANGX_RTC="0"), stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout
+
+
+def test_specialised_kernels_come_from_the_disk_cache_the_second_time(built, tmp_path):
+    """The code objects hiprtc produces are kept under $DANGX_CACHE_DIR: a second process with the same model loads them
+    instead of compiling (DANGX_RTC_VERBOSE reports every compilation)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_shapes as t\n"
+            "from util import make_case\n"
+            "eng = t._run_and_compare(make_case('C2', nside=8, nbands=7), niter=2)\n"
+            "print('kernels', len(eng.rtc_kernels()))\n") % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, DANGX_CACHE_DIR=str(tmp_path / "cache"), DANGX_RTC_VERBOSE="1")
+    runs = [subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+            for _ in range(2)]
+    for r in runs:
+        assert r.returncode == 0 and "kernels 2" in r.stdout, r.stdout
+    assert runs[0].stdout.count("[dangx] specialising") == 2 and "[dangx] specialising" not in runs[1].stdout, (runs[0].stdout, runs[1].stdout)
+    files = sorted(os.listdir(str(tmp_path / "cache")))
+    assert len([f for f in files if f.endswith(".hsaco")]) == 2 and len([f for f in files if f.endswith(".sym")]) == 2, files
