@@ -397,6 +397,21 @@ class Engine:
         self._chk(rc)
         return s.value
 
+    def chisq_current(self, pol_lo, pol_hi):
+        """the local chi^2 sum of the current state: cached sums where a sweep wrote the plane last, one pass over the others"""
+        s = C.c_double(0.0)
+        self._chk(self.lib.dangx_chisq_current(self.h, pol_lo, pol_hi, C.byref(s)))
+        return s.value
+
+    def index_masked_sums(self, entries):
+        """[(comp, nind, map_n), ...] (at most 16) -> (sums, counts) of mask_avg's numerator and denominator, one launch"""
+        n = len(entries)
+        i32 = lambda k: np.ascontiguousarray([e[k] for e in entries], dtype=np.int32)
+        c, j, m = i32(0), i32(1), i32(2)
+        sums, counts = np.zeros(n), np.zeros(n, dtype=np.int64)
+        self._chk(self.lib.dangx_index_masked_sums(self.h, n, c.ctypes.data, j.ctypes.data, m.ctypes.data, sums.ctypes.data, counts.ctypes.data))
+        return sums, counts
+
     def chisq_cached_dev(self, which, pol_lo, pol_hi, out_tensor):
         rc = self.lib.dangx_chisq_cached_dev(self.h, which, pol_lo, pol_hi, out_tensor.data_ptr())
         if rc == 2:

@@ -198,3 +198,40 @@ def test_c1_at_its_own_nside_matches_the_oracle(built):
         assert np.abs(eng.get_indices(l) - orc.indices(l)).max() <= 1e-12, l
     ochisq, _ = orc.chisq(1, 1, ddata.nump)
     assert abs(ddata.chisq - ochisq) <= 1e-10 * ochisq
+
+
+def test_chisq_current_and_the_batched_index_means(built):
+    """dangx_chisq_current = the explicit pass (dangx_sky_model_chisq) whichever kernel wrote the planes last -- a sweep (cached
+    sums), a solve (one pass over that plane only), a plane set, an upload; dangx_index_masked_sums = the single-map reductions,
+    entry by entry."""
+    case = make_case("C2", nside=8, start="truth")
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+
+    def check(tag):
+        for lo, hi in ((1, 1), (2, 3), (1, 3)):
+            a = eng.chisq_current(lo, hi)
+            b = eng.sky_model_chisq(lo, hi)
+            assert abs(a - b) <= 1e-12 * abs(b), (tag, lo, hi, a, b)
+            assert eng.chisq_current(lo, hi) == a, (tag, lo, hi)     # now from the cache: the same number
+
+    check("upload")
+    eng.amp_sample(1, L.FLAG_T, "sample", dpar.seed, da.stream_id(1, 0, 1, 0, 1))
+    check("solve T")
+    eng.index_sample(1, 0, 1, dpar.nsample, "sample", dpar.seed, da.stream_id(1, 1, 1, 0, 1))
+    check("sweep T")
+    eng.amp_sample(2, L.FLAG_QU, "sample", dpar.seed, da.stream_id(1, 0, 2, 0, 8))
+    check("solve QU")
+    da.gibbs_iteration(dpar, ddata, 2)
+    check("plane sets")
+    eng.put_indices(1, eng.get_indices(1) * 1.01)
+    check("indices replaced")
+
+    entries = [(l, j, m) for l, c in enumerate(comps) for j in range(c.nindices) for m in (1, 2, 3)]
+    assert 1 < len(entries) <= 16
+    sums, counts = eng.index_masked_sums(entries)
+    for e, s, n in zip(entries, sums, counts):
+        s1, n1 = eng.index_masked_sum(*e)
+        assert n == n1 and abs(s - s1) <= 1e-13 * max(abs(s1), 1.0), (e, s, s1)
+    with pytest.raises(Exception):
+        eng.index_masked_sums(entries[:1] * 17)
