@@ -87,8 +87,11 @@ def test_specialised_kernels_come_from_the_disk_cache_the_second_time(built, tmp
     env = dict(os.environ, DANGX_CACHE_DIR=str(tmp_path / "cache"), DANGX_RTC_VERBOSE="1")
     runs = [subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
             for _ in range(2)]
+    import re
     for r in runs:
-        assert r.returncode == 0 and "kernels 2" in r.stdout, r.stdout
-    assert runs[0].stdout.count("[dangx] specialising") == 2 and "[dangx] specialising" not in runs[1].stdout, (runs[0].stdout, runs[1].stdout)
+        assert r.returncode == 0 and re.search(r"kernels \d+", r.stdout), r.stdout
+    n = int(re.search(r"kernels (\d+)", runs[0].stdout).group(1))
+    assert n >= 2 and "kernels %d" % n in runs[1].stdout
+    assert runs[0].stdout.count("[dangx] specialising") == n and "[dangx] specialising" not in runs[1].stdout, (runs[0].stdout, runs[1].stdout)
     files = sorted(os.listdir(str(tmp_path / "cache")))
-    assert len([f for f in files if f.endswith(".hsaco")]) == 2 and len([f for f in files if f.endswith(".sym")]) == 2, files
+    assert len([f for f in files if f.endswith(".hsaco")]) == n and len([f for f in files if f.endswith(".sym")]) == n, files
