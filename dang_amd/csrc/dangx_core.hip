@@ -659,25 +659,41 @@ __global__ __launch_bounds__(BLOCK) void k_index_masked_sum(const Model* __restr
     }
 }
 
-// the same for several (component, index, map) triples in one launch: blockIdx.y = entry e, rows 2e (sum) and 2e + 1 (count)
+// the same for several (component, index, map) triples in one launch: every block walks its pixels once (grid stride), reads the
+// mask once per pixel and adds that pixel to every entry's sum; rows 2e (sum) and 2e + 1 (count, the same for every e)
 struct MeanList { int n; int comp[16], nind[16], k[16]; };
 __global__ __launch_bounds__(BLOCK) void k_index_masked_sums(const Model* __restrict__ Mp, MeanList ml, double* __restrict__ partial) {
-    __shared__ double sh[2][BLOCK / 64];
+    __shared__ double sh[17][BLOCK / 64];
     const Model& M = *Mp;
-    const int e = blockIdx.y;
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    double v = 0.0, n = 0.0;
-    if (i < M.npix && !is_masked(M.mask[i])) {
-        v = M.comp[ml.comp[e]].idx[((long long)ml.nind[e] * M.nmaps + (ml.k[e] - 1)) * M.npix + i];
-        n = 1.0;
+    const double* src[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+        src[e] = (e < ml.n) ? M.comp[ml.comp[e]].idx + ((long long)ml.nind[e] * M.nmaps + (ml.k[e] - 1)) * M.npix : nullptr;
+    double v[16], cnt = 0.0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = 0.0;
+    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < M.npix; i += (long long)gridDim.x * BLOCK) {
+        if (is_masked(M.mask[i])) continue;
+        cnt += 1.0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (e < ml.n) v[e] += src[e][i];
     }
-    for (int o = 32; o > 0; o >>= 1) { v += __shfl_down(v, o, 64); n += __shfl_down(n, o, 64); }
-    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = v; sh[1][threadIdx.x >> 6] = n; }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        if (e < ml.n) {
+            for (int o = 32; o > 0; o >>= 1) v[e] += __shfl_down(v[e], o, 64);
+            if ((threadIdx.x & 63) == 0) sh[e][threadIdx.x >> 6] = v[e];
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[16][threadIdx.x >> 6] = cnt;
     __syncthreads();
-    if (threadIdx.x < 2) {
+    if ((int)threadIdx.x < 2 * ml.n) {
+        const int e = threadIdx.x >> 1, r = (threadIdx.x & 1) ? 16 : e;
         double t = 0.0;
-        for (int w = 0; w < BLOCK / 64; ++w) t += sh[threadIdx.x][w];
-        partial[(long long)(2 * e + threadIdx.x) * gridDim.x + blockIdx.x] = t;
+        for (int w = 0; w < BLOCK / 64; ++w) t += sh[r][w];
+        partial[(long long)threadIdx.x * gridDim.x + blockIdx.x] = t;
     }
 }
 
@@ -2819,10 +2835,10 @@ int dangx_index_masked_sums(dangx_ctx* ctx, int n, const int32_t* comp, const in
         ml.comp[e] = comp[e]; ml.nind[e] = nind[e]; ml.k[e] = map_n[e];
     }
     if (sync_model(ctx)) return 1;
-    const unsigned nblk = nblocks(ctx->hm.npix);
+    const unsigned nblk = std::min(nblocks(ctx->hm.npix), 4096u);
     if (ensure_partial(ctx, 2ll * n * nblk)) return 1;
     if (ensure_work(ctx, 64)) return 1;
-    hipLaunchKernelGGL(k_index_masked_sums, dim3(nblk, n), dim3(BLOCK), 0, ctx->stream, ctx->dm, ml, ctx->partial);
+    hipLaunchKernelGGL(k_index_masked_sums, dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->dm, ml, ctx->partial);
     hipLaunchKernelGGL(k_reduce_rows_final, dim3(2 * n), dim3(BLOCK), 0, ctx->stream, ctx->partial, (long long)nblk, 2 * n, ctx->work[0]);
     HIPCHK(ctx, hipGetLastError());
     double out[32];

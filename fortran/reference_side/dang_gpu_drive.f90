@@ -9,8 +9,9 @@
 !   dang_gpu_drive <problem> <result> <nctx> <mode> [tile]
 !     mode  twocall : call sample_cg_groups_gpu ; sample_spectral_parameters_gpu ; sample_calibrators_gpu   (src/dang.f90:101-110)
 !           fused   : call gibbs_iteration_gpu (iterations > 1) ; sample_calibrators_gpu
-!     tile  the problem's maps repeated `tile` times along the pixel axis (a timing run at Nside 1024 from an Nside 8 file: the
-!           random streams are keyed by the global pixel, so every pixel still runs its own chain); no maps are written back
+!     tile  every pixel of the problem's maps stands for `tile` consecutive pixels (a timing run at Nside 1024 from an Nside 8
+!           file; the masked region stays one run of pixels, as a Galactic mask is in RING order; the random streams are keyed by
+!           the global pixel, so every pixel still runs its own chain); no maps are written back
 ! Every iteration ends with write_data_gpu (the ASCII traces, into the directory of <result>) as in src/dang.f90:116-118; the
 ! run ends with dangx_refresh_host_state (what precedes write_maps, :119-121).
 subroutine mpi_allreduce(sendbuf, recvbuf, count, datatype, op, comm, ierror)
@@ -214,17 +215,23 @@ contains
   subroutine tile2(small, big)
     real(c_double), intent(in)  :: small(0:,:)
     real(c_double), intent(out) :: big(0:,:)
-    integer :: q
-    do q = 0, tile-1
-       big(q*npix0:(q+1)*npix0-1, :) = small
+    integer :: p, q
+    do q = 1, size(small, 2)
+       do p = 0, npix0-1
+          big(p*tile:(p+1)*tile-1, q) = small(p, q)
+       end do
     end do
   end subroutine tile2
   subroutine tile3(small, big)
     real(c_double), intent(in)  :: small(0:,:,:)
     real(c_double), intent(out) :: big(0:,:,:)
-    integer :: q
-    do q = 0, tile-1
-       big(q*npix0:(q+1)*npix0-1, :, :) = small
+    integer :: p, q, r
+    do r = 1, size(small, 3)
+       do q = 1, size(small, 2)
+          do p = 0, npix0-1
+             big(p*tile:(p+1)*tile-1, q, r) = small(p, q, r)
+          end do
+       end do
     end do
   end subroutine tile3
 
