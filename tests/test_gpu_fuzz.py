@@ -158,3 +158,54 @@ def test_random_template_group_direct_solve(built, seed):
     # (the whole-vector figure is bounded by the worst global row -- seed 288 of a wide run is the condition-6e18 system of
     # DESIGN section 3, whose rows sit at their rounding floor of 1e-5 |b|)
     assert relg <= 100 * worst + 1e-9 and rel <= 1e-6 + 10 * worst, (seed, which, rel, relg, worst)
+
+
+def _draw_iteration(seed):
+    rng = np.random.default_rng(9000 + seed)
+    nb = int(rng.choice([4, 6, 7, 9, 11, 12, 14, 16, 18]))
+    ncomp = int(rng.integers(2, min(nb - 1, 6) + 1))
+    comps = ["synch"] + [str(c) for c in rng.permutation(POOL[:1] + POOL[2:])[: ncomp - 1]]
+    return dict(nbands=nb, comps=comps, nmaps=int(rng.choice([1, 3, 3])), nside=int(rng.choice([2, 4])),
+                ml_mode=str(rng.choice(["sample", "sample", "optimize"])), nsample=int(rng.choice([1, 4, 10])),
+                prior=str(rng.choice(["gaussian", "gaussian", "uniform"])), step=float(rng.choice([0.2, 0.5, 1.5])),
+                tight=bool(rng.integers(0, 3) == 0), seed=int(seed))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DANGX_GIBBS_FUZZ_SEEDS", "8"))))
+def test_random_model_gibbs_iterations_match_the_reference_order_loop(built, seed):
+    """Whole Gibbs iterations (da.gibbs_iteration: plane-set launches where dangx_plan_fusion allows them, specialised at run time
+    for whatever band count / member list / sweep list the model has) on random models against the oracle run in the
+    REFERENCE's order (every solve, then every sweep)."""
+    cfg = _draw_iteration(seed)
+
+    def tweak(dpar, ddata, bands, comps):
+        dpar.ml_mode, dpar.nsample = cfg["ml_mode"], cfg["nsample"]
+        for c in comps:
+            c.prior_type = [cfg["prior"]] * c.nindices
+            c.step_size = [cfg["step"] * g[1] if g[1] > 0 else 0.0 for g in c.gauss_prior]
+            if cfg["tight"]:
+                c.uni_prior = [[g[0] - g[1], g[0] + g[1]] if g[1] > 0 else u for g, u in zip(c.gauss_prior, c.uni_prior)]
+    case = make_case(None, nside=cfg["nside"], nbands=cfg["nbands"], comps=cfg["comps"], nmaps=cfg["nmaps"], tweak=tweak,
+                     start="truth", nsample=cfg["nsample"])
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+    for it in (1, 2, 3):
+        da.gibbs_iteration(dpar, ddata, it)
+        for g in dpar.cg_groups:
+            for f in g.pol_flag:
+                orc.amp_sample_direct(g.cg_group, f, dpar.ml_mode, dpar.seed, da.stream_id(it, 0, g.cg_group, 0, f), "reference")
+        for l, c in enumerate(comps):
+            for j in range(c.nindices):
+                if c.sample_index[j]:
+                    for f in c.pol_flag[j]:
+                        orc.sample_index_mh(l, j, MAPN[f], dpar.nsample, dpar.ml_mode, dpar.seed, da.stream_id(it, 1, l, j, f))
+    amax = max(np.abs(orc.amplitude(l)).max() for l in range(len(comps)))
+    if amax >= 1e4:
+        pytest.skip("near-degenerate component subset (amplitudes %.1e): accept decisions are not comparable" % amax)
+    for l, c in enumerate(comps):
+        b = orc.amplitude(l)
+        assert np.abs(eng.get_amplitude(l) - b).max() <= 1e-8 * max(amax, 1.0), (cfg, l)
+        if c.nindices:
+            assert np.abs(eng.get_indices(l) - orc.indices(l)).max() <= 1e-11, (cfg, l, eng.rtc_kernels())
+    ochisq, _ = orc.chisq(1, meta["nmaps"], ddata.nump)
+    assert abs(ddata.chisq - ochisq) <= 1e-8 * abs(ochisq) + 1e-10, cfg
