@@ -202,7 +202,9 @@ def test_random_model_gibbs_iterations_match_the_reference_order_loop(built, see
     amax = max(np.abs(orc.amplitude(l)).max() for l in range(len(comps)))
     if amax >= 1e4:
         pytest.skip("near-degenerate component subset (amplitudes %.1e): accept decisions are not comparable" % amax)
-    tol = 1e-8 * max(1.0, amax / 1e3) ** 2      # the block solve amplifies rounding by its condition number (see above)
+    # the block solve amplifies rounding by its condition number, visible as amplitudes above the injected <~ 3e2 (see above);
+    # three iterations feed the amplified differences back through the index sweeps
+    tol = 1e-8 * max(1.0, amax / 3e2) ** 2
     for l, c in enumerate(comps):
         da_max = float(np.abs(eng.get_amplitude(l) - orc.amplitude(l)).max())
         assert da_max <= tol * max(amax, 1.0), (cfg, l, da_max, amax)
@@ -210,5 +212,5 @@ def test_random_model_gibbs_iterations_match_the_reference_order_loop(built, see
             di_max = float(np.abs(eng.get_indices(l) - orc.indices(l)).max())
             assert di_max <= 1e-11, (cfg, l, di_max, eng.rtc_kernels())
     ochisq, _ = orc.chisq(1, meta["nmaps"], ddata.nump)
-    assert abs(ddata.chisq - ochisq) <= 1e-8 * abs(ochisq) * max(1.0, amax / 1e3) ** 2 + 1e-10, cfg
+    assert abs(ddata.chisq - ochisq) <= tol * abs(ochisq) + 1e-10, cfg
     print("gibbs fuzz %d: %d bands, %s, nmaps %d -> %s" % (seed, cfg["nbands"], "+".join(cfg["comps"]), cfg["nmaps"], eng.rtc_kernels()))
