@@ -215,7 +215,7 @@ class Engine:
                 self.put_indices(l, c.indices)
         self._allreduce_cb = None
         rank, nranks = _dist.world()
-        if nranks > 1:
+        if _dist.active():
             self.set_allreduce(_dist.allreduce_sum_inplace_host, is_root=(rank == 0))
 
     def set_allreduce(self, fn, is_root=True):

@@ -6,8 +6,21 @@ contiguous RING ranges these become scalar all-reduces (RCCL over xGMI when the
 process group's backend is "nccl"; gloo on CPU in the tests).  Every BASELINE config
 is per-pixel independent, so there is no other data-path collective.
 """
+import os
+
 import torch
 import torch.distributed as td
+
+
+def _single():
+    """One rank: nothing to exchange -- unless DANGX_DIST_SINGLE=1 asks for the collectives anyway (a one-GPU rehearsal of the
+    nccl = RCCL branches below: tests/test_gpu_multirank.py)."""
+    return td.get_world_size() == 1 and os.environ.get("DANGX_DIST_SINGLE", "0") != "1"
+
+
+def active():
+    """a process group exists and its collectives are to be called"""
+    return td.is_available() and td.is_initialized() and not _single()
 
 
 def world():
@@ -25,7 +38,7 @@ def shard_range(npix_global, rank, nranks):
 
 def allreduce_sum_float(x, device=None):
     """Sum a Python float over all ranks (returns the same value on every rank)."""
-    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+    if not active():
         return float(x)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if td.get_backend() == "nccl" else torch.device("cpu")
@@ -37,7 +50,7 @@ def allreduce_sum_float(x, device=None):
 def allreduce_sum_inplace_host(a):
     """Sum a small host float64 array over all ranks in place: the callback behind dangx_set_allreduce (dot products
     of the device CG, global-amplitude rows of template groups).  nccl process groups reduce on the device (RCCL)."""
-    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+    if not active():
         return a
     if td.get_backend() == "nccl":
         t = torch.from_numpy(a).to(torch.device("cuda", torch.cuda.current_device()))
@@ -51,7 +64,7 @@ def allreduce_sum_inplace_host(a):
 
 def bcast_from_rank0(values):
     """Broadcast a short list of floats from rank 0 (e.g. c%indices(0, k, :), which lives on the first shard)."""
-    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+    if not active():
         return list(values)
     device = torch.device("cuda", torch.cuda.current_device()) if td.get_backend() == "nccl" else torch.device("cpu")
     t = torch.tensor(list(values), dtype=torch.float64, device=device)
@@ -61,7 +74,7 @@ def bcast_from_rank0(values):
 
 def allreduce_sum_(t):
     """In-place sum of a tensor over all ranks (device tensors go through RCCL)."""
-    if td.is_available() and td.is_initialized() and td.get_world_size() > 1:
+    if active():
         td.all_reduce(t, op=td.ReduceOp.SUM)
     return t
 
@@ -69,7 +82,7 @@ def allreduce_sum_(t):
 def gather_maps(local, npix_global, dst=0):
     """Gather pixel-sharded maps [..., npix_local] to `dst` as [..., npix_global] (map output)."""
     rank, n = world()
-    if n == 1:
+    if not active():
         return local
     sizes = [shard_range(npix_global, r, n)[1] for r in range(n)]
     lead = local.shape[:-1]
