@@ -74,7 +74,7 @@ __device__ __forceinline__ void sed_tile(int type, const double* __restrict__ ta
 #pragma unroll
         for (int t = 0; t < TB; ++t) {
             const double l = (lnu9[t] - p.p2) * rp1;
-            colg[t * BLOCK] = exp_nr(-0.5 * (l * l)) * cst[t];
+            colg[t * BLOCK] = exp_sat(-0.5 * (l * l)) * cst[t];
            
         }
         break;

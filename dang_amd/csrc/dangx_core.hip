@@ -612,7 +612,7 @@ __global__ __launch_bounds__(BLOCK) void k_index_mh_coarse(const Model* __restri
                     if (prop < lo || prop > hi) continue;
                     const double lnl_new = lnl_of(prop) + prior(prop);
                     const double diff = lnl_new - lnl_old;
-                    const bool acc = (a.ml_mode == DANGX_ML_OPTIMIZE) ? (diff > 0.0) : ((diff >= 0.0) || (exp_nr(diff) > u3));
+                    const bool acc = (a.ml_mode == DANGX_ML_OPTIMIZE) ? (diff > 0.0) : ((diff >= 0.0) || (exp_sat(diff) > u3));
                     if (acc) { cur = prop; lnl_old = lnl_new; ++nacc; }
                 }
             }
@@ -862,7 +862,7 @@ double host_sed(const Comp& c, double nu, double cmb_cst, double th0, double th1
     switch (c.type) {
     case DANGX_POWERLAW: return std::pow(nu / c.nu_ref, th0);
     case DANGX_MBB: {
-        const double z = H_PLANCK / (K_B * th1);
+        const double z = mbb_z(th1);
         return (std::exp(z * c.nu_ref) - 1.0) / (std::exp(z * nu) - 1.0) * std::pow(nu / c.nu_ref, th0 + 1.0);
     }
     case DANGX_FREEFREE: {
@@ -897,6 +897,9 @@ int sync_model(dangx_ctx* ctx) {
     M.sig = ctx->sig; M.rms = ctx->rms; M.mask = ctx->mask;
     M.all_delta = 1;
     for (int j = 0; j < M.nbands; ++j) if (M.band[j].n != 0) M.all_delta = 0;
+    double nu_hi = 0.0;
+    for (int j = 0; j < M.nbands; ++j) nu_hi = std::max(nu_hi, M.band[j].nu_c);
+    M.mbb_batch_z = 5.0 * nu_hi / 700.0;
     for (int l = 0; l < M.ncomp; ++l)
         if (ctx->desc[l].type == DANGX_TCMB || is_global_type(ctx->desc[l].type)) M.all_delta = 0;  // generic paths only
     const size_t nbp = ctx->bp_nu0.size();

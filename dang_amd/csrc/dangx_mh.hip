@@ -46,7 +46,7 @@ __device__ __forceinline__ double chain_lnl(const ChainCtx& C, double th, int ln
     switch (C.a.mode) {
     case CH_POW: s0 = th; break;
     case CH_MBB_BETA: s0 = th + 1.0; break;
-    case CH_MBB_T: s0 = H_PLANCK / (K_B * th); s1 = exp_nr(s0 * c.nu_ref) - 1.0; break;
+    case CH_MBB_T: s0 = mbb_z(th); s1 = exp_nr(s0 * c.nu_ref) - 1.0; break;
     case CH_LOGN_NUP: s0 = log_pos(th); s1 = C.other; break;
     case CH_LOGN_W: s1 = th; break;
     default: pr = sed_prep(c, first ? th : C.other, first ? C.other : th); break;
@@ -58,8 +58,8 @@ __device__ __forceinline__ double chain_lnl(const ChainCtx& C, double th, int ln
         case CH_POW: s = exp_nr(s0 * c.lnr[j]); break;
         case CH_MBB_BETA: s = C.F(j) * exp_nr(s0 * c.lnr[j]); break;
         case CH_MBB_T: s = s1 / (exp_nr(s0 * M.band[j].nu_c) - 1.0) * C.F(j); break;
-        case CH_LOGN_NUP: { const double l = (c.lnu9[j] - s0) / s1; s = exp_nr(-0.5 * (l * l)) * c.cst[j]; break; }
-        case CH_LOGN_W: { const double l = C.F(j) / s1; s = exp_nr(-0.5 * (l * l)) * c.cst[j]; break; }
+        case CH_LOGN_NUP: { const double l = (c.lnu9[j] - s0) / s1; s = exp_sat(-0.5 * (l * l)) * c.cst[j]; break; }
+        case CH_LOGN_W: { const double l = C.F(j) / s1; s = exp_sat(-0.5 * (l * l)) * c.cst[j]; break; }
         default: s = (c.type == DANGX_HIFIT) ? 0.0 : sed_eval(M, c, j, pr); break;
         }
         // eval_signal (src/dang_component_mod.f90:754-776): amplitude(pix,map) * sed; T_cmb: the sed itself;
@@ -105,13 +105,13 @@ __device__ __forceinline__ double chain_lnl_tiled(const ChainCtx& C, double th, 
     double s0 = 0.0, s1 = 0.0;
     if (MODE == CH_POW) s0 = th;
     else if (MODE == CH_MBB_BETA) s0 = th + 1.0;
-    else { s0 = H_PLANCK / (K_B * th); s1 = exp_nr(s0 * c.nu_ref) - 1.0; }
+    else { s0 = mbb_z(th); s1 = exp_nr(s0 * c.nu_ref) - 1.0; }
     acc0 = 0.0; acc1 = 0.0;
     if (BP) {
         // chain-invariant scalars of the per-sample factor: mbb beta chain: z, A from the fixed temperature;
         // mbb T chain: the fixed beta + 1
         double bz = 0.0, bA = 0.0, bb1 = 0.0;
-        if (MODE == CH_MBB_BETA) { bz = H_PLANCK / (K_B * C.other); bA = exp_nr(bz * c.nu_ref) - 1.0; }
+        if (MODE == CH_MBB_BETA) { bz = mbb_z(C.other); bA = exp_nr(bz * c.nu_ref) - 1.0; }
         if (MODE == CH_MBB_T) bb1 = C.other + 1.0;
         for (int j = 0; j < C.nb; ++j) {
             const Band& b = M.band[j];
@@ -293,7 +293,7 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
     }
     // --- chain-invariant SED factor
     if (a.mode == CH_MBB_BETA) {
-        const double z = H_PLANCK / (K_B * sample1);
+        const double z = mbb_z(sample1);
         const double A = exp_nr(z * c.nu_ref) - 1.0;
         for (int j = 0; j < nb; ++j) C.F(j) = A / (exp_nr(z * tab[(TROWS * M.ncomp) * nb + j]) - 1.0);
     } else if (a.mode == CH_MBB_T) {
@@ -344,8 +344,8 @@ __device__ __forceinline__ unsigned long long index_chain(const Model& M, const 
             if (a.ml_mode == DANGX_ML_OPTIMIZE) {
                 acc = diff > 0.0;  // :443-447
             } else {
-                // :448-454  diff > log(u)  <=>  diff >= 0 or exp_nr(diff) > u   (u in (0,1))
-                acc = (diff >= 0.0) || (exp_nr(diff) > u3);
+                // :448-454  diff > log(u)  <=>  diff >= 0 or exp(diff) > u   (u in (0,1)); diff has no bound: exp_sat
+                acc = (diff >= 0.0) || (exp_sat(diff) > u3);
             }
             if (acc) {
                 cur = prop;

@@ -7,10 +7,12 @@
 // the library call for A/B timing
 #ifdef DX_CHAIN_LIBEXP
 #define CEXP(x) exp(x)
+#define CEXPS(x) exp(x)
 #define CEXP1(x) exp(x)
 #else
-#define CEXP(x) exp_nr(x)
-#define CEXP1(x) exp_nr_v(x)   // a call site that runs once per proposal (dx_math.h: fma_vc)
+#define CEXP(x) exp_nr(x)      // |x| < 1e9: power law, Planck factor (mbb_z)
+#define CEXPS(x) exp_sat(x)    // any x: the log-normal SED, -(ln(nu/nu_p)/w)^2/2 has no bound for a narrow width
+#define CEXP1(x) exp_nr_v(x)   // a call site that runs once per proposal (dx_math.h: fma_vc); any x
 #endif
 // reciprocals of the rms and inside the modified-blackbody SED: v_rcp_f64 + two Newton steps (<= 1 ulp, 6 vector
 // instructions) instead of the IEEE division sequence (11); -DDX_CHAIN_IEEEDIV restores a / b
@@ -103,10 +105,11 @@ struct RegChain {
         double s0 = 0.0, s1 = 0.0;
         if (MODE == CH_POW) s0 = th;
         else if (MODE == CH_MBB_BETA) s0 = th + 1.0;
-        else if (MODE == CH_MBB_T) { s0 = H_PLANCK / (K_B * th); s1 = CEXP(s0 * c.nu_ref) - 1.0; }
+        else if (MODE == CH_MBB_T) { s0 = mbb_z(th); s1 = CEXP(s0 * c.nu_ref) - 1.0; }
         else if (MODE == CH_LOGN_NUP) { s0 = log_pos(th); s1 = other; }  // log(nu/(nu_p*1e9)) = lnu9 - log(nu_p)
         else s1 = th;  // CH_LOGN_W
         acc0 = 0.0; acc1 = 0.0;
+        const bool batch = (MODE == CH_MBB_T) && (s0 * M.mbb_batch_z < 1.0);
         // log-normal: ln(nu/nu_p)/w as a product with 1/w (v_rcp_f64 + two Newton steps, once per evaluation) instead of one
         // IEEE division per band -- the expression the amplitude kernels use for the same SED (sed_tile), <= 1 ulp from it
 #ifdef DX_CHAIN_IEEEDIV
@@ -119,15 +122,37 @@ struct RegChain {
 #pragma unroll
         for (int j0 = 0; j0 < NB; j0 += TT) {
             double s[TT];
+#ifndef DX_CHAIN_NO_BATCH_RCP
+            if (MODE == CH_MBB_T && TT > 1 && batch) {
+                // one reciprocal for the tile's TT Planck denominators (prefix products, invert the last, peel backwards):
+                // 3(TT-1) multiplications and one v_rcp_f64 + Newton instead of TT of them (v_rcp_f64 issues at a quarter of
+                // the fma rate: 6 % of a temperature proposal).  Each 1/den_t carries <= 2(TT-1) more roundings.  `batch` is
+                // false where the product of TT denominators could overflow (sum of h nu/kT over a tile > 700: T < 0.3 K at
+                // 857 GHz) -- those proposals take the one-by-one form below.
+                double den[TT], pre[TT];
+#pragma unroll
+                for (int t = 0; t < TT; ++t) den[t] = CEXP(s0 * k1(M, c, j0 + t)) - 1.0;
+                pre[0] = den[0];
+#pragma unroll
+                for (int t = 1; t < TT; ++t) pre[t] = pre[t - 1] * den[t];
+                double inv = s1 * fast_rcp(pre[TT - 1]);
+#pragma unroll
+                for (int t = TT - 1; t > 0; --t) {
+                    s[t] = (inv * pre[t - 1]) * F[j0 + t];
+                    inv *= den[t];
+                }
+                s[0] = inv * F[j0];
+            } else
+#endif
 #pragma unroll
             for (int t = 0; t < TT; ++t) {
                 const int j = j0 + t;
                 if (MODE == CH_LOGN_NUP) {
                     const double l = (k1(M, c, j) - s0) * rs1;
-                    s[t] = CEXP(-0.5 * (l * l)) * k2(c, j);
+                    s[t] = CEXPS(-0.5 * (l * l)) * k2(c, j);
                 } else if (MODE == CH_LOGN_W) {
                     const double l = F[j] * rs1;
-                    s[t] = CEXP(-0.5 * (l * l)) * k2(c, j);
+                    s[t] = CEXPS(-0.5 * (l * l)) * k2(c, j);
                 } else {
                     const double e = CEXP(s0 * k1(M, c, j));
                     if (MODE == CH_POW) s[t] = e;
@@ -203,7 +228,7 @@ __device__ __forceinline__ void subtract_other(const Model& M, const Comp& c2, i
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const double l2 = (pick(c2.lnu9, j, NB) - pr.p2) * rp1;
-            Dk[j] -= amp2 * (CEXP(-0.5 * (l2 * l2)) * pick(c2.cst, j, NB));
+            Dk[j] -= amp2 * (CEXPS(-0.5 * (l2 * l2)) * pick(c2.cst, j, NB));
         }
         break;
     }
@@ -244,7 +269,7 @@ __device__ __forceinline__ void subtract_other_pair(const Model& M, const Comp& 
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const double l2 = (pick(c2.lnu9, j, NB) - pr.p2) * rp1;
-            const double s = CEXP(-0.5 * (l2 * l2)) * pick(c2.cst, j, NB);
+            const double s = CEXPS(-0.5 * (l2 * l2)) * pick(c2.cst, j, NB);
             Da[j] -= ampa * s; Db[j] -= ampb * s;
         }
         break;
@@ -270,7 +295,7 @@ __device__ __forceinline__ unsigned long long chain_finish(const Model& M, const
     if (SCALE) R.scale();
     // --- chain-invariant SED factor
     if (MODE == CH_MBB_BETA) {
-        const double z = H_PLANCK / (K_B * sample1);
+        const double z = mbb_z(sample1);
         const double A = CEXP(z * c.nu_ref) - 1.0;
 #pragma unroll
         for (int j = 0; j < NB; ++j) R.F[j] = CDIV(A, CEXP(z * pick.nu_c(M, j, NB)) - 1.0);

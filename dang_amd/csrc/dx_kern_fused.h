@@ -60,7 +60,7 @@ __device__ __forceinline__ void sed_column(int type, const double* __restrict__ 
 #pragma unroll
             for (int t = 0; t < TT; ++t) {
                 const double l = (lnu9[j0 + t] - p.p2) * rp1;
-                colg[(j0 + t) * BLOCK] = exp_nr(-0.5 * (l * l)) * cst[j0 + t];
+                colg[(j0 + t) * BLOCK] = exp_sat(-0.5 * (l * l)) * cst[j0 + t];
             }
         }
     }

@@ -90,7 +90,8 @@ __device__ __forceinline__ double log_pos(double x) {
 // of inf / 0), and the kernels never compare such a value with an outcome that depends on it (an accept test
 // `exp(diff) > u` is false either way; `diff >= 0` is tested first).  Six of the library routine's 22 vector
 // instructions are those selects: the Metropolis chains are vector-issue bound, so this is 1/8 of their proposal loop.
-__device__ __forceinline__ double exp_nr(double x) {
+// exp_sat: for arguments of any size (log-normal SED with a narrow width, Planck function at low temperature).
+__device__ __forceinline__ double exp_sat(double x) {
     const double dn = rint(x * 0x1.71547652b82fep+0);
     const double r = fma(dn, -0x1.abc9e3b39803fp-56, fma(dn, -0x1.62e42fefa39efp-1, x));
     double p = fma(r, 0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22);
@@ -105,6 +106,34 @@ __device__ __forceinline__ double exp_nr(double x) {
     p = fma(r, p, 1.0);
     p = fma(r, p, 1.0);
     return ldexp(p, (int)dn);
+}
+
+// exp_nr: the same reduction and polynomial for |x| < 1e9 -- the SED arguments beta ln(nu/nu_ref) and h nu / (k T) with the
+// clamp of mbb_z below.  n = rint(x log2e) comes out of ONE fma with 1.5 * 2^52: the integer then sits in the low word of the
+// sum (two's complement), which saves the v_rndne and the v_cvt_i32 of the form above -- ten exponentials per Metropolis
+// proposal, 2 % of the proposal loop.  (The single rounding of x log2e + 2^52 can pick the neighbouring n when x log2e is
+// within an ulp of a half-integer; r is then just beyond ln2/2 and the result differs in the last bit at most.)
+// -DDX_EXP_RINT restores exp_sat everywhere.
+__device__ __forceinline__ double exp_nr(double x) {
+#ifdef DX_EXP_RINT
+    return exp_sat(x);
+#else
+    const double z = fma(x, 0x1.71547652b82fep+0, 0x1.8p+52);
+    const double dn = z - 0x1.8p+52;
+    const double r = fma(dn, -0x1.abc9e3b39803fp-56, fma(dn, -0x1.62e42fefa39efp-1, x));
+    double p = fma(r, 0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22);
+    p = fma(r, p, 0x1.71dee623fde64p-19);
+    p = fma(r, p, 0x1.a01997c89e6b0p-16);
+    p = fma(r, p, 0x1.a01a014761f6ep-13);
+    p = fma(r, p, 0x1.6c16c1852b7b0p-10);
+    p = fma(r, p, 0x1.1111111122322p-7);
+    p = fma(r, p, 0x1.55555555502a1p-5);
+    p = fma(r, p, 0x1.5555555555511p-3);
+    p = fma(r, p, 0x1.000000000000bp-1);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    return ldexp(p, (int)(unsigned int)(unsigned long long)__double_as_longlong(z));  // the low word of z
+#endif
 }
 
 // the same routine for a call site that runs once per loop iteration (the accept test): coefficients by fma_vc

@@ -28,6 +28,13 @@ constexpr double C_LIGHT = 2.99792458e8;
 constexpr double MISSVAL = -1.6375e30;
 constexpr double H_PLANCK = 1.0545726691251021e-34 * 2.0 * PI;
 
+// h / (k T) of the modified blackbody (src/dang_component_mod.f90:936), kept within +-1e-4 s: below 5e-7 K the Planck factor
+// is exp(> 1e9) = inf either way, and dx::exp_nr needs |z nu| < 1.4e9 (dx_math.h) for frequencies up to 14 THz
+__host__ __device__ inline double mbb_z(double T) {
+    const double z = H_PLANCK / (K_B * T);
+    return z > 1e-4 ? 1e-4 : (z < -1e-4 ? -1e-4 : z);
+}
+
 struct Band {
     double nu_c;  // Hz
     int n;        // 0 = delta
@@ -69,6 +76,7 @@ struct Model {
     const double* bp_nu0;
     const double* bp_tau0;
     double tcmb;
+    double mbb_batch_z;  // 5 max(nu_c) / 700: h/(kT) * this < 1 <=> five Planck denominators can be multiplied without overflow (dx_chain.h)
     double gain[MAXB], offset[MAXB];
     Band band[MAXB];
     Comp comp[MAXC];

@@ -31,7 +31,7 @@ __device__ __forceinline__ double ff_gaunt(double lnu9, double lt15) {
 // B_nu(nu,T)/compute_bnu_prime_RJ(nu)*1e6: evaluate_T_cmb / evaluate_hi_fit (src/dang_component_mod.f90:815-884,
 // B_nu :745-752, compute_bnu_prime_RJ src/dang_bp_mod.f90:160-168)
 __device__ __forceinline__ double planck_rj(double nu, double T) {
-    const double bnu = ((2.0 * H_PLANCK * (nu * nu * nu)) / (C_LIGHT * C_LIGHT)) * (1.0 / (exp_nr((H_PLANCK * nu) / (K_B * T)) - 1));
+    const double bnu = ((2.0 * H_PLANCK * (nu * nu * nu)) / (C_LIGHT * C_LIGHT)) * (1.0 / (exp_sat((H_PLANCK * nu) / (K_B * T)) - 1));
     const double rj = 2.0 * K_B * (nu * nu) / (C_LIGHT * C_LIGHT);
     return bnu / rj;
 }
@@ -45,7 +45,7 @@ __device__ __forceinline__ Prep sed_prep(const Comp& c, double th0, double th1) 
         p.p0 = th0;
         break;
     case DANGX_MBB: {  // :936-943
-        const double z = H_PLANCK / (K_B * th1);
+        const double z = mbb_z(th1);
         p.p0 = th0 + 1.0;
         p.p1 = z;
         p.p2 = exp_nr(z * c.nu_ref) - 1.0;
@@ -110,7 +110,7 @@ __device__ inline double sed_bandpass(const Model& M, const Comp& c, int j, cons
         for (int i = 0; i < n; ++i) {
             const double l = log_pos(nu[i] / p.p0) / p.p1;
             const double q = c.nu_ref / nu[i];
-            s = s + tau[i] * exp_nr(-0.5 * (l * l)) * (q * q);
+            s = s + tau[i] * exp_sat(-0.5 * (l * l)) * (q * q);
         }
         break;
     case DANGX_TCMB:
@@ -136,7 +136,7 @@ __device__ __forceinline__ double sed_eval(const Model& M, const Comp& c, int j,
         return ff_gaunt(c.lnu9[j], p.p0) / p.p1 * c.cst[j];
     case DANGX_LOGNORMAL: {  // :988
         const double l = (c.lnu9[j] - p.p2) / p.p1;
-        return exp_nr(-0.5 * (l * l)) * c.cst[j];
+        return exp_sat(-0.5 * (l * l)) * c.cst[j];
     }
     case DANGX_TCMB:  // :836-846
         return planck_rj(M.band[j].nu_c, p.p0) * 1e6f;
@@ -180,7 +180,7 @@ __device__ __forceinline__ double sed_eval_tab(int type, const double* tab, int 
     case DANGX_FREEFREE: return ff_gaunt(tc[2 * nb], p.p0) / p.p1 * tc[nb];
     case DANGX_LOGNORMAL: {
         const double l2 = (tab[(TROWS * l + 2) * nb + j] - p.p2) / p.p1;
-        return exp_nr(-0.5 * (l2 * l2)) * tc[nb];
+        return exp_sat(-0.5 * (l2 * l2)) * tc[nb];
     }
     case DANGX_CMB: return tc[nb];
     default: return 0.0;
