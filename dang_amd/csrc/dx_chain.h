@@ -3,6 +3,8 @@
 #include "dx_args.h"
 
 
+template <bool V> struct BoolTag { static constexpr bool value = V; };
+
 // the chain's exp: dx::exp_nr = the library routine minus its range selects (dx_math.h); -DDX_CHAIN_LIBEXP restores
 // the library call for A/B timing
 #ifdef DX_CHAIN_LIBEXP
@@ -101,6 +103,8 @@ struct RegChain {
         }
     }
 
+    // BATCH (CH_MBB_T only): the tile's Planck denominators share one reciprocal -- chain_finish decides once per chain
+    template <bool BATCH>
     __device__ __forceinline__ double lnl(const Model& M, const Comp& c, double th, double other, double& acc0, double& acc1) const {
         double s0 = 0.0, s1 = 0.0;
         if (MODE == CH_POW) s0 = th;
@@ -109,7 +113,6 @@ struct RegChain {
         else if (MODE == CH_LOGN_NUP) { s0 = log_pos(th); s1 = other; }  // log(nu/(nu_p*1e9)) = lnu9 - log(nu_p)
         else s1 = th;  // CH_LOGN_W
         acc0 = 0.0; acc1 = 0.0;
-        const bool batch = (MODE == CH_MBB_T) && (s0 * M.mbb_batch_z < 1.0);
         // log-normal: ln(nu/nu_p)/w as a product with 1/w (v_rcp_f64 + two Newton steps, once per evaluation) instead of one
         // IEEE division per band -- the expression the amplitude kernels use for the same SED (sed_tile), <= 1 ulp from it
 #ifdef DX_CHAIN_IEEEDIV
@@ -122,13 +125,11 @@ struct RegChain {
 #pragma unroll
         for (int j0 = 0; j0 < NB; j0 += TT) {
             double s[TT];
-#ifndef DX_CHAIN_NO_BATCH_RCP
-            if (MODE == CH_MBB_T && TT > 1 && batch) {
+            if (MODE == CH_MBB_T && TT > 1 && BATCH) {
                 // one reciprocal for the tile's TT Planck denominators (prefix products, invert the last, peel backwards):
                 // 3(TT-1) multiplications and one v_rcp_f64 + Newton instead of TT of them (v_rcp_f64 issues at a quarter of
-                // the fma rate: 6 % of a temperature proposal).  Each 1/den_t carries <= 2(TT-1) more roundings.  `batch` is
-                // false where the product of TT denominators could overflow (sum of h nu/kT over a tile > 700: T < 0.3 K at
-                // 857 GHz) -- those proposals take the one-by-one form below.
+                // the fma rate: 6 % of a temperature proposal).  Each 1/den_t carries <= 2(TT-1) more roundings.  Only for
+                // chains that cannot reach a temperature where the product of TT denominators overflows (chain_finish).
                 double den[TT], pre[TT];
 #pragma unroll
                 for (int t = 0; t < TT; ++t) den[t] = CEXP(s0 * k1(M, c, j0 + t)) - 1.0;
@@ -143,7 +144,6 @@ struct RegChain {
                 }
                 s[0] = inv * F[j0];
             } else
-#endif
 #pragma unroll
             for (int t = 0; t < TT; ++t) {
                 const int j = j0 + t;
@@ -330,44 +330,72 @@ __device__ __forceinline__ unsigned long long chain_finish(const Model& M, const
     unsigned long long nacc = 0;
     double cur = first ? sample0 : sample1;
     double a0, a1, c0, c1;
-    double lnl = R.lnl(M, c, cur, other, a0, a1);
-    chi[0] = -2.0 * a0; chi[1] = -2.0 * a1;
-    double lnl_old = lnl + prior(cur);
     const double step = c.step[q], lo = c.uni[q][0], hi = c.uni[q][1];
-    if (LP == 1 || DX_CHAIN_PAIR_RNG == 0) {
-        for (int l = 1; l <= a.nsample; ++l) {
-            double u1, u2, u3;
-            uniform3(a.seed, a.stream, gpix, (uint32_t)l, u1, u2, u3);
-            const double prop = cur + rand_normal(0.0, step, u1, u2);  // :414
-            if (prop < lo || prop > hi) continue;                      // :415
-            lnl = R.lnl(M, c, prop, other, c0, c1);
-            const double lnl_new = lnl + prior(prop);
-            const double diff = lnl_new - lnl_old;
-            const bool acc = (a.ml_mode == DANGX_ML_OPTIMIZE) ? (diff > 0.0) : ((diff >= 0.0) || (CEXP1(diff) > u3));  // :443-454
-            if (acc) { cur = prop; lnl_old = lnl_new; a0 = c0; a1 = c1; ++nacc; }
+    auto chain = [&](auto batch_tag) {
+        constexpr bool B = decltype(batch_tag)::value;
+        double lnl = R.template lnl<B>(M, c, cur, other, a0, a1);
+        chi[0] = -2.0 * a0; chi[1] = -2.0 * a1;
+        double lnl_old = lnl + prior(cur);
+        if (LP == 1 || DX_CHAIN_PAIR_RNG == 0) {
+            for (int l = 1; l <= a.nsample; ++l) {
+                double u1, u2, u3;
+                uniform3(a.seed, a.stream, gpix, (uint32_t)l, u1, u2, u3);
+                const double prop = cur + rand_normal(0.0, step, u1, u2);  // :414
+                if (prop < lo || prop > hi) continue;                      // :415
+                lnl = R.template lnl<B>(M, c, prop, other, c0, c1);
+                const double lnl_new = lnl + prior(prop);
+                const double diff = lnl_new - lnl_old;
+                const bool acc = (a.ml_mode == DANGX_ML_OPTIMIZE) ? (diff > 0.0) : ((diff >= 0.0) || (CEXP1(diff) > u3));  // :443-454
+                if (acc) { cur = prop; lnl_old = lnl_new; a0 = c0; a1 = c1; ++nacc; }
+            }
+        } else {
+            // Lane pairs: both lanes of a pixel would draw the SAME numbers for every step (a third of a proposal's instructions).
+            // Instead lane h draws for step l + h, and the two steps take their numbers from the lane that made them: the random
+            // numbers of a pixel are computed once per TWO steps -- the same draws, the same arithmetic, half the instructions.
+            auto mh_step = [&](double g, double u3) {   // one step from the proposal deviate g = rand_normal(0, step) and the accept uniform
+                const double prop = cur + g;                               // :414
+                if (prop < lo || prop > hi) return;                        // :415
+                lnl = R.template lnl<B>(M, c, prop, other, c0, c1);
+                const double lnl_new = lnl + prior(prop);
+                const double diff = lnl_new - lnl_old;
+                const bool acc = (a.ml_mode == DANGX_ML_OPTIMIZE) ? (diff > 0.0) : ((diff >= 0.0) || (CEXP1(diff) > u3));  // :443-454
+                if (acc) { cur = prop; lnl_old = lnl_new; a0 = c0; a1 = c1; ++nacc; }
+            };
+            for (int l = 1; l <= a.nsample; l += 2) {
+                double u1, u2, u3;
+                uniform3(a.seed, a.stream, gpix, (uint32_t)(l + half), u1, u2, u3);
+                const double g = rand_normal(0.0, step, u1, u2);
+                const double go = __shfl_xor(g, 1, 64), uo = __shfl_xor(u3, 1, 64);
+                mh_step(half == 0 ? g : go, half == 0 ? u3 : uo);                          // step l: the even lane's numbers
+                if (l + 1 <= a.nsample) mh_step(half == 0 ? go : g, half == 0 ? uo : u3);  // step l + 1: the odd lane's
+            }
         }
+    };
+#ifdef DX_CHAIN_NO_BATCH_RCP
+    chain(BoolTag<false>{});
+#else
+    if (MODE == CH_MBB_T) {
+        // The chain evaluates the SED at its starting temperature and at proposals inside the hard bounds (:415) only.  If the
+        // lowest of those keeps the sum of h nu / (k T) over a tile of five bands below 700, no product of five Planck
+        // denominators can overflow and the whole chain takes the batched form; otherwise (T < 0.3 K at 857 GHz, T <= 0) the
+        // one-by-one form -- decided once per chain, not per proposal (a branch inside the proposal costs what it saves).
+        const double tmin = fmin(lo, cur);
+#ifdef DX_BATCH_ALWAYS
+        chain(BoolTag<true>{});
+#elif defined(DX_BATCH_LANEWISE)
+        if (tmin > 0.0 && mbb_z(tmin) * M.mbb_batch_z < 1.0) chain(BoolTag<true>{});
+        else chain(BoolTag<false>{});
+#else
+        // (one decision per WAVEFRONT: the one-by-one form is right for every lane, and a branch the scalar unit takes
+        // keeps the loop's control flow free of execution-mask bookkeeping)
+        const bool unsafe = !(tmin > 0.0 && mbb_z(tmin) * M.mbb_batch_z < 1.0);
+        if (__builtin_amdgcn_ballot_w64(unsafe) == 0ull) chain(BoolTag<true>{});
+        else chain(BoolTag<false>{});
+#endif
     } else {
-        // Lane pairs: both lanes of a pixel would draw the SAME numbers for every step (a third of a proposal's instructions).
-        // Instead lane h draws for step l + h, and the two steps take their numbers from the lane that made them: the random
-        // numbers of a pixel are computed once per TWO steps -- the same draws, the same arithmetic, half the instructions.
-        auto mh_step = [&](double g, double u3) {   // one step from the proposal deviate g = rand_normal(0, step) and the accept uniform
-            const double prop = cur + g;                               // :414
-            if (prop < lo || prop > hi) return;                        // :415
-            lnl = R.lnl(M, c, prop, other, c0, c1);
-            const double lnl_new = lnl + prior(prop);
-            const double diff = lnl_new - lnl_old;
-            const bool acc = (a.ml_mode == DANGX_ML_OPTIMIZE) ? (diff > 0.0) : ((diff >= 0.0) || (CEXP1(diff) > u3));  // :443-454
-            if (acc) { cur = prop; lnl_old = lnl_new; a0 = c0; a1 = c1; ++nacc; }
-        };
-        for (int l = 1; l <= a.nsample; l += 2) {
-            double u1, u2, u3;
-            uniform3(a.seed, a.stream, gpix, (uint32_t)(l + half), u1, u2, u3);
-            const double g = rand_normal(0.0, step, u1, u2);
-            const double go = __shfl_xor(g, 1, 64), uo = __shfl_xor(u3, 1, 64);
-            mh_step(half == 0 ? g : go, half == 0 ? u3 : uo);                          // step l: the even lane's numbers
-            if (l + 1 <= a.nsample) mh_step(half == 0 ? go : g, half == 0 ? uo : u3);  // step l + 1: the odd lane's
-        }
+        chain(BoolTag<false>{});
     }
+#endif
     if (final_value) *final_value = cur;
     if (half != 0) {  // the pair's second lane carries the same chain: its sums and counts are the first lane's
         chi[0] = chi[1] = 0.0;

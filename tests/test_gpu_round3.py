@@ -235,3 +235,26 @@ def test_chisq_current_and_the_batched_index_means(built):
         assert n == n1 and abs(s - s1) <= 1e-13 * max(abs(s1), 1.0), (e, s, s1)
     with pytest.raises(Exception):
         eng.index_masked_sums(entries[:1] * 17)
+
+
+@pytest.mark.parametrize("low", [0.05, 12.0])
+def test_temperature_sweep_below_and_above_the_batched_reciprocal_limit(built, low):
+    """The dust-temperature chain shares one reciprocal among a tile's Planck denominators where no proposal can make their
+    product overflow (dx_chain.h, chain_finish); a hard lower bound of 0.05 K (h nu / k T = 820 at 857 GHz) switches the
+    wavefront to the one-by-one form.  Both must be the oracle's chain."""
+    def tweak(dpar, ddata, bands, comps):
+        for c in comps:
+            if c.type == "mbb":
+                c.uni_prior = [list(u) for u in c.uni_prior]
+                c.uni_prior[1][0] = low
+    case = make_case("C2", nside=8, start="truth", tweak=tweak)
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+    for it in (1, 2):
+        da.gibbs_iteration(dpar, ddata, it)
+        _oracle_iteration(orc, dpar, comps, it)
+    for l, c in enumerate(comps):
+        b = orc.amplitude(l)
+        assert np.abs(eng.get_amplitude(l) - b).max() <= 1e-9 * max(np.abs(b).max(), 1.0), l
+        if c.nindices:
+            assert np.abs(eng.get_indices(l) - orc.indices(l)).max() <= 1e-12, l
