@@ -243,7 +243,9 @@ __global__ void k_chi_from_cache(const double* __restrict__ cache, int which, in
 // pixel.  sky(i,k,j) is accumulated over components in component_list order in an LDS column;
 // the residual and chi^2 follow the reference's expressions.  Block partials of
 // sum_k sum_j res^2/rms^2 go to `partial` (second stage: k_reduce).
-__global__ __launch_bounds__(BLOCK) void k_sky_chisq(const Model* __restrict__ Mp, int pol_lo, int pol_hi, double* __restrict__ sky,
+// (4 waves/SIMD asked for: the kernel streams 2 nb maps per plane against a few SED evaluations, and left to itself the register
+// allocator drifts to 130 registers = 3 waves with any small change of the SED helpers: 1.36 -> 1.70 ms per plane at C3)
+__global__ __launch_bounds__(BLOCK, 4) void k_sky_chisq(const Model* __restrict__ Mp, int pol_lo, int pol_hi, double* __restrict__ sky,
                             double* __restrict__ res, double* __restrict__ chi_map, double* __restrict__ partial) {
     extern __shared__ double lds[];  // [nb][BS]
     const Model& M = *Mp;
