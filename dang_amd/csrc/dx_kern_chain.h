@@ -10,8 +10,14 @@ namespace dxk {
 // Two planes of 20 bands (C5) need ~340 registers in one lane: they run as lane pairs (LP = 2, 10 bands per lane, two
 // waves per SIMD); the one-lane form (one wave per SIMD with the overflow in AGPRs) stays selectable with
 // DANGX_CHAIN_PAIR=0 for A/B timing.
+
+// waves per SIMD asked of the register allocator: 3 where one plane of up to 10 bands fits 168 registers, 1 for two planes of
+// more than 12 bands per lane, else 2 (override on the command line for A/B timing)
+#ifndef DX_CHAIN_WAVES
+#define DX_CHAIN_WAVES(SP, NB, LP) (((SP) == 1 && (NB) <= 10) ? 3 : ((SP) == 2 && (NB) / (LP) > 12) ? 1 : 2)
+#endif
 template <int MODE, int SP, int NB, int LP>
-__global__ __launch_bounds__(BLOCK, (SP == 1 && NB <= 10) ? 3 : (SP == 2 && NB / LP > 12) ? 1 : 2) void k_index_mh_reg(const Model* __restrict__ Mp, IndexArgs a,
+__global__ __launch_bounds__(BLOCK, DX_CHAIN_WAVES(SP, NB, LP)) void k_index_mh_reg(const Model* __restrict__ Mp, IndexArgs a,
                                                         unsigned long long* __restrict__ accepted,
                                                         double* __restrict__ chi_partial) {
     const Model& M = *Mp;
@@ -44,7 +50,7 @@ __global__ __launch_bounds__(BLOCK, (SP == 1 && NB <= 10) ? 3 : (SP == 2 && NB /
 // index nind and index nind + 1 of one component on the same planes in one launch (dx_chain.h: index_chain_pair); the
 // first chain has mode MODEA, the second MODEA + 1 (mbb: beta then T; log-normal: nu_p then w)
 template <int MODEA, int SP, int NB, int LP>
-__global__ __launch_bounds__(BLOCK, (SP == 1 && NB <= 10) ? 3 : (SP == 2 && NB / LP > 12) ? 1 : 2) void k_index_mh_pair(const Model* __restrict__ Mp, IndexArgs a, IndexArgs b,
+__global__ __launch_bounds__(BLOCK, DX_CHAIN_WAVES(SP, NB, LP)) void k_index_mh_pair(const Model* __restrict__ Mp, IndexArgs a, IndexArgs b,
                                                         unsigned long long* __restrict__ accepted_a, unsigned long long* __restrict__ accepted_b,
                                                         double* __restrict__ chi_partial) {
     const Model& M = *Mp;
