@@ -12,9 +12,14 @@ namespace dxk {
 // DANGX_CHAIN_PAIR=0 for A/B timing.
 
 // waves per SIMD asked of the register allocator: 3 where one plane of up to 10 bands fits 168 registers, 1 for two planes of
-// more than 12 bands per lane, else 2 (override on the command line for A/B timing)
+// more than 16 bands in one lane, else 2.  (Two planes of 13 / 15 bands need ~260 / ~280 registers: at two waves they spill
+// 6 / 22 and are still 12 % / 8 % faster than at one wave, 17 bands are 2 % slower -- bench.py --nbands N with
+// DANGX_RTC_DEFS=-DDX_CHAIN_ONE_WAVE_FROM=12 against 18; even counts from 14 run as lane pairs and never get here.)
+#ifndef DX_CHAIN_ONE_WAVE_FROM
+#define DX_CHAIN_ONE_WAVE_FROM 16
+#endif
 #ifndef DX_CHAIN_WAVES
-#define DX_CHAIN_WAVES(SP, NB, LP) (((SP) == 1 && (NB) <= 10) ? 3 : ((SP) == 2 && (NB) / (LP) > 12) ? 1 : 2)
+#define DX_CHAIN_WAVES(SP, NB, LP) (((SP) == 1 && (NB) <= 10) ? 3 : ((SP) == 2 && (NB) / (LP) > DX_CHAIN_ONE_WAVE_FROM) ? 1 : 2)
 #endif
 template <int MODE, int SP, int NB, int LP>
 __global__ __launch_bounds__(BLOCK, DX_CHAIN_WAVES(SP, NB, LP)) void k_index_mh_reg(const Model* __restrict__ Mp, IndexArgs a,
