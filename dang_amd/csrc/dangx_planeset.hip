@@ -68,8 +68,9 @@ static bool planeset_args(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& 
     return true;
 }
 
-// Lanes per pixel of the plane-set launch, 0 when this (group, sweeps) takes the separate launches.  One lane while chain and
-// normal equations fit two waves per SIMD (<= 16 bands on one plane, <= 10 on two), lane pairs above 12 bands (even counts).
+// Lanes per pixel of the plane-set launch, 0 when this (group, sweeps) takes the separate launches.  One lane up to 16 bands on
+// one plane and 13 on two (11-13: two waves per SIMD with a few spilled registers, 10 % faster than the separate launches; 14 in
+// one lane is 5 % slower than as lane pairs, 15 slower than the separate launches), lane pairs above (even counts).
 // Measured against the two-launch form on one box (bench.py, DANGX_PLANESET=pairs for the old path): C5 +19 %, C3 +3.7 %, 7 bands
 // +8.6 %, C1 +17 % (launch bound), the 8-rank shard of C3 +3 %, C2 -1 %.  Specialises the kernel when there is no built-in instantiation.
 int dx_planeset_lanes(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl) {
@@ -77,10 +78,11 @@ int dx_planeset_lanes(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl) 
     // DANGX_PLANESET=pairs: only for the shapes that run as lane pairs (A/B switch)
     static const bool small_too = [] { const char* e = getenv("DANGX_PLANESET"); return !(e && e[0] == 'p'); }();
     if (!enabled || sl.n < 1 || sl.n > 4 || ga.ng < 1 || ga.ng > 6) return 0;
-    const int nb = ctx->hm.nbands, Sp = sl.s2 - sl.s1 + 1, cap = (Sp == 2) ? 10 : 16;
+    static const int cap2 = [] { const char* e = getenv("DANGX_PS_CAP2"); return e ? atoi(e) : 13; }();  // A/B switch
+    const int nb = ctx->hm.nbands, Sp = sl.s2 - sl.s1 + 1, cap = (Sp == 2) ? cap2 : 16;
     int lanes = 0;
-    if (nb > 12 && nb % 2 == 0 && nb / 2 <= cap) lanes = 2;
-    else if (small_too && nb <= cap) lanes = 1;
+    if (small_too && nb <= cap) lanes = 1;
+    else if (nb > 12 && nb % 2 == 0 && nb / 2 <= cap) lanes = 2;
     if (!lanes) return 0;
     for (int q = 0; q < sl.n; ++q) {
         const int m = sl.s[q].mode;
