@@ -80,10 +80,6 @@ int dx_planeset_lanes(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl) 
     if (!enabled || sl.n < 1 || sl.n > 4 || ga.ng < 1 || ga.ng > 6) return 0;
     static const int cap2 = [] { const char* e = getenv("DANGX_PS_CAP2"); return e ? atoi(e) : 13; }();  // A/B switch
     const int nb = ctx->hm.nbands, Sp = sl.s2 - sl.s1 + 1, cap = (Sp == 2) ? cap2 : 16;
-    int lanes = 0;
-    if (small_too && nb <= cap) lanes = 1;
-    else if (nb > 12 && nb % 2 == 0 && nb / 2 <= cap) lanes = 2;
-    if (!lanes) return 0;
     for (int q = 0; q < sl.n; ++q) {
         const int m = sl.s[q].mode;
         if (m < CH_POW || m > CH_LOGN_W) return 0;
@@ -91,7 +87,11 @@ int dx_planeset_lanes(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl) 
     }
     FusedArgs fa;
     if (!planeset_args(ctx, ga, sl, fa)) return 0;
-    if (planeset_lds(ga.ng, nb, fa.nv, lanes) > 80u * 1024u) return 0;
+    // one lane where registers (cap) and the members' SED columns (two blocks per CU: 80 KB each) allow it, else lane pairs
+    int lanes = 0;
+    if (small_too && nb <= cap && planeset_lds(ga.ng, nb, fa.nv, 1) <= 80u * 1024u) lanes = 1;
+    else if (nb > 12 && nb % 2 == 0 && nb / 2 <= cap && planeset_lds(ga.ng, nb, fa.nv, 2) <= 80u * 1024u) lanes = 2;
+    if (!lanes) return 0;
     if (planeset_builtin(nb, ga.ng, lanes, sl)) return lanes;
     return dx_rtc_get(ctx, "dx_kern_planeset.h", planeset_name(Sp, nb, ga.ng, lanes, sl)) ? lanes : 0;
 }
