@@ -246,6 +246,107 @@ __global__ __launch_bounds__(BLOCK, NG <= 4 ? 4 : 3) void k_amp_reg(const Model*
     for (int g = 0; g < NG; ++g) as_global_w(M.comp[a.gc[g]].amp)[(long long)(k - 1) * npix + i] = bv[g];  // unpack, :1327-1354
 }
 
+// update_sky_model + compute_chisq (src/dang_data_mod.f90:339-396, 494-526) of ONE plane on the same schedule: the plane's
+// components with a non-zero amplitude play the group (sky = sum of amplitude * SED in component order), the residual replaces
+// the normal equations.  The run-time-typed kernel of dangx_core.hip (k_sky_chisq) spends 1.36 ms per C3 plane on the same
+// numbers; this one is bound by the 2 nb map loads like k_amp_reg.  Block partials -> partial[blockIdx.x].
+template <int NG, int TB>
+__global__ __launch_bounds__(BLOCK, NG <= 4 ? 4 : 3) void k_chisq_reg(const Model* __restrict__ Mp, GroupArgs a, AmpRegArgs ra,
+                                                                     double* __restrict__ partial) {
+    extern __shared__ double lds[];  // as k_amp_reg
+    __shared__ double wsum[BLOCK / 64];
+    const Model& M = *Mp;
+    const int npix = M.npix, nb = M.nbands, tid = threadIdx.x;
+    double* tab = lds;
+    double* prl = lds + (TROWS * NG + 3) * nb + tid;
+    double* col = prl + 3 * ra.nv * BLOCK;
+    const long long u = (long long)blockIdx.x * BLOCK + tid;
+    const bool in_range = u < npix;
+    const int i = in_range ? (int)u : 0;
+    const int k = flag_map(a.flag, 0);
+    const double mk = as_global(M.mask)[i];
+    double th[NG][2], av[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) av[g] = as_global(M.comp[a.gc[g]].amp)[(long long)(k - 1) * npix + i];
+#pragma unroll
+    for (int v = 0; v < NG; ++v) {
+        th[v][0] = th[v][1] = 0.0;
+        if (v < ra.nv) {
+            const Comp& c = M.comp[a.gc[ra.vcomp[v]]];
+            const gcptr ix = as_global(c.idx) + (long long)(k - 1) * npix + i;
+            if (c.nind > 0) th[v][0] = ix[0];
+            if (c.nind > 1) th[v][1] = ix[(long long)M.nmaps * npix];
+        }
+    }
+    sed_table_build(M, tab, tid, BLOCK, a.gc, NG);
+    const bool live = in_range && !is_masked(mk);
+    if (live) {
+#pragma unroll
+        for (int v = 0; v < NG; ++v)
+            if (v < ra.nv) { prl[(3 * v + 0) * BLOCK] = th[v][0]; prl[(3 * v + 1) * BLOCK] = th[v][1]; }
+#pragma unroll 1
+        for (int v = 0; v < ra.nv; ++v) {
+            const Comp& c = M.comp[a.gc[ra.vcomp[v]]];
+            const Prep pr = sed_prep(c, prl[(3 * v + 0) * BLOCK], prl[(3 * v + 1) * BLOCK]);
+            prl[(3 * v + 0) * BLOCK] = pr.p0;
+            prl[(3 * v + 1) * BLOCK] = pr.p1;
+            prl[(3 * v + 2) * BLOCK] = pr.p2;
+        }
+    }
+    __syncthreads();
+    double chi = 0.0;
+    if (live) {
+        const double* gain = tab + (TROWS * NG + 1) * nb;
+        const double* offs = gain + nb;
+        const long long bstride = (long long)M.nmaps * npix;
+        const gcptr sigp = as_global(M.sig) + (long long)(k - 1) * npix + i;
+        const gcptr rmsp = as_global(M.rms) + (long long)(k - 1) * npix + i;
+#pragma unroll 1
+        for (int j0 = 0; j0 < nb; j0 += TB) {
+            double dcur[TB], rcur[TB];
+#pragma unroll
+            for (int t = 0; t < TB; ++t) {
+                dcur[t] = sigp[(j0 + t) * bstride];
+                rcur[t] = rmsp[(j0 + t) * bstride];
+            }
+#pragma unroll 1
+            for (int v = 0; v < ra.nv; ++v) {
+                const Prep pr = {prl[(3 * v + 0) * BLOCK], prl[(3 * v + 1) * BLOCK], prl[(3 * v + 2) * BLOCK]};
+                sed_tile<TB>(ra.vtype[v], tab, nb, NG, ra.vcomp[v], j0, pr, col + (v * TB) * BLOCK);
+            }
+            const double* mp[NG];
+            int ms[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const bool var = ra.vslot[g] >= 0;
+                mp[g] = var ? col + (ra.vslot[g] * TB) * BLOCK : tab + (TROWS * g + 2 + k) * nb + j0;
+                ms[g] = var ? BLOCK : 1;
+            }
+#pragma unroll
+            for (int t = 0; t < TB; ++t) {
+                double d = dcur[t];
+                if (k == 1) {  // res = (sig - offset)/gain - sky on the temperature plane, :379-391
+                    const double gj = gain[j0 + t], oj = offs[j0 + t];
+                    if (gj != 1.0 || oj != 0.0) d = (d - oj) / gj;
+                }
+                double sky = 0.0;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) sky = sky + av[g] * mp[g][t * ms[g]];  // component order, :349-356
+                const double r = (d - sky) * fast_rcp(rcur[t]);
+                chi = fma(r, r, chi);  // :505-523
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) chi += __shfl_down(chi, o, 64);
+    if ((tid & 63) == 0) wsum[tid >> 6] = chi;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < BLOCK / 64; ++w) t += wsum[w];
+        partial[blockIdx.x] = t;
+    }
+}
+
 template <int TB>
 size_t amp_reg_lds(int NG, int nb, int nv) { return ((size_t)(TROWS * NG + 3) * nb + (size_t)nv * (TB + 3) * BLOCK) * sizeof(double); }
 
@@ -275,6 +376,28 @@ int launch_ng(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, long lon
         }
     }
     return -1;  // the LDS-column kernel is the better fit
+}
+
+template <int NG, int TB>
+int launch_chi_tb(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, double* partial) {
+    const size_t ldsz = amp_reg_lds<TB>(NG, ctx->hm.nbands, ra.nv);
+    hipLaunchKernelGGL((k_chisq_reg<NG, TB>), dim3(nblocks(ctx->hm.npix)), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, partial);
+    return 0;
+}
+template <int NG>
+int launch_chi_ng(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, double* partial) {
+    const int nb = ctx->hm.nbands;
+    const size_t want = (160u * 1024u) / (NG <= 4 ? 4 : 3), most = 80u * 1024u;
+    for (const size_t cap : {want, most}) {
+        if (nb % 5 == 0 && amp_reg_lds<5>(NG, nb, ra.nv) <= cap) return launch_chi_tb<NG, 5>(ctx, a, ra, partial);
+        if (nb % 4 == 0 && amp_reg_lds<4>(NG, nb, ra.nv) <= cap) return launch_chi_tb<NG, 4>(ctx, a, ra, partial);
+        if (nb % 3 == 0 && amp_reg_lds<3>(NG, nb, ra.nv) <= cap) return launch_chi_tb<NG, 3>(ctx, a, ra, partial);
+        if (nb % 5 && nb % 4 && nb % 3) {
+            if (nb % 2 == 0 && amp_reg_lds<2>(NG, nb, ra.nv) <= cap) return launch_chi_tb<NG, 2>(ctx, a, ra, partial);
+            if (nb % 2 && amp_reg_lds<1>(NG, nb, ra.nv) <= cap) return launch_chi_tb<NG, 1>(ctx, a, ra, partial);
+        }
+    }
+    return -1;
 }
 
 }  // namespace
@@ -307,6 +430,43 @@ int dx_launch_amp_reg(dangx_ctx* ctx, const GroupArgs& a, long long SN) {
     case 4: return launch_ng<4>(ctx, a, ra, SN);
     case 5: return launch_ng<5>(ctx, a, ra, SN);
     case 6: return launch_ng<6>(ctx, a, ra, SN);
+    default: return -1;
+    }
+}
+
+// chi^2 block partials of plane k (1..nmaps) into partial[0 .. nblocks(npix)): 0 when launched, -1 when the plane needs the
+// run-time-typed kernel (bandpass-integrated bands, global or T_cmb components, more than six components with an amplitude on
+// the plane, none at all)
+int dx_launch_chisq_reg(dangx_ctx* ctx, int k, double* partial) {
+    static const bool enabled = [] { const char* e = getenv("DANGX_CHISQ_FAST"); return !(e && e[0] == '0'); }();  // A/B switch
+    if (!enabled || !ctx->hm.all_delta || k < 1 || k > ctx->dims.nmaps) return -1;
+    GroupArgs a = {};
+    a.ng = 0;
+    for (int l = 0; l < ctx->hm.ncomp; ++l) {
+        const Comp& c = ctx->hm.comp[l];
+        if (!((ctx->plane_nz[l] >> (k - 1)) & 1u)) continue;  // amplitude 0 everywhere on the plane: 0 * sed
+        if (c.type < DANGX_POWERLAW || c.type > DANGX_CMB || a.ng >= 6) return -1;
+        a.gc[a.ng++] = l;
+    }
+    if (a.ng < 1) return -1;
+    a.flag = (k == 1) ? DANGX_FLAG_T : (k == 2) ? DANGX_FLAG_Q : DANGX_FLAG_U;
+    AmpRegArgs ra;
+    ra.nv = 0;
+    for (int g = 0; g < MAXG; ++g) { ra.vslot[g] = -1; ra.vcomp[g] = 0; ra.vtype[g] = 0; }
+    for (int g = 0; g < a.ng; ++g) {
+        const Comp& c = ctx->hm.comp[a.gc[g]];
+        if (!(((unsigned)c.const_planes >> (k - 1)) & 1u)) {
+            ra.vcomp[ra.nv] = (signed char)g; ra.vtype[ra.nv] = (signed char)c.type;
+            ra.vslot[g] = (signed char)ra.nv++;
+        }
+    }
+    switch (a.ng) {
+    case 1: return launch_chi_ng<1>(ctx, a, ra, partial);
+    case 2: return launch_chi_ng<2>(ctx, a, ra, partial);
+    case 3: return launch_chi_ng<3>(ctx, a, ra, partial);
+    case 4: return launch_chi_ng<4>(ctx, a, ra, partial);
+    case 5: return launch_chi_ng<5>(ctx, a, ra, partial);
+    case 6: return launch_chi_ng<6>(ctx, a, ra, partial);
     default: return -1;
     }
 }

@@ -2361,6 +2361,26 @@ static int sky_chisq_launch(dangx_ctx* ctx, int pol_lo, int pol_hi, double* sky_
     while (bs > 64 && (size_t)ctx->hm.nbands * bs * sizeof(double) > 32 * 1024) bs >>= 1;
     const unsigned nblk = nblocks(ctx->hm.npix, bs);
     constexpr int RSTAGE = 128;
+    // delta bandpasses, diffuse components, no maps asked for: one launch per plane on the amplitude kernel's schedule
+    // (k_chisq_reg, dangx_ampreg.hip), the planes' block partials side by side and summed together
+    if (!sky_d && !res_d && !chi_d && ctx->hm.all_delta) {
+        const unsigned nb256 = nblocks(ctx->hm.npix);
+        const int npl = pol_hi - pol_lo + 1;
+        if (ensure_partial(ctx, (long long)npl * nb256 + RSTAGE)) return 1;
+        bool all = true;
+        {
+            Timed t(ctx, DANGX_K_SKY_CHISQ);
+            for (int k = pol_lo; k <= pol_hi && all; ++k) all = dx_launch_chisq_reg(ctx, k, ctx->partial + (long long)(k - pol_lo) * nb256) == 0;
+        }
+        if (all) {
+            Timed t(ctx, DANGX_K_REDUCE);
+            double* stage = ctx->partial + (long long)npl * nb256;
+            hipLaunchKernelGGL(k_reduce_rows, dim3(RSTAGE), dim3(BLOCK), 0, ctx->stream, ctx->partial, (long long)npl * nb256, 1, stage);
+            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(BLOCK), 0, ctx->stream, stage, (long long)RSTAGE, out_dev);
+            HIPCHK(ctx, hipGetLastError());
+            return 0;
+        }
+    }
     if (ensure_partial(ctx, (long long)nblk + RSTAGE)) return 1;
     {
         Timed t(ctx, DANGX_K_SKY_CHISQ);

@@ -258,3 +258,36 @@ def test_temperature_sweep_below_and_above_the_batched_reciprocal_limit(built, l
         assert np.abs(eng.get_amplitude(l) - b).max() <= 1e-9 * max(np.abs(b).max(), 1.0), l
         if c.nindices:
             assert np.abs(eng.get_indices(l) - orc.indices(l)).max() <= 1e-12, l
+
+
+@pytest.mark.parametrize("config,nside,nbands", [("C3", 8, None), ("C5", 4, None), ("C2", 8, 7), ("C1", 8, None)])
+def test_chisq_on_the_amplitude_schedule_is_the_run_time_typed_pass(built, config, nside, nbands):
+    """dangx_sky_model_chisq without map outputs runs k_chisq_reg (one launch per plane, the plane's components with a non-zero
+    amplitude as the group); asking for the maps runs the run-time-typed k_sky_chisq.  The same chi^2 (different SED
+    reciprocals: 1e-12), the oracle's chi^2, also with a gain and an offset on the temperature plane, a component switched
+    off on one plane, and a spatially constant index plane."""
+    def tweak(dpar, ddata, bands, comps):
+        ddata.gain = np.asarray(ddata.gain, dtype=np.float64).copy()
+        ddata.offset = np.asarray(ddata.offset, dtype=np.float64).copy()
+        ddata.gain[1] = 1.02
+        ddata.offset[0] = 0.3
+        comps[1].indices[0, 0, :] = comps[1].indices[0, 0, 0]      # synchrotron beta constant on the T plane
+    kw = dict(nbands=nbands) if nbands else {}
+    case = make_case(config, nside=nside, start="truth", tweak=tweak, **kw)
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+    nm = meta["nmaps"]
+    for lo, hi in ((1, 1), (1, nm)) + (((2, 3),) if nm == 3 else ()):
+        fast = eng.sky_model_chisq(lo, hi)
+        slow = eng.sky_model_chisq(lo, hi, want_maps=True)[0]
+        want, _ = orc.chisq(lo, hi, 1.0)
+        assert abs(fast - slow) <= 1e-12 * abs(slow), (lo, hi, fast, slow)
+        assert abs(fast / meta["nbands"] - want) <= 1e-11 * abs(want), (lo, hi, fast / meta["nbands"], want)
+    # a component with no amplitude on a plane drops out of that plane's launch
+    l = 1
+    a = eng.get_amplitude(l)
+    a[0] = 0.0
+    eng.put_amplitude(l, a)
+    fast = eng.sky_model_chisq(1, 1)
+    slow = eng.sky_model_chisq(1, 1, want_maps=True)[0]
+    assert abs(fast - slow) <= 1e-12 * abs(slow)
