@@ -168,7 +168,7 @@ def fortran_seam(config_name, nsample, steps=10):
     out = {"what": "it/s through the Fortran wrapper on %s tiled to %d pixels (%d timed iterations each)" % (config_name, full_npix, steps)}
     with tempfile.TemporaryDirectory() as tmp:
         fin = os.path.join(tmp, "in.bin")
-        fdrive.write_problem(fin, dpar, ddata, comps, meta, niter=steps + 2)
+        fdrive.write_problem(fin, dpar, ddata, comps, meta, niter=steps + 3)
         for mode in ("twocall", "fused"):
             txt = fdrive.run(fin, os.path.join(tmp, "out_%s.bin" % mode), nctx=1, mode=mode, tile=tile)
             secs = [float(l.split("=")[1].split()[0]) for l in txt.splitlines() if l.startswith("drive seconds per iteration")]

@@ -12,7 +12,7 @@ sys.path.insert(0, ".")
 from dang_amd import fdrive, synth, _build
 _build.build_reference_drive()
 dpar, ddata, bands, comps, meta = synth.make_sky("C3", nside=8, nsample=10)
-fdrive.write_problem(sys.argv[1], dpar, ddata, comps, meta, niter=12)
+fdrive.write_problem(sys.argv[1], dpar, ddata, comps, meta, niter=13)
 print("tile", 12 * synth.CONFIGS["C3"]["nside"] ** 2 // meta["npix_global"])
 PY
 exe=$(python3 -c "import sys; sys.path.insert(0,'.'); from dang_amd import _build; print(_build.build_reference_drive())")
