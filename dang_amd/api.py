@@ -375,19 +375,6 @@ class Engine:
             C.byref(bad) if want_counts else None, acc.ctypes.data if want_counts else None))
         return bad.value, [int(a) for a in acc]
 
-    def plane_sweeps_sample(self, group, flag, ml_mode, sweeps, nsample, seed_index, want_counts=True):
-        """index_sample(comp, nind, map_n of the flag, ...) for every (comp, nind, stream) of `sweeps` -- the sweeps of
-        sample_spectral_parameters on one plane set, the amplitude phase having been a call of its own
-        (dangx_plane_sweeps_sample: one launch where the plane-set kernel covers the model).  Returns [accepted per sweep]."""
-        n = len(sweeps)
-        comp = np.ascontiguousarray([s[0] for s in sweeps], dtype=np.int32)
-        nind = np.ascontiguousarray([s[1] for s in sweeps], dtype=np.int32)
-        strm = np.ascontiguousarray([s[2] for s in sweeps], dtype=np.uint64)
-        acc = np.zeros(n, dtype=np.int64)
-        self._chk(self.lib.dangx_plane_sweeps_sample(self.h, group, flag, L.ML_CODES[ml_mode], n, comp.ctypes.data, nind.ctypes.data,
-                                                     strm.ctypes.data, nsample, seed_index, acc.ctypes.data if want_counts else None))
-        return [int(a) for a in acc]
-
     def sky_model_chisq(self, pol_lo, pol_hi, want_maps=False):
         s = C.c_double(0.0)
         if want_maps:
@@ -820,7 +807,6 @@ def sample_spectral_parameters(dpar: DangParams, ddata: DangData, it=2, verbose=
     eng = ddata.engine
     sampled = False
     info = []
-    done = _plane_sweeps_first(dpar, eng, it, skip)
     for l, c in enumerate(eng.component_list):
         if c.nindices == 0 or not any(c.sample_index):
             continue
@@ -830,9 +816,6 @@ def sample_spectral_parameters(dpar: DangParams, ddata: DangData, it=2, verbose=
             if not c.sample_index[j]:
                 continue
             for f in c.pol_flag[j]:
-                if (l, j, f) in done:       # ran with the other sweeps of its plane set (below)
-                    info.append((l, j, f, done[(l, j, f)]))
-                    continue
                 if (l, j, f) in skip or (j, f) in paired:
                     continue
                 if (f in _MAPN and j + 1 < c.nindices and _plain_sweep(eng, c, j) and _plain_sweep(eng, c, j + 1)
@@ -874,34 +857,6 @@ def sample_spectral_parameters(dpar: DangParams, ddata: DangData, it=2, verbose=
         if verbose:
             print("%6d - Chisq: %16.5E" % (it, ddata.chisq))
     return info
-
-
-def _plane_sweeps_first(dpar, eng, it, skip):
-    """The plain per-pixel sweeps of sample_spectral_parameters, plane set by plane set, through Engine.plane_sweeps_sample:
-    {(component, index, flag): accepted}.  Sweeps on disjoint planes read and write disjoint planes, so a plane set's sweeps
-    may run together (in the reference's order among themselves) before the loop over components reaches them -- provided no
-    sampled flag overlaps another (Q beside Q+U), every sweep is a plain one, and no T_cmb component (whose sweep moves the
-    global T_CMB) is in the model.  Plane sets this does not hold for stay with the loop."""
-    comps = eng.component_list
-    if any(c.type == "T_cmb" for c in comps):
-        return {}
-    sweeps = [(l, j, f) for l, c in enumerate(comps) for j in range(c.nindices) if c.sample_index[j] for f in c.pol_flag[j]]
-    flags = sorted({f for _, _, f in sweeps})
-    out = {}
-    for f in flags:
-        if f not in _MAPN or any(f2 != f and (_planes(f2) & _planes(f)) for f2 in flags):
-            continue
-        mine = [(l, j) for l, j, g in sweeps if g == f]
-        if len(mine) < 2 or any((l, j, f) in skip for l, j in mine) or not all(_plain_sweep(eng, comps[l], j) for l, j in mine):
-            continue
-        groups = {comps[l].cg_group for l, j in mine}
-        if len(groups) != 1:
-            continue
-        acc = eng.plane_sweeps_sample(groups.pop(), f, dpar.ml_mode, [(l, j, stream_id(it, 1, l, j, f)) for l, j in mine],
-                                      dpar.nsample, dpar.seed)
-        for (l, j), a in zip(mine, acc):
-            out[(l, j, f)] = a
-    return out
 
 
 def gibbs_iteration(dpar: DangParams, ddata: DangData, it, verbose=False):

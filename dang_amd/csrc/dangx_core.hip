@@ -2182,32 +2182,9 @@ int dangx_amp_index_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int
 // 40-75), in the reference's order.  Where k_plane_set covers the model (dx_kern_planeset.h: many bands and members, every swept
 // component a member of the group) all of it is ONE launch with the members' SED columns kept in LDS; everything else IS those
 // calls (through dangx_amp_index_sample / dangx_index_sample_pair where they apply).
-static int plane_set_impl(dangx_ctx* ctx, bool solve, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed_amp,
-                          uint64_t stream_amp, int i_max, double converge, int nsweeps, const int32_t* comp, const int32_t* nind,
-                          const uint64_t* stream, int nsample, uint64_t seed_index, int* cg_iters, int64_t* n_not_spd, int64_t* accepted);
-
 int dangx_plane_set_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed_amp, uint64_t stream_amp,
                            int i_max, double converge, int nsweeps, const int32_t* comp, const int32_t* nind, const uint64_t* stream,
                            int nsample, uint64_t seed_index, int* cg_iters, int64_t* n_not_spd, int64_t* accepted) {
-    return plane_set_impl(ctx, true, group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, i_max, converge, nsweeps, comp, nind, stream,
-                          nsample, seed_index, cg_iters, n_not_spd, accepted);
-}
-
-// dangx_index_sample(comp[s], nind[s], map_n of the flag, ...) for s = 0 .. nsweeps-1: the passes of sample_spectral_parameters
-// on ONE plane set (src/dang_sample_mod.f90:40-75) when the amplitude phase was a call of its own (the two-call seam,
-// src/dang.f90:101-106).  Where the plane-set kernel covers the model (every swept component an amplitude-sampled member of
-// `group`, nothing else on the planes) they are ONE launch (k_plane_sweeps: the members' SED columns evaluated once and kept in
-// LDS across the sweeps); everything else IS those calls (dangx_index_sample_pair where two indices of a component follow
-// each other).
-int dangx_plane_sweeps_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int nsweeps, const int32_t* comp, const int32_t* nind,
-                              const uint64_t* stream, int nsample, uint64_t seed_index, int64_t* accepted) {
-    return plane_set_impl(ctx, false, group, flag, ml_mode, DANGX_SOLVER_DIRECT, DANGX_FLUCT_REFERENCE, 0, 0, 0, 0.0, nsweeps, comp, nind, stream,
-                          nsample, seed_index, nullptr, nullptr, accepted);
-}
-
-static int plane_set_impl(dangx_ctx* ctx, bool solve, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed_amp,
-                          uint64_t stream_amp, int i_max, double converge, int nsweeps, const int32_t* comp, const int32_t* nind,
-                          const uint64_t* stream, int nsample, uint64_t seed_index, int* cg_iters, int64_t* n_not_spd, int64_t* accepted) {
     if (!ctx || nsweeps < 1 || !comp || !nind || !stream) return 1;
     (void)hipSetDevice(ctx->device);
     if (sync_model(ctx)) return 1;
@@ -2227,12 +2204,8 @@ static int plane_set_impl(dangx_ctx* ctx, bool solve, int group, int flag, int m
     SweepList sl;
     std::memset(&sl, 0, sizeof(sl));
     if (can) {
-        if (make_group(ctx, group, flag, g)) {
-            if (solve) return 1;
-            ctx->err.clear();   // the sweeps alone do not need the group: they take the separate launches
-            can = false;
-        }
-        can = can && g.nt == 0 && g.no == 0 && g.nuc == 0;
+        if (make_group(ctx, group, flag, g)) return 1;
+        can = g.nt == 0 && g.no == 0 && g.nuc == 0;
         for (int l = 0; can && l < ctx->hm.ncomp; ++l)
             if (ctx->desc[l].type == DANGX_TCMB) can = false;
     }
@@ -2259,19 +2232,16 @@ static int plane_set_impl(dangx_ctx* ctx, bool solve, int group, int flag, int m
         sl.nsample = nsample; sl.ml_mode = ml_mode; sl.seed = seed_index;
         sl.s1 = (map_n == -1) ? 2 : map_n; sl.s2 = (map_n == -1) ? 3 : map_n;
         g.ml_mode = ml_mode; g.fluct = fluct_mode; g.seed = seed_amp; g.stream = stream_amp;
-        lanes = dx_planeset_lanes(ctx, g, sl, solve);
+        lanes = dx_planeset_lanes(ctx, g, sl);
     }
     if (!lanes) {  // the calls this entry point stands for, through the two-step fusions where they apply
         int s = 0;
         int64_t acc = 0, acc2 = 0;
-        int rc = 0;
-        if (solve) {
-            rc = dangx_amp_index_sample(ctx, group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, i_max, converge, comp[0], nind[0],
+        int rc = dangx_amp_index_sample(ctx, group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, i_max, converge, comp[0], nind[0],
                                         map_n, nsample, seed_index, stream[0], cg_iters, n_not_spd, accepted ? &acc : nullptr);
-            if (rc) return rc;
-            if (accepted) accepted[0] = acc;
-        }
-        for (s = solve ? 1 : 0; s < nsweeps; ++s) {
+        if (rc) return rc;
+        if (accepted) accepted[0] = acc;
+        for (s = 1; s < nsweeps; ++s) {
             if (s + 1 < nsweeps && comp[s + 1] == comp[s] && nind[s + 1] == nind[s] + 1) {
                 rc = dangx_index_sample_pair(ctx, comp[s], nind[s], map_n, nsample, ml_mode, seed_index, stream[s], stream[s + 1],
                                              accepted ? &acc : nullptr, accepted ? &acc2 : nullptr);
@@ -2289,13 +2259,10 @@ static int plane_set_impl(dangx_ctx* ctx, bool solve, int group, int flag, int m
     // ---- one launch.  Bookkeeping of dangx_amp_sample (the planes' cached chi^2 is stale, the members' amplitudes are about to
     // be written) and of the sweeps (their chi^2 by-product: before = the state the solve leaves, after = the last sweep's)
     const int Sp = sl.s2 - sl.s1 + 1;
-    // the sweeps alone: their "before" chi^2 is the state the amplitude phase left only if no sweep has run on the planes since
-    const bool wb = solve || !ctx->touched_since_amp[sl.s1 - 1];
-    if (solve)
-        for (int k = sl.s1; k <= sl.s2; ++k) {
-            ctx->chi_before_valid[k - 1] = ctx->chi_after_valid[k - 1] = ctx->touched_since_amp[k - 1] = false;
-            for (int q = 0; q < g.ng; ++q) ctx->plane_nz[g.gc[q]] |= 1u << (k - 1);
-        }
+    for (int k = sl.s1; k <= sl.s2; ++k) {
+        ctx->chi_before_valid[k - 1] = ctx->chi_after_valid[k - 1] = ctx->touched_since_amp[k - 1] = false;
+        for (int q = 0; q < g.ng; ++q) ctx->plane_nz[g.gc[q]] |= 1u << (k - 1);
+    }
     for (int q = 0; q < sl.n; ++q)
         for (int e = 0; e <= sl.s[q].pair; ++e) {
             if (map_n == -1) ctx->qu_equal[sl.s[q].comp] |= 1u << (sl.s[q].nind + e);
@@ -2311,7 +2278,7 @@ static int plane_set_impl(dangx_ctx* ctx, bool solve, int group, int flag, int m
         bool ok;
         {
             Timed t(ctx, DANGX_K_AMP_INDEX);
-            ok = dx_launch_planeset(ctx, g, sl, lanes, nblk, accepted ? ctx->counters + 4 : nullptr, solve);
+            ok = dx_launch_planeset(ctx, g, sl, lanes, nblk, accepted ? ctx->counters + 4 : nullptr);
         }
         ctx->partial = saved;
         if (!ok) return fail(ctx, "the plane-set launch failed after its kernel was prepared");
@@ -2319,11 +2286,8 @@ static int plane_set_impl(dangx_ctx* ctx, bool solve, int group, int flag, int m
     HIPCHK(ctx, hipGetLastError());
     {
         auto& pend = ctx->chi_pend[ctx->chi_npend++];
-        pend.nblk = nblk; pend.s1 = sl.s1; pend.s2 = sl.s2; pend.wb = wb ? 1 : 0;
-        for (int k = sl.s1; k <= sl.s2; ++k) {
-            if (wb) ctx->chi_before_valid[k - 1] = true;
-            ctx->chi_after_valid[k - 1] = ctx->touched_since_amp[k - 1] = true;
-        }
+        pend.nblk = nblk; pend.s1 = sl.s1; pend.s2 = sl.s2; pend.wb = 1;
+        for (int k = sl.s1; k <= sl.s2; ++k) ctx->chi_before_valid[k - 1] = ctx->chi_after_valid[k - 1] = ctx->touched_since_amp[k - 1] = true;
     }
     (void)Sp;
     if (n_not_spd || accepted) {

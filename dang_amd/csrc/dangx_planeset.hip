@@ -15,10 +15,10 @@ static size_t planeset_lds(int ng, int nb, int nv, int lanes) {
 static void item_codes(const SweepList& sl, int code[4]) {
     for (int q = 0; q < 4; ++q) code[q] = (q < sl.n) ? sl.s[q].mode + 8 * sl.s[q].pair : 0;
 }
-static std::string planeset_name(int Sp, int nb, int ng, int lanes, const SweepList& sl, bool solve) {
+static std::string planeset_name(int Sp, int nb, int ng, int lanes, const SweepList& sl) {
     int c[4];
     item_codes(sl, c);
-    std::string s = std::string(solve ? "dxk::k_plane_set<" : "dxk::k_plane_sweeps<") + std::to_string(Sp) + ", " + std::to_string(nb) + ", " + std::to_string(ng) + ", " + std::to_string(lanes);
+    std::string s = "dxk::k_plane_set<" + std::to_string(Sp) + ", " + std::to_string(nb) + ", " + std::to_string(ng) + ", " + std::to_string(lanes);
     for (int q = 0; q < 4; ++q) s += ", " + std::to_string(c[q]);
     return s + ">";
 }
@@ -73,7 +73,7 @@ static bool planeset_args(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& 
 // one lane is 5 % slower than as lane pairs, 15 slower than the separate launches), lane pairs above (even counts).
 // Measured against the two-launch form on one box (bench.py, DANGX_PLANESET=pairs for the old path): C5 +19 %, C3 +3.7 %, 7 bands
 // +8.6 %, C1 +17 % (launch bound), the 8-rank shard of C3 +3 %, C2 -1 %.  Specialises the kernel when there is no built-in instantiation.
-int dx_planeset_lanes(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl, bool solve) {
+int dx_planeset_lanes(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl) {
     static const bool enabled = [] { const char* e = getenv("DANGX_PLANESET"); return !(e && e[0] == '0'); }();
     // DANGX_PLANESET=pairs: only for the shapes that run as lane pairs (A/B switch)
     static const bool small_too = [] { const char* e = getenv("DANGX_PLANESET"); return !(e && e[0] == 'p'); }();
@@ -92,24 +92,24 @@ int dx_planeset_lanes(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl, 
     if (small_too && nb <= cap && planeset_lds(ga.ng, nb, fa.nv, 1) <= 80u * 1024u) lanes = 1;
     else if (nb > 12 && nb % 2 == 0 && nb / 2 <= cap && planeset_lds(ga.ng, nb, fa.nv, 2) <= 80u * 1024u) lanes = 2;
     if (!lanes) return 0;
-    if (solve && planeset_builtin(nb, ga.ng, lanes, sl)) return lanes;   // the sweeps alone (k_plane_sweeps): specialised at run time
-    return dx_rtc_get(ctx, "dx_kern_planeset.h", planeset_name(Sp, nb, ga.ng, lanes, sl, solve)) ? lanes : 0;
+    if (planeset_builtin(nb, ga.ng, lanes, sl)) return lanes;
+    return dx_rtc_get(ctx, "dx_kern_planeset.h", planeset_name(Sp, nb, ga.ng, lanes, sl)) ? lanes : 0;
 }
 
 // accp: per-sweep counters (sum over items of 1 + pair entries) or null
-bool dx_launch_planeset(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl, int lanes, unsigned nblk, unsigned long long* accp, bool solve) {
+bool dx_launch_planeset(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl, int lanes, unsigned nblk, unsigned long long* accp) {
     FusedArgs fa;
     if (lanes < 1 || lanes > 2 || !planeset_args(ctx, ga, sl, fa)) return false;
     const int nb = ctx->hm.nbands, ng = ga.ng, Sp = sl.s2 - sl.s1 + 1;
     const size_t ldsz = planeset_lds(ng, nb, fa.nv, lanes);
-    if (solve && planeset_builtin(nb, ng, lanes, sl)) {
+    if (planeset_builtin(nb, ng, lanes, sl)) {
         if (nb == 20) launch_builtin<20, 6, 2, CH_POW, CH_MBB_BETA + 8, CH_LOGN_NUP>(ctx, ga, fa, sl, Sp, nblk, ldsz, accp);
         else if (nb == 10) launch_builtin<10, 4, 1, CH_POW, CH_MBB_BETA + 8, 0>(ctx, ga, fa, sl, Sp, nblk, ldsz, accp);
         else if (nb == 5) launch_builtin<5, 3, 1, CH_POW, CH_MBB_BETA + 8, 0>(ctx, ga, fa, sl, Sp, nblk, ldsz, accp);
         else launch_builtin<3, 2, 1, CH_POW, CH_MBB_BETA + 8, 0>(ctx, ga, fa, sl, Sp, nblk, ldsz, accp);
         return true;
     }
-    hipFunction_t fn = dx_rtc_get(ctx, "dx_kern_planeset.h", planeset_name(Sp, nb, ng, lanes, sl, solve));
+    hipFunction_t fn = dx_rtc_get(ctx, "dx_kern_planeset.h", planeset_name(Sp, nb, ng, lanes, sl));
     if (!fn) return false;
     const Model* dm = ctx->dm;
     GroupArgs gg = ga;

@@ -198,6 +198,6 @@ int dx_fused_lanes(dangx_ctx* ctx, const GroupArgs& ga, const IndexArgs& a, int 
 bool dx_launch_fused(dangx_ctx* ctx, const GroupArgs& ga, const IndexArgs& a, int Sp, int lanes, unsigned nblk, unsigned long long* accp);
 int dx_mh_reg_lanes(int nb, int Sp);  // lanes per pixel of the register chain (dangx_mhreg.hip)
 // a group's solve and every sweep on its planes in one launch (dangx_planeset.hip): lanes per pixel, 0 = the separate launches
-int dx_planeset_lanes(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl, bool solve = true);
-bool dx_launch_planeset(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl, int lanes, unsigned nblk, unsigned long long* accp, bool solve = true);
+int dx_planeset_lanes(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl);
+bool dx_launch_planeset(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl, int lanes, unsigned nblk, unsigned long long* accp);
 bool dx_launch_mh_reg(dangx_ctx* ctx, const IndexArgs& a, int Sp, unsigned nblk, unsigned long long* accp);

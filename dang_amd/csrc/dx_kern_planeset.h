@@ -128,12 +128,10 @@ __device__ __forceinline__ void ps_item(const Model& M, const SweepList& sl, con
 // the modes inside one kernel costs the register allocator ~200 spills (three inlined chains share one frame); a model's
 // sweep sequence is fixed for a run, so it is part of the specialisation: C5 = <POW, MBB_BETA + 8, LOGN_NUP> is built in, any
 // other sequence is compiled on first use (dangx_rtc.hip).
-// SOLVE = false: the sweeps alone (k_plane_sweeps) -- what sample_spectral_parameters does on a plane set when the amplitude
-// phase was a call of its own: the members' amplitudes are read instead of solved for, everything else is the same code.
-template <bool SOLVE, int SP, int NB, int NG, int LP, int C0, int C1, int C2, int C3>
-__device__ __forceinline__ void plane_set_body(const Model* __restrict__ Mp, const GroupArgs& ga, const FusedArgs& fa, const SweepList& sl,
-                                               unsigned long long* __restrict__ not_spd, unsigned long long* __restrict__ accepted,
-                                               double* __restrict__ chi_partial) {
+template <int SP, int NB, int NG, int LP, int C0, int C1, int C2, int C3>
+__global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP)) void k_plane_set(const Model* __restrict__ Mp, GroupArgs ga, FusedArgs fa, SweepList sl,
+                                                        unsigned long long* __restrict__ not_spd, unsigned long long* __restrict__ accepted,
+                                                        double* __restrict__ chi_partial) {
     constexpr int NBL = NB / LP;
     extern __shared__ double lds[];  // [constant table | per-lane columns: nv*NBL rows of SEDs]
     const Model& M = *Mp;
@@ -182,11 +180,6 @@ __device__ __forceinline__ void plane_set_body(const Model* __restrict__ Mp, con
                 const double* rmsp = M.rms + (long long)(k - 1) * npix + i;
 #pragma unroll
                 for (int j = 0; j < NBL; ++j) { R0.D[kk][j] = sigp[(jb + j) * bstride]; R0.ISr[kk][j] = rmsp[(jb + j) * bstride]; }
-            }
-            if (!SOLVE) {  // the sweeps alone: 1/sigma as the solve would have left it
-#pragma unroll
-                for (int j = 0; j < NBL; ++j) R0.set_is(kk, j, fast_rcp(R0.ISr[kk][j]));
-                continue;
             }
             double eta = 0.0, f0 = 0.0;
             if (sample) {
@@ -312,20 +305,6 @@ __device__ __forceinline__ void plane_set_body(const Model* __restrict__ Mp, con
             chi_partial[(long long)tid * gridDim.x + blockIdx.x] = s;
         }
     }
-}
-
-template <int SP, int NB, int NG, int LP, int C0, int C1, int C2, int C3>
-__global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP)) void k_plane_set(const Model* __restrict__ Mp, GroupArgs ga, FusedArgs fa, SweepList sl,
-                                                        unsigned long long* __restrict__ not_spd, unsigned long long* __restrict__ accepted,
-                                                        double* __restrict__ chi_partial) {
-    plane_set_body<true, SP, NB, NG, LP, C0, C1, C2, C3>(Mp, ga, fa, sl, not_spd, accepted, chi_partial);
-}
-
-template <int SP, int NB, int NG, int LP, int C0, int C1, int C2, int C3>
-__global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP)) void k_plane_sweeps(const Model* __restrict__ Mp, GroupArgs ga, FusedArgs fa, SweepList sl,
-                                                        unsigned long long* __restrict__ not_spd, unsigned long long* __restrict__ accepted,
-                                                        double* __restrict__ chi_partial) {
-    plane_set_body<false, SP, NB, NG, LP, C0, C1, C2, C3>(Mp, ga, fa, sl, not_spd, accepted, chi_partial);
 }
 
 }  // namespace dxk

@@ -314,31 +314,6 @@ contains
     end if
   end subroutine dangx_sky_plane_set_sample
 
-  ! the sweeps of sample_spectral_parameters on one plane set, the amplitude phase having been a call of its own
-  ! (dangx_plane_sweeps_sample: one launch per context where the plane-set kernel covers the model, the separate sweeps otherwise)
-  subroutine dangx_sky_plane_sweeps_sample(sky, group, flag, ml_mode, nsweeps, comp, nind, stream, nsample, seed_index, accepted)
-    type(dangx_sky), intent(in) :: sky
-    integer, intent(in) :: group, flag, ml_mode, nsweeps, nsample
-    integer(c_int32_t), intent(in) :: comp(nsweeps), nind(nsweeps)      ! 0-based
-    integer(c_int64_t), intent(in) :: seed_index, stream(nsweeps)
-    integer(c_int64_t), intent(out), optional :: accepted(nsweeps)
-    integer(c_int64_t) :: nacc(nsweeps)
-    integer :: r
-    if (present(accepted)) then
-       accepted = 0
-       do r = 1, sky%nctx
-          call dangx_check(sky%ctx(r), dangx_plane_sweeps_sample(sky%ctx(r), group, flag, ml_mode, nsweeps, comp, nind, stream, nsample, &
-               seed_index, accepted=nacc), 'dangx_plane_sweeps_sample')
-          accepted = accepted + nacc
-       end do
-    else
-       do r = 1, sky%nctx
-          call dangx_check(sky%ctx(r), dangx_plane_sweeps_sample(sky%ctx(r), group, flag, ml_mode, nsweeps, comp, nind, stream, nsample, &
-               seed_index), 'dangx_plane_sweeps_sample')
-       end do
-    end if
-  end subroutine dangx_sky_plane_sweeps_sample
-
   ! sample_index_mh with sample_nside /= nside (src/dang_sample_mod.f90:199-217, 332-483) over the contexts: the three
   ! phases of dangx_index_sample_coarse, the shards' buffers added in shard order between them
   subroutine dangx_sky_index_sample_coarse(sky, comp, nind, map_n, nsample, ml_mode, seed, stream, nside, sample_nside, accepted)

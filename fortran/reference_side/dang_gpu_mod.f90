@@ -500,71 +500,9 @@ contains
     type(dang_data)   :: ddata
     type(dang_params) :: dpar
     logical(lgt) :: sampled
-    logical, allocatable :: skip(:)
-    call plane_sweeps_first(dpar, skip)
-    call run_sweeps(dpar, ddata, skip=skip, sampled=sampled)
+    call run_sweeps(dpar, ddata, sampled=sampled)
     if (sampled) call gpu_chisq(ddata, .true.)            ! update_sky_model + write_stats_to_term, :81-84
   end subroutine sample_spectral_parameters_gpu
-
-  ! The plain per-pixel sweeps of sample_spectral_parameters, plane set by plane set (dangx_plane_sweeps_sample: one launch per
-  ! plane set where the plane-set kernel covers the model).  Sweeps on disjoint planes read and write disjoint planes, so the
-  ! sweeps of a plane set may run together, in the reference's order among themselves, before the loop over components reaches
-  ! them -- provided no sampled poltype flag overlaps another, every sweep on the planes is a plain one of components of ONE
-  ! CG group, and no T_cmb component (whose sweep moves the global T_CMB) is in the model.  skip(e) = sweep e of the loop's
-  ! order is done; plane sets this does not hold for stay with the loop.
-  subroutine plane_sweeps_first(dpar, skip)
-    type(dang_params) :: dpar
-    logical, allocatable, intent(out) :: skip(:)
-    type(dang_comps), pointer :: cc
-    integer(c_int32_t), allocatable :: sc(:), sn(:), sf(:), sg(:), lc(:), ln(:)
-    integer(c_int64_t), allocatable :: ls(:)
-    logical, allocatable :: plain(:)
-    integer(i4b) :: i, j, k, e, e2, ns, nl, f, mode
-    logical :: ok
-    ns = 0
-    do i = 1, ncomp
-       cc => component_list(i)%p
-       do j = 1, cc%nindices
-          if (cc%sample_index(j)) ns = ns + cc%nflag(j)
-       end do
-    end do
-    allocate(skip(ns), sc(ns), sn(ns), sf(ns), sg(ns), plain(ns), lc(ns), ln(ns), ls(ns))
-    skip = .false.
-    ns = 0
-    do i = 1, ncomp
-       cc => component_list(i)%p
-       if (trim(cc%type) == 'T_cmb') return
-       do j = 1, cc%nindices
-          if (.not. cc%sample_index(j)) cycle
-          do k = 1, cc%nflag(j)
-             ns = ns + 1; sc(ns) = i-1; sn(ns) = j-1; sf(ns) = cc%pol_flag(j,k); sg(ns) = cc%cg_group
-             plain(ns) = plain_sweep(cc, j)
-          end do
-       end do
-    end do
-    mode = merge(DANGX_ML_SAMPLE, DANGX_ML_OPTIMIZE, trim(dpar%ml_mode) == 'sample')
-    do e = 1, ns
-       f = sf(e)
-       if (skip(e) .or. map_of_flag(f) == 0) cycle
-       if (any(sf(1:e-1) == f)) cycle                      ! this flag's plane set was looked at already
-       ok = .true.; nl = 0
-       do e2 = 1, ns
-          if (sf(e2) == f) then
-             nl = nl + 1; lc(nl) = sc(e2); ln(nl) = sn(e2)
-             ls(nl) = dangx_stream_id(iter, 1, int(sc(e2)), int(sn(e2)), f)
-             ok = ok .and. plain(e2) .and. sg(e2) == sg(e)
-          else if (iand(planes_of_flag(int(sf(e2))), planes_of_flag(f)) /= 0) then
-             ok = .false.                                  ! another flag shares a plane (Q beside Q+U)
-          end if
-       end do
-       if (.not. ok .or. nl < 2) cycle
-       do e2 = 1, nl
-          write(*,fmt='(a,i4)') 'Sampling per-pixel at nside ', nside
-       end do
-       call dangx_sky_plane_sweeps_sample(gpu_sky, int(sg(e)), f, mode, nl, lc(1:nl), ln(1:nl), ls(1:nl), nsample, gpu_seed)
-       where (sf == f) skip = .true.
-    end do
-  end subroutine plane_sweeps_first
 
   ! One pass of the main loop for an iteration in which both phases run (src/dang.f90:101-106, iter > 1):
   !     call sample_cg_groups_gpu(dpar, ddata); call sample_spectral_parameters_gpu(dpar, ddata)

@@ -243,15 +243,6 @@ int dangx_plane_set_sample(dangx_ctx *ctx, int group, int flag, int ml_mode, int
                            const uint64_t *stream, int nsample, uint64_t seed_index, int *cg_iters, int64_t *n_not_spd,
                            int64_t *accepted);
 
-/* ---- the same without the solve: exactly dangx_index_sample(comp[s], nind[s], map_n(flag), nsample, ml_mode, seed_index, stream[s],
- * &accepted[s]) for s = 0 .. nsweeps-1 -- the passes of sample_spectral_parameters (src/dang_sample_mod.f90:40-75) on ONE plane set
- * when the amplitude phase was a call of its own (the two calls of src/dang.f90:101-106).  Where every swept component is an
- * amplitude-sampled member of CG group `group` and nothing else lives on the planes, the sweeps are ONE launch that evaluates the
- * members' SED columns once and keeps them in LDS; every other case IS those calls (dangx_index_sample_pair where two indices of
- * a component follow each other).  accepted[nsweeps] nullable. */
-int dangx_plane_sweeps_sample(dangx_ctx *ctx, int group, int flag, int ml_mode, int nsweeps, const int32_t *comp, const int32_t *nind,
-                              const uint64_t *stream, int nsample, uint64_t seed_index, int64_t *accepted);
-
 /* ---- sky model + chi^2: update_sky_model + compute_chisq
  * (src/dang_data_mod.f90:339-396, 494-526).  pol_lo..pol_hi = ddata%pol_type range.
  * chisq_sum receives the LOCAL sum over unmasked pixels and planes of

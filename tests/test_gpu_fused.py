@@ -334,64 +334,3 @@ def test_c5_gibbs_iteration_matches_the_oracle_loop(built):
     assert_indices_close(eng, orc, comps)
     ochisq, _ = orc.chisq(1, 3, ddata.nump)
     assert abs(ddata.chisq - ochisq) <= 1e-9 * ochisq
-
-
-@pytest.mark.parametrize("config,nside,nbands", [("C3", 8, None), ("C5", 4, None), ("C2", 8, 7)])
-def test_plane_sweeps_launch_is_the_separate_sweeps(built, config, nside, nbands):
-    """dangx_plane_sweeps_sample: the sweeps of sample_spectral_parameters on one plane set in ONE launch (k_plane_sweeps: the
-    members' SED columns once, amplitudes read instead of solved for), after an amplitude phase that was a call of its own.
-    Against the oracle's sweeps in the same order and against the separate launches (accepted counts per sweep, indices,
-    the chi^2 by-products before and after), and through da.sample_spectral_parameters -- the two-call form of the loop."""
-    kw = dict(nbands=nbands) if nbands else {}
-    case = make_case(config, nside=nside, start="truth", **kw)
-    dpar, ddata, bands, comps, meta = case
-    eng, orc = pair(case)
-    two = da.Engine(bands, copy.deepcopy(comps), ddata, npix_global=meta["npix_global"], pix0=meta["pix0"], device=0)
-    nm = meta["nmaps"]
-    for it in (1, 2):
-        for g in dpar.cg_groups:
-            f = g.pol_flag[0]
-            sa = da.stream_id(it, 0, g.cg_group, 0, f)
-            for e in (eng, two):
-                e.amp_sample(g.cg_group, f, "sample", 5, sa)
-            orc.amp_sample_direct(g.cg_group, f, "sample", 5, sa, "reference")
-        for g in dpar.cg_groups:
-            f = g.pol_flag[0]
-            sw = _plane_sweeps(comps, g.cg_group, f)
-            eng.profile(True)
-            accs = eng.plane_sweeps_sample(g.cg_group, f, "sample", [(l, j, da.stream_id(it, 1, l, j, f)) for l, j in sw], 10, 5)
-            prof = eng.profile_get()
-            assert prof["k_amp_index"]["launches"] == 1 and "k_index_mh" not in prof and "k_amp_direct" not in prof, prof
-            for q, (l, j) in enumerate(sw):
-                s = da.stream_id(it, 1, l, j, f)
-                oacc = orc.sample_index_mh(l, j, MAPN[f], 10, "sample", 5, s)
-                tacc = two.index_sample(l, j, MAPN[f], 10, "sample", 5, s)
-                assert accs[q] == oacc == tacc, (it, l, j, accs[q], oacc, tacc)
-        assert any(n.startswith("dxk::k_plane_sweeps<") for n in eng.rtc_kernels()), eng.rtc_kernels()
-        assert_indices_close(eng, orc, comps)
-        for l, c in enumerate(comps):
-            if c.nindices:
-                assert np.abs(eng.get_indices(l) - two.get_indices(l)).max() <= 1e-12, l
-        for which in (0, 1):
-            a, b = eng.chisq_cached(which, 1, nm), two.chisq_cached(which, 1, nm)
-            assert a is not None and b is not None and abs(a - b) <= 1e-11 * abs(b), (which, a, b)
-    # the orchestrator's two-call form takes the same route
-    before = len(eng.rtc_kernels())
-    eng.profile(True)
-    da.sample_cg_groups(dpar, ddata, it=3)
-    da.sample_spectral_parameters(dpar, ddata, it=3)
-    prof = eng.profile_get()
-    assert "k_index_mh" not in prof and prof["k_amp_index"]["launches"] == len(dpar.cg_groups), prof
-    assert len(eng.rtc_kernels()) == before
-    for g in dpar.cg_groups:
-        f = g.pol_flag[0]
-        orc.amp_sample_direct(g.cg_group, f, dpar.ml_mode, dpar.seed, da.stream_id(3, 0, g.cg_group, 0, f), "reference")
-    for l, c in enumerate(comps):
-        for j in range(c.nindices):
-            if c.sample_index[j]:
-                for f in c.pol_flag[j]:
-                    orc.sample_index_mh(l, j, MAPN[f], dpar.nsample, dpar.ml_mode, dpar.seed, da.stream_id(3, 1, l, j, f))
-    assert_amps_close(eng, orc, len(comps), TOL_AMP)
-    assert_indices_close(eng, orc, comps)
-    ochisq, _ = orc.chisq(1, nm, ddata.nump)
-    assert abs(ddata.chisq - ochisq) <= 1e-9 * ochisq
