@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Long Gibbs run as a sampler sanity check: python tools/soak.py [nside] [iterations] [reference|correct].
+DANGX_SOAK_TWOCALL=1: the two calls instead of da.gibbs_iteration.
 Prints the chi^2 trajectory, the number of non-SPD blocks met, and the spread of the sampled indices."""
 import os
 import sys
@@ -21,10 +22,13 @@ for fluct in modes:
     marks = sorted(set([1, 2, 5, 10, 20, 50, 100, 200] + list(range(400, niter + 1, 400)) + [niter]))
     tr, nbad = [], 0
     for it in range(1, niter + 1):
-        info = da.sample_cg_groups(dpar, ddata, it=it, defer_chisq=(it > 1))
+        if it > 1 and os.environ.get("DANGX_SOAK_TWOCALL", "0") != "1":
+            info, _ = da.gibbs_iteration(dpar, ddata, it)        # the plane-set launches bench.py runs
+        else:
+            info = da.sample_cg_groups(dpar, ddata, it=it, defer_chisq=(it > 1))
+            if it > 1:
+                da.sample_spectral_parameters(dpar, ddata, it=it)
         nbad += sum(b for (_, _, _, b) in info)
-        if it > 1:
-            da.sample_spectral_parameters(dpar, ddata, it=it)
         if not np.isfinite(ddata.chisq):
             print("non-finite chi^2 at iteration", it)
             break
