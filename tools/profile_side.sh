@@ -12,10 +12,10 @@ $B --shard-of 8 --steps 20 --warmup 3             > "$out/${tag}_z_shard_of_8.js
 $B --nbands 9 --steps 10 --warmup 3               > "$out/${tag}_z_nbands9.json"      2>> "$out/err.log"
 $B --config C1 --steps 200 --warmup 20            > "$out/${tag}_c1.json"             2>> "$out/err.log"
 $B --config C2 --steps 100 --warmup 10            > "$out/${tag}_c2.json"             2>> "$out/err.log"
-for f in "$out"/*.json; do python3 -c "
-import json,sys; d=json.load(open('$f')); print('$(basename $f)', round(d['value'],3), d['unit'], round(d['ms_per_step'],3), 'ms')"; done
 # the big ones (176 GB resident; bandpass-integrated bands): pass "big" as the second argument
 if [ "${2:-}" = big ]; then
   $B --nside 4096 --steps 3 --warmup 1   > "$out/${tag}_z_nside4096.json"   2>> "$out/err.log"
   $B --bandpass 16 --steps 5 --warmup 2  > "$out/${tag}_z_bandpass16.json" 2>> "$out/err.log"
 fi
+for f in "$out"/*.json; do python3 -c "
+import json,sys; d=json.load(open('$f')); print('$(basename $f)', round(d['value'],3), d['unit'], round(d['ms_per_step'],3), 'ms')"; done
