@@ -95,3 +95,18 @@ def test_specialised_kernels_come_from_the_disk_cache_the_second_time(built, tmp
     assert runs[0].stdout.count("[dangx] specialising") == n and "[dangx] specialising" not in runs[1].stdout, (runs[0].stdout, runs[1].stdout)
     files = sorted(os.listdir(str(tmp_path / "cache")))
     assert len([f for f in files if f.endswith(".hsaco")]) == n and len([f for f in files if f.endswith(".sym")]) == n, files
+
+
+@pytest.mark.parametrize("nbands", [13, 15])
+def test_thirteen_and_fifteen_bands(built, nbands):
+    """Odd band counts above 10 cannot split over lane pairs.  13: both plane sets still run as ONE launch each in one lane (two
+    planes of 13 bands at two waves per SIMD with a few spilled registers); 15: the T plane set does, the Q+U plane set takes the
+    separate solve and chains (at two waves per SIMD as well).  Same numbers as the oracle either way."""
+    eng = _run_and_compare(make_case("C3", nside=4, nbands=nbands), niter=2)
+    names = eng.rtc_kernels()
+    assert "dxk::k_plane_set<1, %d, 4, 1, 1, 10, 0, 0>" % nbands in names, names
+    if nbands == 13:
+        assert "dxk::k_plane_set<2, 13, 4, 1, 1, 10, 0, 0>" in names, names
+    else:
+        assert not any(n.startswith("dxk::k_plane_set<2,") for n in names), names
+        assert any(n.startswith("dxk::k_index_mh_") and n.endswith(", 2, 15, 1>") for n in names), names
