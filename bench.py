@@ -240,6 +240,8 @@ def main():
                     "(+2.5%% at the 8-rank shard size, -2%% at the 2- and 4-rank sizes).  0 = auto: 2 from 8 ranks on")
     ap.add_argument("--shard-of", type=int, default=0, help="diagnostic: with --gpus 1, run ONE rank's shard of an N-rank run "
                     "(rank 0 of N, no process group): the per-rank time at that shard size on one GPU")
+    ap.add_argument("--equal-shards", action="store_true", help="shard by pixel count instead of by unmasked pixel count (the "
+                    "ranks that hold the masked band then idle: A/B of the balanced boundaries)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for rehearsing "
                                                       "the N>1 path with several ranks on ONE GPU)")
     args = ap.parse_args()
@@ -277,7 +279,8 @@ def main():
     log("building synthetic sky %s on %s" % (args.config, dev))
     shard_of = args.shard_of if (args.shard_of > 1 and world == 1) else 0
     dpar, ddata, bands, comps, meta = synth.make_sky(args.config, nside=args.nside, nbands=args.nbands, device=dev, rank=rank,
-                                                     nranks=shard_of if shard_of else world, nsample=args.nsample, as_numpy=False)
+                                                     nranks=shard_of if shard_of else world, nsample=args.nsample, as_numpy=False,
+                                                     balance=not args.equal_shards)
     if args.bandpass > 0:
         import numpy as np
         for b in bands[1::2]:
@@ -461,13 +464,14 @@ def main():
             "n_gpus": world, "ranks_seen": ranks_seen, "backend": (args.backend if world > 1 else None), "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: Nside=%d, %d bands, %d components (%s), %s, NUMSAMPLE=%d, per-pixel indices, "
-                                   "direct block solve, reference fluctuation term%s; pixel-sharded over %d rank(s), %d stream(s) per rank%s"
+                                   "direct block solve, reference fluctuation term%s; pixel-sharded over %d rank(s)%s, %d stream(s) per rank%s"
                                    % (args.config, meta["nside"], nb, len(meta["phys"]), "+".join(meta["phys"]),
                                       "IQU" if nmaps == 3 else "I", args.nsample,
                                       (", each group's solve and every sweep on its planes in ONE launch (dangx_plane_set_sample)" if "k_index_mh" not in prof else
                                        ", each group's solve and the first sweep on its planes in one launch, consecutive indices of a component in one launch")
                                       if "k_amp_index" in prof else "",
-                                      world, 2 if two else 1,
+                                      world, (" (contiguous RING ranges of equal " + ("pixel" if args.equal_shards else "unmasked-pixel") + " count)")
+                                      if max(world, shard_of) > 1 else "", 2 if two else 1,
                                       ("; DIAGNOSTIC: every second band integrated over a %d-sample bandpass" % args.bandpass
                                        if args.bandpass else "") +
                                       ("; DIAGNOSTIC: %d bands instead of the configuration's; kernels specialised at run time: %s"

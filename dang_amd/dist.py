@@ -29,11 +29,58 @@ def world():
     return 0, 1
 
 
-def shard_range(npix_global, rank, nranks):
-    """Contiguous range [pix0, pix0+npix) of RING pixels owned by `rank`."""
+def shard_range(npix_global, rank, nranks, bounds=None):
+    """Contiguous range [pix0, pix0+npix) of RING pixels owned by `rank`: equal ranges, or the ranges between the
+    given boundaries (balanced_bounds_run / balanced_bounds_mask)."""
+    if bounds is not None:
+        return int(bounds[rank]), int(bounds[rank + 1] - bounds[rank])
     base, rem = divmod(int(npix_global), int(nranks))
     pix0 = rank * base + min(rank, rem)
     return pix0, base + (1 if rank < rem else 0)
+
+
+# a masked pixel costs a kernel almost nothing (its lanes leave at once); 32 : 1 is close enough to balance by
+_W_UNMASKED, _W_MASKED = 32, 1
+
+
+def balanced_bounds_run(npix_global, nranks, m0, m1):
+    """Shard boundaries b[0..nranks] of CONTIGUOUS RING ranges with equal WORK instead of equal pixel counts, for a mask that
+    is one run of masked pixels [m0, m1) (a Galactic band in RING order): equal ranges leave the ranks that hold the masked
+    band with little to do and make the others 1/(unmasked fraction) slower than the average -- 11 % at 8 ranks with a 10 % mask.
+    Results do not depend on the boundaries (random streams are keyed by the global pixel)."""
+    n, m0, m1 = int(npix_global), int(m0), int(m1)
+
+    def cum(i):   # weight of pixels [0, i)
+        over = min(max(i - m0, 0), m1 - m0)
+        return _W_UNMASKED * (i - over) + _W_MASKED * over
+
+    total = cum(n)
+    bounds = [0]
+    for r in range(1, nranks):
+        target = (total * r) // nranks
+        lo, hi = bounds[-1], n
+        while lo < hi:          # smallest i with cum(i) >= target
+            mid = (lo + hi) // 2
+            if cum(mid) >= target:
+                hi = mid
+            else:
+                lo = mid + 1
+        bounds.append(lo)
+    bounds.append(n)
+    return bounds
+
+
+def balanced_bounds_mask(mask, nranks):
+    """The same for any mask (1-D array over the global sky, 0 / missing value = masked)."""
+    import numpy as np
+    m = np.asarray(mask)
+    w = np.where((m == 0.0) | (m == -1.6375e30), _W_MASKED, _W_UNMASKED).astype(np.int64)
+    c = np.cumsum(w)
+    total = int(c[-1])
+    bounds = [0] + [int(np.searchsorted(c, (total * r) // nranks, side="left")) + 1 for r in range(1, nranks)] + [m.size]
+    for r in range(1, len(bounds)):
+        bounds[r] = max(bounds[r], bounds[r - 1])
+    return bounds
 
 
 def allreduce_sum_float(x, device=None):

@@ -100,13 +100,14 @@ def sed_torch(ctype, nu_hz, nu_ref_hz, th0, th1):
 
 def make_sky(config="C1", nside=None, nbands=None, comps=None, nmaps=None, device="cpu", rank=0, nranks=1,
              seed_data=20240601, seed_sampler=1234, nsample=10, mask_frac=(0.45, 0.55), start="prior",
-             as_numpy=None, solver="direct", fluct_mode="reference", gain=None, offset=None):
+             as_numpy=None, solver="direct", fluct_mode="reference", gain=None, offset=None, balance=False):
     """Build (dpar, ddata, bands, component_list, truth) for one pixel shard.
 
     start = 'prior' (amplitudes 0, indices at the prior mean) or 'truth'.
     as_numpy: return numpy arrays (default when device == 'cpu').
+    balance: shard boundaries by work (unmasked pixels) instead of by pixel count.
     """
-    from .dist import shard_range
+    from .dist import balanced_bounds_run, shard_range
 
     cfg = dict(CONFIGS[config]) if config else {}
     nside = nside or cfg["nside"]
@@ -117,7 +118,10 @@ def make_sky(config="C1", nside=None, nbands=None, comps=None, nmaps=None, devic
         as_numpy = (str(device) == "cpu")
     dev = torch.device(device)
     npix_global = 12 * nside * nside
-    pix0, npix = shard_range(npix_global, rank, nranks)
+    bounds = None
+    if balance and nranks > 1:   # shards of equal work: the masked band is one run of RING pixels (dist.balanced_bounds_run)
+        bounds = balanced_bounds_run(npix_global, nranks, math.ceil(mask_frac[0] * npix_global), math.ceil(mask_frac[1] * npix_global))
+    pix0, npix = shard_range(npix_global, rank, nranks, bounds)
     pix = torch.arange(pix0, pix0 + npix, dtype=torch.int64, device=dev)
 
     freqs = band_freqs_ghz(nbands)

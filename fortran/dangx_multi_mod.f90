@@ -39,15 +39,47 @@ contains
     npix = base + merge(1_c_int64_t, 0_c_int64_t, r < rem)
   end subroutine dangx_shard_range
 
-  ! nctx contexts over the sky; context r runs on device devices(r) (or r modulo the device count)
-  subroutine dangx_sky_create(sky, npix_global, nmaps, nbands, ncomp, nctx, devices)
+  ! Boundaries bounds(0:n) of n contiguous RING ranges of equal WORK: a masked pixel costs a kernel almost nothing, so equal
+  ! ranges leave the contexts that hold a Galactic mask's band with little to do (dang_amd/dist.py: balanced_bounds_mask;
+  ! weights 32 : 1).  Results do not depend on the boundaries (the random streams are keyed by the global pixel).
+  subroutine dangx_balanced_bounds(mask, n, bounds)
+    real(c_double), intent(in)      :: mask(0:)
+    integer, intent(in)             :: n
+    integer(c_int64_t), intent(out) :: bounds(0:n)
+    integer(c_int64_t) :: total, acc, i, np
+    integer :: r
+    np = size(mask, kind=c_int64_t)
+    total = 0
+    do i = 0, np-1
+       total = total + merge(1_c_int64_t, 32_c_int64_t, mask(i) == 0.d0 .or. mask(i) == -1.6375d30)
+    end do
+    bounds(0) = 0; bounds(n) = np
+    acc = 0; r = 1
+    do i = 0, np-1
+       if (r >= n) exit
+       acc = acc + merge(1_c_int64_t, 32_c_int64_t, mask(i) == 0.d0 .or. mask(i) == -1.6375d30)
+       do while (r < n)
+          if (acc < (total*r)/n) exit
+          bounds(r) = i + 1; r = r + 1
+       end do
+    end do
+    do while (r < n)
+       bounds(r) = np; r = r + 1
+    end do
+  end subroutine dangx_balanced_bounds
+
+  ! nctx contexts over the sky; context r runs on device devices(r) (or r modulo the device count).  mask (the full-sky mask,
+  ! masks(:,1)) present: shards of equal work instead of equal pixel count.
+  subroutine dangx_sky_create(sky, npix_global, nmaps, nbands, ncomp, nctx, devices, mask)
     type(dangx_sky), intent(out)   :: sky
     integer(c_int64_t), intent(in) :: npix_global
     integer, intent(in)            :: nmaps, nbands, ncomp, nctx
     integer, intent(in), optional  :: devices(:)
+    real(c_double), intent(in), optional :: mask(0:)
     type(dangx_dims) :: dims
     integer(c_int) :: ndev
     integer :: r, dev
+    integer(c_int64_t) :: bounds(0:DANGX_MAX_CTX)
     if (nctx < 1 .or. nctx > DANGX_MAX_CTX) then
        write(*,*) 'dangx_sky_create: bad number of contexts ', nctx
        stop 1
@@ -59,8 +91,13 @@ contains
     end if
     sky%nctx = nctx; sky%npix_global = npix_global
     sky%nmaps = nmaps; sky%nbands = nbands; sky%ncomp = ncomp
+    if (present(mask) .and. nctx > 1) call dangx_balanced_bounds(mask, nctx, bounds(0:nctx))
     do r = 1, nctx
-       call dangx_shard_range(npix_global, r-1, nctx, sky%pix0(r), sky%npix(r))
+       if (present(mask) .and. nctx > 1) then
+          sky%pix0(r) = bounds(r-1); sky%npix(r) = bounds(r) - bounds(r-1)
+       else
+          call dangx_shard_range(npix_global, r-1, nctx, sky%pix0(r), sky%npix(r))
+       end if
        dev = mod(r-1, ndev)
        if (present(devices)) dev = devices(r)
        dims = dangx_dims(int(sky%npix(r), c_int32_t), nmaps, nbands, ncomp, sky%pix0(r), npix_global, dev, 0)

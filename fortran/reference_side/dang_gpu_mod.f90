@@ -120,6 +120,7 @@ contains
     integer(c_int32_t), allocatable, target :: icorr(:)
     integer(c_int) :: ndev
     integer(c_int64_t) :: p0, np
+    integer(c_int64_t), allocatable :: bnds(:)
     integer :: i, j, nctx, r
 
     call dangx_check(c_null_ptr, dangx_device_count(ndev), 'dangx_device_count')
@@ -127,7 +128,10 @@ contains
     if (present(ngpu)) nctx = ngpu
     if (numprocs > 1) then
        ! one context on this rank's range [p0, p0+np) of the sky: a one-context sky whose window starts at p0
-       call dangx_shard_range(int(npix, c_int64_t), rank, numprocs, p0, np)
+       allocate(bnds(0:numprocs))                           ! shards of equal work (unmasked pixels), the same on every rank
+       call dangx_balanced_bounds(ddata%masks(:,1), numprocs, bnds)
+       p0 = bnds(rank); np = bnds(rank+1) - bnds(rank)
+       deallocate(bnds)
        gpu_pix0 = int(p0, i4b)
        gpu_sky%nctx = 1; gpu_sky%npix_global = npix; gpu_sky%nmaps = nmaps; gpu_sky%nbands = nbands; gpu_sky%ncomp = ncomp
        gpu_sky%pix0(1) = p0; gpu_sky%npix(1) = np
@@ -139,7 +143,7 @@ contains
        ! the sky-wide chains (full-sky index mode, tuner, gain draw) run behind the ABI on EVERY rank with keyed random
        ! numbers: same draws everywhere, nothing to seed here
     else
-       call dangx_sky_create(gpu_sky, int(npix, c_int64_t), nmaps, nbands, ncomp, nctx)
+       call dangx_sky_create(gpu_sky, int(npix, c_int64_t), nmaps, nbands, ncomp, nctx, mask=ddata%masks(:,1))
     end if
 
     do j = 1, nbands
