@@ -52,10 +52,10 @@ def test_self_launched_ranks_report_their_count(built):
 
 
 @pytest.mark.gpu
-def test_six_rank_rehearsal_of_the_sharded_path_on_one_gpu(built):
+def test_five_rank_rehearsal_of_the_sharded_path_on_one_gpu(built):
     """The N-rank data path with what one GPU allows (no 8-GPU node has been available to any round; a box admits six
-    processes on its card): bench.py launches 6 gloo ranks on cuda:0 over the C3 model at Nside 256, each on its RING shard with
-    the two-stream form the 8-rank runs take (T chain and Q+U chain on separate HIP streams).  All ranks are seen by the
+    processes on its card, and the test runner may be one of them): bench.py launches 5 gloo ranks on cuda:0 over the C3 model at Nside 256, each on its RING shard (boundaries by
+    unmasked pixel count) with the two-stream form the 8-rank runs take (T chain and Q+U chain on separate HIP streams).  All ranks are seen by the
     all-reduce, and chi^2 equals the one-rank value -- the sky does not depend on how it is sharded.  RCCL itself stays
     unexercised."""
     def run(*extra):
@@ -65,9 +65,14 @@ def test_six_rank_rehearsal_of_the_sharded_path_on_one_gpu(built):
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         assert len(lines) == 1, r.stdout
         return json.loads(lines[0])
-    six = run("--gpus", "6", "--backend", "gloo", "--streams", "2")
+    five = run("--gpus", "5", "--backend", "gloo", "--streams", "2")
     one = run("--gpus", "1")
-    assert six["n_gpus"] == 6 and six["ranks_seen"] == 6 and six["backend"] == "gloo"
-    assert "6 rank(s), 2 stream(s) per rank" in six["config"]["workload"]
+    assert five["n_gpus"] == 5 and five["ranks_seen"] == 5 and five["backend"] == "gloo"
+    assert "5 rank(s) (contiguous RING ranges of equal unmasked-pixel count), 2 stream(s) per rank" in five["config"]["workload"]
     for k in ("chisq_after_amp", "chisq_after_index"):
-        assert abs(six["config"][k] - one["config"][k]) <= 1e-12 * abs(one["config"][k]), k
+        assert abs(five["config"][k] - one["config"][k]) <= 1e-12 * abs(one["config"][k]), k
+    # the old split by pixel count: the same sky
+    eq = run("--gpus", "2", "--backend", "gloo", "--equal-shards")
+    assert "equal pixel count" in eq["config"]["workload"]
+    for k in ("chisq_after_amp", "chisq_after_index"):
+        assert abs(eq["config"][k] - one["config"][k]) <= 1e-12 * abs(one["config"][k]), k
