@@ -319,9 +319,17 @@ int dispatch_schur(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs* sa, long
 }  // namespace
 
 int dx_launch_schur_pass1(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev) {
+    const int rc = dx_launch_schur_pass1_reg(ctx, a, sa, SN, rows_dev);  // template / monopole members on the amplitude kernel's schedule
+    if (rc >= 0) return rc;
     return dispatch_schur(ctx, a, &sa, SN, rows_dev);
 }
-int dx_launch_schur_pass2(dangx_ctx* ctx, const GroupArgs& a, long long SN) { return dispatch_schur(ctx, a, nullptr, SN, nullptr); }
+int dx_launch_schur_pass2(dangx_ctx* ctx, const GroupArgs& a, long long SN) {
+    // template / monopole members, delta bands, nothing else on the planes: the amplitude kernel's schedule (dangx_ampreg.hip)
+    if (dx_launch_amp_reg_templates(ctx, a, SN) == 0) return 0;
+    return dispatch_schur(ctx, a, nullptr, SN, nullptr);
+}
 int dx_launch_schur_resid(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev) {
+    const int rc = dx_launch_schur_resid_reg(ctx, a, sa, SN, rows_dev);  // template / monopole members on the amplitude kernel's schedule
+    if (rc >= 0) return rc;
     return dispatch_schur(ctx, a, &sa, SN, rows_dev, true);
 }

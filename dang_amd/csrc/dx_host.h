@@ -166,6 +166,10 @@ int dx_launch_amp(dangx_ctx* ctx, const GroupArgs& a, long long SN);
 // latency-hiding form of the direct solve (dangx_ampreg.hip): 0 = launched, -1 = case not covered
 int dx_launch_amp_reg(dangx_ctx* ctx, const GroupArgs& a, long long SN);
 int dx_launch_chisq_reg(dangx_ctx* ctx, int k, double* partial);  // dangx_ampreg.hip
+int dx_launch_amp_reg_templates(dangx_ctx* ctx, const GroupArgs& a, long long SN);  // pass 2 of a template group's Schur solve
+struct SchurArgs;
+int dx_launch_schur_resid_reg(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);  // its residual pass
+int dx_launch_schur_pass1_reg(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);  // its pass 1
 int dx_launch_rhs(dangx_ctx* ctx, const GroupArgs& a, long long SN, double* b);
 int dx_launch_Ax(dangx_ctx* ctx, const GroupArgs& a, long long SN, const double* x, double* res, double* part);
 int dx_launch_sample_vector(dangx_ctx* ctx, const GroupArgs& a, long long SN, const double* eta, double* res);

@@ -346,3 +346,48 @@ def test_T_cmb_as_an_amplitude_sampled_group_member(built):
     it_g, _ = eng2.amp_sample(1, L.FLAG_T, "optimize", 8, 9, solver="cg", i_max=60, converge=1e-8)
     it_o = orc2.amp_sample_cg(1, L.FLAG_T, "optimize", 8, 9, i_max=60, converge=1e-8)
     assert abs(it_g - it_o) <= 1
+
+
+@pytest.mark.parametrize("which,group,flag", [(("template",), 2, L.FLAG_QU), (("monopole",), 1, L.FLAG_T)])
+def test_schur_passes_on_the_amplitude_schedule_are_the_run_time_typed_ones(built, which, group, flag):
+    """Groups whose global members are templates / monopoles run the three passes of the Schur solve on the amplitude
+    kernel's schedule (dangx_ampreg.hip: k_schur_pass1_reg, k_amp_reg<.., true>, k_schur_resid_reg); DANGX_SCHUR_FAST=0 keeps the
+    run-time-typed passes of dangx_schur.hip.  Same amplitudes (the reciprocals and square roots differ in their last bits --
+    which also shows that two different sets of kernels ran) and the same refinement report."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "import test_gpu_templates as t\n"
+            "from util import pair\n"
+            "case = t._case(%r, %d, nside=8, skip_band0=True)\n"
+            "dpar, ddata, bands, comps, meta = case\n"
+            "eng, orc = pair(case)\n"
+            "out = {}\n"
+            "for ml in ('optimize', 'sample'):\n"
+            "    it, bad = eng.amp_sample(%d, %d, ml, 8, 9)\n"
+            "    (rb, rt), steps = eng.schur_info()\n"
+            "    out[ml] = dict(it=it, bad=bad, rb=rb, steps=steps,\n"
+            "                   amp=[eng.get_amplitude(l).tolist() for l, c in enumerate(comps) if c.cg_group == %d and c.type not in %r],\n"
+            "                   tamp=[eng.get_template_amplitudes(l).tolist() for l, c in enumerate(comps) if c.type in %r])\n"
+            "print('RESULT ' + json.dumps(out))\n") % (root, os.path.join(root, "tests"), which, group, group, flag, group, which, which)
+    res = {}
+    for fast in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DANGX_SCHUR_FAST=fast), stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=600)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+        assert r.returncode == 0 and lines, r.stdout[-3000:]
+        res[fast] = json.loads(lines[-1][7:])
+    same_bits = True
+    for ml in ("optimize", "sample"):
+        a, b = res["1"][ml], res["0"][ml]
+        assert a["it"] == b["it"] and a["bad"] == b["bad"] == 0
+        assert a["rb"] <= 1e-9 and b["rb"] <= 1e-9, (a["rb"], b["rb"])
+        for x, y in zip(a["amp"] + a["tamp"], b["amp"] + b["tamp"]):
+            x, y = np.asarray(x), np.asarray(y)
+            assert np.abs(x - y).max() <= 1e-9 * max(np.abs(y).max(), 1.0)
+            same_bits = same_bits and np.array_equal(x, y)
+    assert not same_bits
