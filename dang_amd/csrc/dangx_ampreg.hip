@@ -20,82 +20,9 @@
 // no change).  tools/ubench/stream_planes.hip: the same loads and stores with no arithmetic take 0.48 ms (5.8 TB/s).
 // Divisions by the rms, inside the mbb SED and in the Cholesky use v_rcp_f64 / v_rsq_f64 plus two Newton steps
 // (<= 1 ulp) instead of the IEEE division / sqrt sequences (12 / 18 fp64 instructions each).
-#include "dx_ampdata.h"
+#include "dx_ampreg.h"
 
 namespace {
-
-// Map pointers come out of the Model block as generic pointers, which the compiler can only load through FLAT
-// instructions -- and a FLAT load counts on lgkmcnt as well as vmcnt, so every wait for an LDS read (the constant table,
-// the SED columns) would also wait for all map loads in flight.  Viewed through the global address space they are
-// global_load instructions (vmcnt only) and phase A really runs under the map loads.
-typedef const double __attribute__((address_space(1)))* gcptr;
-typedef double __attribute__((address_space(1)))* gptr;
-__device__ __forceinline__ gcptr as_global(const double* p) { return reinterpret_cast<gcptr>(reinterpret_cast<uintptr_t>(p)); }
-__device__ __forceinline__ gptr as_global_w(double* p) { return reinterpret_cast<gptr>(reinterpret_cast<uintptr_t>(p)); }
-
-constexpr int MAXU = 4;  // templates / monopoles whose signal the HT form of the kernel removes from the data
-struct AmpRegArgs {
-    signed char vslot[MAXG];  // LDS column slot of group member g, -1: its SED is a row of the constant table
-    signed char vcomp[MAXG];  // group member of slot v
-    signed char vtype[MAXG];  // its component type
-    int nv;                   // members with a column
-    // HT form (pass 2 of the Schur solve of a template group): d_j -= cu[w][j] * template_w(pixel, plane) for w < nu, where
-    // cu[w][j] = template_amplitudes(j, plane) on EVERY band for a member of the group (the new global amplitudes) and on
-    // the bands it is not fitted at for a non-member (src/dang_cg_mod.f90:445-460)
-    int nu;
-    int ucomp[MAXU];
-    unsigned umember;         // bit w: component ucomp[w] is a global-amplitude member of the group
-    // residual pass (k_schur_resid_reg): global row r belongs to template slot rowu[r]; bit r of rowmono: a monopole's row
-    signed char rowu[8];
-    unsigned rowmono;
-};
-constexpr int RMAXF = 8;      // global rows the residual pass on this schedule carries per thread
-
-// SEDs of one varying component for the TB bands of a tile -> its LDS column.  Same expressions as sed_eval_tab
-// (dx_sed.h); the per-pixel state p comes from sed_prep.
-template <int TB>
-__device__ __forceinline__ void sed_tile(int type, const double* __restrict__ tab, int nb, int NG, int g, int j0, const Prep& p,
-                                         double* __restrict__ colg) {
-    const double* lnr = tab + (TROWS * g) * nb + j0;
-    const double* cst = lnr + nb;
-    const double* lnu9 = cst + nb;
-    const double* nuc = tab + (TROWS * NG) * nb + j0;
-    switch (type) {
-    case DANGX_POWERLAW:  // src/dang_component_mod.f90:908
-#pragma unroll
-        for (int t = 0; t < TB; ++t) { colg[t * BLOCK] = exp_nr(p.p0 * lnr[t]); }
-        break;
-    case DANGX_MBB: {  // :947-948, in two passes of TB chains each (bounds the registers the scheduler may spend)
-        double f[TB];
-#pragma unroll
-        for (int t = 0; t < TB; ++t) { f[t] = p.p2 * fast_rcp(exp_nr(p.p1 * nuc[t]) - 1.0); }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < TB; ++t) { colg[t * BLOCK] = f[t] * exp_nr(p.p0 * lnr[t]); }
-        break;
-    }
-    case DANGX_FREEFREE: {  // :1026-1027
-        const double rp1 = fast_rcp(p.p1);
-#pragma unroll
-        for (int t = 0; t < TB; ++t) { colg[t * BLOCK] = (ff_gaunt(lnu9[t], p.p0) * rp1) * cst[t]; }
-        break;
-    }
-    case DANGX_LOGNORMAL: {  // :988
-        const double rp1 = fast_rcp(p.p1);
-#pragma unroll
-        for (int t = 0; t < TB; ++t) {
-            const double l = (lnu9[t] - p.p2) * rp1;
-            colg[t * BLOCK] = exp_sat(-0.5 * (l * l)) * cst[t];
-           
-        }
-        break;
-    }
-    default:  // cmb: 1/a2t(bp), :799-800
-#pragma unroll
-        for (int t = 0; t < TB; ++t) colg[t * BLOCK] = cst[t];
-        break;
-    }
-}
 
 template <int NG, int TB, bool HT = false>
 __global__ __launch_bounds__(BLOCK, NG <= 4 ? 4 : 3) void k_amp_reg(const Model* __restrict__ Mp, GroupArgs a, AmpRegArgs ra,
@@ -375,388 +302,6 @@ __global__ __launch_bounds__(BLOCK, NG <= 4 ? 4 : 3) void k_chisq_reg(const Mode
     }
 }
 
-// Pass 1 of the Schur solve of a template group (dangx_schur.hip: k_schur_pass1, whose header derives the sums) on this
-// kernel's schedule, for groups whose global members are templates / monopoles fitted at up to SS bands: the normal equations of
-// the diffuse members as k_amp_reg forms them, with the vectors W_j = M_j / sigma_j^2, d_j / sigma_j^2, eta / sigma_j and
-// 1 / sigma_j^2 of the bands that carry a global row kept in REGISTERS (slot = sa.bslot[j]) instead of LDS columns; after the
-// Cholesky factor the R^2 + 3R row values of the unit and one block reduction for all of them.
-//   rows [0, R^2): S[r][r'] ; [R^2, R^2+R): t[r] ; [R^2+R, R^2+2R): fluctuation sum of natural row r ; [R^2+2R, R^2+3R): G[r][r]
-template <int NG, int TB, int SS>
-__global__ __launch_bounds__(BLOCK, 2) void k_schur_pass1_reg(const Model* __restrict__ Mp, GroupArgs a, AmpRegArgs ra, SchurArgs sa,
-                                                             double* __restrict__ rowpartial, unsigned long long* __restrict__ not_spd) {
-    constexpr int NV = SS * SS + 3 * SS;   // row values of a unit (R <= SS)
-    extern __shared__ double lds[];
-    __shared__ double wsum[NV][BLOCK / 64];
-    const Model& M = *Mp;
-    const int npix = M.npix, nb = M.nbands, tid = threadIdx.x, R = sa.nrows;
-    double* tab = lds;
-    double* cu = lds + (TROWS * NG + 3) * nb;   // templates' amplitudes on the bands they are NOT fitted at (:445-460)
-    double* prl = lds + (TROWS * NG + 3 + ra.nu) * nb + tid;
-    double* col = prl + 3 * ra.nv * BLOCK;
-    const long long u = (long long)blockIdx.x * BLOCK + tid;
-    const bool in_range = u < npix;
-    const int i = in_range ? (int)u : 0;
-    const int k = flag_map(a.flag, (int)blockIdx.y);
-    const double mk = as_global(M.mask)[i];
-    double th[NG][2], tv[MAXU];
-#pragma unroll
-    for (int w = 0; w < MAXU; ++w) tv[w] = (w < ra.nu) ? as_global(M.comp[ra.ucomp[w]].tmpl)[(long long)(k - 1) * npix + i] : 0.0;
-#pragma unroll
-    for (int v = 0; v < NG; ++v) {
-        th[v][0] = th[v][1] = 0.0;
-        if (v < ra.nv) {
-            const Comp& c = M.comp[a.gc[ra.vcomp[v]]];
-            const gcptr ix = as_global(c.idx) + (long long)(k - 1) * npix + i;
-            if (c.nind > 0) th[v][0] = ix[0];
-            if (c.nind > 1) th[v][1] = ix[(long long)M.nmaps * npix];
-        }
-    }
-    for (int t = tid; t < ra.nu * nb; t += BLOCK) {
-        const int w = t / nb, j = t - w * nb;
-        const Comp& c = M.comp[ra.ucomp[w]];
-        cu[t] = ((c.corr_mask >> j) & 1) ? 0.0 : c.tamp[k - 1][j];
-    }
-    sed_table_build(M, tab, tid, BLOCK, a.gc, NG);
-    const bool sample = (a.ml_mode == DANGX_ML_SAMPLE);
-    double eta = 0.0, f0 = 0.0;
-    if (sample) {
-        double u1, u2;
-        uniform2(a.seed, a.stream, (unsigned long long)(M.pix0 + i), (uint32_t)k, u1, u2);
-        eta = rand_normal(0.0, 1.0, u1, u2);
-    }
-    bool live = in_range && !is_masked(mk);
-    if (live) {
-#pragma unroll
-        for (int v = 0; v < NG; ++v)
-            if (v < ra.nv) { prl[(3 * v + 0) * BLOCK] = th[v][0]; prl[(3 * v + 1) * BLOCK] = th[v][1]; }
-#pragma unroll 1
-        for (int v = 0; v < ra.nv; ++v) {
-            const Comp& c = M.comp[a.gc[ra.vcomp[v]]];
-            const Prep pr = sed_prep(c, prl[(3 * v + 0) * BLOCK], prl[(3 * v + 1) * BLOCK]);
-            prl[(3 * v + 0) * BLOCK] = pr.p0;
-            prl[(3 * v + 1) * BLOCK] = pr.p1;
-            prl[(3 * v + 2) * BLOCK] = pr.p2;
-        }
-    }
-    __syncthreads();
-    double rv[NV];
-#pragma unroll
-    for (int e = 0; e < NV; ++e) rv[e] = 0.0;
-    if (live) {
-        double A[NG * (NG + 1) / 2], bv[NG];
-        double Wv[SS][NG], dn[SS], en[SS], iv[SS];
-#pragma unroll
-        for (int q = 0; q < NG * (NG + 1) / 2; ++q) A[q] = 0.0;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) bv[g] = 0.0;
-#pragma unroll
-        for (int sl = 0; sl < SS; ++sl) {
-            dn[sl] = en[sl] = iv[sl] = 0.0;
-#pragma unroll
-            for (int g = 0; g < NG; ++g) Wv[sl][g] = 0.0;
-        }
-        const double* gain = tab + (TROWS * NG + 1) * nb;
-        const long long bstride = (long long)M.nmaps * npix;
-        const gcptr sigp = as_global(M.sig) + (long long)(k - 1) * npix + i;
-        const gcptr rmsp = as_global(M.rms) + (long long)(k - 1) * npix + i;
-#pragma unroll 1
-        for (int j0 = 0; j0 < nb; j0 += TB) {
-            double dcur[TB], rcur[TB];
-#pragma unroll
-            for (int t = 0; t < TB; ++t) {
-                dcur[t] = sigp[(j0 + t) * bstride];
-                rcur[t] = rmsp[(j0 + t) * bstride];
-            }
-#pragma unroll 1
-            for (int v = 0; v < ra.nv; ++v) {
-                const Prep pr = {prl[(3 * v + 0) * BLOCK], prl[(3 * v + 1) * BLOCK], prl[(3 * v + 2) * BLOCK]};
-                sed_tile<TB>(ra.vtype[v], tab, nb, NG, ra.vcomp[v], j0, pr, col + (v * TB) * BLOCK);
-            }
-            const double* mp[NG];
-            int ms[NG];
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const bool var = ra.vslot[g] >= 0;
-                mp[g] = var ? col + (ra.vslot[g] * TB) * BLOCK : tab + (TROWS * g + 2 + k) * nb + j0;
-                ms[g] = var ? BLOCK : 1;
-            }
-#pragma unroll
-            for (int t = 0; t < TB; ++t) {
-                const int j = j0 + t;
-                double d = dcur[t];
-                if (k == 1) { const double gj = gain[j]; if (gj != 1.0) d = d / gj; }  // :371
-#pragma unroll
-                for (int w = 0; w < MAXU; ++w)
-                    if (w < ra.nu) d = d - cu[w * nb + j] * tv[w];
-                const double is = fast_rcp(rcur[t]);
-                const double inv = is * is;
-                double mrow[NG];
-#pragma unroll
-                for (int g = 0; g < NG; ++g) mrow[g] = mp[g][t * ms[g]];
-                const int slot = sa.bslot[j];   // uniform
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    const double t2 = mrow[g] * inv;
-                    bv[g] += d * t2;
-#pragma unroll
-                    for (int h = 0; h <= g; ++h) A[g * (g + 1) / 2 + h] += t2 * mrow[h];
-#pragma unroll
-                    for (int sl = 0; sl < SS; ++sl) Wv[sl][g] = (sl == slot) ? t2 : Wv[sl][g];
-                }
-                f0 += (eta * is) * mrow[NG - 1];
-#pragma unroll
-                for (int sl = 0; sl < SS; ++sl)
-                    if (sl == slot) { dn[sl] = d * inv; en[sl] = eta * is; iv[sl] = inv; }
-            }
-        }
-        bv[0] += f0;
-        // ---- Cholesky A = L L^t (ri[g] = 1 / L_gg), yh = L^-1 b, Q_sl = L^-1 W_sl
-        bool ok = true;
-        double ri[NG];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-#pragma unroll
-            for (int h = 0; h <= g; ++h) {
-                double sacc = A[g * (g + 1) / 2 + h];
-#pragma unroll
-                for (int t = 0; t < h; ++t) sacc -= A[g * (g + 1) / 2 + t] * A[h * (h + 1) / 2 + t];
-                if (h == g) {
-                    if (!(sacc > 0.0) || !(sacc < 1.0e300)) ok = false;
-                    ri[g] = fast_rsqrt(sacc);
-                } else {
-                    A[g * (g + 1) / 2 + h] = sacc * ri[h];
-                }
-            }
-        }
-        if (!ok) {
-            atomicAdd(not_spd, 1ull);
-            live = false;
-        } else {
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                double sacc = bv[g];
-#pragma unroll
-                for (int t = 0; t < g; ++t) sacc -= A[g * (g + 1) / 2 + t] * bv[t];
-                bv[g] = sacc * ri[g];   // yh
-            }
-#pragma unroll
-            for (int sl = 0; sl < SS; ++sl)
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    double sacc = Wv[sl][g];
-#pragma unroll
-                    for (int t = 0; t < g; ++t) sacc -= A[g * (g + 1) / 2 + t] * Wv[sl][t];
-                    Wv[sl][g] = sacc * ri[g];   // Q_sl
-                }
-            // ---- the unit's row values
-#pragma unroll
-            for (int r = 0; r < SS; ++r) {
-                if (r < R) {
-                    const int sl = sa.bslot[sa.rj[r]];
-                    double s_r = 0.0, dns = 0.0, ens = 0.0, ivs = 0.0, dot = 0.0, Qr[NG];
-#pragma unroll
-                    for (int w = 0; w < MAXU; ++w) s_r = (ra.rowu[r] == w) ? tv[w] : s_r;
-#pragma unroll
-                    for (int q = 0; q < SS; ++q)
-                        if (q == sl) {
-                            dns = dn[q]; ens = en[q]; ivs = iv[q];
-#pragma unroll
-                            for (int g = 0; g < NG; ++g) Qr[g] = Wv[q][g];
-                        }
-                    const double w_r = ((ra.rowmono >> r) & 1u) ? 1.0 : s_r;   // :857
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) dot += Qr[g] * bv[g];
-                    rv[SS * SS + r] = dns * s_r - w_r * dot;            // t[r]
-                    rv[SS * SS + SS + r] = ens * w_r;                    // fluctuation sum of natural row r
-                    rv[SS * SS + 2 * SS + r] = w_r * s_r * ivs;          // G[r][r]
-#pragma unroll
-                    for (int r2 = 0; r2 < SS; ++r2) {
-                        if (r2 < R) {
-                            const int sl2 = sa.bslot[sa.rj[r2]];
-                            double s2 = 0.0, dot2 = 0.0;
-#pragma unroll
-                            for (int w = 0; w < MAXU; ++w) s2 = (ra.rowu[r2] == w) ? tv[w] : s2;
-#pragma unroll
-                            for (int q = 0; q < SS; ++q)
-                                if (q == sl2) {
-#pragma unroll
-                                    for (int g = 0; g < NG; ++g) dot2 += Qr[g] * Wv[q][g];
-                                }
-                            rv[r * SS + r2] = ((sl == sl2) ? w_r * s2 * ivs : 0.0) - w_r * s2 * dot2;
-                        }
-                    }
-                }
-            }
-        }
-    }
-    // ---- one block reduction for all row values (wave tree, then the four wave sums in order)
-#pragma unroll
-    for (int e = 0; e < NV; ++e) {
-        double v = rv[e];
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if ((tid & 63) == 0) wsum[e][tid >> 6] = v;
-    }
-    __syncthreads();
-    if (tid < NV) {
-        // slot e of the SS-strided layout -> row of the R-strided layout the host reads
-        int row = -1;
-        if (tid < SS * SS) { const int r = tid / SS, r2 = tid - r * SS; if (r < R && r2 < R) row = r * R + r2; }
-        else { const int q3 = (tid - SS * SS) / SS, r = (tid - SS * SS) - q3 * SS; if (r < R) row = R * R + q3 * R + r; }
-        if (row >= 0) {
-            double t = 0.0;
-            for (int w = 0; w < BLOCK / 64; ++w) t += wsum[tid][w];
-            const long long nblk = (long long)gridDim.x * gridDim.y, blk = (long long)blockIdx.y * gridDim.x + blockIdx.x;
-            rowpartial[(long long)row * nblk + blk] = t;
-        }
-    }
-}
-
-// Residual of the GLOBAL rows of a template group's system at the current state (dangx_schur.hip: k_schur_resid, whose
-// comment defines the three row blocks) on the same schedule, for groups whose global members are templates / monopoles:
-//   cu[w][j]  = template_amplitudes of template w on the bands it is NOT fitted at (removed from the data, :445-460)
-//   gm[w][j]  = template_amplitudes of a MEMBER on its fitted bands (part of the model A x)
-// rows [0,R): b - A x without the fluctuation term, [R,2R): the row of b, [2R,3R): the size of the terms.
-// RR: rows the thread carries (4 or 8): the 3 RR row values live in registers for the whole band loop, and with 8 of them the
-// amplitude kernel's four waves per SIMD cost 73 spilled registers.
-template <int NG, int TB, int RR>
-__global__ __launch_bounds__(BLOCK, RR <= 4 ? (NG <= 4 ? 4 : 3) : 2) void k_schur_resid_reg(const Model* __restrict__ Mp, GroupArgs a, AmpRegArgs ra, SchurArgs sa,
-                                                                           double* __restrict__ rowpartial) {
-    extern __shared__ double lds[];
-    __shared__ double wsum[3 * RR][BLOCK / 64];
-    const Model& M = *Mp;
-    const int npix = M.npix, nb = M.nbands, tid = threadIdx.x, R = sa.nrows;
-    double* tab = lds;
-    double* cu = lds + (TROWS * NG + 3) * nb;
-    double* gm = cu + ra.nu * nb;
-    double* prl = lds + (TROWS * NG + 3 + 2 * ra.nu) * nb + tid;
-    double* col = prl + 3 * ra.nv * BLOCK;
-    const long long u = (long long)blockIdx.x * BLOCK + tid;
-    const bool in_range = u < npix;
-    const int i = in_range ? (int)u : 0;
-    const int k = flag_map(a.flag, (int)blockIdx.y);
-    const double mk = as_global(M.mask)[i];
-    double th[NG][2], av[NG], tv[MAXU];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) av[g] = as_global(M.comp[a.gc[g]].amp)[(long long)(k - 1) * npix + i];
-#pragma unroll
-    for (int w = 0; w < MAXU; ++w) tv[w] = (w < ra.nu) ? as_global(M.comp[ra.ucomp[w]].tmpl)[(long long)(k - 1) * npix + i] : 0.0;
-#pragma unroll
-    for (int v = 0; v < NG; ++v) {
-        th[v][0] = th[v][1] = 0.0;
-        if (v < ra.nv) {
-            const Comp& c = M.comp[a.gc[ra.vcomp[v]]];
-            const gcptr ix = as_global(c.idx) + (long long)(k - 1) * npix + i;
-            if (c.nind > 0) th[v][0] = ix[0];
-            if (c.nind > 1) th[v][1] = ix[(long long)M.nmaps * npix];
-        }
-    }
-    for (int t = tid; t < ra.nu * nb; t += BLOCK) {
-        const int w = t / nb, j = t - w * nb;
-        const Comp& c = M.comp[ra.ucomp[w]];
-        const bool member = (ra.umember >> w) & 1u, fitted = (c.corr_mask >> j) & 1;
-        cu[t] = fitted ? 0.0 : c.tamp[k - 1][j];
-        gm[t] = (member && fitted) ? c.tamp[k - 1][j] : 0.0;
-    }
-    sed_table_build(M, tab, tid, BLOCK, a.gc, NG);
-    const bool live = in_range && !is_masked(mk);
-    if (live) {
-#pragma unroll
-        for (int v = 0; v < NG; ++v)
-            if (v < ra.nv) { prl[(3 * v + 0) * BLOCK] = th[v][0]; prl[(3 * v + 1) * BLOCK] = th[v][1]; }
-#pragma unroll 1
-        for (int v = 0; v < ra.nv; ++v) {
-            const Comp& c = M.comp[a.gc[ra.vcomp[v]]];
-            const Prep pr = sed_prep(c, prl[(3 * v + 0) * BLOCK], prl[(3 * v + 1) * BLOCK]);
-            prl[(3 * v + 0) * BLOCK] = pr.p0;
-            prl[(3 * v + 1) * BLOCK] = pr.p1;
-            prl[(3 * v + 2) * BLOCK] = pr.p2;
-        }
-    }
-    __syncthreads();
-    double rv[3 * RR];
-#pragma unroll
-    for (int e = 0; e < 3 * RR; ++e) rv[e] = 0.0;
-    if (live) {
-        const double* gain = tab + (TROWS * NG + 1) * nb;
-        const long long bstride = (long long)M.nmaps * npix;
-        const gcptr sigp = as_global(M.sig) + (long long)(k - 1) * npix + i;
-        const gcptr rmsp = as_global(M.rms) + (long long)(k - 1) * npix + i;
-#pragma unroll 1
-        for (int j0 = 0; j0 < nb; j0 += TB) {
-            bool any = false;   // uniform: a tile without a global row needs neither its maps nor its SEDs
-#pragma unroll
-            for (int t = 0; t < TB; ++t) any = any || sa.bslot[j0 + t] >= 0;
-            if (!any) continue;
-            double dcur[TB], rcur[TB];
-#pragma unroll
-            for (int t = 0; t < TB; ++t) {
-                dcur[t] = sigp[(j0 + t) * bstride];
-                rcur[t] = rmsp[(j0 + t) * bstride];
-            }
-#pragma unroll 1
-            for (int v = 0; v < ra.nv; ++v) {
-                const Prep pr = {prl[(3 * v + 0) * BLOCK], prl[(3 * v + 1) * BLOCK], prl[(3 * v + 2) * BLOCK]};
-                sed_tile<TB>(ra.vtype[v], tab, nb, NG, ra.vcomp[v], j0, pr, col + (v * TB) * BLOCK);
-            }
-            const double* mp[NG];
-            int ms[NG];
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const bool var = ra.vslot[g] >= 0;
-                mp[g] = var ? col + (ra.vslot[g] * TB) * BLOCK : tab + (TROWS * g + 2 + k) * nb + j0;
-                ms[g] = var ? BLOCK : 1;
-            }
-#pragma unroll
-            for (int t = 0; t < TB; ++t) {
-                const int j = j0 + t;
-                if (sa.bslot[j] < 0) continue;
-                double d = dcur[t];
-                if (k == 1) { const double gj = gain[j]; if (gj != 1.0) d = d / gj; }  // compute_rhs' data, :367-378
-                double model = 0.0;
-#pragma unroll
-                for (int g = 0; g < NG; ++g) model = model + av[g] * mp[g][t * ms[g]];
-#pragma unroll
-                for (int w = 0; w < MAXU; ++w)
-                    if (w < ra.nu) { d = d - cu[w * nb + j] * tv[w]; model = model + gm[w * nb + j] * tv[w]; }
-                const double is = fast_rcp(rcur[t]);
-                const double inv = is * is;
-#pragma unroll
-                for (int r = 0; r < RR; ++r) {
-                    if (r < R && (int)sa.rj[r] == j) {
-                        double st = 0.0;
-#pragma unroll
-                        for (int w = 0; w < MAXU; ++w) st = (ra.rowu[r] == w) ? tv[w] : st;
-                        const double wgt = ((ra.rowmono >> r) & 1u) ? 1.0 : st;   // :857
-                        const double bterm = d * inv * st, mterm = wgt * (model * inv);
-                        rv[3 * r] = bterm - mterm;
-                        rv[3 * r + 1] = bterm;
-                        rv[3 * r + 2] = fabs(bterm) + fabs(mterm);
-                    }
-                }
-            }
-        }
-    }
-    // ---- block sums of the 3R values: wave tree, then the four wave sums in order (as block_row_sum)
-#pragma unroll
-    for (int e = 0; e < 3 * RR; ++e) {
-        if (e < 3 * R) {
-            double v = rv[e];
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-            if ((tid & 63) == 0) wsum[e][tid >> 6] = v;
-        }
-    }
-    __syncthreads();
-    if (tid < 3 * R) {
-        const int r = tid / 3, q3 = tid - 3 * r;
-        double t = 0.0;
-        for (int w = 0; w < BLOCK / 64; ++w) t += wsum[tid][w];
-        const long long nblk = (long long)gridDim.x * gridDim.y, blk = (long long)blockIdx.y * gridDim.x + blockIdx.x;
-        rowpartial[(long long)(q3 * R + r) * nblk + blk] = t;
-    }
-}
-
-template <int TB>
-size_t amp_reg_lds(int NG, int nb, int nv, int nu = 0) { return ((size_t)(TROWS * NG + 3 + nu) * nb + (size_t)nv * (TB + 3) * BLOCK) * sizeof(double); }
 
 template <int NG, int TB, bool HT = false>
 int launch_tb(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, long long SN) {
@@ -810,131 +355,11 @@ int launch_chi_ng(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, doub
 
 }  // namespace
 
-static int amp_reg_members(dangx_ctx* ctx, const GroupArgs& a, AmpRegArgs& ra);
-
 // Pass 2 of the Schur solve of a group with template / monopole members (dangx_schur.hip: k_schur_pass2) on this kernel's
 // schedule: the block solve of the diffuse members with the global members' signal -- at the amplitudes the host has just
 // solved for -- and every other template's unfitted bands removed from the data.  0 when launched, -1 when the group needs
 // the run-time-typed pass (a hi_fit member, bandpass-integrated bands, other components on the planes, more than MAXU
-// templates / monopoles in the model).
-static bool template_group_args(dangx_ctx* ctx, const GroupArgs& a, AmpRegArgs& ra) {
-    static const bool enabled = [] { const char* e = getenv("DANGX_SCHUR_FAST"); return !(e && e[0] == '0'); }();  // A/B switch
-    if (!enabled || a.no != 0 || a.ng < 1 || a.nuc < 1 || a.nuc > MAXU) return false;
-    for (int j = 0; j < ctx->hm.nbands; ++j)
-        if (ctx->hm.band[j].n != 0) return false;
-    for (int l = 0; l < ctx->hm.ncomp; ++l)
-        if (ctx->desc[l].type == DANGX_TCMB) return false;
-    if (amp_reg_members(ctx, a, ra)) return false;
-    ra.nu = a.nuc; ra.umember = 0u; ra.rowmono = 0u;
-    for (int r = 0; r < 8; ++r) ra.rowu[r] = -1;
-    for (int w = 0; w < a.nuc; ++w) {
-        const int l = a.uc[w];
-        if (ctx->desc[l].type != DANGX_TEMPLATE && ctx->desc[l].type != DANGX_MONOPOLE) return false;
-        ra.ucomp[w] = l;
-        for (int t = 0; t < a.nt; ++t) if (a.tc[t] == l) ra.umember |= 1u << w;
-    }
-    for (int t = 0; t < a.nt; ++t) {   // every global member must be among them (a hi_fit member is not: generic pass)
-        bool found = false;
-        for (int w = 0; w < a.nuc; ++w) found = found || a.uc[w] == a.tc[t];
-        if (!found) return false;
-    }
-    return true;
-}
-
-template <int NG, int TB>
-int launch_resid_tb(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, const SchurArgs& sa, long long SN, double* rows_dev) {
-    const int planes = flag_planes_h(a.flag), nrows = 3 * sa.nrows;
-    const unsigned gx = nblocks(SN / planes), nblk = gx * planes;
-    if (ensure_partial(ctx, (long long)nrows * nblk)) return 1;
-    const size_t ldsz = amp_reg_lds<TB>(NG, ctx->hm.nbands, ra.nv, 2 * ra.nu);
-    if (sa.nrows <= 4)
-        hipLaunchKernelGGL((k_schur_resid_reg<NG, TB, 4>), dim3(gx, planes), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial);
-    else
-        hipLaunchKernelGGL((k_schur_resid_reg<NG, TB, RMAXF>), dim3(gx, planes), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial);
-    dx_reduce_rows_to(ctx, ctx->partial, nblk, nrows, rows_dev);
-    HIPCHK(ctx, hipGetLastError());
-    return 0;
-}
-template <int NG>
-int launch_resid_ng(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, const SchurArgs& sa, long long SN, double* rows_dev) {
-    const int nb = ctx->hm.nbands, nu = 2 * ra.nu;
-    const size_t most = 80u * 1024u;
-    if (nb % 5 == 0 && amp_reg_lds<5>(NG, nb, ra.nv, nu) <= most) return launch_resid_tb<NG, 5>(ctx, a, ra, sa, SN, rows_dev);
-    if (nb % 4 == 0 && amp_reg_lds<4>(NG, nb, ra.nv, nu) <= most) return launch_resid_tb<NG, 4>(ctx, a, ra, sa, SN, rows_dev);
-    if (nb % 3 == 0 && amp_reg_lds<3>(NG, nb, ra.nv, nu) <= most) return launch_resid_tb<NG, 3>(ctx, a, ra, sa, SN, rows_dev);
-    if (nb % 2 == 0 && amp_reg_lds<2>(NG, nb, ra.nv, nu) <= most) return launch_resid_tb<NG, 2>(ctx, a, ra, sa, SN, rows_dev);
-    if (amp_reg_lds<1>(NG, nb, ra.nv, nu) <= most) return launch_resid_tb<NG, 1>(ctx, a, ra, sa, SN, rows_dev);
-    return -1;
-}
-
-// the residual pass of the Schur solve (dangx_schur.hip: k_schur_resid) on this schedule: 0 launched, 1 error, -1 not covered
-int dx_launch_schur_resid_reg(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev) {
-    AmpRegArgs ra;
-    if (sa.nrows < 1 || sa.nrows > RMAXF || !template_group_args(ctx, a, ra)) return -1;
-    for (int r = 0; r < sa.nrows; ++r) {
-        const int l = a.tc[sa.rt[r]];
-        for (int w = 0; w < ra.nu; ++w) if (ra.ucomp[w] == l) ra.rowu[r] = (signed char)w;
-        if (ra.rowu[r] < 0) return -1;
-        if (ctx->desc[l].type == DANGX_MONOPOLE) ra.rowmono |= 1u << r;
-    }
-    switch (a.ng) {
-    case 1: return launch_resid_ng<1>(ctx, a, ra, sa, SN, rows_dev);
-    case 2: return launch_resid_ng<2>(ctx, a, ra, sa, SN, rows_dev);
-    case 3: return launch_resid_ng<3>(ctx, a, ra, sa, SN, rows_dev);
-    case 4: return launch_resid_ng<4>(ctx, a, ra, sa, SN, rows_dev);
-    case 5: return launch_resid_ng<5>(ctx, a, ra, sa, SN, rows_dev);
-    case 6: return launch_resid_ng<6>(ctx, a, ra, sa, SN, rows_dev);
-    default: return -1;
-    }
-}
-
-template <int NG, int TB>
-int launch_pass1_tb(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, const SchurArgs& sa, long long SN, double* rows_dev) {
-    const int planes = flag_planes_h(a.flag), R = sa.nrows, nrows = R * R + 3 * R;
-    const unsigned gx = nblocks(SN / planes), nblk = gx * planes;
-    if (ensure_partial(ctx, (long long)nrows * nblk)) return 1;
-    const size_t ldsz = amp_reg_lds<TB>(NG, ctx->hm.nbands, ra.nv, ra.nu);
-    HIPCHK(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL((k_schur_pass1_reg<NG, TB, 4>), dim3(gx, planes), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial, ctx->counters);
-    dx_reduce_rows_to(ctx, ctx->partial, nblk, nrows, rows_dev);
-    HIPCHK(ctx, hipGetLastError());
-    return 0;
-}
-template <int NG>
-int launch_pass1_ng(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, const SchurArgs& sa, long long SN, double* rows_dev) {
-    const int nb = ctx->hm.nbands;
-    const size_t most = 80u * 1024u;
-    if (nb % 5 == 0 && amp_reg_lds<5>(NG, nb, ra.nv, ra.nu) <= most) return launch_pass1_tb<NG, 5>(ctx, a, ra, sa, SN, rows_dev);
-    if (nb % 4 == 0 && amp_reg_lds<4>(NG, nb, ra.nv, ra.nu) <= most) return launch_pass1_tb<NG, 4>(ctx, a, ra, sa, SN, rows_dev);
-    if (nb % 3 == 0 && amp_reg_lds<3>(NG, nb, ra.nv, ra.nu) <= most) return launch_pass1_tb<NG, 3>(ctx, a, ra, sa, SN, rows_dev);
-    if (nb % 2 == 0 && amp_reg_lds<2>(NG, nb, ra.nv, ra.nu) <= most) return launch_pass1_tb<NG, 2>(ctx, a, ra, sa, SN, rows_dev);
-    if (amp_reg_lds<1>(NG, nb, ra.nv, ra.nu) <= most) return launch_pass1_tb<NG, 1>(ctx, a, ra, sa, SN, rows_dev);
-    return -1;
-}
-
-// pass 1 of the Schur solve (dangx_schur.hip: k_schur_pass1) on this schedule: 0 launched, 1 error, -1 not covered (more than
-// four global rows or fitted bands, a hi_fit member, bandpass-integrated bands, the textbook fluctuation term ...)
-int dx_launch_schur_pass1_reg(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev) {
-    AmpRegArgs ra;
-    if (sa.nrows < 1 || sa.nrows > 4 || sa.nslots > 4 || !template_group_args(ctx, a, ra)) return -1;
-    if (a.ml_mode == DANGX_ML_SAMPLE && a.fluct != DANGX_FLUCT_REFERENCE) return -1;
-    for (int r = 0; r < sa.nrows; ++r) {
-        const int l = a.tc[sa.rt[r]];
-        for (int w = 0; w < ra.nu; ++w) if (ra.ucomp[w] == l) ra.rowu[r] = (signed char)w;
-        if (ra.rowu[r] < 0) return -1;
-        if (ctx->desc[l].type == DANGX_MONOPOLE) ra.rowmono |= 1u << r;
-    }
-    switch (a.ng) {
-    case 1: return launch_pass1_ng<1>(ctx, a, ra, sa, SN, rows_dev);
-    case 2: return launch_pass1_ng<2>(ctx, a, ra, sa, SN, rows_dev);
-    case 3: return launch_pass1_ng<3>(ctx, a, ra, sa, SN, rows_dev);
-    case 4: return launch_pass1_ng<4>(ctx, a, ra, sa, SN, rows_dev);
-    case 5: return launch_pass1_ng<5>(ctx, a, ra, sa, SN, rows_dev);
-    case 6: return launch_pass1_ng<6>(ctx, a, ra, sa, SN, rows_dev);
-    default: return -1;
-    }
-}
-
+// templates / monopoles in the model; dx_ampreg.h: template_group_args).  Passes 1 and 3: dangx_schurreg.hip.
 int dx_launch_amp_reg_templates(dangx_ctx* ctx, const GroupArgs& a, long long SN) {
     if (a.ml_mode == DANGX_ML_SAMPLE && a.fluct != DANGX_FLUCT_REFERENCE) return -1;
     AmpRegArgs ra;
@@ -948,27 +373,6 @@ int dx_launch_amp_reg_templates(dangx_ctx* ctx, const GroupArgs& a, long long SN
     case 6: return launch_ng<6, true>(ctx, a, ra, SN);
     default: return -1;
     }
-}
-
-// the diffuse members' roles: table row or LDS column; non-zero: a member type this kernel does not evaluate
-static int amp_reg_members(dangx_ctx* ctx, const GroupArgs& a, AmpRegArgs& ra) {
-    ra.nv = 0; ra.nu = 0; ra.umember = 0u; ra.rowmono = 0u;
-    for (int w = 0; w < MAXU; ++w) ra.ucomp[w] = 0;
-    for (int r = 0; r < 8; ++r) ra.rowu[r] = -1;
-    unsigned planes = 0;
-    for (int pl = 0; pl < flag_planes_h(a.flag); ++pl)
-        planes |= 1u << (((a.flag & DANGX_FLAG_QU) ? 2 + pl : (a.flag & DANGX_FLAG_T) ? 1 : (a.flag & DANGX_FLAG_Q) ? 2 : 3) - 1);
-    for (int g = 0; g < MAXG; ++g) { ra.vslot[g] = -1; ra.vcomp[g] = 0; ra.vtype[g] = 0; }
-    for (int g = 0; g < a.ng; ++g) {
-        const Comp& c = ctx->hm.comp[a.gc[g]];
-        if (c.type < DANGX_POWERLAW || c.type > DANGX_CMB) return 1;
-        // constant on EVERY plane of this launch -> a table row; otherwise evaluated per unit
-        if (((unsigned)c.const_planes & planes) != planes) {
-            ra.vcomp[ra.nv] = (signed char)g; ra.vtype[ra.nv] = (signed char)c.type;
-            ra.vslot[g] = (signed char)ra.nv++;
-        }
-    }
-    return 0;
 }
 
 // returns 0 when launched, -1 when this form does not cover the case (the caller falls back to k_amp_direct)
