@@ -24,7 +24,7 @@
 
 namespace {
 
-template <int NG, int TB, bool HT = false>
+template <int NG, int TB, bool HT = false, bool HF = false>
 __global__ __launch_bounds__(BLOCK, NG <= 4 ? 4 : 3) void k_amp_reg(const Model* __restrict__ Mp, GroupArgs a, AmpRegArgs ra,
                                                                    unsigned long long* __restrict__ not_spd) {
     extern __shared__ double lds[];  // [constant table (| HT: nu rows of template coefficients) | per-thread columns: 3*nv rows of sed_prep state, nv*TB rows of SEDs]
@@ -54,15 +54,15 @@ __global__ __launch_bounds__(BLOCK, NG <= 4 ? 4 : 3) void k_amp_reg(const Model*
             if (c.nind > 1) th[v][1] = ix[(long long)M.nmaps * npix];
         }
     }
-    double tv[MAXU];
+    double tv[MAXU], tT[MAXU];
     if (HT) {
-#pragma unroll
-        for (int w = 0; w < MAXU; ++w) tv[w] = (w < ra.nu) ? as_global(M.comp[ra.ucomp[w]].tmpl)[(long long)(k - 1) * npix + i] : 0.0;
+        gl_load(M, ra, i, k, npix, tv, tT);
         for (int t = tid; t < ra.nu * nb; t += BLOCK) {
             const int w = t / nb, j = t - w * nb;
             const Comp& c = M.comp[ra.ucomp[w]];
-            const bool member = (ra.umember >> w) & 1u, fitted = (c.corr_mask >> j) & 1;
-            cu[t] = (member || !fitted) ? c.tamp[k - 1][j] : 0.0;
+            const bool member = (ra.umember >> w) & 1u, inuc = (ra.uinuc >> w) & 1u, fitted = (c.corr_mask >> j) & 1;
+            // a member: its new amplitude on the bands it is fitted at; a template / monopole, member or not: its amplitude on the others
+            cu[t] = ((member && fitted) || (inuc && !fitted)) ? c.tamp[k - 1][j] : 0.0;
         }
     }
     sed_table_build(M, tab, tid, BLOCK, a.gc, NG);
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(BLOCK, NG <= 4 ? 4 : 3) void k_amp_reg(const Model*
             if (HT) {
 #pragma unroll
                 for (int w = 0; w < MAXU; ++w)
-                    if (w < ra.nu) d = d - cu[w * nb + j0 + t] * tv[w];
+                    if (w < ra.nu) d = d - cu[w * nb + j0 + t] * gl_sed<HF>(ra, w, tv, tT, tab[(TROWS * NG) * nb + j0 + t]);
             }
             const double is = fast_rcp(rcur[t]);
             const double inv = is * is;
@@ -303,29 +303,29 @@ __global__ __launch_bounds__(BLOCK, NG <= 4 ? 4 : 3) void k_chisq_reg(const Mode
 }
 
 
-template <int NG, int TB, bool HT = false>
+template <int NG, int TB, bool HT = false, bool HF = false>
 int launch_tb(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, long long SN) {
     const size_t ldsz = amp_reg_lds<TB>(NG, ctx->hm.nbands, ra.nv, HT ? ra.nu : 0);
     Timed t(ctx, DANGX_K_AMP_DIRECT);
     const int planes = flag_planes_h(a.flag);
-    hipLaunchKernelGGL((k_amp_reg<NG, TB, HT>), dim3(nblocks(SN / planes), planes), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, ctx->counters);
+    hipLaunchKernelGGL((k_amp_reg<NG, TB, HT, HF>), dim3(nblocks(SN / planes), planes), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, ctx->counters);
     return 0;
 }
 
 // band tile: the largest of 5 / 4 / 3 dividing nb whose LDS footprint lets as many blocks stay resident as the
 // registers allow (4 for NG <= 4, else 3); failing that the largest that leaves two blocks per CU
-template <int NG, bool HT = false>
+template <int NG, bool HT = false, bool HF = false>
 int launch_ng(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, long long SN) {
     const int nb = ctx->hm.nbands, nu = HT ? ra.nu : 0;
     const size_t want = (160u * 1024u) / (NG <= 4 ? 4 : 3), most = 80u * 1024u;
     for (const size_t cap : {want, most}) {
-        if (nb % 5 == 0 && amp_reg_lds<5>(NG, nb, ra.nv, nu) <= cap) return launch_tb<NG, 5, HT>(ctx, a, ra, SN);
-        if (nb % 4 == 0 && amp_reg_lds<4>(NG, nb, ra.nv, nu) <= cap) return launch_tb<NG, 4, HT>(ctx, a, ra, SN);
-        if (nb % 3 == 0 && amp_reg_lds<3>(NG, nb, ra.nv, nu) <= cap) return launch_tb<NG, 3, HT>(ctx, a, ra, SN);
+        if (nb % 5 == 0 && amp_reg_lds<5>(NG, nb, ra.nv, nu) <= cap) return launch_tb<NG, 5, HT, HF>(ctx, a, ra, SN);
+        if (nb % 4 == 0 && amp_reg_lds<4>(NG, nb, ra.nv, nu) <= cap) return launch_tb<NG, 4, HT, HF>(ctx, a, ra, SN);
+        if (nb % 3 == 0 && amp_reg_lds<3>(NG, nb, ra.nv, nu) <= cap) return launch_tb<NG, 3, HT, HF>(ctx, a, ra, SN);
         // band counts that 3, 4 and 5 do not divide (7, 11, 13, 14 ...): tiles of two bands, or of one
         if (nb % 5 && nb % 4 && nb % 3) {
-            if (nb % 2 == 0 && amp_reg_lds<2>(NG, nb, ra.nv, nu) <= cap) return launch_tb<NG, 2, HT>(ctx, a, ra, SN);
-            if (nb % 2 && amp_reg_lds<1>(NG, nb, ra.nv, nu) <= cap) return launch_tb<NG, 1, HT>(ctx, a, ra, SN);
+            if (nb % 2 == 0 && amp_reg_lds<2>(NG, nb, ra.nv, nu) <= cap) return launch_tb<NG, 2, HT, HF>(ctx, a, ra, SN);
+            if (nb % 2 && amp_reg_lds<1>(NG, nb, ra.nv, nu) <= cap) return launch_tb<NG, 1, HT, HF>(ctx, a, ra, SN);
         }
     }
     return -1;  // the LDS-column kernel is the better fit
@@ -365,12 +365,12 @@ int dx_launch_amp_reg_templates(dangx_ctx* ctx, const GroupArgs& a, long long SN
     AmpRegArgs ra;
     if (!template_group_args(ctx, a, ra)) return -1;
     switch (a.ng) {
-    case 1: return launch_ng<1, true>(ctx, a, ra, SN);
-    case 2: return launch_ng<2, true>(ctx, a, ra, SN);
-    case 3: return launch_ng<3, true>(ctx, a, ra, SN);
-    case 4: return launch_ng<4, true>(ctx, a, ra, SN);
-    case 5: return launch_ng<5, true>(ctx, a, ra, SN);
-    case 6: return launch_ng<6, true>(ctx, a, ra, SN);
+    case 1: return ra.uhifit ? launch_ng<1, true, true>(ctx, a, ra, SN) : launch_ng<1, true>(ctx, a, ra, SN);
+    case 2: return ra.uhifit ? launch_ng<2, true, true>(ctx, a, ra, SN) : launch_ng<2, true>(ctx, a, ra, SN);
+    case 3: return ra.uhifit ? launch_ng<3, true, true>(ctx, a, ra, SN) : launch_ng<3, true>(ctx, a, ra, SN);
+    case 4: return ra.uhifit ? launch_ng<4, true, true>(ctx, a, ra, SN) : launch_ng<4, true>(ctx, a, ra, SN);
+    case 5: return ra.uhifit ? launch_ng<5, true, true>(ctx, a, ra, SN) : launch_ng<5, true>(ctx, a, ra, SN);
+    case 6: return ra.uhifit ? launch_ng<6, true, true>(ctx, a, ra, SN) : launch_ng<6, true>(ctx, a, ra, SN);
     default: return -1;
     }
 }
@@ -411,7 +411,7 @@ int dx_launch_chisq_reg(dangx_ctx* ctx, int k, double* partial) {
     if (a.ng < 1) return -1;
     a.flag = (k == 1) ? DANGX_FLAG_T : (k == 2) ? DANGX_FLAG_Q : DANGX_FLAG_U;
     AmpRegArgs ra;
-    ra.nv = 0; ra.nu = 0; ra.umember = 0u; ra.rowmono = 0u;
+    ra.nv = 0; ra.nu = 0; ra.umember = 0u; ra.rowmono = 0u; ra.uinuc = 0u; ra.uhifit = 0u;
     for (int w = 0; w < MAXU; ++w) ra.ucomp[w] = 0;
     for (int r = 0; r < 8; ++r) ra.rowu[r] = -1;
     for (int g = 0; g < MAXG; ++g) { ra.vslot[g] = -1; ra.vcomp[g] = 0; ra.vtype[g] = 0; }

@@ -13,7 +13,7 @@ namespace {
 // 1 / sigma_j^2 of the bands that carry a global row kept in REGISTERS (slot = sa.bslot[j]) instead of LDS columns; after the
 // Cholesky factor the R^2 + 3R row values of the unit and one block reduction for all of them.
 //   rows [0, R^2): S[r][r'] ; [R^2, R^2+R): t[r] ; [R^2+R, R^2+2R): fluctuation sum of natural row r ; [R^2+2R, R^2+3R): G[r][r]
-template <int NG, int TB, int SS>
+template <int NG, int TB, int SS, bool HF>
 __global__ __launch_bounds__(BLOCK, 2) void k_schur_pass1_reg(const Model* __restrict__ Mp, GroupArgs a, AmpRegArgs ra, SchurArgs sa,
                                                              double* __restrict__ rowpartial, unsigned long long* __restrict__ not_spd) {
     constexpr int NV = SS * SS + 3 * SS;   // row values of a unit (R <= SS)
@@ -30,9 +30,8 @@ __global__ __launch_bounds__(BLOCK, 2) void k_schur_pass1_reg(const Model* __res
     const int i = in_range ? (int)u : 0;
     const int k = flag_map(a.flag, (int)blockIdx.y);
     const double mk = as_global(M.mask)[i];
-    double th[NG][2], tv[MAXU];
-#pragma unroll
-    for (int w = 0; w < MAXU; ++w) tv[w] = (w < ra.nu) ? as_global(M.comp[ra.ucomp[w]].tmpl)[(long long)(k - 1) * npix + i] : 0.0;
+    double th[NG][2], tv[MAXU], tT[MAXU];
+    gl_load(M, ra, i, k, npix, tv, tT);
 #pragma unroll
     for (int v = 0; v < NG; ++v) {
         th[v][0] = th[v][1] = 0.0;
@@ -46,7 +45,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_schur_pass1_reg(const Model* __res
     for (int t = tid; t < ra.nu * nb; t += BLOCK) {
         const int w = t / nb, j = t - w * nb;
         const Comp& c = M.comp[ra.ucomp[w]];
-        cu[t] = ((c.corr_mask >> j) & 1) ? 0.0 : c.tamp[k - 1][j];
+        cu[t] = (((ra.uinuc >> w) & 1u) && !((c.corr_mask >> j) & 1)) ? c.tamp[k - 1][j] : 0.0;
     }
     sed_table_build(M, tab, tid, BLOCK, a.gc, NG);
     const bool sample = (a.ml_mode == DANGX_ML_SAMPLE);
@@ -117,7 +116,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_schur_pass1_reg(const Model* __res
                 if (k == 1) { const double gj = gain[j]; if (gj != 1.0) d = d / gj; }  // :371
 #pragma unroll
                 for (int w = 0; w < MAXU; ++w)
-                    if (w < ra.nu) d = d - cu[w * nb + j] * tv[w];
+                    if (w < ra.nu && ((ra.uinuc >> w) & 1u)) d = d - cu[w * nb + j] * tv[w];
                 const double is = fast_rcp(rcur[t]);
                 const double inv = is * is;
                 double mrow[NG];
@@ -194,7 +193,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_schur_pass1_reg(const Model* __res
                     const int sl = __builtin_amdgcn_readfirstlane(sa.bslot[sa.rj[r]]);
                     double s_r = 0.0, dns = 0.0, ens = 0.0, ivs = 0.0, dot = 0.0, Qr[NG];
 #pragma unroll
-                    for (int w = 0; w < MAXU; ++w) s_r = (ra.rowu[r] == w) ? tv[w] : s_r;
+                    for (int w = 0; w < MAXU; ++w) s_r = (ra.rowu[r] == w) ? gl_sed<HF>(ra, w, tv, tT, tab[(TROWS * NG) * nb + sa.rj[r]]) : s_r;
 #pragma unroll
                     for (int q = 0; q < SS; ++q)
                         if (q == sl) {
@@ -214,7 +213,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_schur_pass1_reg(const Model* __res
                             const int sl2 = __builtin_amdgcn_readfirstlane(sa.bslot[sa.rj[r2]]);
                             double s2 = 0.0, dot2 = 0.0;
 #pragma unroll
-                            for (int w = 0; w < MAXU; ++w) s2 = (ra.rowu[r2] == w) ? tv[w] : s2;
+                            for (int w = 0; w < MAXU; ++w) s2 = (ra.rowu[r2] == w) ? gl_sed<HF>(ra, w, tv, tT, tab[(TROWS * NG) * nb + sa.rj[r2]]) : s2;
 #pragma unroll
                             for (int q = 0; q < SS; ++q)
                                 if (q == sl2) {
@@ -260,7 +259,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_schur_pass1_reg(const Model* __res
 // rows [0,R): b - A x without the fluctuation term, [R,2R): the row of b, [2R,3R): the size of the terms.
 // RR: rows the thread carries (4 or 8): the 3 RR row values live in registers for the whole band loop, and with 8 of them the
 // amplitude kernel's four waves per SIMD cost 73 spilled registers.
-template <int NG, int TB, int RR>
+template <int NG, int TB, int RR, bool HF>
 __global__ __launch_bounds__(BLOCK, RR <= 4 ? (NG <= 4 ? 4 : 3) : 2) void k_schur_resid_reg(const Model* __restrict__ Mp, GroupArgs a, AmpRegArgs ra, SchurArgs sa,
                                                                            double* __restrict__ rowpartial) {
     extern __shared__ double lds[];
@@ -277,11 +276,10 @@ __global__ __launch_bounds__(BLOCK, RR <= 4 ? (NG <= 4 ? 4 : 3) : 2) void k_schu
     const int i = in_range ? (int)u : 0;
     const int k = flag_map(a.flag, (int)blockIdx.y);
     const double mk = as_global(M.mask)[i];
-    double th[NG][2], av[NG], tv[MAXU];
+    double th[NG][2], av[NG], tv[MAXU], tT[MAXU];
 #pragma unroll
     for (int g = 0; g < NG; ++g) av[g] = as_global(M.comp[a.gc[g]].amp)[(long long)(k - 1) * npix + i];
-#pragma unroll
-    for (int w = 0; w < MAXU; ++w) tv[w] = (w < ra.nu) ? as_global(M.comp[ra.ucomp[w]].tmpl)[(long long)(k - 1) * npix + i] : 0.0;
+    gl_load(M, ra, i, k, npix, tv, tT);
 #pragma unroll
     for (int v = 0; v < NG; ++v) {
         th[v][0] = th[v][1] = 0.0;
@@ -296,7 +294,7 @@ __global__ __launch_bounds__(BLOCK, RR <= 4 ? (NG <= 4 ? 4 : 3) : 2) void k_schu
         const int w = t / nb, j = t - w * nb;
         const Comp& c = M.comp[ra.ucomp[w]];
         const bool member = (ra.umember >> w) & 1u, fitted = (c.corr_mask >> j) & 1;
-        cu[t] = fitted ? 0.0 : c.tamp[k - 1][j];
+        cu[t] = (((ra.uinuc >> w) & 1u) && !fitted) ? c.tamp[k - 1][j] : 0.0;
         gm[t] = (member && fitted) ? c.tamp[k - 1][j] : 0.0;
     }
     sed_table_build(M, tab, tid, BLOCK, a.gc, NG);
@@ -359,7 +357,11 @@ __global__ __launch_bounds__(BLOCK, RR <= 4 ? (NG <= 4 ? 4 : 3) : 2) void k_schu
                 for (int g = 0; g < NG; ++g) model = model + av[g] * mp[g][t * ms[g]];
 #pragma unroll
                 for (int w = 0; w < MAXU; ++w)
-                    if (w < ra.nu) { d = d - cu[w * nb + j] * tv[w]; model = model + gm[w * nb + j] * tv[w]; }
+                    if (w < ra.nu) {
+                        const double sw = gl_sed<HF>(ra, w, tv, tT, tab[(TROWS * NG) * nb + j]);
+                        d = d - cu[w * nb + j] * sw;
+                        model = model + gm[w * nb + j] * sw;
+                    }
                 const double is = fast_rcp(rcur[t]);
                 const double inv = is * is;
 #pragma unroll
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(BLOCK, RR <= 4 ? (NG <= 4 ? 4 : 3) : 2) void k_schu
                     if (r < R && (int)sa.rj[r] == j) {
                         double st = 0.0;
 #pragma unroll
-                        for (int w = 0; w < MAXU; ++w) st = (ra.rowu[r] == w) ? tv[w] : st;
+                        for (int w = 0; w < MAXU; ++w) st = (ra.rowu[r] == w) ? gl_sed<HF>(ra, w, tv, tT, tab[(TROWS * NG) * nb + j]) : st;
                         const double wgt = ((ra.rowmono >> r) & 1u) ? 1.0 : st;   // :857
                         const double bterm = d * inv * st, mterm = wgt * (model * inv);
                         rv[3 * r] = bterm - mterm;
@@ -403,10 +405,14 @@ int launch_resid_tb(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, co
     const unsigned gx = nblocks(SN / planes), nblk = gx * planes;
     if (ensure_partial(ctx, (long long)nrows * nblk)) return 1;
     const size_t ldsz = amp_reg_lds<TB>(NG, ctx->hm.nbands, ra.nv, 2 * ra.nu);
-    if (sa.nrows <= 4)
-        hipLaunchKernelGGL((k_schur_resid_reg<NG, TB, 4>), dim3(gx, planes), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial);
+    if (sa.nrows <= 4 && !ra.uhifit)
+        hipLaunchKernelGGL((k_schur_resid_reg<NG, TB, 4, false>), dim3(gx, planes), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial);
+    else if (sa.nrows <= 4)
+        hipLaunchKernelGGL((k_schur_resid_reg<NG, TB, 4, true>), dim3(gx, planes), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial);
+    else if (!ra.uhifit)
+        hipLaunchKernelGGL((k_schur_resid_reg<NG, TB, RMAXF, false>), dim3(gx, planes), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial);
     else
-        hipLaunchKernelGGL((k_schur_resid_reg<NG, TB, RMAXF>), dim3(gx, planes), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial);
+        hipLaunchKernelGGL((k_schur_resid_reg<NG, TB, RMAXF, true>), dim3(gx, planes), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial);
     dx_reduce_rows_to(ctx, ctx->partial, nblk, nrows, rows_dev);
     HIPCHK(ctx, hipGetLastError());
     return 0;
@@ -455,7 +461,10 @@ int launch_pass1_tb(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, co
     if (ensure_partial(ctx, (long long)nrows * nblk)) return 1;
     const size_t ldsz = amp_reg_lds<TB>(NG, ctx->hm.nbands, ra.nv, ra.nu);
     HIPCHK(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL((k_schur_pass1_reg<NG, TB, 4>), dim3(gx, planes), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial, ctx->counters);
+    if (ra.uhifit)
+        hipLaunchKernelGGL((k_schur_pass1_reg<NG, TB, 4, true>), dim3(gx, planes), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial, ctx->counters);
+    else
+        hipLaunchKernelGGL((k_schur_pass1_reg<NG, TB, 4, false>), dim3(gx, planes), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial, ctx->counters);
     dx_reduce_rows_to(ctx, ctx->partial, nblk, nrows, rows_dev);
     HIPCHK(ctx, hipGetLastError());
     return 0;

@@ -28,6 +28,8 @@ struct AmpRegArgs {
     int nu;
     int ucomp[MAXU];
     unsigned umember;         // bit w: component ucomp[w] is a global-amplitude member of the group
+    unsigned uinuc;           // bit w: a template / monopole (removed on its unfitted bands whichever group it belongs to)
+    unsigned uhifit;          // bit w: a hi_fit member: sed = template * B_nu(T(pixel)) / RJ * 1e6 (src/dang_component_mod.f90:850-884)
     // residual pass (k_schur_resid_reg): global row r belongs to template slot rowu[r]; bit r of rowmono: a monopole's row
     signed char rowu[8];
     unsigned rowmono;
@@ -80,12 +82,29 @@ __device__ __forceinline__ void sed_tile(int type, const double* __restrict__ ta
     }
 }
 
+// SED of global member w at this unit and band: template(pix, plane), times the Planck-to-RJ factor at the pixel's temperature
+// for a hi_fit member (the expression of comp_sed, dx_sed.h)
+// HF = false: no hi_fit member in the launch (the Planck factor then costs the template-only kernels no registers)
+template <bool HF>
+__device__ __forceinline__ double gl_sed(const AmpRegArgs& ra, int w, const double* tv, const double* tT, double nu) {
+    if (HF && ((ra.uhifit >> w) & 1u)) return tv[w] * (planck_rj(nu, tT[w]) * 1e6f);
+    return tv[w];
+}
+// template values (and, for hi_fit members, temperatures) of the unit
+__device__ __forceinline__ void gl_load(const Model& M, const AmpRegArgs& ra, int i, int k, int npix, double* tv, double* tT) {
+#pragma unroll
+    for (int w = 0; w < MAXU; ++w) {
+        tv[w] = (w < ra.nu) ? as_global(M.comp[ra.ucomp[w]].tmpl)[(long long)(k - 1) * npix + i] : 0.0;
+        tT[w] = (w < ra.nu && ((ra.uhifit >> w) & 1u)) ? as_global(M.comp[ra.ucomp[w]].idx)[(long long)(k - 1) * npix + i] : 1.0;
+    }
+}
+
 template <int TB>
 size_t amp_reg_lds(int NG, int nb, int nv, int nu = 0) { return ((size_t)(TROWS * NG + 3 + nu) * nb + (size_t)nv * (TB + 3) * BLOCK) * sizeof(double); }
 
 // the diffuse members' roles: table row or LDS column; non-zero: a member type this kernel does not evaluate
 inline int amp_reg_members(dangx_ctx* ctx, const GroupArgs& a, AmpRegArgs& ra) {
-    ra.nv = 0; ra.nu = 0; ra.umember = 0u; ra.rowmono = 0u;
+    ra.nv = 0; ra.nu = 0; ra.umember = 0u; ra.rowmono = 0u; ra.uinuc = 0u; ra.uhifit = 0u;
     for (int w = 0; w < MAXU; ++w) ra.ucomp[w] = 0;
     for (int r = 0; r < 8; ++r) ra.rowu[r] = -1;
     unsigned planes = 0;
@@ -108,23 +127,32 @@ inline int amp_reg_members(dangx_ctx* ctx, const GroupArgs& a, AmpRegArgs& ra) {
 // plus the templates' slots; false: the group needs the run-time-typed passes of dangx_schur.hip
 inline bool template_group_args(dangx_ctx* ctx, const GroupArgs& a, AmpRegArgs& ra) {
     static const bool enabled = [] { const char* e = getenv("DANGX_SCHUR_FAST"); return !(e && e[0] == '0'); }();  // A/B switch
-    if (!enabled || a.no != 0 || a.ng < 1 || a.nuc < 1 || a.nuc > MAXU) return false;
+    if (!enabled || a.no != 0 || a.ng < 1 || a.nt < 1 || a.nuc > MAXU) return false;
     for (int j = 0; j < ctx->hm.nbands; ++j)
         if (ctx->hm.band[j].n != 0) return false;
     for (int l = 0; l < ctx->hm.ncomp; ++l)
         if (ctx->desc[l].type == DANGX_TCMB) return false;
     if (amp_reg_members(ctx, a, ra)) return false;
-    ra.nu = a.nuc; ra.umember = 0u; ra.rowmono = 0u;
+    ra.nu = a.nuc; ra.umember = 0u; ra.rowmono = 0u; ra.uinuc = 0u; ra.uhifit = 0u;
     for (int r = 0; r < 8; ++r) ra.rowu[r] = -1;
     for (int w = 0; w < a.nuc; ++w) {
         const int l = a.uc[w];
         if (ctx->desc[l].type != DANGX_TEMPLATE && ctx->desc[l].type != DANGX_MONOPOLE) return false;
         ra.ucomp[w] = l;
+        ra.uinuc |= 1u << w;
         for (int t = 0; t < a.nt; ++t) if (a.tc[t] == l) ra.umember |= 1u << w;
     }
-    for (int t = 0; t < a.nt; ++t) {   // every global member must be among them (a hi_fit member is not: generic pass)
+    for (int t = 0; t < a.nt; ++t) {   // hi_fit members take slots of their own (they are not in the uc list)
+        const int l = a.tc[t];
+        if (ctx->desc[l].type != DANGX_HIFIT) continue;
+        if (ra.nu >= MAXU || ctx->desc[l].nindices < 1) return false;
+        ra.ucomp[ra.nu] = l;
+        ra.umember |= 1u << ra.nu; ra.uhifit |= 1u << ra.nu;
+        ++ra.nu;
+    }
+    for (int t = 0; t < a.nt; ++t) {   // every global member must have a slot
         bool found = false;
-        for (int w = 0; w < a.nuc; ++w) found = found || a.uc[w] == a.tc[t];
+        for (int w = 0; w < ra.nu; ++w) found = found || ra.ucomp[w] == a.tc[t];
         if (!found) return false;
     }
     return true;

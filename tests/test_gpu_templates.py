@@ -348,9 +348,9 @@ def test_T_cmb_as_an_amplitude_sampled_group_member(built):
     assert abs(it_g - it_o) <= 1
 
 
-@pytest.mark.parametrize("which,group,flag", [(("template",), 2, L.FLAG_QU), (("monopole",), 1, L.FLAG_T)])
+@pytest.mark.parametrize("which,group,flag", [(("template",), 2, L.FLAG_QU), (("monopole",), 1, L.FLAG_T), (("monopole", "hi_fit"), 1, L.FLAG_T)])
 def test_schur_passes_on_the_amplitude_schedule_are_the_run_time_typed_ones(built, which, group, flag):
-    """Groups whose global members are templates / monopoles run the three passes of the Schur solve on the amplitude
+    """Groups whose global members are templates / monopoles / hi_fit components run the passes of the Schur solve on the amplitude
     kernel's schedule (dangx_ampreg.hip: k_schur_pass1_reg, k_amp_reg<.., true>, k_schur_resid_reg); DANGX_SCHUR_FAST=0 keeps the
     run-time-typed passes of dangx_schur.hip.  Same amplitudes (the reciprocals and square roots differ in their last bits --
     which also shows that two different sets of kernels ran) and the same refinement report."""
