@@ -382,12 +382,15 @@ def test_schur_passes_on_the_amplitude_schedule_are_the_run_time_typed_ones(buil
         assert r.returncode == 0 and lines, r.stdout[-3000:]
         res[fast] = json.loads(lines[-1][7:])
     same_bits = True
+    # a monopole beside hi_fit is a near-degenerate pair (condition ~1e8, cf. test_direct_solve_with_global_components...):
+    # its residual floor and the agreement of two roundings of the same solve are correspondingly looser
+    tol = 1e-6 if "hi_fit" in which else 1e-9
     for ml in ("optimize", "sample"):
         a, b = res["1"][ml], res["0"][ml]
         assert a["it"] == b["it"] and a["bad"] == b["bad"] == 0
-        assert a["rb"] <= 1e-9 and b["rb"] <= 1e-9, (a["rb"], b["rb"])
+        assert a["rb"] <= tol and b["rb"] <= tol, (a["rb"], b["rb"])
         for x, y in zip(a["amp"] + a["tamp"], b["amp"] + b["tamp"]):
             x, y = np.asarray(x), np.asarray(y)
-            assert np.abs(x - y).max() <= 1e-9 * max(np.abs(y).max(), 1.0)
+            assert np.abs(x - y).max() <= tol * max(np.abs(y).max(), 1.0)
             same_bits = same_bits and np.array_equal(x, y)
     assert not same_bits
