@@ -5,8 +5,20 @@
 // solve takes 7.3 ms instead of 13.9: pass 1 3.8 (6.6), pass 2 = k_amp_reg<.., true> 1.6 (3.7), residual check 1.6 (3.3).
 #include "dx_ampreg.h"
 
-namespace {
+// Compiled four times (dang_amd/_build.py): -DDX_SCHUR_PART=1 (pass 1) / 2 (the residual pass) x -DDX_SCHUR_HF=0 (groups without
+// a hi_fit member; these units also hold the public launchers) / 1 (kernels that carry the Planck factor of hi_fit members):
+// four units of ~45 kernels build side by side instead of one of 180.
+#ifndef DX_SCHUR_HF
+#define DX_SCHUR_HF 0
+#endif
+#ifndef DX_SCHUR_PART      // 1: pass 1, 2: the residual pass (four units in all)
+#define DX_SCHUR_PART 1
+#endif
 
+namespace {
+constexpr bool HFV = DX_SCHUR_HF != 0;
+
+#if DX_SCHUR_PART == 1
 // Pass 1 of the Schur solve of a template group (dangx_schur.hip: k_schur_pass1, whose header derives the sums) on this
 // kernel's schedule, for groups whose global members are templates / monopoles fitted at up to SS bands: the normal equations of
 // the diffuse members as k_amp_reg forms them, with the vectors W_j = M_j / sigma_j^2, d_j / sigma_j^2, eta / sigma_j and
@@ -252,6 +264,8 @@ __global__ __launch_bounds__(BLOCK, 2) void k_schur_pass1_reg(const Model* __res
     }
 }
 
+#endif
+#if DX_SCHUR_PART == 2
 // Residual of the GLOBAL rows of a template group's system at the current state (dangx_schur.hip: k_schur_resid, whose
 // comment defines the three row blocks) on the same schedule, for groups whose global members are templates / monopoles:
 //   cu[w][j]  = template_amplitudes of template w on the bands it is NOT fitted at (removed from the data, :445-460)
@@ -405,14 +419,10 @@ int launch_resid_tb(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, co
     const unsigned gx = nblocks(SN / planes), nblk = gx * planes;
     if (ensure_partial(ctx, (long long)nrows * nblk)) return 1;
     const size_t ldsz = amp_reg_lds<TB>(NG, ctx->hm.nbands, ra.nv, 2 * ra.nu);
-    if (sa.nrows <= 4 && !ra.uhifit)
-        hipLaunchKernelGGL((k_schur_resid_reg<NG, TB, 4, false>), dim3(gx, planes), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial);
-    else if (sa.nrows <= 4)
-        hipLaunchKernelGGL((k_schur_resid_reg<NG, TB, 4, true>), dim3(gx, planes), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial);
-    else if (!ra.uhifit)
-        hipLaunchKernelGGL((k_schur_resid_reg<NG, TB, RMAXF, false>), dim3(gx, planes), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial);
+    if (sa.nrows <= 4)
+        hipLaunchKernelGGL((k_schur_resid_reg<NG, TB, 4, HFV>), dim3(gx, planes), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial);
     else
-        hipLaunchKernelGGL((k_schur_resid_reg<NG, TB, RMAXF, true>), dim3(gx, planes), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial);
+        hipLaunchKernelGGL((k_schur_resid_reg<NG, TB, RMAXF, HFV>), dim3(gx, planes), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial);
     dx_reduce_rows_to(ctx, ctx->partial, nblk, nrows, rows_dev);
     HIPCHK(ctx, hipGetLastError());
     return 0;
@@ -429,12 +439,40 @@ int launch_resid_ng(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, co
     return -1;
 }
 
+#endif
 }  // namespace
 
 // the residual pass of the Schur solve (dangx_schur.hip: k_schur_resid) on this schedule: 0 launched, 1 error, -1 not covered
+#if DX_SCHUR_HF
+#define DX_RESID_WORKER dx_schurreg_resid_hf1
+#define DX_PASS1_WORKER dx_schurreg_pass1_hf1
+#else
+#define DX_RESID_WORKER dx_schurreg_resid_hf0
+#define DX_PASS1_WORKER dx_schurreg_pass1_hf0
+int dx_schurreg_resid_hf1(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
+int dx_schurreg_pass1_hf1(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
+int dx_schurreg_resid_hf0(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
+int dx_schurreg_pass1_hf0(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
+static bool group_has_hifit(dangx_ctx* ctx, const GroupArgs& a) {
+    for (int t = 0; t < a.nt; ++t) if (ctx->desc[a.tc[t]].type == DANGX_HIFIT) return true;
+    return false;
+}
+#if DX_SCHUR_PART == 2
 int dx_launch_schur_resid_reg(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev) {
+    return group_has_hifit(ctx, a) ? dx_schurreg_resid_hf1(ctx, a, sa, SN, rows_dev) : dx_schurreg_resid_hf0(ctx, a, sa, SN, rows_dev);
+}
+#else
+int dx_launch_schur_pass1_reg(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev) {
+    return group_has_hifit(ctx, a) ? dx_schurreg_pass1_hf1(ctx, a, sa, SN, rows_dev) : dx_schurreg_pass1_hf0(ctx, a, sa, SN, rows_dev);
+}
+#endif
+#endif
+
+#if DX_SCHUR_PART == 2
+int DX_RESID_WORKER(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev) {
     AmpRegArgs ra;
     if (sa.nrows < 1 || sa.nrows > RMAXF || !template_group_args(ctx, a, ra)) return -1;
+    if ((ra.uhifit != 0u) != HFV) return -1;
     for (int r = 0; r < sa.nrows; ++r) {
         const int l = a.tc[sa.rt[r]];
         for (int w = 0; w < ra.nu; ++w) if (ra.ucomp[w] == l) ra.rowu[r] = (signed char)w;
@@ -451,7 +489,9 @@ int dx_launch_schur_resid_reg(dangx_ctx* ctx, const GroupArgs& a, const SchurArg
     default: return -1;
     }
 }
+#endif
 
+#if DX_SCHUR_PART == 1
 namespace {
 
 template <int NG, int TB>
@@ -461,10 +501,7 @@ int launch_pass1_tb(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, co
     if (ensure_partial(ctx, (long long)nrows * nblk)) return 1;
     const size_t ldsz = amp_reg_lds<TB>(NG, ctx->hm.nbands, ra.nv, ra.nu);
     HIPCHK(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));
-    if (ra.uhifit)
-        hipLaunchKernelGGL((k_schur_pass1_reg<NG, TB, 4, true>), dim3(gx, planes), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial, ctx->counters);
-    else
-        hipLaunchKernelGGL((k_schur_pass1_reg<NG, TB, 4, false>), dim3(gx, planes), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial, ctx->counters);
+    hipLaunchKernelGGL((k_schur_pass1_reg<NG, TB, 4, HFV>), dim3(gx, planes), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial, ctx->counters);
     dx_reduce_rows_to(ctx, ctx->partial, nblk, nrows, rows_dev);
     HIPCHK(ctx, hipGetLastError());
     return 0;
@@ -485,9 +522,10 @@ int launch_pass1_ng(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, co
 
 // pass 1 of the Schur solve (dangx_schur.hip: k_schur_pass1) on this schedule: 0 launched, 1 error, -1 not covered (more than
 // four global rows or fitted bands, a hi_fit member, bandpass-integrated bands, the textbook fluctuation term ...)
-int dx_launch_schur_pass1_reg(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev) {
+int DX_PASS1_WORKER(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev) {
     AmpRegArgs ra;
     if (sa.nrows < 1 || sa.nrows > 4 || sa.nslots > 4 || !template_group_args(ctx, a, ra)) return -1;
+    if ((ra.uhifit != 0u) != HFV) return -1;
     if (a.ml_mode == DANGX_ML_SAMPLE && a.fluct != DANGX_FLUCT_REFERENCE) return -1;
     for (int r = 0; r < sa.nrows; ++r) {
         const int l = a.tc[sa.rt[r]];
@@ -505,3 +543,5 @@ int dx_launch_schur_pass1_reg(dangx_ctx* ctx, const GroupArgs& a, const SchurArg
     default: return -1;
     }
 }
+
+#endif
