@@ -242,6 +242,11 @@ def main():
                     "(rank 0 of N, no process group): the per-rank time at that shard size on one GPU")
     ap.add_argument("--equal-shards", action="store_true", help="shard by pixel count instead of by unmasked pixel count (the "
                     "ranks that hold the masked band then idle: A/B of the balanced boundaries)")
+    ap.add_argument("--gather", action="store_true", help="after the timed region: gather the pixel-sharded synchrotron amplitude and "
+                    "index maps to rank 0 (dist.gather_maps with the run's shard boundaries -- north_star's 'gather for map output') "
+                    "and report their checksum, which does not depend on the number of ranks")
+    ap.add_argument("--calibrated", action="store_true", help="diagnostic (not a BASELINE config): band gains /= 1 and offsets /= 0 on the "
+                    "T plane (the state after sample_calibrators and a fitted monopole): the plane-set launches must stay")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for rehearsing "
                                                       "the N>1 path with several ranks on ONE GPU)")
     args = ap.parse_args()
@@ -280,7 +285,9 @@ def main():
     shard_of = args.shard_of if (args.shard_of > 1 and world == 1) else 0
     dpar, ddata, bands, comps, meta = synth.make_sky(args.config, nside=args.nside, nbands=args.nbands, device=dev, rank=rank,
                                                      nranks=shard_of if shard_of else world, nsample=args.nsample, as_numpy=False,
-                                                     balance=not args.equal_shards)
+                                                     balance=not args.equal_shards,
+                                                     gain=[1.0 + 0.01 * ((j % 3) - 1) for j in range(args.nbands or synth.CONFIGS[args.config]["nbands"])] if args.calibrated else None,
+                                                     offset=[0.5 * ((j % 4) - 1.5) for j in range(args.nbands or synth.CONFIGS[args.config]["nbands"])] if args.calibrated else None)
     if args.bandpass > 0:
         import numpy as np
         for b in bands[1::2]:
@@ -303,23 +310,13 @@ def main():
         chisq_P = torch.zeros(2, dtype=torch.float64, device=dev)
     eng_of = (lambda f: engP if (two and f != 1) else eng)
 
-    # the first sampled (component, index) of every (CG group, flag): its sweep directly follows that group's solve on
-    # the same planes, and nothing else touches those planes in between -- the pair goes through ONE entry point
-    # (dangx_amp_index_sample: one kernel launch where the model allows it, bit for bit the two calls' result)
-    first_sweep = {}
-    if not args.no_fuse:
-        for g in dpar.cg_groups:
-            for f in g.pol_flag:
-                for l, c in enumerate(comps):
-                    hit = [j for j in range(c.nindices) if c.sample_index[j] and f in c.pol_flag[j]] if c.cg_group == g.cg_group else []
-                    if hit:
-                        first_sweep[(g.cg_group, f)] = (l, hit[0])
-                        break
+    # Which sweeps go with which solve: ONE rule for every Python host (da.plan_plane_sets = dangx_plan_fusion behind the ABI plus
+    # the foreign-flag guard): the first sampled (component, index) of a (CG group, flag) directly follows that group's solve on
+    # the same planes, and EVERY sweep on the group's planes follows it through the same entry point (dangx_plane_set_sample:
+    # one launch where the model allows it; for C3 it IS the fused solve + first sweep and the paired dust sweeps)
+    plane_sets = {} if args.no_fuse else da.plan_plane_sets(dpar, eng)
+    first_sweep = {k: v[0] for k, v in plane_sets.items()}
     fused_sweeps = set((l, j, f) for (grp, f), (l, j) in first_sweep.items())
-    # ... and EVERY sweep on the group's planes follows it through the same entry point (dangx_plane_set_sample: one launch for
-    # many-band, many-member models such as C5; for C3 it IS the fused solve + first sweep and the paired dust sweeps)
-    plane_sets = {(grp, f): [(l, j) for l, c in enumerate(comps) for j in range(c.nindices) if c.sample_index[j] and f in c.pol_flag[j]]
-                  for (grp, f) in first_sweep}
     in_plane_set = set((l, j, f) for (grp, f), lst in plane_sets.items() for l, j in lst)
     # what one iteration launches on the index side, for the byte accounting: (planes, index values written) per launch
     index_launches = []
@@ -429,6 +426,24 @@ def main():
         td.all_reduce(ones)   # every rank contributes 1 through the same process group the chi^2 uses
         ranks_seen = int(round(float(ones.item())))
     chisq = (chisq_buf / nb / ddata.nump).tolist()
+    gathered = None
+    if args.gather:
+        # map output (north_star: "a gather for map output"): the shards of two state maps to rank 0, reassembled with the SAME
+        # boundaries the sky was split by; the checksum (sum of the doubles' bit patterns mod 2^63) is what a one-rank run gives
+        from dang_amd import dist
+        lsyn = [l for l, c in enumerate(comps) if c.nindices == 1][0]
+        tg = time.perf_counter()
+        full = [dist.gather_maps(t, meta["npix_global"], dst=0, bounds=meta["bounds"]) for t in (comps[lsyn].amplitude, comps[lsyn].indices[0])]
+        fence()
+        if rank == 0:
+            ck = 0
+            for t in full:
+                assert t.shape[-1] == meta["npix_global"]
+                bits = t.contiguous().view(torch.int64)
+                ck = (ck + int((bits & 0x7FFFFFFF).sum().item()) + 3 * int(((bits >> 31) & 0x7FFFFFFF).sum().item())) % (1 << 62)
+            gathered = {"maps": "amplitude and index 0 of component %d (%s)" % (lsyn, comps[lsyn].label), "npix": meta["npix_global"],
+                        "bytes": sum(t.numel() * 8 for t in full), "ms": 1e3 * (time.perf_counter() - tg), "checksum": ck,
+                        "bounds": "work-balanced" if meta["bounds"] is not None else "equal ranges"}
 
     if rank == 0:
         # dominant kernel (largest total time on this rank) and its HBM roofline fraction
@@ -453,7 +468,7 @@ def main():
             bytes_per_launch = 8.0 * meta["npix"] * nmaps * ((2 * nb + nidx_ + 1 + nphys_) + (2 * nb + nphys_ + nidx_ + 1 + nidx_s_)) / launches_per_step
         achieved = bytes_per_launch / (prof[dom]["avg_ms"] * 1e-3) / 1e9
         standard = (world == 1 and args.nside is None and args.nbands is None and args.nsample == 10 and not args.bandpass
-                    and not shard_of and not args.no_fuse)   # what the committed profiles are of
+                    and not shard_of and not args.no_fuse and not args.calibrated)   # what the committed profiles are of
         # B_iter = 8 N_sp [(2nb + nidx + 1 + nc) + (2nb + nc + nidx + 1 + nidx_s)] over the WHOLE sky
         nphys = len(meta["phys"])
         nidx = sum(c.nindices for c in comps[:nphys])
@@ -476,7 +491,8 @@ def main():
                                        if args.bandpass else "") +
                                       ("; DIAGNOSTIC: %d bands instead of the configuration's; kernels specialised at run time: %s"
                                        % (args.nbands, ", ".join(eng.rtc_kernels()) or "none") if args.nbands else "") +
-                                      ("; DIAGNOSTIC: ONE rank's shard of a %d-rank run" % shard_of if shard_of else "")),
+                                      ("; DIAGNOSTIC: ONE rank's shard of a %d-rank run" % shard_of if shard_of else "") +
+                                      ("; DIAGNOSTIC: band gains /= 1 and offsets /= 0 on the T plane" if args.calibrated else "")),
                        "npix": meta["npix_global"], "chisq_after_amp": chisq[0], "chisq_after_index": chisq[1]},
             # The dominant kernel is bound by fp64 VECTOR ISSUE, not by HBM: achieved / peak / frac are that roofline -- vector
             # lane-operations per second (the instruction count of the committed SQ-counter profile x 64, per launch, over
@@ -496,6 +512,8 @@ def main():
             "kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"],
                             "ms_per_step": round(v["total_ms"] / args.steps, 4)} for k, v in prof.items()},
         }
+        if gathered is not None:
+            out["gather"] = gathered
         if world == 1 and not args.no_cpu_baseline:
             try:
                 log("timing the CPU oracle (cpu_baseline)")

@@ -743,6 +743,24 @@ def _planes(flag):
     return {L.FLAG_T: 1, L.FLAG_Q: 2, L.FLAG_U: 4, L.FLAG_QU: 6}.get(flag, 7)
 
 
+def plan_plane_sets(dpar, eng):
+    """{(cg_group, flag): [(component, index), ...]} -- for every solve that may be issued together with sweeps
+    (fusable_first_sweeps), the sweeps that go with it through ONE entry point (Engine.plane_set_sample): every sampled index
+    on the group's planes in the reference's order when all of them carry this flag and no sampled index of ANOTHER flag touches
+    one of the planes (a Q sweep beside a Q+U group would otherwise be reordered against src/dang_sample_mod.f90:40-75);
+    else only the first sweep.  The one place this rule lives for the Python hosts (sample_cg_groups, bench.py)."""
+    comps = eng.component_list
+    out = {}
+    for (grp, f), first in fusable_first_sweeps(dpar, eng).items():
+        same = [(l, j) for l, c in enumerate(comps) for j in range(c.nindices) if c.sample_index[j] and f in c.pol_flag[j]]
+        foreign = any(c.sample_index[j] and f2 != f and (_planes(f2) & _planes(f))
+                      for c in comps for j in range(c.nindices) for f2 in c.pol_flag[j])
+        if foreign or not same or same[0] != tuple(first):
+            same = [tuple(first)]        # another flag shares a plane: only the first sweep goes with the solve
+        out[(grp, f)] = same
+    return out
+
+
 def sample_cg_groups(dpar: DangParams, ddata: DangData, it=1, verbose=False, defer_chisq=False, fuse_first=None, it_index=None):
     """sample_cg_groups(dpar, ddata), src/dang_cg_mod.f90:142-177.
 
@@ -755,24 +773,18 @@ def sample_cg_groups(dpar: DangParams, ddata: DangData, it=1, verbose=False, def
     sample_spectral_parameters(skip=...).  See gibbs_iteration."""
     eng = ddata.engine
     info = []
-    fusable = fusable_first_sweeps(dpar, eng) if fuse_first is not None else {}
+    plane_sets = plan_plane_sets(dpar, eng) if fuse_first is not None else {}
     for g in dpar.cg_groups:
         if not g.sample:
             continue
         has_global = any(c.cg_group == g.cg_group and c.type in ("template", "monopole", "hi_fit") for c in eng.component_list)
         for f in g.pol_flag:
-            first = fusable.get((g.cg_group, f))
-            if first is not None:
+            same = plane_sets.get((g.cg_group, f))
+            if same is not None:
                 # the solve with EVERY sweep on its planes, in the reference's order (all of them are plain per-pixel sweeps and
                 # nothing else touches these planes, so pulling them forward leaves the loop's result unchanged): one entry
                 # point -- one launch for many-band, many-member models, the two-step fusions otherwise
                 iti = it if it_index is None else it_index
-                same = [(l, j) for l, c in enumerate(eng.component_list) for j in range(c.nindices)
-                        if c.sample_index[j] and f in c.pol_flag[j]]
-                foreign = any(c.sample_index[j] and f2 != f and (_planes(f2) & _planes(f))
-                              for c in eng.component_list for j in range(c.nindices) for f2 in c.pol_flag[j])
-                if foreign or same[0] != tuple(first):
-                    same = [tuple(first)]        # another flag shares a plane: only the first sweep goes with the solve
                 bad, accs = eng.plane_set_sample(g.cg_group, f, dpar.ml_mode, dpar.seed, stream_id(it, 0, g.cg_group, 0, f),
                                                  [(l, j, stream_id(iti, 1, l, j, f)) for l, j in same], dpar.nsample, dpar.seed,
                                                  solver=dpar.solver, fluct_mode=dpar.fluct_mode, i_max=g.i_max, converge=g.converge)

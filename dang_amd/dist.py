@@ -126,15 +126,23 @@ def allreduce_sum_(t):
     return t
 
 
-def gather_maps(local, npix_global, dst=0):
-    """Gather pixel-sharded maps [..., npix_local] to `dst` as [..., npix_global] (map output)."""
+def gather_maps(local, npix_global, dst=0, bounds=None):
+    """Gather pixel-sharded maps [..., npix_local] to `dst` as [..., npix_global] (map output; what the reference's write_maps
+    consumes, src/dang_data_mod.f90:573-664).  `bounds`: the shard boundaries b[0..nranks] the sky was split by (shard_range's
+    argument: balanced_bounds_run / balanced_bounds_mask, synth.make_sky's meta["bounds"]); None = equal ranges."""
     rank, n = world()
     if not active():
         return local
-    sizes = [shard_range(npix_global, r, n)[1] for r in range(n)]
+    if bounds is not None and (len(bounds) != n + 1 or int(bounds[0]) != 0 or int(bounds[-1]) != int(npix_global)):
+        raise ValueError("gather_maps: bounds must be the %d shard boundaries of a sky of %d pixels" % (n + 1, npix_global))
+    sizes = [shard_range(npix_global, r, n, bounds)[1] for r in range(n)]
+    if local.shape[-1] != sizes[rank]:
+        raise ValueError("gather_maps: rank %d holds %d pixels, its shard has %d (wrong bounds?)" % (rank, local.shape[-1], sizes[rank]))
+    if local.is_cuda and td.get_backend() != "nccl":
+        local = local.cpu()     # gloo gathers host tensors only (rehearsals of the N-rank path on one GPU)
     lead = local.shape[:-1]
-    # gloo and nccl both want equal-size tensors: shards of a pixel count that the rank count does not divide differ by
-    # one pixel, so every shard is padded to the largest and trimmed on dst
+    # gloo and nccl both want equal-size tensors: shards differ in size (by one pixel when the rank count does not divide the
+    # sky, by the masked run with work-balanced boundaries), so every shard is padded to the largest and trimmed on dst
     big = max(sizes)
     send = local.contiguous()
     if send.shape[-1] < big:

@@ -198,5 +198,6 @@ def make_sky(config="C1", nside=None, nbands=None, comps=None, nmaps=None, devic
     dpar = DangParams(ml_mode="sample", nsample=nsample, cg_groups=groups, seed=seed_sampler, solver=solver,
                       fluct_mode=fluct_mode)
     meta = dict(nside=nside, npix_global=npix_global, pix0=pix0, npix=npix, nbands=nbands, nmaps=nmaps,
-                ncomp=len(component_list), freqs_ghz=freqs, truth=truth, phys=phys)
+                ncomp=len(component_list), freqs_ghz=freqs, truth=truth, phys=phys,
+                bounds=bounds)   # shard boundaries (None = equal ranges): what dist.gather_maps needs to reassemble the sky
     return dpar, ddata, bands, component_list, meta

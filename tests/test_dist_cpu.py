@@ -100,3 +100,55 @@ def test_balanced_shard_boundaries():
         assert [dist.shard_range(npix, r, n, b) for r in range(n)] == [(b[r], b[r + 1] - b[r]) for r in range(n)]
     # equal ranges when nothing is masked
     assert dist.balanced_bounds_run(1000, 4, 0, 0) == [0, 250, 500, 750, 1000]
+
+
+def _balanced_worker(rank, world, port, out):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), here]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_ffi as O
+    from dang_amd import dist, synth, stream_id
+    # a mask off the centre of the RING order: the work-balanced shards are then all of different size
+    dpar, ddata, bands, comps, meta = synth.make_sky("C2", nside=8, rank=rank, nranks=world, start="truth", balance=True,
+                                                     mask_frac=(0.15, 0.40))
+    assert meta["bounds"] is not None and meta["npix"] == meta["bounds"][rank + 1] - meta["bounds"][rank]
+    orc = O.Oracle(bands, comps, ddata, pix0=meta["pix0"])
+    orc.amp_sample_direct(1, 1, "sample", dpar.seed, stream_id(1, 0, 1, 0, 1), "reference")
+    orc.sample_index_mh(1, 0, 1, 5, "sample", dpar.seed, stream_id(2, 1, 1, 0, 1))
+    amp = dist.gather_maps(torch.from_numpy(orc.amplitude(1)), meta["npix_global"], dst=0, bounds=meta["bounds"])
+    idx = dist.gather_maps(torch.from_numpy(orc.indices(1)), meta["npix_global"], dst=0, bounds=meta["bounds"])
+    err = None
+    b = meta["bounds"]
+    if all(b[r + 1] - b[r] != dist.shard_range(meta["npix_global"], r, world)[1] for r in range(world)):
+        # the equal-range sizes fit NO shard here (so no rank enters the collective): refused, not trimmed
+        try:
+            dist.gather_maps(torch.from_numpy(orc.amplitude(1)), meta["npix_global"], dst=0)
+        except ValueError as e:
+            err = str(e)
+    sizes = [None] * world
+    td.all_gather_object(sizes, (meta["npix"], err is not None))
+    if rank == 0:
+        np.savez(out, amp=amp.numpy(), idx=idx.numpy(), sizes=np.array([s[0] for s in sizes]), refused=np.array([s[1] for s in sizes]))
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_gather_maps_with_work_balanced_shard_boundaries(tmp_path):
+    """north_star's "gather for map output" with the boundaries bench.py and the Fortran MPI path shard by (equal unmasked pixel
+    count, dist.balanced_bounds_run): 5 ranks, shards of five different sizes; the gathered maps are the one-rank maps bit for
+    bit, and gather_maps refuses shards that do not fit the boundaries it was given."""
+    import oracle_ffi as O
+    from dang_amd import synth, stream_id
+    out = str(tmp_path / "bal.npz")
+    mp.spawn(_balanced_worker, args=(5, _free_port(), out), nprocs=5, join=True)
+    got = np.load(out)
+    assert len(set(got["sizes"].tolist())) >= 3 and got["sizes"].sum() == 12 * 8 * 8, got["sizes"]
+    assert got["refused"].all()
+    dpar, ddata, bands, comps, meta = synth.make_sky("C2", nside=8, start="truth", mask_frac=(0.15, 0.40))
+    orc = O.Oracle(bands, comps, ddata)
+    orc.amp_sample_direct(1, 1, "sample", dpar.seed, stream_id(1, 0, 1, 0, 1), "reference")
+    orc.sample_index_mh(1, 0, 1, 5, "sample", dpar.seed, stream_id(2, 1, 1, 0, 1))
+    assert np.array_equal(got["amp"], orc.amplitude(1))
+    assert np.array_equal(got["idx"], orc.indices(1))
