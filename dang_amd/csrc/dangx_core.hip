@@ -1857,9 +1857,14 @@ int dangx_sky_amp_sample(dangx_ctx* const* ctxs, int nctx, int group, int flag, 
     if (cg_iters) *cg_iters = 0;
     if (n_not_spd) *n_not_spd = 0;
     if (probe.nt == 0 && solver != DANGX_SOLVER_CG) {  // block diagonal: every shard on its own
-        for (int r = 0; r < nctx; ++r)
+        for (int r = 0; r < nctx; ++r) {
+            if (n_not_spd) {  // the amplitude kernels add to counters[0]: each context starts its launch from zero, on its own stream
+                (void)hipSetDevice(ctxs[r]->device);
+                HIPCHK(c0, hipMemsetAsync(ctxs[r]->counters, 0, sizeof(unsigned long long), ctxs[r]->stream));
+            }
             if (dangx_amp_sample(ctxs[r], group, flag, ml_mode, solver, fluct_mode, seed, stream, i_max, converge, nullptr, nullptr))
                 return bubble(ctxs[r]);
+        }
         if (n_not_spd)   // the counters are read after every device has its launch
             for (int r = 0; r < nctx; ++r) {
                 unsigned long long v = 0;

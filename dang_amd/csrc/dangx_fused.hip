@@ -93,9 +93,12 @@ static bool fused_args(dangx_ctx* ctx, const GroupArgs& ga, const IndexArgs& a, 
     }
     if (fa.gself < 0) return false;
     // band calibration in use (a gain /= 1 or an offset /= 0): the T-plane data are rescaled differently by the solve
-    // (d / gain) and by the chain ((d - offset) / gain); the kernel carries neither, such models take the two launches
-    for (int j = 0; j < ctx->hm.nbands; ++j)
-        if (ctx->hm.gain[j] != 1.0 || ctx->hm.offset[j] != 0.0) return false;
+    // (d / gain, src/dang_cg_mod.f90:371) and by the chain ((d - offset) / gain, src/dang_sample_mod.f90:174); the T launch reads
+    // both from the block's table, the Q / U / Q+U launches are not concerned
+    fa.cal = 0;
+    if (a.s1 == 1)
+        for (int j = 0; j < ctx->hm.nbands; ++j)
+            if (ctx->hm.gain[j] != 1.0 || ctx->hm.offset[j] != 0.0) fa.cal = 1;
     return true;
 }
 

@@ -63,8 +63,12 @@ static bool planeset_args(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& 
             fa.vslot[g] = (signed char)fa.nv++;
         }
     }
-    for (int j = 0; j < ctx->hm.nbands; ++j)
-        if (ctx->hm.gain[j] != 1.0 || ctx->hm.offset[j] != 0.0) return false;
+    // band calibration (src/dang_cg_mod.f90:371, src/dang_sample_mod.f90:174) only rescales the temperature plane: the Q / U / Q+U
+    // launches never see it, the T launch reads gain and offset from the block's table
+    fa.cal = 0;
+    if (sl.s1 == 1)
+        for (int j = 0; j < ctx->hm.nbands; ++j)
+            if (ctx->hm.gain[j] != 1.0 || ctx->hm.offset[j] != 0.0) fa.cal = 1;
     return true;
 }
 

@@ -10,6 +10,8 @@ struct FusedArgs {
     signed char vtype[MAXG];  // its component type (power law, modified blackbody, free-free or log-normal)
     int nv;                   // members with a column
     int gself;                // group member whose index is sampled
+    int cal;                  // the launch is on the temperature plane and some band has gain /= 1 or offset /= 0: the solve takes
+                              // d / gain (src/dang_cg_mod.f90:371), the chains (d - offset) / gain (src/dang_sample_mod.f90:174)
 };
 
 #ifndef DX_FUSED_WAVES
@@ -164,7 +166,8 @@ __global__ __launch_bounds__(BLOCK, DX_FUSED_WAVES(SP, NB)) void k_amp_index(con
             }
 #pragma unroll
             for (int j = 0; j < NBL; ++j) {
-                const double d = R.D[kk][j];  // the launcher takes this kernel only with unit gains and zero offsets (:371)
+                double d = R.D[kk][j];
+                if (SP == 1 && fa.cal) d = d / tab[(TROWS * NG + 1) * NB + jb + j];  // T / gain, no offset (:371)
                 const double is = fast_rcp(R.ISr[kk][j]);
                 R.set_is(kk, j, is);  // = CDIV(1.0, rms) of the chain's staging
                 const double inv = is * is;
@@ -233,6 +236,11 @@ __global__ __launch_bounds__(BLOCK, DX_FUSED_WAVES(SP, NB)) void k_amp_index(con
             }
             // ---- the chain's staged plane: data_raw (:173-177) minus every other component (:180-196), in
             // component_list order = member order; the members' SEDs are the ones the solve just used
+            if (SP == 1 && fa.cal) {  // data_raw = (sig - offset) / gain on the temperature plane (:174)
+                const double* gn = tab + (TROWS * NG + 1) * NB + jb;
+#pragma unroll
+                for (int j = 0; j < NBL; ++j) R.D[kk][j] = (R.D[kk][j] - gn[NB + j]) / gn[j];
+            }
             R.amp[kk] = 0.0;
 #pragma unroll
             for (int g = 0; g < NG; ++g) {

@@ -12,7 +12,7 @@
 // launches give, lane association of the band sums aside), and after its chain only the column of the member that moved is
 // evaluated again.  The maps are re-read per sweep (that is cheap: the kernels are bound by vector issue, not by HBM).
 //
-// Requirements checked by the launcher (dangx_planeset.hip): delta bands, unit gains / zero offsets, direct solver with the
+// Requirements checked by the launcher (dangx_planeset.hip): delta bands, direct solver with the
 // reference fluctuation term, every swept component an amplitude-sampled member of the group with a register-chain mode (chisq
 // likelihood, gaussian / uniform prior), no other component on the planes, and -- for Q+U -- index maps that are equal on the
 // two planes for every member that varies (true once a Q+U sweep has written them, :465; tracked on the host).
@@ -48,6 +48,11 @@ __device__ __forceinline__ void ps_stage(const Model& M, RegChain<MODE, SP, NBL,
             for (int j = 0; j < NBL; ++j) { R.D[kk][j] = sigp[(jb + j) * bstride]; rv[j] = rmsp[(jb + j) * bstride]; }
 #pragma unroll
             for (int j = 0; j < NBL; ++j) R.set_is(kk, j, fast_rcp(rv[j]));
+        }
+        if (SP == 1 && fa.cal) {  // data_raw = (sig - offset) / gain on the temperature plane (:174); R0 / the loads hold sig
+            const double* gn = tab + (TROWS * NG + 1) * NB + jb;
+#pragma unroll
+            for (int j = 0; j < NBL; ++j) R.D[kk][j] = (R.D[kk][j] - gn[NB + j]) / gn[j];
         }
         // the members' amplitudes on this plane: what THIS lane stored after the solve (both lanes of a pair store the same
         // values, so that neither reads memory its partner wrote)
@@ -202,7 +207,8 @@ __global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP)) void k_plane_set(co
             }
 #pragma unroll
             for (int j = 0; j < NBL; ++j) {
-                const double d = R0.D[kk][j];
+                double d = R0.D[kk][j];
+                if (SP == 1 && fa.cal) d = d / tab[(TROWS * NG + 1) * NB + jb + j];  // T / gain, no offset (:371)
                 const double is = fast_rcp(R0.ISr[kk][j]);
                 R0.set_is(kk, j, is);
                 const double inv = is * is;

@@ -1,0 +1,81 @@
+"""Round-4 additions (one test per review item, each against the oracle or an invariant of the path)."""
+import copy
+
+import numpy as np
+import pytest
+
+import dang_amd as da
+from dang_amd import _lib as L
+
+import oracle_ffi as O
+from util import MAPN, make_case, pair, shard_engines
+
+pytestmark = pytest.mark.gpu
+
+
+def test_non_spd_count_over_several_contexts_starts_from_zero(built):
+    """dangx_sky_amp_sample on a diffuse group over three contexts: the count of non-SPD pixel blocks ('left unchanged', what the
+    Fortran two-call path prints per group) is THIS call's, not the sum of every earlier launch on the contexts -- two calls
+    give the same count, and it is what the three contexts report one by one."""
+    def tweak(dpar, ddata, bands, comps):
+        # the dust set of the T group becomes a second synchrotron with the same index everywhere: identical SED columns, every
+        # block of group 1 exactly singular
+        comps[2].type, comps[2].nu_ref, comps[2].nindices = comps[1].type, comps[1].nu_ref, 1
+        comps[2].indices = comps[2].indices[:1].copy()
+        for q in ("ind_label", "sample_index", "index_mode", "lnl_type", "prior_type", "gauss_prior", "uni_prior", "step_size", "pol_flag"):
+            setattr(comps[2], q, copy.deepcopy(getattr(comps[1], q)))
+        comps[1].indices[:] = -3.0
+        comps[2].indices[:] = -3.0
+    case = make_case("C2", nside=4, start="truth", tweak=tweak)
+    engs = shard_engines(case, 3)
+    _, bad1 = da.sky_amp_sample(engs, 1, L.FLAG_T, "optimize", 8, 9)
+    _, bad2 = da.sky_amp_sample(engs, 1, L.FLAG_T, "optimize", 8, 9)
+    each = [e.amp_sample(1, L.FLAG_T, "optimize", 8, 9)[1] for e in engs]
+    assert bad1 > 0 and bad2 == bad1 == sum(each), (bad1, bad2, each)
+    # a regular group on the same contexts afterwards: zero, whatever the counters held
+    _, bad3 = da.sky_amp_sample(engs, 2, L.FLAG_QU, "optimize", 8, 9)
+    assert bad3 == 0
+
+
+@pytest.mark.parametrize("config,nside", [("C3", 8), ("C2", 8), ("C5", 4)])
+def test_plane_set_launches_stay_under_band_calibration(built, config, nside):
+    """Band gains /= 1 and offsets /= 0 (the state sample_calibrators and a fitted monopole leave in ddata%gain / ddata%offset):
+    the solve takes T / gain without the offset (src/dang_cg_mod.f90:371), the chains and chi^2 (T - offset) / gain
+    (src/dang_sample_mod.f90:174, src/dang_data_mod.f90:384), Q and U are never rescaled -- quirk 6.  Both plane sets must still be
+    ONE launch each (profile: nothing but the plane-set bucket and the chi^2 reductions), and the loop -- gibbs_iteration, then
+    sample_calibrators as src/dang.f90:101-111 orders them -- must match the oracle's loop in the reference's order."""
+    nb = {"C2": 5, "C3": 10, "C5": 20}[config]
+    gain = [1.0 + 0.01 * ((j % 3) - 1) for j in range(nb)]
+    offset = [0.5 * ((j % 4) - 1.5) for j in range(nb)]
+    case = make_case(config, nside=nside, start="truth", gain=gain, offset=offset)
+    dpar, ddata, bands, comps, meta = case
+    ddata.fit_gain = [(j % 2 == 1) for j in range(nb)]
+    eng, orc = pair(case)
+    ddata.gain = np.array(ddata.gain, dtype=np.float64)     # the oracle keeps its own copy of the calibration
+    for it in (2, 3):
+        eng.profile(True)
+        da.gibbs_iteration(dpar, ddata, it)
+        prof = eng.profile_get()
+        eng.profile(False)
+        assert set(prof) <= {"k_amp_index", "k_reduce"} and prof["k_amp_index"]["launches"] == 2, prof
+        for g in dpar.cg_groups:
+            orc.amp_sample_direct(g.cg_group, g.pol_flag[0], "sample", dpar.seed, da.stream_id(it, 0, g.cg_group, 0, g.pol_flag[0]), "reference")
+        for l, c in enumerate(comps):
+            for j in range(c.nindices):
+                if c.sample_index[j]:
+                    f = c.pol_flag[j][0]
+                    orc.sample_index_mh(l, j, MAPN[f], dpar.nsample, "sample", dpar.seed, da.stream_id(it, 1, l, j, f))
+        ochisq, _ = orc.chisq(1, 3, ddata.nump)
+        assert abs(ddata.chisq - ochisq) <= 1e-9 * ochisq, (it, ddata.chisq, ochisq)
+        # sample_calibrators (:487-518): the fitted bands' gains move, the next iteration runs on them
+        assert da.sample_calibrators(dpar, ddata, it=it)
+        for j in range(nb):
+            if ddata.fit_gain[j]:
+                go = orc.fit_band_gain(j, "sample", dpar.seed, da.stream_id(it, 2, 0, 0, 0))
+                assert abs(ddata.gain[j] - go) <= 1e-11 * abs(go), (it, j, ddata.gain[j], go)
+                orc.gain[j] = go
+    for l in range(len(comps)):
+        a, b = eng.get_amplitude(l), orc.amplitude(l)
+        assert np.abs(a - b).max() <= 1e-9 * max(np.abs(b).max(), 1e-30), l
+        if comps[l].nindices:
+            assert np.abs(eng.get_indices(l) - orc.indices(l)).max() <= 1e-12, l

@@ -55,3 +55,25 @@ def assert_indices_close(eng, orc, comps, tol=TOL_INDEX, what=""):
             a, b = eng.get_indices(l), orc.indices(l)
             d = np.abs(a - b).max()
             assert d <= tol, "component %d index mismatch %.3e > %.1e %s" % (l, d, tol, what)
+
+
+def shard_engines(case, nsh, bounds=None, device=0):
+    """`nsh` pixel-shard contexts of ONE process over the case's whole-sky host arrays (contiguous RING ranges, dist.shard_range),
+    each with its own copies of the state maps -- what dangx_multi_mod / the dangx_sky_* entry points drive."""
+    dpar, ddata, bands, comps, meta = case
+    engs = []
+    for r in range(nsh):
+        pix0, npix = da.dist.shard_range(meta["npix_global"], r, nsh, bounds)
+        sl = slice(pix0, pix0 + npix)
+        cs = copy.deepcopy(comps)
+        for c in cs:
+            c.amplitude = np.ascontiguousarray(c.amplitude[:, sl])
+            if c.indices is not None:
+                c.indices = np.ascontiguousarray(c.indices[:, :, sl])
+            if getattr(c, "template", None) is not None:
+                c.template = np.ascontiguousarray(c.template[:, sl])
+        dd = da.DangData(sig_map=np.ascontiguousarray(ddata.sig_map[:, :, sl]), rms_map=np.ascontiguousarray(ddata.rms_map[:, :, sl]),
+                         masks=np.ascontiguousarray(ddata.masks[:, sl]), gain=ddata.gain, offset=ddata.offset, pol_type=ddata.pol_type,
+                         nump=ddata.nump)
+        engs.append(da.Engine(bands, cs, dd, npix_global=meta["npix_global"], pix0=pix0, device=device))
+    return engs
