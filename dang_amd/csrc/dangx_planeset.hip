@@ -7,8 +7,10 @@
 #include "dx_host.h"
 #include "dx_kern_planeset.h"
 
-static size_t planeset_lds(int ng, int nb, int nv, int lanes) {
-    return ((size_t)(TROWS * ng + 3) * nb + (size_t)nv * (nb / lanes) * BLOCK) * sizeof(double);
+// Sp planes: the resident-residual form (DX_PS_RESIDENT: lane pairs) parks 1 / rms of the lane's bands in its column
+static size_t planeset_lds(int ng, int nb, int nv, int lanes, int Sp) {
+    const int rows = DX_PS_RESIDENT(lanes) ? (nv > Sp ? nv : Sp) : nv;
+    return ((size_t)(TROWS * ng + 3) * nb + (size_t)rows * (nb / lanes) * BLOCK) * sizeof(double);
 }
 
 // the sweep items as template arguments: chain mode + 8 for an item that carries the component's next index too, 0 = none
@@ -93,8 +95,8 @@ int dx_planeset_lanes(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl) 
     if (!planeset_args(ctx, ga, sl, fa)) return 0;
     // one lane where registers (cap) and the members' SED columns (two blocks per CU: 80 KB each) allow it, else lane pairs
     int lanes = 0;
-    if (small_too && nb <= cap && planeset_lds(ga.ng, nb, fa.nv, 1) <= 80u * 1024u) lanes = 1;
-    else if (nb > 12 && nb % 2 == 0 && nb / 2 <= cap && planeset_lds(ga.ng, nb, fa.nv, 2) <= 80u * 1024u) lanes = 2;
+    if (small_too && nb <= cap && planeset_lds(ga.ng, nb, fa.nv, 1, Sp) <= 80u * 1024u) lanes = 1;
+    else if (nb > 12 && nb % 2 == 0 && nb / 2 <= cap && planeset_lds(ga.ng, nb, fa.nv, 2, Sp) <= 80u * 1024u) lanes = 2;
     if (!lanes) return 0;
     if (planeset_builtin(nb, ga.ng, lanes, sl)) return lanes;
     return dx_rtc_get(ctx, "dx_kern_planeset.h", planeset_name(Sp, nb, ga.ng, lanes, sl)) ? lanes : 0;
@@ -105,7 +107,7 @@ bool dx_launch_planeset(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl
     FusedArgs fa;
     if (lanes < 1 || lanes > 2 || !planeset_args(ctx, ga, sl, fa)) return false;
     const int nb = ctx->hm.nbands, ng = ga.ng, Sp = sl.s2 - sl.s1 + 1;
-    const size_t ldsz = planeset_lds(ng, nb, fa.nv, lanes);
+    const size_t ldsz = planeset_lds(ng, nb, fa.nv, lanes, Sp);
     if (planeset_builtin(nb, ng, lanes, sl)) {
         if (nb == 20) launch_builtin<20, 6, 2, CH_POW, CH_MBB_BETA + 8, CH_LOGN_NUP>(ctx, ga, fa, sl, Sp, nblk, ldsz, accp);
         else if (nb == 10) launch_builtin<10, 4, 1, CH_POW, CH_MBB_BETA + 8, 0>(ctx, ga, fa, sl, Sp, nblk, ldsz, accp);

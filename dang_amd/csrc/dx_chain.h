@@ -104,8 +104,14 @@ struct RegChain {
     }
 
     // BATCH (CH_MBB_T only): the tile's Planck denominators share one reciprocal -- chain_finish decides once per chain
-    template <bool BATCH>
-    __device__ __forceinline__ double lnl(const Model& M, const Comp& c, double th, double other, double& acc0, double& acc1) const {
+    // OP: what the band loop does with the component's signal a/rms * s (the resident-residual form of k_plane_set, LNL_ADD /
+    // LNL_SUB: D holds the FULL residual (d - sum of all members) / rms between the sweeps of a launch):
+    //   LNL_EVAL  r = D - a' s, acc += r^2                      -- a likelihood evaluation (every proposal)
+    //   LNL_ADD   r = D, D += a' s, acc += r^2                  -- the chain's FIRST evaluation, at the current index values: the
+    //             member's own signal goes back into the cleaned data, and lnL of the current state is the residual's
+    //   LNL_SUB   D -= a' s                                      -- after the chain, at the values it ended on: the residual again
+    template <bool BATCH, int OP = 0>
+    __device__ __forceinline__ double lnl(const Model& M, const Comp& c, double th, double other, double& acc0, double& acc1) {
         double s0 = 0.0, s1 = 0.0;
         if (MODE == CH_POW) s0 = th;
         else if (MODE == CH_MBB_BETA) s0 = th + 1.0;
@@ -164,11 +170,25 @@ struct RegChain {
             for (int t = 0; t < TT; ++t) {
                 const int j = j0 + t;
 #ifdef DX_CHAIN_SCALED
+                if (OP == 1) {
+                    const double r0 = D[0][j];
+                    D[0][j] = fma(is(0, j), s[t], r0);
+                    acc0 = fma(r0, r0, acc0);
+                    if (SP == 2) {
+                        const double r1 = D[SP - 1][j];
+                        D[SP - 1][j] = fma(is(SP - 1, j), s[t], r1);
+                        acc1 = fma(r1, r1, acc1);
+                    }
+                } else if (OP == 2) {
+                    D[0][j] = fma(-is(0, j), s[t], D[0][j]);
+                    if (SP == 2) D[SP - 1][j] = fma(-is(SP - 1, j), s[t], D[SP - 1][j]);
+                } else {
                 const double r0 = fma(-is(0, j), s[t], D[0][j]);
                 acc0 = fma(r0, r0, acc0);
                 if (SP == 2) {
                     const double r1 = fma(-is(SP - 1, j), s[t], D[SP - 1][j]);
                     acc1 = fma(r1, r1, acc1);
+                }
                 }
 #else
                 const double r0 = (D[0][j] - amp[0] * s[t]) * is(0, j);
@@ -180,6 +200,7 @@ struct RegChain {
 #endif
             }
         }
+        if (OP == 2) return 0.0;
         if (LP > 1) {  // the other half's band sum: a + b on one lane, b + a on the other -- the same value
             acc0 += __shfl_xor(acc0, 1, 64);
             if (SP == 2) acc1 += __shfl_xor(acc1, 1, 64);
@@ -285,7 +306,9 @@ __device__ __forceinline__ void subtract_other_pair(const Model& M, const Comp& 
 // the lane's bands and the component's amplitudes; sample0/1 are its two current index values on the first plane.
 // SCALE = false: the planes are already d/rms and amp/rms (a second chain of the same component on the same planes,
 // k_index_mh_pair); final_value (nullable) receives the value the chain ends at.
-template <int MODE, int SP, int NB, int LP, bool SCALE = true, class RC>
+// ADD / SUB (k_plane_set's resident-residual form, see RegChain::lnl): R.D arrives as the full residual and the first evaluation
+// puts the component's own signal back (ADD); after the chain the signal at the values it ended on is taken out again (SUB).
+template <int MODE, int SP, int NB, int LP, bool SCALE = true, bool ADD = false, bool SUB = false, class RC>
 __device__ __forceinline__ unsigned long long chain_finish(const Model& M, const IndexArgs& a, const Comp& c, RC& R,
                                                            const BandPick<LP>& pick, double sample0, double sample1, int i, int half,
                                                            double chi[4], double* final_value = nullptr) {
@@ -333,7 +356,7 @@ __device__ __forceinline__ unsigned long long chain_finish(const Model& M, const
     const double step = c.step[q], lo = c.uni[q][0], hi = c.uni[q][1];
     auto chain = [&](auto batch_tag) {
         constexpr bool B = decltype(batch_tag)::value;
-        double lnl = R.template lnl<B>(M, c, cur, other, a0, a1);
+        double lnl = R.template lnl<B, ADD ? 1 : 0>(M, c, cur, other, a0, a1);
         chi[0] = -2.0 * a0; chi[1] = -2.0 * a1;
         double lnl_old = lnl + prior(cur);
         if (LP == 1 || DX_CHAIN_PAIR_RNG == 0) {
@@ -370,6 +393,7 @@ __device__ __forceinline__ unsigned long long chain_finish(const Model& M, const
                 if (l + 1 <= a.nsample) mh_step(half == 0 ? go : g, half == 0 ? uo : u3);  // step l + 1: the odd lane's
             }
         }
+        if (SUB) { double u0_, u1_; (void)R.template lnl<B, 2>(M, c, cur, other, u0_, u1_); }
     };
 #ifdef DX_CHAIN_NO_BATCH_RCP
     chain(BoolTag<false>{});

@@ -24,6 +24,20 @@
 #define DX_PS_WAVES(SP, NB, LP) (((NB) / (LP) <= 5) ? 3 : 2)
 #endif
 
+// Resident-residual form (lane pairs by default): between the sweeps of a launch the lane keeps the FULL residual
+// (d - sum over every member) / rms of its bands in registers and 1 / rms in its LDS column (the SED columns are dead once the
+// solve has used them): a sweep's cleaned data are residual + own signal (added back by the chain's first likelihood evaluation,
+// which needs the member's SED at the current index values anyway), and after the chain the signal at the values it ended on
+// is taken out again.  Nothing is re-read from HBM between the sweeps, no reciprocal of the rms is formed twice, and "every other
+// component" (src/dang_sample_mod.f90:180-196) is removed once instead of once per sweep.  The cleaned data differ from the
+// re-staged ones by the rounding of one more addition (|d| eps): the parity tolerance of the index maps, not bit for bit --
+// which is why the one-lane instantiations, whose tests hold them bit for bit to the separate launches, keep re-staging
+// (-DDX_PS_RESIDENT_ALL=1 for A/B timing).
+#ifndef DX_PS_RESIDENT_ALL
+#define DX_PS_RESIDENT_ALL 0
+#endif
+#define DX_PS_RESIDENT(LP) ((LP) > 1 || DX_PS_RESIDENT_ALL)
+
 namespace dxk {
 
 template <int V> struct ItemCode { static constexpr int value = V; };
@@ -79,6 +93,72 @@ __device__ __forceinline__ void ps_stage(const Model& M, RegChain<MODE, SP, NBL,
 
 // one item of the sweep list for member gself: stage, chain (and the paired chain of index nind + 1 on the same staged planes,
 // as index_chain_pair does), count; leaves the member's two index values in sample0 / sample1
+// The same item in the resident-residual form: R0.D holds the full residual / rms of the lane's bands, the lane's LDS column
+// rows 0 .. SP*NBL-1 hold 1 / rms.  LAST: nothing follows, the residual need not be restored.
+template <int MODE, int PAIR, int SP, int NBL, int LP, int NG, bool FIRST, bool LAST, typename RFirst>
+__device__ __forceinline__ void ps_item_res(const Model& M, const SweepList& sl, const SweepItem& it, RFirst& R0, int i, int half,
+                                            int jb, int NB, const double* __restrict__ tab, const double* __restrict__ col,
+                                            double& sample0, double& sample1, double chi_first[4],
+                                            double chi_last[4], unsigned long long* __restrict__ accepted, int slot) {
+    const Comp& c = M.comp[it.comp];
+    const BandPick<LP> pick = {half};
+    const int npix = M.npix;
+    IndexArgs a;
+    a.comp = it.comp; a.nind = it.nind; a.s1 = sl.s1; a.s2 = sl.s2; a.nsample = sl.nsample; a.ml_mode = sl.ml_mode; a.mode = MODE;
+    a.bp = 0; a.others = 0u; a.seed = sl.seed; a.stream = it.stream;
+    RegChain<MODE, SP, NBL, LP, true> R;
+    R.set_kt(tab, NB, NG, it.gmember, jb);
+    // the column is read through an address the compiler cannot trace back to the stores after the solve: forwarded, the
+    // SP * NBL values of 1 / rms would stay in registers across every chain of the launch (100 spilled registers)
+    int zo = 0;
+    asm volatile("" : "+v"(zo));   // (an offset of zero: the pointer stays an LDS pointer)
+    const double* colr = col + zo;
+#pragma unroll
+    for (int kk = 0; kk < SP; ++kk) {
+        R.amp[kk] = c.amp[(long long)(sl.s1 + kk - 1) * npix + i];   // what this lane stored after the solve
+#pragma unroll
+        for (int j = 0; j < NBL; ++j) { R.D[kk][j] = R0.D[kk][j]; R.ISr[kk][j] = colr[(kk * NBL + j) * BLOCK] * R.amp[kk]; }
+    }
+    double chia[4] = {0.0, 0.0, 0.0, 0.0}, va;
+    unsigned long long na = chain_finish<MODE, SP, NBL, LP, false, true, (!PAIR && !LAST)>(M, a, c, R, pick, sample0, sample1, i, half, chia, &va);
+    if (it.nind == 0) sample0 = va; else sample1 = va;
+    if (FIRST) { chi_first[0] = chia[0]; chi_first[1] = chia[1]; }
+    chi_last[2] = chia[2]; chi_last[3] = chia[3];
+    unsigned long long nb_ = 0ull;
+    if (PAIR) {
+        constexpr int MODEB = (MODE == CH_MBB_BETA || MODE == CH_LOGN_NUP) ? MODE + 1 : MODE;
+        RegChain<MODEB, SP, NBL, LP, true> RB;
+        RB.set_kt(tab, NB, NG, it.gmember, jb);
+#pragma unroll
+        for (int kk = 0; kk < SP; ++kk) {
+            RB.amp[kk] = R.amp[kk];
+#pragma unroll
+            for (int j = 0; j < NBL; ++j) { RB.D[kk][j] = R.D[kk][j]; RB.ISr[kk][j] = R.ISr[kk][j]; }
+        }
+        IndexArgs b = a;
+        b.nind = it.nind + 1; b.stream = it.stream2; b.mode = MODEB;
+        double chib[4] = {0.0, 0.0, 0.0, 0.0}, vb;
+        nb_ = chain_finish<MODEB, SP, NBL, LP, false, false, !LAST>(M, b, c, RB, pick, sample0, sample1, i, half, chib, &vb);
+        if (b.nind == 0) sample0 = vb; else sample1 = vb;
+        chi_last[2] = chib[2]; chi_last[3] = chib[3];
+        if (!LAST) {
+#pragma unroll
+            for (int kk = 0; kk < SP; ++kk)
+#pragma unroll
+                for (int j = 0; j < NBL; ++j) R0.D[kk][j] = RB.D[kk][j];
+        }
+    } else if (!LAST) {
+#pragma unroll
+        for (int kk = 0; kk < SP; ++kk)
+#pragma unroll
+            for (int j = 0; j < NBL; ++j) R0.D[kk][j] = R.D[kk][j];
+    }
+    if (accepted) {
+        if (na) atomicAdd(accepted + slot, na);
+        if (nb_) atomicAdd(accepted + slot + 1, nb_);
+    }
+}
+
 template <int MODE, int PAIR, int SP, int NBL, int LP, int NG, bool FIRST, typename RFirst>
 __device__ __forceinline__ void ps_item(const Model& M, const SweepList& sl, const SweepItem& it, const FusedArgs& fa, RFirst& R0, int i, int half,
                                         int jb, int NB, const double* __restrict__ tab, const double* __restrict__ col,
@@ -138,7 +218,8 @@ __global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP)) void k_plane_set(co
                                                         unsigned long long* __restrict__ not_spd, unsigned long long* __restrict__ accepted,
                                                         double* __restrict__ chi_partial) {
     constexpr int NBL = NB / LP;
-    extern __shared__ double lds[];  // [constant table | per-lane columns: nv*NBL rows of SEDs]
+    constexpr bool RES = DX_PS_RESIDENT(LP);
+    extern __shared__ double lds[];  // [constant table | per-lane columns: nv*NBL rows of SEDs (RES: at least SP*NBL rows)]
     const Model& M = *Mp;
     const int npix = M.npix, tid = threadIdx.x;
     double* tab = lds;
@@ -270,11 +351,54 @@ __global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP)) void k_plane_set(co
                 for (int g = 0; g < NG; ++g) M.comp[ga.gc[g]].amp[(long long)(k - 1) * npix + i] = bv[g];
             } else {
                 if (half == 0) atomicAdd(not_spd, 1ull);  // x keeps its value: the sweeps run on the old amplitudes
+                if (RES) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) bv[g] = M.comp[ga.gc[g]].amp[(long long)(k - 1) * npix + i];
+                }
             }
+            if (RES) {
+                if (SP == 1 && fa.cal) {
+                    const double* gn = tab + (TROWS * NG + 1) * NB + jb;
+#pragma unroll
+                    for (int j = 0; j < NBL; ++j) R0.D[kk][j] = (R0.D[kk][j] - gn[NB + j]) / gn[j];
+                }
+                // the plane's full residual in units of the rms: data_raw (:173-177) minus EVERY member in component_list order
+                // (:180-196 removes all but the sampled one; its own signal returns in the chain's first evaluation).  Member by member,
+                // each through ONE base address and compile-time offsets (a run-time stride costs one address register per load: the
+                // solve's band loop above pays that)
+                const int zo = 0;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const double amp2 = bv[g];
+                    if (fa.vslot[g] >= 0) {
+                        const double* m = col + (fa.vslot[g] * NBL) * BLOCK + zo;
+#pragma unroll
+                        for (int j = 0; j < NBL; ++j) R0.D[kk][j] -= amp2 * m[j * BLOCK];
+                    } else {
+                        const double* m = tab + (TROWS * g + 2 + k) * NB + jb + zo;
+#pragma unroll
+                        for (int j = 0; j < NBL; ++j) R0.D[kk][j] -= amp2 * m[j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NBL; ++j) {
+                    R0.D[kk][j] *= R0.ISr[kk][j];
+                    // pinned here: the optimiser otherwise sinks this arithmetic below the next plane's solve (its result is first
+                    // used by the chains) while the column reads stay, and NG * NBL loaded values are spilled across that solve
+                    asm volatile("" : "+v"(R0.D[kk][j]));
+                }
+            }
+        }
+        if (RES) {  // 1 / rms of the lane's bands -> its LDS column (the SED columns are dead from here on)
+#pragma unroll
+            for (int kk = 0; kk < SP; ++kk)
+#pragma unroll
+                for (int j = 0; j < NBL; ++j) col[(kk * NBL + j) * BLOCK] = R0.ISr[kk][j];
+            __builtin_amdgcn_sched_barrier(0);  // the first chain's prologue (random numbers, 1/rms x amplitude) stays below: 1/rms is dead here
         }
         // ---- the sweeps of the plane set, in the reference's order.  The first one reuses the solve's map registers (R0).
         int slot = 0;
-        auto run = [&](auto code_tag, auto first_tag, int q) {
+        auto run = [&](auto code_tag, auto first_tag, auto last_tag, int q) {
             constexpr int CODE = decltype(code_tag)::value;
             constexpr bool FIRST = decltype(first_tag)::value;
             if constexpr (CODE != 0) {
@@ -283,18 +407,25 @@ __global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP)) void k_plane_set(co
                 double sample0, sample1, unused[4];
                 // a component's sweeps are consecutive and travel in ONE item: no lane reads here what its partner wrote
                 load_theta(M, c, i, sl.s1, sample0, sample1);
+                if constexpr (RES) {
+                    constexpr bool LAST = decltype(last_tag)::value;
+                    ps_item_res<(CODE & 7), (CODE >> 3), SP, NBL, LP, NG, FIRST, LAST>(M, sl, it, R0, i, half, jb, NB, tab, col, sample0, sample1,
+                                                                                      FIRST ? chi : unused, chi, accepted, slot);
+                    slot += 1 + (CODE >> 3);
+                } else {
                 ps_item<(CODE & 7), (CODE >> 3), SP, NBL, LP, NG, FIRST>(M, sl, it, fa, R0, i, half, jb, NB, tab, col, ga, sample0, sample1,
                                                                         FIRST ? chi : unused, chi, accepted, slot);
                 slot += 1 + (CODE >> 3);
                 // the member that moved: its SED column at the new indices (both lanes hold the same values)
                 if (q + 1 < sl.n && fa.vslot[it.gmember] >= 0)
                     sed_column<NBL>(c.type, tab, NB, NG, it.gmember, jb, sed_prep(c, sample0, sample1), col + (fa.vslot[it.gmember] * NBL) * BLOCK);
+                }
             }
         };
-        run(ItemCode<C0>{}, ItemFirst<true>{}, 0);
-        run(ItemCode<C1>{}, ItemFirst<false>{}, 1);
-        run(ItemCode<C2>{}, ItemFirst<false>{}, 2);
-        run(ItemCode<C3>{}, ItemFirst<false>{}, 3);
+        run(ItemCode<C0>{}, ItemFirst<true>{}, ItemFirst<C1 == 0>{}, 0);
+        run(ItemCode<C1>{}, ItemFirst<false>{}, ItemFirst<C2 == 0>{}, 1);
+        run(ItemCode<C2>{}, ItemFirst<false>{}, ItemFirst<C3 == 0>{}, 2);
+        run(ItemCode<C3>{}, ItemFirst<false>{}, ItemFirst<true>{}, 3);
     }
     if (chi_partial) {
         __shared__ double sh[4][BLOCK / 64];
