@@ -24,17 +24,18 @@
 #define DX_PS_WAVES(SP, NB, LP) (((NB) / (LP) <= 5) ? 3 : 2)
 #endif
 
-// Resident-residual form (lane pairs by default): between the sweeps of a launch the lane keeps the FULL residual
-// (d - sum over every member) / rms of its bands in registers and 1 / rms in its LDS column (the SED columns are dead once the
-// solve has used them): a sweep's cleaned data are residual + own signal (added back by the chain's first likelihood evaluation,
-// which needs the member's SED at the current index values anyway), and after the chain the signal at the values it ended on
-// is taken out again.  Nothing is re-read from HBM between the sweeps, no reciprocal of the rms is formed twice, and "every other
-// component" (src/dang_sample_mod.f90:180-196) is removed once instead of once per sweep.  The cleaned data differ from the
-// re-staged ones by the rounding of one more addition (|d| eps): the parity tolerance of the index maps, not bit for bit --
-// which is why the one-lane instantiations, whose tests hold them bit for bit to the separate launches, keep re-staging
-// (-DDX_PS_RESIDENT_ALL=1 for A/B timing).
+// Resident-residual form: between the sweeps of a launch the lane keeps the FULL residual (d - sum over every member) / rms of
+// its bands in registers and 1 / rms in its LDS column (the SED columns are dead once the solve has used them): a sweep's cleaned
+// data are residual + own signal (added back by the chain's first likelihood evaluation, which needs the member's SED at the
+// current index values anyway), and after the chain the signal at the values it ended on is taken out again.  Nothing is re-read
+// from HBM between the sweeps, no reciprocal of the rms is formed twice, and "every other component"
+// (src/dang_sample_mod.f90:180-196) is removed once instead of once per sweep.  The cleaned data differ from the re-staged ones by
+// the rounding of one more addition (|d| eps): same proposals, an accept decision could differ only where |diff - ln u| is of that
+// size, chi^2 sums agree to rounding -- the parity tolerance, no longer bit for bit the separate launches.
+// Measured on one device (tools/ab_bench.sh): C5 126.6 -> 112.5 ms, C3 11.7 -> 11.1 ms, C2 +4 %.
+// -DDX_PS_RESIDENT_ALL=0 keeps re-staging in the one-lane instantiations (A/B timing).
 #ifndef DX_PS_RESIDENT_ALL
-#define DX_PS_RESIDENT_ALL 0
+#define DX_PS_RESIDENT_ALL 1
 #endif
 #define DX_PS_RESIDENT(LP) ((LP) > 1 || DX_PS_RESIDENT_ALL)
 

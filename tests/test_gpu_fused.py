@@ -171,8 +171,8 @@ def test_index_sample_pair_equals_the_two_sweeps_bitwise(built, config, nside, m
 @pytest.mark.parametrize("config,nside", [("C3", 8), ("C2", 8)])
 def test_python_mirror_gibbs_iteration_equals_the_two_phases(built, config, nside):
     """da.gibbs_iteration (solves issued with the first sweeps, consecutive indices paired) against da.sample_cg_groups +
-    a sample_spectral_parameters that makes every sweep on its own: same state and same chi^2 after each of three
-    iterations, bit for bit."""
+    a sample_spectral_parameters that makes every sweep on its own: the same state, bit for bit, and the same chi^2 to rounding
+    after each of three iterations."""
     case_a = make_case(config, nside=nside)
     case_b = make_case(config, nside=nside)
     for case in (case_a, case_b):
@@ -192,7 +192,9 @@ def test_python_mirror_gibbs_iteration_equals_the_two_phases(built, config, nsid
             assert np.array_equal(dda.engine.get_amplitude(l), eng.get_amplitude(l)), (it, l)
             if c.nindices:
                 assert np.array_equal(dda.engine.get_indices(l), eng.get_indices(l)), (it, l)
-        assert dda.engine.chisq_cached(1, 1, 3) == eng.chisq_cached(1, 1, 3)
+        # (the plane-set launch keeps the residual between its sweeps instead of re-staging the maps: same proposals, same accept
+        # decisions, same maps -- the chi^2 sums agree to the rounding of the residuals)
+        assert abs(dda.engine.chisq_cached(1, 1, 3) - eng.chisq_cached(1, 1, 3)) <= 1e-12 * eng.chisq_cached(1, 1, 3)
         assert dda.chisq == dda.engine.chisq_cached(1, 1, 3) / case_a[4]["nbands"] / dda.nump
 
 
@@ -295,7 +297,8 @@ def test_plane_set_launch_against_the_oracle(built, nbands):
 
 
 def test_plane_set_entry_is_the_separate_calls_where_the_kernel_does_not_apply(built):
-    """C3 (10 bands): dangx_plane_set_sample IS dangx_amp_index_sample + dangx_index_sample_pair -- bit for bit the separate calls"""
+    """C3 (10 bands): dangx_plane_set_sample against dangx_amp_sample + dangx_index_sample per sweep: the same maps, bit for bit
+    (same proposals, same accept decisions), the same accepted counts, chi^2 by-products equal to rounding"""
     case = make_case("C3", nside=8, start="truth")
     dpar, ddata, bands, comps, meta = case
     one, two = _engines(case)
@@ -312,8 +315,8 @@ def test_plane_set_entry_is_the_separate_calls_where_the_kernel_does_not_apply(b
             assert np.array_equal(one.get_amplitude(l), two.get_amplitude(l)), l
             if c.nindices:
                 assert np.array_equal(one.get_indices(l), two.get_indices(l)), l
-        for which in (0, 1):
-            assert one.chisq_cached(which, 1, 3) == two.chisq_cached(which, 1, 3)
+        for which in (0, 1):   # maps bit for bit; the sums from the resident residual agree with the re-staged ones to rounding
+            assert abs(one.chisq_cached(which, 1, 3) - two.chisq_cached(which, 1, 3)) <= 1e-12 * two.chisq_cached(which, 1, 3)
 
 
 def test_c5_gibbs_iteration_matches_the_oracle_loop(built):
