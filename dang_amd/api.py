@@ -375,6 +375,19 @@ class Engine:
             C.byref(bad) if want_counts else None, acc.ctypes.data if want_counts else None))
         return bad.value, [int(a) for a in acc]
 
+    def plane_sweeps_sample(self, flag, sweeps, nsample, ml_mode, seed, want_counts=True):
+        """index_sample(comp, nind, map_n of the flag, ...) for every (comp, nind, stream) of `sweeps` -- the passes of
+        sample_spectral_parameters on ONE plane set, in the reference's order (dangx_plane_sweeps_sample: one launch on the
+        amplitudes in memory where the plane-set kernel covers the model, those calls otherwise).  Returns accepted counts."""
+        n = len(sweeps)
+        comp = np.ascontiguousarray([s[0] for s in sweeps], dtype=np.int32)
+        nind = np.ascontiguousarray([s[1] for s in sweeps], dtype=np.int32)
+        strm = np.ascontiguousarray([s[2] for s in sweeps], dtype=np.uint64)
+        acc = np.zeros(n, dtype=np.int64)
+        self._chk(self.lib.dangx_plane_sweeps_sample(self.h, flag, n, comp.ctypes.data, nind.ctypes.data, strm.ctypes.data, nsample,
+                                                     L.ML_CODES[ml_mode], seed, acc.ctypes.data if want_counts else None))
+        return [int(a) for a in acc]
+
     def sky_model_chisq(self, pol_lo, pol_hi, want_maps=False):
         s = C.c_double(0.0)
         if want_maps:
@@ -705,7 +718,9 @@ def sky_amp_sample(engines, group, flag, ml_mode, seed, stream, solver="direct",
 def compute_chisq(ddata):
     """update_sky_model + compute_chisq (src/dang_data_mod.f90:339-396, 494-526); all-reduced over shards."""
     eng = ddata.engine
-    s = eng.sky_model_chisq(ddata.pol_type[0], ddata.pol_type[-1])
+    # the sums the last solve / sweep on each plane left behind (by-products of those launches), one pass over the planes that
+    # have none (dangx_chisq_current); Engine.sky_model_chisq is the explicit pass with the map outputs
+    s = eng.chisq_current(ddata.pol_type[0], ddata.pol_type[-1])
     s = _dist.allreduce_sum_float(s)
     ddata.chisq = s / eng.nbands / ddata.nump
     return ddata.chisq

@@ -1452,6 +1452,7 @@ int ensure_state(dangx_ctx* ctx, int comp) {
         HIPCHK(ctx, hipMemset(ctx->idx[comp], 0, plane * nind));
         ctx->own_idx[comp] = true; ctx->dirty = true;
         ctx->qu_equal[comp] = (1u << nind) - 1u;
+        idx_written(ctx, comp);
     }
     return 0;
 }
@@ -1641,6 +1642,7 @@ int dangx_upload_data(dangx_ctx* ctx, const double* sig, const double* rms, cons
         return 1;
     ctx->dirty = true;
     invalidate_chi(ctx);
+    idx_written(ctx, -1);   // a new mask
     return 0;
 }
 
@@ -1652,6 +1654,7 @@ int dangx_adopt_device_data(dangx_ctx* ctx, const double* sig, const double* rms
     ctx->mask = const_cast<double*>(mask);
     ctx->dirty = true;
     invalidate_chi(ctx);
+    idx_written(ctx, -1);
     return 0;
 }
 
@@ -1672,6 +1675,7 @@ int dangx_put_indices(dangx_ctx* ctx, int comp, const double* ind) {
     if (!ctx || !ind || check_comp(ctx, comp) || ensure_state(ctx, comp)) return 1;
     if (!ctx->idx[comp]) return fail(ctx, "component has no indices");
     invalidate_chi(ctx);
+    idx_written(ctx, comp);
     {   // planes on which every index map is spatially constant
         const long long np = ctx->dims.npix;
         ctx->idx_const[comp] = 0;
@@ -1750,6 +1754,8 @@ int dangx_adopt_device_state(dangx_ctx* ctx, int comp, double* amp_dev, double* 
         ctx->plane_nz[comp] = f;
     }
     ctx->idx[comp] = (ctx->desc[comp].nindices > 0) ? idx_dev : nullptr; ctx->own_idx[comp] = false;
+    ctx->idx_ext[comp] = true;   // the caller may write these maps at any time
+    idx_written(ctx, comp);
     ctx->idx_const[comp] = 0;
     if (ctx->idx[comp]) {   // planes on which every index map is spatially constant (one small kernel, once)
         const int nind = ctx->desc[comp].nindices, nmaps = ctx->dims.nmaps;
@@ -1795,6 +1801,9 @@ int64_t dangx_group_size(dangx_ctx* ctx, int group, int flag) {
     return (int64_t)a.ng * flag_planes_h(flag) * ctx->hm.npix + a.nglob;
 }
 
+static int planeset_launch(dangx_ctx* ctx, const GroupArgs& g, const SweepList& sl, int lanes, int solve, int64_t* n_not_spd, int64_t* accepted);
+static bool planeset_group(dangx_ctx* ctx, const GroupArgs& g);
+
 int dangx_amp_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed,
                      uint64_t stream, int i_max, double converge, int* cg_iters, int64_t* n_not_spd) {
     if (!ctx) return 1;
@@ -1828,6 +1837,20 @@ int dangx_amp_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solve
     if (ctx->defer_amp) {  // dangx_amp_index_sample: the launch waits for the index sweep it is fused with
         ctx->pending = a; ctx->pending_SN = SN; ctx->have_pending = true;
         return 0;
+    }
+    // The amplitude phase with chi^2 of the state it leaves as a by-product (src/dang_cg_mod.f90:172-173 asks for it after every
+    // group): the plane-set kernel without sweep items forms the residual of the new amplitudes anyway -- where it covers the
+    // model (delta bands, the group's members the only components on the planes, reference fluctuation term) the statistics need
+    // no pass of their own over the maps.  DANGX_AMP_CHI=0: the stand-alone amplitude kernel (A/B timing).
+    static const bool with_chi = [] { const char* e = getenv("DANGX_AMP_CHI"); return !(e && e[0] == '0'); }();
+    if (with_chi && ctx->hm.all_delta != 0 && (ml_mode == DANGX_ML_OPTIMIZE || fluct_mode == DANGX_FLUCT_REFERENCE) && planeset_group(ctx, a)) {
+        SweepList sl;
+        std::memset(&sl, 0, sizeof(sl));
+        sl.s1 = (flag & DANGX_FLAG_QU) ? 2 : (flag & DANGX_FLAG_T) ? 1 : (flag & DANGX_FLAG_Q) ? 2 : 3;
+        sl.s2 = (flag & DANGX_FLAG_QU) ? 3 : sl.s1;
+        sl.ml_mode = ml_mode;
+        const int lanes = dx_planeset_lanes(ctx, a, sl, 1);
+        if (lanes) return planeset_launch(ctx, a, sl, lanes, 1, n_not_spd, nullptr);
     }
     if (n_not_spd) HIPCHK(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));
     if (dx_launch_amp(ctx, a, SN)) return 1;
@@ -1974,6 +1997,7 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
         unsigned touched = 0;
         if (map_n == -1) touched = 6u; else if (map_n >= 1 && map_n <= 3) touched = 1u << (map_n - 1);
         if (ctx->idx_const[comp] & touched) { ctx->idx_const[comp] &= ~touched; ctx->dirty = true; }
+        idx_written(ctx, comp);
         if (nind >= 0 && nind < DANGX_MAX_IND) {  // a Q+U sweep writes one value to both planes (:465); a Q or U sweep to one
             if (map_n == -1) ctx->qu_equal[comp] |= 1u << nind;
             else if (map_n == 2 || map_n == 3) ctx->qu_equal[comp] &= ~(1u << nind);
@@ -2181,6 +2205,102 @@ int dangx_amp_index_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int
     return 0;
 }
 
+// One k_plane_set launch (dx_kern_planeset.h) with its bookkeeping: solve = 1 starts with the group's amplitude solve (what
+// dangx_amp_sample records: the planes' cached chi^2 is stale, the members' amplitudes are about to be written), sl.n sweep items
+// follow (what dangx_index_sample records per sweep).  The chi^2 by-products go to the ring: with a solve "before" = the state the
+// solve leaves and "after" = the last sweep's (both the same value without sweeps); without, as for any sweep.
+static int planeset_launch(dangx_ctx* ctx, const GroupArgs& g, const SweepList& sl, int lanes, int solve, int64_t* n_not_spd, int64_t* accepted) {
+    const bool qu = sl.s2 > sl.s1;
+    bool wb = true;
+    if (solve) {
+        for (int k = sl.s1; k <= sl.s2; ++k) {
+            ctx->chi_before_valid[k - 1] = ctx->chi_after_valid[k - 1] = ctx->touched_since_amp[k - 1] = false;
+            for (int q = 0; q < g.ng; ++q) ctx->plane_nz[g.gc[q]] |= 1u << (k - 1);
+        }
+    } else {
+        wb = !ctx->touched_since_amp[sl.s1 - 1];
+    }
+    for (int q = 0; q < sl.n; ++q)
+        for (int e = 0; e <= sl.s[q].pair; ++e) {
+            idx_written(ctx, sl.s[q].comp);
+            if (qu) ctx->qu_equal[sl.s[q].comp] |= 1u << (sl.s[q].nind + e);
+            else if (sl.s1 == 2 || sl.s1 == 3) ctx->qu_equal[sl.s[q].comp] &= ~(1u << (sl.s[q].nind + e));
+        }
+    const unsigned nblk = nblocks((long long)ctx->hm.npix * lanes, BLOCK);
+    double* chi_buf = nullptr;
+    if (chi_next(ctx, nblk, &chi_buf)) return 1;
+    HIPCHK(ctx, hipMemsetAsync(ctx->counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
+    {
+        double* saved = ctx->partial;
+        ctx->partial = chi_buf;
+        bool ok;
+        {
+            Timed t(ctx, !solve ? DANGX_K_INDEX_MH : sl.n ? DANGX_K_AMP_INDEX : DANGX_K_AMP_DIRECT);
+            ok = dx_launch_planeset(ctx, g, sl, lanes, solve, nblk, accepted ? ctx->counters + 4 : nullptr);
+        }
+        ctx->partial = saved;
+        if (!ok) return fail(ctx, "the plane-set launch failed after its kernel was prepared");
+    }
+    HIPCHK(ctx, hipGetLastError());
+    {
+        auto& pend = ctx->chi_pend[ctx->chi_npend++];
+        pend.nblk = nblk; pend.s1 = sl.s1; pend.s2 = sl.s2; pend.wb = wb ? 1 : 0;
+        for (int k = sl.s1; k <= sl.s2; ++k) {
+            if (wb) ctx->chi_before_valid[k - 1] = true;
+            ctx->chi_after_valid[k - 1] = true;
+            ctx->touched_since_amp[k - 1] = sl.n > 0 || (!solve && ctx->touched_since_amp[k - 1]);
+        }
+    }
+    if (n_not_spd || accepted) {
+        unsigned long long v[16];
+        HIPCHK(ctx, hipMemcpyAsync(v, ctx->counters, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (n_not_spd) *n_not_spd = (int64_t)v[0];
+        if (accepted) {   // the kernel counts per item (1 + pair entries each); the items follow the list's order
+            int slot = 4, s = 0;
+            for (int q = 0; q < sl.n; ++q)
+                for (int e = 0; e <= sl.s[q].pair; ++e) accepted[s++] = (int64_t)v[slot++];
+        }
+    }
+    return 0;
+}
+
+// the sweeps (comp[s], nind[s]), s = 0 .. nsweeps-1, as the items of a plane-set launch over group g's members: consecutive
+// indices of a component travel in one item.  false: some sweep has no register-chain form, or the list is too long
+static bool planeset_items(dangx_ctx* ctx, const GroupArgs& g, int map_n, int nsweeps, const int32_t* comp, const int32_t* nind,
+                           const uint64_t* stream, SweepList& sl) {
+    const unsigned touched = (map_n == -1) ? 6u : 1u << (map_n - 1);
+    std::memset(&sl, 0, sizeof(sl));
+    for (int s = 0; s < nsweeps; ++s) {
+        const dangx_comp_desc& d = ctx->desc[comp[s]];
+        int gm = -1;
+        for (int q = 0; q < g.ng; ++q) if (g.gc[q] == comp[s]) gm = q;
+        if (!(gm >= 0 && !(ctx->idx_const[comp[s]] & touched) && d.lnl_type[nind[s]] == DANGX_LNL_CHISQ &&
+              d.prior_type[nind[s]] != DANGX_PRIOR_JEFFREYS && (d.type == DANGX_POWERLAW || d.type == DANGX_MBB || d.type == DANGX_LOGNORMAL)))
+            return false;
+        const int mode = (d.type == DANGX_POWERLAW) ? CH_POW : (d.type == DANGX_MBB) ? (nind[s] == 0 ? CH_MBB_BETA : CH_MBB_T) : (nind[s] == 0 ? CH_LOGN_NUP : CH_LOGN_W);
+        if (sl.n > 0 && sl.s[sl.n - 1].comp == comp[s] && !sl.s[sl.n - 1].pair && sl.s[sl.n - 1].nind + 1 == nind[s] &&
+            (sl.s[sl.n - 1].mode == CH_MBB_BETA || sl.s[sl.n - 1].mode == CH_LOGN_NUP)) {
+            sl.s[sl.n - 1].pair = 1; sl.s[sl.n - 1].stream2 = stream[s];   // index nind + 1 of the same component: one item
+            continue;
+        }
+        for (int q = 0; q < sl.n; ++q) if (sl.s[q].comp == comp[s]) return false;  // a component's sweeps must be consecutive
+        if (sl.n == DX_MAX_SWEEPS) return false;
+        SweepItem& it = sl.s[sl.n++];
+        it.comp = comp[s]; it.nind = nind[s]; it.mode = mode; it.pair = 0; it.gmember = gm; it.stream = stream[s]; it.stream2 = 0;
+    }
+    sl.s1 = (map_n == -1) ? 2 : map_n; sl.s2 = (map_n == -1) ? 3 : map_n;
+    return true;
+}
+
+// a group whose members are the only components with a signal on the planes of the flag: what every plane-set launch needs
+static bool planeset_group(dangx_ctx* ctx, const GroupArgs& g) {
+    if (!(g.nt == 0 && g.no == 0 && g.nuc == 0)) return false;
+    for (int l = 0; l < ctx->hm.ncomp; ++l)
+        if (ctx->desc[l].type == DANGX_TCMB) return false;
+    return true;
+}
+
 // dangx_amp_sample(group, flag, ...) followed by dangx_index_sample(comp[s], nind[s], map_n of the flag, ...) for s = 0 ..
 // nsweeps-1 -- everything one iteration of the main loop does on ONE plane set of a CG group: the solve of sample_cg_groups
 // (src/dang_cg_mod.f90:166-171) and the passes of sample_spectral_parameters that touch these planes (src/dang_sample_mod.f90:
@@ -2201,7 +2321,6 @@ int dangx_plane_set_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int
     if (n_not_spd) *n_not_spd = 0;
     static const bool enabled = [] { const char* e = getenv("DANGX_FUSE"); return !(e && e[0] == '0'); }();
     // ---- does the one-launch form cover this?  (the conditions of dangx_amp_index_sample, for every sweep of the list)
-    const unsigned touched = (map_n == -1) ? 6u : 1u << (map_n - 1);
     bool can = enabled && nsweeps <= 2 * DX_MAX_SWEEPS && solver == DANGX_SOLVER_DIRECT && ctx->hm.all_delta != 0 &&
                (ml_mode == DANGX_ML_OPTIMIZE || fluct_mode == DANGX_FLUCT_REFERENCE) &&
                (ml_mode == DANGX_ML_SAMPLE || ml_mode == DANGX_ML_OPTIMIZE);
@@ -2210,34 +2329,13 @@ int dangx_plane_set_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int
     std::memset(&sl, 0, sizeof(sl));
     if (can) {
         if (make_group(ctx, group, flag, g)) return 1;
-        can = g.nt == 0 && g.no == 0 && g.nuc == 0;
-        for (int l = 0; can && l < ctx->hm.ncomp; ++l)
-            if (ctx->desc[l].type == DANGX_TCMB) can = false;
-    }
-    for (int s = 0; can && s < nsweeps; ++s) {
-        const dangx_comp_desc& d = ctx->desc[comp[s]];
-        int gm = -1;
-        for (int q = 0; q < g.ng; ++q) if (g.gc[q] == comp[s]) gm = q;
-        can = gm >= 0 && !(ctx->idx_const[comp[s]] & touched) && d.lnl_type[nind[s]] == DANGX_LNL_CHISQ &&
-              d.prior_type[nind[s]] != DANGX_PRIOR_JEFFREYS && (d.type == DANGX_POWERLAW || d.type == DANGX_MBB || d.type == DANGX_LOGNORMAL);
-        if (!can) break;
-        const int mode = (d.type == DANGX_POWERLAW) ? CH_POW : (d.type == DANGX_MBB) ? (nind[s] == 0 ? CH_MBB_BETA : CH_MBB_T) : (nind[s] == 0 ? CH_LOGN_NUP : CH_LOGN_W);
-        if (sl.n > 0 && sl.s[sl.n - 1].comp == comp[s] && !sl.s[sl.n - 1].pair && sl.s[sl.n - 1].nind + 1 == nind[s] &&
-            (sl.s[sl.n - 1].mode == CH_MBB_BETA || sl.s[sl.n - 1].mode == CH_LOGN_NUP)) {
-            sl.s[sl.n - 1].pair = 1; sl.s[sl.n - 1].stream2 = stream[s];   // index nind + 1 of the same component: one item
-            continue;
-        }
-        for (int q = 0; q < sl.n; ++q) if (sl.s[q].comp == comp[s]) can = false;  // a component's sweeps must be consecutive
-        if (!can || sl.n == DX_MAX_SWEEPS) { can = false; break; }
-        SweepItem& it = sl.s[sl.n++];
-        it.comp = comp[s]; it.nind = nind[s]; it.mode = mode; it.pair = 0; it.gmember = gm; it.stream = stream[s]; it.stream2 = 0;
+        can = planeset_group(ctx, g) && planeset_items(ctx, g, map_n, nsweeps, comp, nind, stream, sl);
     }
     int lanes = 0;
     if (can) {
         sl.nsample = nsample; sl.ml_mode = ml_mode; sl.seed = seed_index;
-        sl.s1 = (map_n == -1) ? 2 : map_n; sl.s2 = (map_n == -1) ? 3 : map_n;
         g.ml_mode = ml_mode; g.fluct = fluct_mode; g.seed = seed_amp; g.stream = stream_amp;
-        lanes = dx_planeset_lanes(ctx, g, sl);
+        lanes = dx_planeset_lanes(ctx, g, sl, 1);
     }
     if (!lanes) {  // the calls this entry point stands for, through the two-step fusions where they apply
         int s = 0;
@@ -2261,49 +2359,52 @@ int dangx_plane_set_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int
         }
         return 0;
     }
-    // ---- one launch.  Bookkeeping of dangx_amp_sample (the planes' cached chi^2 is stale, the members' amplitudes are about to
-    // be written) and of the sweeps (their chi^2 by-product: before = the state the solve leaves, after = the last sweep's)
-    const int Sp = sl.s2 - sl.s1 + 1;
-    for (int k = sl.s1; k <= sl.s2; ++k) {
-        ctx->chi_before_valid[k - 1] = ctx->chi_after_valid[k - 1] = ctx->touched_since_amp[k - 1] = false;
-        for (int q = 0; q < g.ng; ++q) ctx->plane_nz[g.gc[q]] |= 1u << (k - 1);
-    }
-    for (int q = 0; q < sl.n; ++q)
-        for (int e = 0; e <= sl.s[q].pair; ++e) {
-            if (map_n == -1) ctx->qu_equal[sl.s[q].comp] |= 1u << (sl.s[q].nind + e);
-            else if (map_n == 2 || map_n == 3) ctx->qu_equal[sl.s[q].comp] &= ~(1u << (sl.s[q].nind + e));
+    return planeset_launch(ctx, g, sl, lanes, 1, n_not_spd, accepted);
+}
+
+// dangx_index_sample(comp[s], nind[s], map_n of the flag, ...) for s = 0 .. nsweeps-1: the passes of sample_spectral_parameters
+// (src/dang_sample_mod.f90:40-75) that touch ONE plane set, in the reference's order -- what the two-call seam issues after
+// sample_cg_groups has returned.  Where k_plane_set covers the model (every swept component an amplitude-sampled member of ONE CG
+// group whose members are the only components on these planes, register-chain modes) the sweeps are one launch on the amplitudes
+// in memory (SOLVE = 0: one staging of the maps, the residual kept between the sweeps); everything else IS those calls, with
+// consecutive indices of a component through dangx_index_sample_pair.
+int dangx_plane_sweeps_sample(dangx_ctx* ctx, int flag, int nsweeps, const int32_t* comp, const int32_t* nind, const uint64_t* stream,
+                              int nsample, int ml_mode, uint64_t seed, int64_t* accepted) {
+    if (!ctx || nsweeps < 1 || !comp || !nind || !stream) return 1;
+    (void)hipSetDevice(ctx->device);
+    if (sync_model(ctx)) return 1;
+    const int map_n = (flag == DANGX_FLAG_T) ? 1 : (flag == DANGX_FLAG_Q) ? 2 : (flag == DANGX_FLAG_U) ? 3 : (flag == DANGX_FLAG_QU) ? -1 : 0;
+    if (map_n == 0) return fail(ctx, "flag must be exactly one of T(1), Q(2), U(4), Q+U(8)");
+    for (int s = 0; s < nsweeps; ++s)
+        if (check_comp(ctx, comp[s]) || nind[s] < 0 || nind[s] >= ctx->desc[comp[s]].nindices) return fail(ctx, "sweep list: component / index out of range");
+    static const bool enabled = [] { const char* e = getenv("DANGX_FUSE"); return !(e && e[0] == '0'); }();
+    bool can = enabled && nsweeps <= 2 * DX_MAX_SWEEPS && ctx->hm.all_delta != 0 && (ml_mode == DANGX_ML_SAMPLE || ml_mode == DANGX_ML_OPTIMIZE);
+    const int group = ctx->desc[comp[0]].cg_group;
+    for (int s = 0; can && s < nsweeps; ++s) can = ctx->desc[comp[s]].cg_group == group && ctx->desc[comp[s]].sample_amplitude;
+    GroupArgs g;
+    SweepList sl;
+    int lanes = 0;
+    if (can) {
+        if (make_group(ctx, group, flag, g)) return 1;
+        if (planeset_group(ctx, g) && planeset_items(ctx, g, map_n, nsweeps, comp, nind, stream, sl)) {
+            sl.nsample = nsample; sl.ml_mode = ml_mode; sl.seed = seed;
+            g.ml_mode = ml_mode; g.fluct = DANGX_FLUCT_REFERENCE; g.seed = 0; g.stream = 0;
+            lanes = dx_planeset_lanes(ctx, g, sl, 0);
         }
-    const unsigned nblk = nblocks((long long)ctx->hm.npix * lanes, BLOCK);
-    double* chi_buf = nullptr;
-    if (chi_next(ctx, nblk, &chi_buf)) return 1;
-    HIPCHK(ctx, hipMemsetAsync(ctx->counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
-    {
-        double* saved = ctx->partial;
-        ctx->partial = chi_buf;
-        bool ok;
-        {
-            Timed t(ctx, DANGX_K_AMP_INDEX);
-            ok = dx_launch_planeset(ctx, g, sl, lanes, nblk, accepted ? ctx->counters + 4 : nullptr);
-        }
-        ctx->partial = saved;
-        if (!ok) return fail(ctx, "the plane-set launch failed after its kernel was prepared");
     }
-    HIPCHK(ctx, hipGetLastError());
-    {
-        auto& pend = ctx->chi_pend[ctx->chi_npend++];
-        pend.nblk = nblk; pend.s1 = sl.s1; pend.s2 = sl.s2; pend.wb = 1;
-        for (int k = sl.s1; k <= sl.s2; ++k) ctx->chi_before_valid[k - 1] = ctx->chi_after_valid[k - 1] = ctx->touched_since_amp[k - 1] = true;
-    }
-    (void)Sp;
-    if (n_not_spd || accepted) {
-        unsigned long long v[16];
-        HIPCHK(ctx, hipMemcpyAsync(v, ctx->counters, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        if (n_not_spd) *n_not_spd = (int64_t)v[0];
-        if (accepted) {   // the kernel counts per item (1 + pair entries each); the items follow the list's order
-            int slot = 4, s = 0;
-            for (int q = 0; q < sl.n; ++q)
-                for (int e = 0; e <= sl.s[q].pair; ++e) accepted[s++] = (int64_t)v[slot++];
+    if (lanes) return planeset_launch(ctx, g, sl, lanes, 0, nullptr, accepted);
+    int64_t acc = 0, acc2 = 0;
+    for (int s = 0; s < nsweeps; ++s) {
+        if (s + 1 < nsweeps && comp[s + 1] == comp[s] && nind[s + 1] == nind[s] + 1) {
+            const int rc = dangx_index_sample_pair(ctx, comp[s], nind[s], map_n, nsample, ml_mode, seed, stream[s], stream[s + 1],
+                                                   accepted ? &acc : nullptr, accepted ? &acc2 : nullptr);
+            if (rc) return rc;
+            if (accepted) { accepted[s] = acc; accepted[s + 1] = acc2; }
+            ++s;
+        } else {
+            const int rc = dangx_index_sample(ctx, comp[s], nind[s], map_n, nsample, ml_mode, seed, stream[s], accepted ? &acc : nullptr);
+            if (rc) return rc;
+            if (accepted) accepted[s] = acc;
         }
     }
     return 0;
@@ -2748,6 +2849,7 @@ int dangx_coarse_writeback(dangx_ctx* ctx, int comp, int nind, int map_n, int ns
         ctx->touched_since_amp[k - 1] = true;
         ctx->idx_const[comp] &= ~(1u << (k - 1));
     }
+    idx_written(ctx, comp);
     if (map_n == -1) ctx->qu_equal[comp] |= 1u << nind;
     else if (map_n == 2 || map_n == 3) ctx->qu_equal[comp] &= ~(1u << nind);
     ctx->dirty = true;
@@ -2817,6 +2919,7 @@ int dangx_index_sample_coarse(dangx_ctx* ctx, int comp, int nind, int map_n, int
         ctx->touched_since_amp[k - 1] = true;
         ctx->idx_const[comp] &= ~(1u << (k - 1));
     }
+    idx_written(ctx, comp);
     if (map_n == -1) ctx->qu_equal[comp] |= 1u << nind;
     else if (map_n == 2 || map_n == 3) ctx->qu_equal[comp] &= ~(1u << nind);
     ctx->dirty = true;
@@ -2864,6 +2967,15 @@ int dangx_index_masked_sums(dangx_ctx* ctx, int n, const int32_t* comp, const in
         if (map_n[e] < 1 || map_n[e] > ctx->dims.nmaps) return fail(ctx, "map_n must be a map number (1..nmaps)");
         ml.comp[e] = comp[e]; ml.nind[e] = nind[e]; ml.k[e] = map_n[e];
     }
+    // what is still valid from an earlier call (nothing has written these maps or the mask since) is answered from the host:
+    // the statistics after an amplitude phase (src/dang_cg_mod.f90:173) repeat the index means of the phase before
+    bool all_cached = true;
+    for (int e = 0; e < n; ++e)
+        if (ctx->idx_ext[comp[e]] || !ctx->idxsum_ok[comp[e]][nind[e]][map_n[e] - 1]) all_cached = false;
+    if (all_cached) {
+        for (int e = 0; e < n; ++e) { sums[e] = ctx->idxsum[comp[e]][nind[e]][map_n[e] - 1]; counts[e] = ctx->idxcnt[comp[e]][nind[e]][map_n[e] - 1]; }
+        return 0;
+    }
     if (sync_model(ctx)) return 1;
     const unsigned nblk = std::min(nblocks(ctx->hm.npix), 4096u);
     if (ensure_partial(ctx, 2ll * n * nblk)) return 1;
@@ -2874,7 +2986,11 @@ int dangx_index_masked_sums(dangx_ctx* ctx, int n, const int32_t* comp, const in
     double out[32];
     HIPCHK(ctx, hipMemcpyAsync(out, ctx->work[0], sizeof(double) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    for (int e = 0; e < n; ++e) { sums[e] = out[2 * e]; counts[e] = (int64_t)out[2 * e + 1]; }
+    for (int e = 0; e < n; ++e) {
+        sums[e] = out[2 * e]; counts[e] = (int64_t)out[2 * e + 1];
+        ctx->idxsum[comp[e]][nind[e]][map_n[e] - 1] = sums[e]; ctx->idxcnt[comp[e]][nind[e]][map_n[e] - 1] = counts[e];
+        ctx->idxsum_ok[comp[e]][nind[e]][map_n[e] - 1] = !ctx->idx_ext[comp[e]];
+    }
     return 0;
 }
 
@@ -2965,6 +3081,7 @@ int dangx_fill_index(dangx_ctx* ctx, int comp, int nind, int map_n, double value
         else if (ctx->idx_const[comp] & (1u << (k - 1))) ctx->idx_val[comp][k - 1][nind] = value;
         ctx->chi_before_valid[k - 1] = ctx->chi_after_valid[k - 1] = false;
     }
+    idx_written(ctx, comp);
     if (map_n == -1) ctx->qu_equal[comp] |= 1u << nind;
     else if (map_n == 2 || map_n == 3) ctx->qu_equal[comp] &= ~(1u << nind);
     ctx->dirty = true;

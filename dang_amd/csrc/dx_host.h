@@ -42,6 +42,12 @@ struct dangx_ctx {
     unsigned idx_const[MAXC] = {}; // bit k-1: every index of the component is spatially constant on plane k
     unsigned qu_equal[MAXC] = {};  // bit q: index map q of the component is equal on the Q and U planes for every pixel
     double idx_val[MAXC][3][MAXI] = {};
+    // masked sums of the index maps (dangx_index_masked_sums: what write_stats_to_term prints after EVERY phase,
+    // src/dang_data_mod.f90:540-567) are kept until something writes the map or the mask: an amplitude phase does not move them
+    bool idxsum_ok[MAXC][MAXI][3] = {};
+    double idxsum[MAXC][MAXI][3] = {};
+    long long idxcnt[MAXC][MAXI][3] = {};
+    bool idx_ext[MAXC] = {};       // the maps live in a buffer of the caller's (dangx_adopt_device_state): never cached
     std::vector<double> bp_nu0, bp_tau0;
     double *d_bp_nu0 = nullptr, *d_bp_tau0 = nullptr, *d_bp_lnr = nullptr;  // lnr: [ncomp][samples]
     bool bp_dirty = true;  // bandpass samples or component reference frequencies changed since the last upload
@@ -114,6 +120,13 @@ struct dangx_ctx {
 inline void invalidate_chi(dangx_ctx* ctx) {
     for (int k = 0; k < 3; ++k) ctx->chi_before_valid[k] = ctx->chi_after_valid[k] = false;
     ctx->chi_npend = 0;  // block partials still waiting in the ring belong to that model too: nobody may read them
+}
+
+// an index map of component `comp` (comp < 0: any map, or the mask) is about to change: its cached masked sums are stale
+inline void idx_written(dangx_ctx* ctx, int comp) {
+    for (int l = 0; l < MAXC; ++l)
+        if (comp < 0 || l == comp)
+            for (int q = 0; q < MAXI; ++q) for (int k = 0; k < 3; ++k) ctx->idxsum_ok[l][q][k] = false;
 }
 
 inline int fail(dangx_ctx* ctx, const std::string& msg) {
@@ -202,6 +215,6 @@ int dx_fused_lanes(dangx_ctx* ctx, const GroupArgs& ga, const IndexArgs& a, int 
 bool dx_launch_fused(dangx_ctx* ctx, const GroupArgs& ga, const IndexArgs& a, int Sp, int lanes, unsigned nblk, unsigned long long* accp);
 int dx_mh_reg_lanes(int nb, int Sp);  // lanes per pixel of the register chain (dangx_mhreg.hip)
 // a group's solve and every sweep on its planes in one launch (dangx_planeset.hip): lanes per pixel, 0 = the separate launches
-int dx_planeset_lanes(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl);
-bool dx_launch_planeset(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl, int lanes, unsigned nblk, unsigned long long* accp);
+int dx_planeset_lanes(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl, int solve);
+bool dx_launch_planeset(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl, int lanes, int solve, unsigned nblk, unsigned long long* accp);
 bool dx_launch_mh_reg(dangx_ctx* ctx, const IndexArgs& a, int Sp, unsigned nblk, unsigned long long* accp);

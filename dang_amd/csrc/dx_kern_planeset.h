@@ -1,124 +1,65 @@
-// dx_kern_planeset.h -- k_plane_set (template): ONE launch for everything a Gibbs iteration does on one plane set (T, or Q+U) of
-// a CG group without global-amplitude members: the group's amplitude solve, then every index sweep on these planes in the
+// dx_kern_planeset.h -- k_plane_set (template): ONE launch for what a Gibbs iteration does on one plane set (T, or Q+U) of a CG
+// group without global-amplitude members: the group's amplitude solve (SOLVE), then the index sweeps on these planes in the
 // reference's order (sample_cg_groups, src/dang_cg_mod.f90:166-171, followed by the passes of sample_spectral_parameters that
-// touch these planes, src/dang_sample_mod.f90:40-75).
+// touch these planes, src/dang_sample_mod.f90:40-75).  Three uses of the one template:
+//   SOLVE = 1, sweep items      the whole iteration of the plane set (dangx_plane_set_sample; bench.py, gibbs_iteration_gpu)
+//   SOLVE = 1, no items         the amplitude phase alone, with chi^2 of the state it leaves as a by-product: what the
+//                               two-call seam's sample_cg_groups needs for its statistics (src/dang_cg_mod.f90:172-173) without a
+//                               pass of its own (dangx_amp_sample)
+//   SOLVE = 0, sweep items      the index phase alone on the amplitudes in memory (dangx_plane_sweeps_sample: the two-call
+//                               seam's sample_spectral_parameters)
 //
-// Why: every sweep of a plane set stages the plane set again -- 2*nb map planes and, to remove "every other component"
-// (src/dang_sample_mod.f90:180-196), the SEDs of all the other members at all bands.  For a model with many members and many
-// bands (C5: 6 members, 20 bands) that is 100 SED evaluations per pixel and plane per sweep, a fifth to a third of the sweep,
-// and between two sweeps only ONE member's SED changes.  Here the members' SED columns stay in LDS across the sweeps (k_amp_index
-// already builds them for the solve); a sweep forms its cleaned data d - sum_{g /= c} a_g s_g from the columns, in component
-// order, with the products the separate sweep would form (same values, same order: the index maps are what the separate
-// launches give, lane association of the band sums aside), and after its chain only the column of the member that moved is
-// evaluated again.  The maps are re-read per sweep (that is cheap: the kernels are bound by vector issue, not by HBM).
+// Resident residual.  The members' SED columns are evaluated once into the lane's LDS column; the solve uses them; then the
+// lane forms the FULL residual (d - sum over every member) / rms of its bands in registers and parks 1 / rms in its LDS column
+// (the SED columns are dead by then).  A sweep's cleaned data (src/dang_sample_mod.f90:173-196: data_raw minus every OTHER
+// component) are residual + own signal: the chain's first likelihood evaluation, which needs the member's SED at the current
+// index values anyway, adds it back (RegChain::lnl, LNL_ADD), and after the chain the signal at the values it ended on is taken
+// out again (LNL_SUB).  Nothing is read from HBM twice, no reciprocal of the rms is formed twice, and "every other component"
+// is removed once instead of once per sweep.  Against re-staging the maps for every sweep (round 3's form of this kernel) the
+// cleaned data differ by the rounding of one more addition (|d| eps): same proposals, an accept decision could differ only
+// where |diff - ln u| is of that size (none in 3.8e8 decisions of a full-size run), chi^2 sums agree to rounding -- the parity
+// tolerance of the index maps.  Same device, tools/ab_bench.sh: C5 126.6 -> 112.5 ms per iteration, C3 11.7 -> 11.1 ms, C2 +4 %.
 //
-// Requirements checked by the launcher (dangx_planeset.hip): delta bands, direct solver with the
-// reference fluctuation term, every swept component an amplitude-sampled member of the group with a register-chain mode (chisq
-// likelihood, gaussian / uniform prior), no other component on the planes, and -- for Q+U -- index maps that are equal on the
-// two planes for every member that varies (true once a Q+U sweep has written them, :465; tracked on the host).
+// Requirements checked by the launcher (dangx_planeset.hip): delta bands, direct solver with the reference fluctuation term,
+// every swept component an amplitude-sampled member of the group with a register-chain mode (chisq likelihood, gaussian /
+// uniform prior), no other component on the planes, and -- for Q+U -- index maps that are equal on the two planes for every
+// member that varies (true once a Q+U sweep has written them, :465; tracked on the host).  Band calibration: the T launch reads
+// gain and offset from the block's table (solve: d / gain, src/dang_cg_mod.f90:371; chains and chi^2: (d - offset) / gain,
+// src/dang_sample_mod.f90:174, src/dang_data_mod.f90:384); Q and U are never rescaled.
 #pragma once
 #include "dx_kern_fused.h"
 
 // resident waves per SIMD the register allocation aims at: three for small shapes (<= 5 bands per lane), two otherwise
 #ifndef DX_PS_WAVES
-#define DX_PS_WAVES(SP, NB, LP) (((NB) / (LP) <= 5) ? 3 : 2)
+#define DX_PS_WAVES(SP, NB, LP, SOLVE, C0) (((NB) / (LP) <= 5) ? 3 : 2)
 #endif
-
-// Resident-residual form: between the sweeps of a launch the lane keeps the FULL residual (d - sum over every member) / rms of
-// its bands in registers and 1 / rms in its LDS column (the SED columns are dead once the solve has used them): a sweep's cleaned
-// data are residual + own signal (added back by the chain's first likelihood evaluation, which needs the member's SED at the
-// current index values anyway), and after the chain the signal at the values it ended on is taken out again.  Nothing is re-read
-// from HBM between the sweeps, no reciprocal of the rms is formed twice, and "every other component"
-// (src/dang_sample_mod.f90:180-196) is removed once instead of once per sweep.  The cleaned data differ from the re-staged ones by
-// the rounding of one more addition (|d| eps): same proposals, an accept decision could differ only where |diff - ln u| is of that
-// size, chi^2 sums agree to rounding -- the parity tolerance, no longer bit for bit the separate launches.
-// Measured on one device (tools/ab_bench.sh): C5 126.6 -> 112.5 ms, C3 11.7 -> 11.1 ms, C2 +4 %.
-// -DDX_PS_RESIDENT_ALL=0 keeps re-staging in the one-lane instantiations (A/B timing).
-#ifndef DX_PS_RESIDENT_ALL
-#define DX_PS_RESIDENT_ALL 1
-#endif
-#define DX_PS_RESIDENT(LP) ((LP) > 1 || DX_PS_RESIDENT_ALL)
 
 namespace dxk {
 
 template <int V> struct ItemCode { static constexpr int value = V; };
-template <bool V> struct ItemFirst { static constexpr bool value = V; };
+template <bool V> struct ItemFlag { static constexpr bool value = V; };
 
-// the cleaned data of a sweep of member `gself` from the members' SED columns: data_raw (:173-177) minus every other member in
-// component_list order (:180-196).  FIRST: R already holds this plane set's d and 1/sigma (the solve just used them).
-template <int MODE, int SP, int NBL, int LP, int NG, bool FIRST>
-__device__ __forceinline__ void ps_stage(const Model& M, RegChain<MODE, SP, NBL, LP, true>& R, const FusedArgs& fa, int gself, int s1, int i,
-                                         int jb, int NB, const double* __restrict__ tab, const double* __restrict__ col,
-                                         const GroupArgs& ga) {
-    const int npix = M.npix;
-    const long long bstride = (long long)M.nmaps * npix;
-#pragma unroll
-    for (int kk = 0; kk < SP; ++kk) {
-        const int k = s1 + kk;
-        if (!FIRST) {
-            const double* sigp = M.sig + (long long)(k - 1) * npix + i;
-            const double* rmsp = M.rms + (long long)(k - 1) * npix + i;
-            double rv[NBL];
-#pragma unroll
-            for (int j = 0; j < NBL; ++j) { R.D[kk][j] = sigp[(jb + j) * bstride]; rv[j] = rmsp[(jb + j) * bstride]; }
-#pragma unroll
-            for (int j = 0; j < NBL; ++j) R.set_is(kk, j, fast_rcp(rv[j]));
-        }
-        if (SP == 1 && fa.cal) {  // data_raw = (sig - offset) / gain on the temperature plane (:174); R0 / the loads hold sig
-            const double* gn = tab + (TROWS * NG + 1) * NB + jb;
-#pragma unroll
-            for (int j = 0; j < NBL; ++j) R.D[kk][j] = (R.D[kk][j] - gn[NB + j]) / gn[j];
-        }
-        // the members' amplitudes on this plane: what THIS lane stored after the solve (both lanes of a pair store the same
-        // values, so that neither reads memory its partner wrote)
-        double av[NG];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) av[g] = M.comp[ga.gc[g]].amp[(long long)(k - 1) * npix + i];
-        R.amp[kk] = av[0];
-#pragma unroll
-        for (int g = 1; g < NG; ++g) R.amp[kk] = (g == gself) ? av[g] : R.amp[kk];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g == gself) continue;
-            const double amp2 = av[g];
-            const bool var = fa.vslot[g] >= 0;
-            const double* mp = var ? col + (fa.vslot[g] * NBL) * BLOCK : tab + (TROWS * g + 2 + k) * NB + jb;  // else csed of plane k
-            int ms = var ? BLOCK : 1;
-            asm volatile("" : "+s"(ms));  // keeps the NBL addresses of a member out of registers between members (k_amp_index)
-#pragma unroll
-            for (int j = 0; j < NBL; ++j) R.D[kk][j] -= amp2 * mp[j * ms];
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
-// one item of the sweep list for member gself: stage, chain (and the paired chain of index nind + 1 on the same staged planes,
-// as index_chain_pair does), count; leaves the member's two index values in sample0 / sample1
-// The same item in the resident-residual form: R0.D holds the full residual / rms of the lane's bands, the lane's LDS column
-// rows 0 .. SP*NBL-1 hold 1 / rms.  LAST: nothing follows, the residual need not be restored.
+// one item of the sweep list for member it.gmember: chain (and the paired chain of index nind + 1, as index_chain_pair does);
+// R0.D holds the full residual / rms of the lane's bands, rows 0 .. SP*NBL-1 of the lane's LDS column hold 1 / rms.  Leaves the
+// member's two index values in sample0 / sample1.  LAST: nothing follows, the residual need not be restored.
 template <int MODE, int PAIR, int SP, int NBL, int LP, int NG, bool FIRST, bool LAST, typename RFirst>
-__device__ __forceinline__ void ps_item_res(const Model& M, const SweepList& sl, const SweepItem& it, RFirst& R0, int i, int half,
-                                            int jb, int NB, const double* __restrict__ tab, const double* __restrict__ col,
-                                            double& sample0, double& sample1, double chi_first[4],
-                                            double chi_last[4], unsigned long long* __restrict__ accepted, int slot) {
+__device__ __forceinline__ void ps_item(const Model& M, const SweepList& sl, const SweepItem& it, RFirst& R0, int i, int half,
+                                        int jb, int NB, const double* __restrict__ tab, const double* __restrict__ col,
+                                        double& sample0, double& sample1, double chi_first[4],
+                                        double chi_last[4], unsigned long long* __restrict__ accepted, int slot) {
     const Comp& c = M.comp[it.comp];
     const BandPick<LP> pick = {half};
     const int npix = M.npix;
     IndexArgs a;
     a.comp = it.comp; a.nind = it.nind; a.s1 = sl.s1; a.s2 = sl.s2; a.nsample = sl.nsample; a.ml_mode = sl.ml_mode; a.mode = MODE;
     a.bp = 0; a.others = 0u; a.seed = sl.seed; a.stream = it.stream;
-    RegChain<MODE, SP, NBL, LP, true> R;
+    RegChain<MODE, SP, NBL, LP, true> R;   // per-band constants from the block's table in LDS
     R.set_kt(tab, NB, NG, it.gmember, jb);
-    // the column is read through an address the compiler cannot trace back to the stores after the solve: forwarded, the
-    // SP * NBL values of 1 / rms would stay in registers across every chain of the launch (100 spilled registers)
-    int zo = 0;
-    asm volatile("" : "+v"(zo));   // (an offset of zero: the pointer stays an LDS pointer)
-    const double* colr = col + zo;
 #pragma unroll
     for (int kk = 0; kk < SP; ++kk) {
-        R.amp[kk] = c.amp[(long long)(sl.s1 + kk - 1) * npix + i];   // what this lane stored after the solve
+        R.amp[kk] = c.amp[(long long)(sl.s1 + kk - 1) * npix + i];   // the lane's own store after the solve, or the map in memory
 #pragma unroll
-        for (int j = 0; j < NBL; ++j) { R.D[kk][j] = R0.D[kk][j]; R.ISr[kk][j] = colr[(kk * NBL + j) * BLOCK] * R.amp[kk]; }
+        for (int j = 0; j < NBL; ++j) { R.D[kk][j] = R0.D[kk][j]; R.ISr[kk][j] = col[(kk * NBL + j) * BLOCK] * R.amp[kk]; }
     }
     double chia[4] = {0.0, 0.0, 0.0, 0.0}, va;
     unsigned long long na = chain_finish<MODE, SP, NBL, LP, false, true, (!PAIR && !LAST)>(M, a, c, R, pick, sample0, sample1, i, half, chia, &va);
@@ -127,7 +68,7 @@ __device__ __forceinline__ void ps_item_res(const Model& M, const SweepList& sl,
     chi_last[2] = chia[2]; chi_last[3] = chia[3];
     unsigned long long nb_ = 0ull;
     if (PAIR) {
-        constexpr int MODEB = (MODE == CH_MBB_BETA || MODE == CH_LOGN_NUP) ? MODE + 1 : MODE;
+        constexpr int MODEB = (MODE == CH_MBB_BETA || MODE == CH_LOGN_NUP) ? MODE + 1 : MODE;  // only those two modes have a pair
         RegChain<MODEB, SP, NBL, LP, true> RB;
         RB.set_kt(tab, NB, NG, it.gmember, jb);
 #pragma unroll
@@ -154,54 +95,6 @@ __device__ __forceinline__ void ps_item_res(const Model& M, const SweepList& sl,
 #pragma unroll
             for (int j = 0; j < NBL; ++j) R0.D[kk][j] = R.D[kk][j];
     }
-    if (accepted) {
-        if (na) atomicAdd(accepted + slot, na);
-        if (nb_) atomicAdd(accepted + slot + 1, nb_);
-    }
-}
-
-template <int MODE, int PAIR, int SP, int NBL, int LP, int NG, bool FIRST, typename RFirst>
-__device__ __forceinline__ void ps_item(const Model& M, const SweepList& sl, const SweepItem& it, const FusedArgs& fa, RFirst& R0, int i, int half,
-                                        int jb, int NB, const double* __restrict__ tab, const double* __restrict__ col,
-                                        const GroupArgs& ga, double& sample0, double& sample1, double chi_first[4],
-                                        double chi_last[4], unsigned long long* __restrict__ accepted, int slot) {
-    const Comp& c = M.comp[it.comp];
-    const BandPick<LP> pick = {half};
-    IndexArgs a;
-    a.comp = it.comp; a.nind = it.nind; a.s1 = sl.s1; a.s2 = sl.s2; a.nsample = sl.nsample; a.ml_mode = sl.ml_mode; a.mode = MODE;
-    a.bp = 0; a.others = 0u; a.seed = sl.seed; a.stream = it.stream;
-    RegChain<MODE, SP, NBL, LP, true> R;   // per-band constants from the block's table in LDS
-    R.set_kt(tab, NB, NG, it.gmember, jb);
-    if (FIRST) {  // the solve's registers: d and 1/sigma of this plane set
-#pragma unroll
-        for (int kk = 0; kk < SP; ++kk)
-#pragma unroll
-            for (int j = 0; j < NBL; ++j) { R.D[kk][j] = R0.D[kk][j]; R.ISr[kk][j] = R0.ISr[kk][j]; }
-    }
-    ps_stage<MODE, SP, NBL, LP, NG, FIRST>(M, R, fa, it.gmember, sl.s1, i, jb, NB, tab, col, ga);
-    double chia[4] = {0.0, 0.0, 0.0, 0.0}, va;
-    unsigned long long na = chain_finish<MODE, SP, NBL, LP>(M, a, c, R, pick, sample0, sample1, i, half, chia, &va);
-    if (it.nind == 0) sample0 = va; else sample1 = va;
-    if (FIRST) { chi_first[0] = chia[0]; chi_first[1] = chia[1]; }
-    chi_last[2] = chia[2]; chi_last[3] = chia[3];
-    unsigned long long nb_ = 0ull;
-    if (PAIR) {
-        constexpr int MODEB = (MODE == CH_MBB_BETA || MODE == CH_LOGN_NUP) ? MODE + 1 : MODE;  // only those two modes have a pair
-        RegChain<MODEB, SP, NBL, LP, true> RB;
-        RB.set_kt(tab, NB, NG, it.gmember, jb);
-#pragma unroll
-        for (int kk = 0; kk < SP; ++kk) {
-            RB.amp[kk] = R.amp[kk];
-#pragma unroll
-            for (int j = 0; j < NBL; ++j) { RB.D[kk][j] = R.D[kk][j]; RB.ISr[kk][j] = R.ISr[kk][j]; }
-        }
-        IndexArgs b = a;
-        b.nind = it.nind + 1; b.stream = it.stream2; b.mode = MODEB;
-        double chib[4] = {0.0, 0.0, 0.0, 0.0}, vb;
-        nb_ = chain_finish<MODEB, SP, NBL, LP, false>(M, b, c, RB, pick, sample0, sample1, i, half, chib, &vb);
-        if (b.nind == 0) sample0 = vb; else sample1 = vb;
-        chi_last[2] = chib[2]; chi_last[3] = chib[3];
-    }
     if (accepted) {  // per-sweep counters ([slot], [slot + 1] for the paired sweep): a diagnostic output, so one atomic per lane that
         // accepted something (this code runs inside the pixel's live branch: no cross-lane reduction here)
         if (na) atomicAdd(accepted + slot, na);
@@ -214,13 +107,12 @@ __device__ __forceinline__ void ps_item(const Model& M, const SweepList& sl, con
 // the modes inside one kernel costs the register allocator ~200 spills (three inlined chains share one frame); a model's
 // sweep sequence is fixed for a run, so it is part of the specialisation: C5 = <POW, MBB_BETA + 8, LOGN_NUP> is built in, any
 // other sequence is compiled on first use (dangx_rtc.hip).
-template <int SP, int NB, int NG, int LP, int C0, int C1, int C2, int C3>
-__global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP)) void k_plane_set(const Model* __restrict__ Mp, GroupArgs ga, FusedArgs fa, SweepList sl,
+template <int SP, int NB, int NG, int LP, int SOLVE, int C0, int C1, int C2, int C3>
+__global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP, SOLVE, C0)) void k_plane_set(const Model* __restrict__ Mp, GroupArgs ga, FusedArgs fa, SweepList sl,
                                                         unsigned long long* __restrict__ not_spd, unsigned long long* __restrict__ accepted,
                                                         double* __restrict__ chi_partial) {
     constexpr int NBL = NB / LP;
-    constexpr bool RES = DX_PS_RESIDENT(LP);
-    extern __shared__ double lds[];  // [constant table | per-lane columns: nv*NBL rows of SEDs (RES: at least SP*NBL rows)]
+    extern __shared__ double lds[];  // [constant table | per-lane column: max(nv, SP) * NBL rows -- the SEDs, then 1 / rms]
     const Model& M = *Mp;
     const int npix = M.npix, tid = threadIdx.x;
     double* tab = lds;
@@ -257,8 +149,7 @@ __global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP)) void k_plane_set(co
             load_theta(M, c2, i, sl.s1, t0v, t1v);
             sed_column<NBL>(fa.vtype[v], tab, NB, NG, fa.vcomp[v], jb, sed_prep(c2, t0v, t1v), col + (v * NBL) * BLOCK);
         }
-        // ---- the block solves of the plane set (k_amp_index's), amplitudes kept for the sweeps
-        RegChain<CH_POW, SP, NBL, LP> R0;  // storage for the maps of the plane set: d and 1/sigma
+        RegChain<CH_POW, SP, NBL, LP> R0;  // storage for the maps of the plane set: d and 1/sigma, then the residual
 #pragma unroll
         for (int kk = 0; kk < SP; ++kk) {
             const int k = sl.s1 + kk;
@@ -268,165 +159,170 @@ __global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP)) void k_plane_set(co
 #pragma unroll
                 for (int j = 0; j < NBL; ++j) { R0.D[kk][j] = sigp[(jb + j) * bstride]; R0.ISr[kk][j] = rmsp[(jb + j) * bstride]; }
             }
-            double eta = 0.0, f0 = 0.0;
-            if (sample) {
-                double u1, u2;
-                uniform2(ga.seed, ga.stream, gpix, (uint32_t)k, u1, u2);
-                eta = rand_normal(0.0, 1.0, u1, u2);
-            }
-            double A[NG * (NG + 1) / 2], bv[NG];
+            double bv[NG];
+            if (SOLVE) {
+                // ---- the block solve of unit (i, k) (k_amp_index's), amplitudes stored for the sweeps
+                double eta = 0.0, f0 = 0.0;
+                if (sample) {
+                    double u1, u2;
+                    uniform2(ga.seed, ga.stream, gpix, (uint32_t)k, u1, u2);
+                    eta = rand_normal(0.0, 1.0, u1, u2);
+                }
+                double A[NG * (NG + 1) / 2];
 #pragma unroll
-            for (int q = 0; q < NG * (NG + 1) / 2; ++q) A[q] = 0.0;
+                for (int q = 0; q < NG * (NG + 1) / 2; ++q) A[q] = 0.0;
 #pragma unroll
-            for (int g = 0; g < NG; ++g) bv[g] = 0.0;
-            const double* mp[NG];
-            int ms[NG];
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const bool var = fa.vslot[g] >= 0;
-                mp[g] = var ? col + (fa.vslot[g] * NBL) * BLOCK : tab + (TROWS * g + 2 + k) * NB + jb;
-                ms[g] = var ? BLOCK : 1;
-            }
-#pragma unroll
-            for (int j = 0; j < NBL; ++j) {
-                double d = R0.D[kk][j];
-                if (SP == 1 && fa.cal) d = d / tab[(TROWS * NG + 1) * NB + jb + j];  // T / gain, no offset (:371)
-                const double is = fast_rcp(R0.ISr[kk][j]);
-                R0.set_is(kk, j, is);
-                const double inv = is * is;
-                double mrow[NG];
-#pragma unroll
-                for (int g = 0; g < NG; ++g) mrow[g] = mp[g][j * ms[g]];
+                for (int g = 0; g < NG; ++g) bv[g] = 0.0;
+                const double* mp[NG];
+                int ms[NG];
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
-                    const double t2 = mrow[g] * inv;
-                    bv[g] += d * t2;
-#pragma unroll
-                    for (int h = 0; h <= g; ++h) A[g * (g + 1) / 2 + h] += t2 * mrow[h];
-                }
-                f0 += (eta * is) * mrow[NG - 1];
-                if (j % DX_FUSED_GRP == DX_FUSED_GRP - 1) __builtin_amdgcn_sched_barrier(0);
-            }
-            if (LP > 1) {
-#pragma unroll
-                for (int q = 0; q < NG * (NG + 1) / 2; ++q) A[q] += __shfl_xor(A[q], 1, 64);
-#pragma unroll
-                for (int g = 0; g < NG; ++g) bv[g] += __shfl_xor(bv[g], 1, 64);
-                f0 += __shfl_xor(f0, 1, 64);
-            }
-            bv[0] += f0;
-            bool ok = true;
-            double ri[NG];
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-#pragma unroll
-                for (int h = 0; h <= g; ++h) {
-                    double s = A[g * (g + 1) / 2 + h];
-#pragma unroll
-                    for (int t = 0; t < h; ++t) s -= A[g * (g + 1) / 2 + t] * A[h * (h + 1) / 2 + t];
-                    if (h == g) {
-                        if (!(s > 0.0) || !(s < 1.0e300)) ok = false;
-                        ri[g] = fast_rsqrt(s);
-                    } else {
-                        A[g * (g + 1) / 2 + h] = s * ri[h];
-                    }
-                }
-            }
-            if (ok) {
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    double s = bv[g];
-#pragma unroll
-                    for (int t = 0; t < g; ++t) s -= A[g * (g + 1) / 2 + t] * bv[t];
-                    bv[g] = s * ri[g];
-                }
-#pragma unroll
-                for (int g = NG - 1; g >= 0; --g) {
-                    double s = bv[g];
-#pragma unroll
-                    for (int t = g + 1; t < NG; ++t) s -= A[t * (t + 1) / 2 + g] * bv[t];
-                    bv[g] = s * ri[g];
-                }
-                // both lanes of a pair store (the same values): each lane later re-reads only what it wrote itself
-#pragma unroll
-                for (int g = 0; g < NG; ++g) M.comp[ga.gc[g]].amp[(long long)(k - 1) * npix + i] = bv[g];
-            } else {
-                if (half == 0) atomicAdd(not_spd, 1ull);  // x keeps its value: the sweeps run on the old amplitudes
-                if (RES) {
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) bv[g] = M.comp[ga.gc[g]].amp[(long long)(k - 1) * npix + i];
-                }
-            }
-            if (RES) {
-                if (SP == 1 && fa.cal) {
-                    const double* gn = tab + (TROWS * NG + 1) * NB + jb;
-#pragma unroll
-                    for (int j = 0; j < NBL; ++j) R0.D[kk][j] = (R0.D[kk][j] - gn[NB + j]) / gn[j];
-                }
-                // the plane's full residual in units of the rms: data_raw (:173-177) minus EVERY member in component_list order
-                // (:180-196 removes all but the sampled one; its own signal returns in the chain's first evaluation).  Member by member,
-                // each through ONE base address and compile-time offsets (a run-time stride costs one address register per load: the
-                // solve's band loop above pays that)
-                const int zo = 0;
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    const double amp2 = bv[g];
-                    if (fa.vslot[g] >= 0) {
-                        const double* m = col + (fa.vslot[g] * NBL) * BLOCK + zo;
-#pragma unroll
-                        for (int j = 0; j < NBL; ++j) R0.D[kk][j] -= amp2 * m[j * BLOCK];
-                    } else {
-                        const double* m = tab + (TROWS * g + 2 + k) * NB + jb + zo;
-#pragma unroll
-                        for (int j = 0; j < NBL; ++j) R0.D[kk][j] -= amp2 * m[j];
-                    }
+                    const bool var = fa.vslot[g] >= 0;
+                    mp[g] = var ? col + (fa.vslot[g] * NBL) * BLOCK : tab + (TROWS * g + 2 + k) * NB + jb;  // else csed of plane k
+                    ms[g] = var ? BLOCK : 1;
                 }
 #pragma unroll
                 for (int j = 0; j < NBL; ++j) {
-                    R0.D[kk][j] *= R0.ISr[kk][j];
-                    // pinned here: the optimiser otherwise sinks this arithmetic below the next plane's solve (its result is first
-                    // used by the chains) while the column reads stay, and NG * NBL loaded values are spilled across that solve
-                    asm volatile("" : "+v"(R0.D[kk][j]));
+                    double d = R0.D[kk][j];
+                    if (SP == 1 && fa.cal) d = d / tab[(TROWS * NG + 1) * NB + jb + j];  // T / gain, no offset (:371)
+                    const double is = fast_rcp(R0.ISr[kk][j]);
+                    R0.set_is(kk, j, is);
+                    const double inv = is * is;
+                    double mrow[NG];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) mrow[g] = mp[g][j * ms[g]];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        const double t2 = mrow[g] * inv;
+                        bv[g] += d * t2;
+#pragma unroll
+                        for (int h = 0; h <= g; ++h) A[g * (g + 1) / 2 + h] += t2 * mrow[h];
+                    }
+                    f0 += (eta * is) * mrow[NG - 1];
+                    if (j % DX_FUSED_GRP == DX_FUSED_GRP - 1) __builtin_amdgcn_sched_barrier(0);
+                }
+                if (LP > 1) {
+#pragma unroll
+                    for (int q = 0; q < NG * (NG + 1) / 2; ++q) A[q] += __shfl_xor(A[q], 1, 64);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) bv[g] += __shfl_xor(bv[g], 1, 64);
+                    f0 += __shfl_xor(f0, 1, 64);
+                }
+                bv[0] += f0;
+                bool ok = true;
+                double ri[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+#pragma unroll
+                    for (int h = 0; h <= g; ++h) {
+                        double s = A[g * (g + 1) / 2 + h];
+#pragma unroll
+                        for (int t = 0; t < h; ++t) s -= A[g * (g + 1) / 2 + t] * A[h * (h + 1) / 2 + t];
+                        if (h == g) {
+                            if (!(s > 0.0) || !(s < 1.0e300)) ok = false;
+                            ri[g] = fast_rsqrt(s);
+                        } else {
+                            A[g * (g + 1) / 2 + h] = s * ri[h];
+                        }
+                    }
+                }
+                if (ok) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        double s = bv[g];
+#pragma unroll
+                        for (int t = 0; t < g; ++t) s -= A[g * (g + 1) / 2 + t] * bv[t];
+                        bv[g] = s * ri[g];
+                    }
+#pragma unroll
+                    for (int g = NG - 1; g >= 0; --g) {
+                        double s = bv[g];
+#pragma unroll
+                        for (int t = g + 1; t < NG; ++t) s -= A[t * (t + 1) / 2 + g] * bv[t];
+                        bv[g] = s * ri[g];
+                    }
+                    // both lanes of a pair store (the same values): each lane later re-reads only what it wrote itself
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) M.comp[ga.gc[g]].amp[(long long)(k - 1) * npix + i] = bv[g];
+                } else {
+                    if (half == 0) atomicAdd(not_spd, 1ull);  // x keeps its value: the sweeps run on the old amplitudes
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) bv[g] = M.comp[ga.gc[g]].amp[(long long)(k - 1) * npix + i];
+                }
+            } else {  // the index phase alone: the amplitudes of the last solve
+#pragma unroll
+                for (int g = 0; g < NG; ++g) bv[g] = M.comp[ga.gc[g]].amp[(long long)(k - 1) * npix + i];
+#pragma unroll
+                for (int j = 0; j < NBL; ++j) R0.set_is(kk, j, fast_rcp(R0.ISr[kk][j]));
+            }
+            // ---- the plane's full residual in units of the rms: data_raw (:173-177) minus EVERY member in component_list order
+            // (:180-196 removes all but the sampled one; its own signal returns in the chain's first evaluation).  Member by member,
+            // each through ONE base address and compile-time offsets (a run-time stride costs one address register per load: the
+            // solve's band loop above pays that)
+            if (SP == 1 && fa.cal) {  // data_raw = (sig - offset) / gain on the temperature plane (:174)
+                const double* gn = tab + (TROWS * NG + 1) * NB + jb;
+#pragma unroll
+                for (int j = 0; j < NBL; ++j) R0.D[kk][j] = (R0.D[kk][j] - gn[NB + j]) / gn[j];
+            }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const double amp2 = bv[g];
+                if (fa.vslot[g] >= 0) {
+                    const double* m = col + (fa.vslot[g] * NBL) * BLOCK;
+#pragma unroll
+                    for (int j = 0; j < NBL; ++j) R0.D[kk][j] -= amp2 * m[j * BLOCK];
+                } else {
+                    const double* m = tab + (TROWS * g + 2 + k) * NB + jb;
+#pragma unroll
+                    for (int j = 0; j < NBL; ++j) R0.D[kk][j] -= amp2 * m[j];
                 }
             }
+#pragma unroll
+            for (int j = 0; j < NBL; ++j) {
+                R0.D[kk][j] *= R0.ISr[kk][j];
+                // pinned here: the optimiser otherwise sinks this arithmetic below the next plane's solve (its result is first used
+                // by the chains) while the column reads stay, and NG * NBL loaded values are spilled across that solve
+                asm volatile("" : "+v"(R0.D[kk][j]));
+            }
         }
-        if (RES) {  // 1 / rms of the lane's bands -> its LDS column (the SED columns are dead from here on)
+        if (C0 == 0) {  // no sweep follows: chi^2 of the state the solve leaves is the residual's (both the "before" and "after" slots)
+#pragma unroll
+            for (int kk = 0; kk < SP; ++kk) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < NBL; ++j) acc = fma(R0.D[kk][j], R0.D[kk][j], acc);
+                if (LP > 1) acc += __shfl_xor(acc, 1, 64);
+                if (half == 0) { chi[kk] = acc; chi[2 + kk] = acc; }
+            }
+        } else {
+            // 1 / rms of the lane's bands -> its LDS column (the SED columns are dead from here on)
 #pragma unroll
             for (int kk = 0; kk < SP; ++kk)
 #pragma unroll
                 for (int j = 0; j < NBL; ++j) col[(kk * NBL + j) * BLOCK] = R0.ISr[kk][j];
-            __builtin_amdgcn_sched_barrier(0);  // the first chain's prologue (random numbers, 1/rms x amplitude) stays below: 1/rms is dead here
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- the sweeps of the plane set, in the reference's order.  The first one reuses the solve's map registers (R0).
+        // ---- the sweeps of the plane set, in the reference's order
         int slot = 0;
         auto run = [&](auto code_tag, auto first_tag, auto last_tag, int q) {
             constexpr int CODE = decltype(code_tag)::value;
             constexpr bool FIRST = decltype(first_tag)::value;
+            constexpr bool LAST = decltype(last_tag)::value;
             if constexpr (CODE != 0) {
                 const SweepItem it = sl.s[q];
                 const Comp& c = M.comp[it.comp];
                 double sample0, sample1, unused[4];
                 // a component's sweeps are consecutive and travel in ONE item: no lane reads here what its partner wrote
                 load_theta(M, c, i, sl.s1, sample0, sample1);
-                if constexpr (RES) {
-                    constexpr bool LAST = decltype(last_tag)::value;
-                    ps_item_res<(CODE & 7), (CODE >> 3), SP, NBL, LP, NG, FIRST, LAST>(M, sl, it, R0, i, half, jb, NB, tab, col, sample0, sample1,
-                                                                                      FIRST ? chi : unused, chi, accepted, slot);
-                    slot += 1 + (CODE >> 3);
-                } else {
-                ps_item<(CODE & 7), (CODE >> 3), SP, NBL, LP, NG, FIRST>(M, sl, it, fa, R0, i, half, jb, NB, tab, col, ga, sample0, sample1,
-                                                                        FIRST ? chi : unused, chi, accepted, slot);
+                ps_item<(CODE & 7), (CODE >> 3), SP, NBL, LP, NG, FIRST, LAST>(M, sl, it, R0, i, half, jb, NB, tab, col, sample0, sample1,
+                                                                              FIRST ? chi : unused, chi, accepted, slot);
                 slot += 1 + (CODE >> 3);
-                // the member that moved: its SED column at the new indices (both lanes hold the same values)
-                if (q + 1 < sl.n && fa.vslot[it.gmember] >= 0)
-                    sed_column<NBL>(c.type, tab, NB, NG, it.gmember, jb, sed_prep(c, sample0, sample1), col + (fa.vslot[it.gmember] * NBL) * BLOCK);
-                }
             }
         };
-        run(ItemCode<C0>{}, ItemFirst<true>{}, ItemFirst<C1 == 0>{}, 0);
-        run(ItemCode<C1>{}, ItemFirst<false>{}, ItemFirst<C2 == 0>{}, 1);
-        run(ItemCode<C2>{}, ItemFirst<false>{}, ItemFirst<C3 == 0>{}, 2);
-        run(ItemCode<C3>{}, ItemFirst<false>{}, ItemFirst<true>{}, 3);
+        run(ItemCode<C0>{}, ItemFlag<true>{}, ItemFlag<C1 == 0>{}, 0);
+        run(ItemCode<C1>{}, ItemFlag<false>{}, ItemFlag<C2 == 0>{}, 1);
+        run(ItemCode<C2>{}, ItemFlag<false>{}, ItemFlag<C3 == 0>{}, 2);
+        run(ItemCode<C3>{}, ItemFlag<false>{}, ItemFlag<true>{}, 3);
     }
     if (chi_partial) {
         __shared__ double sh[4][BLOCK / 64];

@@ -164,6 +164,16 @@ module dangx_mod
        integer(c_int64_t), intent(out), optional :: n_not_spd
        integer(c_int64_t), intent(out), optional :: accepted(*)
      end function
+     integer(c_int) function dangx_plane_sweeps_sample(ctx, flag, nsweeps, comp, nind, stream, nsample, ml_mode, seed, accepted) &
+          bind(C, name='dangx_plane_sweeps_sample')
+       import :: c_int, c_ptr, c_int32_t, c_int64_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: flag, nsweeps, nsample, ml_mode
+       integer(c_int64_t), value :: seed
+       integer(c_int32_t), intent(in) :: comp(*), nind(*)          ! 0-based, in sample_spectral_parameters' order
+       integer(c_int64_t), intent(in) :: stream(*)
+       integer(c_int64_t), intent(out), optional :: accepted(*)
+     end function
      integer(c_int) function dangx_set_template(ctx, comp, tmpl, corr, nfit) bind(C, name='dangx_set_template')
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx, tmpl, corr        ! corr: integer(c_int32_t)(nbands), 1 = fitted band

@@ -351,6 +351,29 @@ contains
     end if
   end subroutine dangx_sky_plane_set_sample
 
+  ! dangx_sky_index_sample(comp(s), nind(s), ...) for the sweeps of ONE plane set, in the reference's order, through
+  ! dangx_plane_sweeps_sample: one launch per context where the plane-set kernel covers the model, those calls otherwise
+  subroutine dangx_sky_plane_sweeps_sample(sky, flag, nsweeps, comp, nind, stream, nsample, ml_mode, seed, accepted)
+    type(dangx_sky), intent(in) :: sky
+    integer, intent(in) :: flag, nsweeps, nsample, ml_mode
+    integer(c_int32_t), intent(in) :: comp(nsweeps), nind(nsweeps)      ! 0-based
+    integer(c_int64_t), intent(in) :: seed, stream(nsweeps)
+    integer(c_int64_t), intent(out), optional :: accepted(nsweeps)
+    integer(c_int64_t) :: nacc(nsweeps)
+    integer :: r
+    if (present(accepted)) accepted = 0
+    do r = 1, sky%nctx
+       if (present(accepted)) then
+          call dangx_check(sky%ctx(r), dangx_plane_sweeps_sample(sky%ctx(r), flag, nsweeps, comp, nind, stream, nsample, ml_mode, seed, nacc), &
+               'dangx_plane_sweeps_sample')
+          accepted = accepted + nacc
+       else
+          call dangx_check(sky%ctx(r), dangx_plane_sweeps_sample(sky%ctx(r), flag, nsweeps, comp, nind, stream, nsample, ml_mode, seed), &
+               'dangx_plane_sweeps_sample')
+       end if
+    end do
+  end subroutine dangx_sky_plane_sweeps_sample
+
   ! sample_index_mh with sample_nside /= nside (src/dang_sample_mod.f90:199-217, 332-483) over the contexts: the three
   ! phases of dangx_index_sample_coarse, the shards' buffers added in shard order between them
   subroutine dangx_sky_index_sample_coarse(sky, comp, nind, map_n, nsample, ml_mode, seed, stream, nside, sample_nside, accepted)

@@ -416,13 +416,41 @@ contains
     logical, intent(in), optional :: skip(:)
     logical(lgt), intent(out)     :: sampled
     type(dang_comps), pointer :: cc
-    integer(i4b) :: i, j, k, e, map_n, mode, flag
+    integer(i4b) :: i, j, k, e, map_n, mode, flag, ns, n, q
     integer(c_int64_t) :: nacc, stream
     integer(c_int32_t) :: tuned(2)
     real(c_double) :: step, val
     logical(lgt) :: pair_done, pairable, skip_next
+    integer(c_int32_t), allocatable :: fc(:), fn(:), ff(:), fg(:)
+    integer(c_int64_t), allocatable :: fs(:)
+    logical, allocatable :: fplain(:), done(:)
     sampled = .false.
     mode = merge(DANGX_ML_SAMPLE, DANGX_ML_OPTIMIZE, trim(dpar%ml_mode) == 'sample')
+    ! the sweeps of the iteration as a flat list in the loop's order: consecutive plain per-pixel sweeps with ONE flag whose
+    ! components belong to one CG group go through dangx_plane_sweeps_sample -- one launch on the plane set where the model allows it
+    ns = 0
+    do i = 1, ncomp
+       cc => component_list(i)%p
+       do j = 1, cc%nindices
+          if (cc%sample_index(j)) ns = ns + cc%nflag(j)
+       end do
+    end do
+    allocate(fc(ns), fn(ns), ff(ns), fg(ns), fs(ns), fplain(ns), done(ns))
+    ns = 0
+    do i = 1, ncomp
+       cc => component_list(i)%p
+       do j = 1, cc%nindices
+          if (.not. cc%sample_index(j)) cycle
+          do k = 1, cc%nflag(j)
+             ns = ns + 1
+             fc(ns) = i-1; fn(ns) = j-1; ff(ns) = cc%pol_flag(j,k); fg(ns) = cc%cg_group
+             fs(ns) = dangx_stream_id(iter, 1, i-1, j-1, cc%pol_flag(j,k))
+             fplain(ns) = plain_sweep(cc, j) .and. cc%sample_amplitude .and. map_of_flag(cc%pol_flag(j,k)) /= 0
+             if (present(skip)) fplain(ns) = fplain(ns) .and. .not. skip(ns)
+          end do
+       end do
+    end do
+    done = .false.
     e = 0
     do i = 1, ncomp
        cc => component_list(i)%p
@@ -434,12 +462,29 @@ contains
           if (.not. cc%sample_index(j)) cycle
           do k = 1, cc%nflag(j)
              e = e + 1
+             if (done(e)) then                            ! went with an earlier sweep of its plane set (one launch)
+                write(*,fmt='(a,i4)') 'Sampling per-pixel at nside ', cc%sample_nside(j)
+                cycle
+             end if
              if (pair_done) then                          ! this index went with the one before it (one launch)
                 pair_done = .false.
                 cycle
              end if
              if (present(skip)) then
                 if (skip(e)) cycle
+             end if
+             if (fplain(e)) then                          ! how many sweeps from here on share this plane set?
+                n = 1
+                do while (e + n <= ns)
+                   if (.not. (fplain(e+n) .and. ff(e+n) == ff(e) .and. fg(e+n) == fg(e))) exit
+                   n = n + 1
+                end do
+                if (n >= 2) then
+                   write(*,fmt='(a,i4)') 'Sampling per-pixel at nside ', cc%sample_nside(j)
+                   call dangx_sky_plane_sweeps_sample(gpu_sky, int(ff(e)), n, fc(e:e+n-1), fn(e:e+n-1), fs(e:e+n-1), nsample, mode, gpu_seed)
+                   done(e+1:e+n-1) = .true.
+                   cycle
+                end if
              end if
              flag = cc%pol_flag(j,k)
              map_n = map_of_flag(flag)

@@ -243,6 +243,18 @@ int dangx_plane_set_sample(dangx_ctx *ctx, int group, int flag, int ml_mode, int
                            const uint64_t *stream, int nsample, uint64_t seed_index, int *cg_iters, int64_t *n_not_spd,
                            int64_t *accepted);
 
+/* ---- the index phase of ONE plane set in one call: exactly
+ * dangx_index_sample(comp[s], nind[s], map_n(flag), nsample, ml_mode, seed, stream[s], &accepted[s]) for s = 0 .. nsweeps-1 -- the
+ * passes of sample_spectral_parameters (src/dang_sample_mod.f90:40-75) that touch the planes of `flag`, in the reference's order:
+ * what the two-call seam (src/dang.f90:101, 106) issues after sample_cg_groups has returned.  Sweeps on disjoint planes are
+ * independent (c%indices(:, k, :) is per plane), so a caller may collect the sweeps of a plane set from the reference's
+ * component-major loop.  Where every swept component is an amplitude-sampled member of ONE CG group whose members are the only
+ * components on these planes (delta bands, chisq likelihood, gaussian / uniform priors) the sweeps are ONE kernel launch on the
+ * amplitudes in memory: one staging of the maps, the residual kept in registers between the sweeps; every other case IS the
+ * calls above (consecutive indices of a component through dangx_index_sample_pair).  accepted[nsweeps] nullable. */
+int dangx_plane_sweeps_sample(dangx_ctx *ctx, int flag, int nsweeps, const int32_t *comp, const int32_t *nind, const uint64_t *stream,
+                              int nsample, int ml_mode, uint64_t seed, int64_t *accepted);
+
 /* ---- sky model + chi^2: update_sky_model + compute_chisq
  * (src/dang_data_mod.f90:339-396, 494-526).  pol_lo..pol_hi = ddata%pol_type range.
  * chisq_sum receives the LOCAL sum over unmasked pixels and planes of

@@ -79,3 +79,85 @@ def test_plane_set_launches_stay_under_band_calibration(built, config, nside):
         assert np.abs(a - b).max() <= 1e-9 * max(np.abs(b).max(), 1e-30), l
         if comps[l].nindices:
             assert np.abs(eng.get_indices(l) - orc.indices(l)).max() <= 1e-12, l
+
+
+def _plane_sweep_list(comps, group, flag, it):
+    return [(l, j, da.stream_id(it, 1, l, j, flag)) for l, c in enumerate(comps) for j in range(c.nindices)
+            if c.cg_group == group and c.sample_index[j] and flag in c.pol_flag[j]]
+
+
+@pytest.mark.parametrize("config,nside", [("C3", 8), ("C2", 8), ("C5", 4), ("C1", 8)])
+def test_two_call_seam_launches_match_the_oracle(built, config, nside):
+    """The two halves of the two-call seam (src/dang.f90:101, 106) as they now run: dangx_amp_sample = the plane-set kernel without
+    sweep items, whose residual gives chi^2 of the state the solve leaves (src/dang_cg_mod.f90:172-173) without a pass of its own;
+    dangx_plane_sweeps_sample = the sweeps of a plane set in one launch on the amplitudes in memory.  Against the oracle's solves
+    and sweeps (amplitudes 1e-9, indices 1e-12, accepted counts equal, chi^2 1e-10 -- also against the explicit pass), and the
+    profile shows no chi^2 pass and no stand-alone sweep launch."""
+    case = make_case(config, nside=nside, start="truth")
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+    nmaps = meta["nmaps"]
+    for it in (2, 3):
+        eng.profile(True)
+        for g in dpar.cg_groups:
+            f = g.pol_flag[0]
+            s = da.stream_id(it, 0, g.cg_group, 0, f)
+            _, bad = eng.amp_sample(g.cg_group, f, "sample", dpar.seed, s)
+            assert bad == orc.amp_sample_direct(g.cg_group, f, "sample", dpar.seed, s, "reference")
+        chi_amp = eng.chisq_current(1, nmaps)                   # by-product of the solves: no launch but the reductions
+        prof = eng.profile_get()
+        assert "k_sky_chisq" not in prof and prof["k_amp_direct"]["launches"] == len(dpar.cg_groups), prof
+        eng.profile(False)
+        ochi, _ = orc.chisq(1, nmaps, 1.0)
+        assert abs(chi_amp / meta["nbands"] - ochi) <= 1e-10 * ochi, (it, chi_amp / meta["nbands"], ochi)
+        assert abs(eng.sky_model_chisq(1, nmaps) - chi_amp) <= 1e-10 * chi_amp     # the explicit pass agrees
+        eng.profile(True)
+        for g in dpar.cg_groups:
+            f = g.pol_flag[0]
+            sw = _plane_sweep_list(comps, g.cg_group, f, it)
+            acc = eng.plane_sweeps_sample(f, sw, dpar.nsample, "sample", dpar.seed)
+            for (l, j, st), a in zip(sw, acc):
+                assert a == orc.sample_index_mh(l, j, MAPN[f], dpar.nsample, "sample", dpar.seed, st), (it, l, j)
+        prof = eng.profile_get()
+        eng.profile(False)
+        assert prof["k_index_mh"]["launches"] == len(dpar.cg_groups), prof       # one launch per plane set
+        before, after = eng.chisq_cached(0, 1, nmaps), eng.chisq_cached(1, 1, nmaps)
+        assert abs(before - chi_amp) <= 1e-10 * chi_amp                          # what the first sweeps saw = what the solves left
+        ochi, _ = orc.chisq(1, nmaps, 1.0)
+        assert abs(after / meta["nbands"] - ochi) <= 1e-10 * ochi
+    for l in range(len(comps)):
+        a, b = eng.get_amplitude(l), orc.amplitude(l)
+        assert np.abs(a - b).max() <= 1e-9 * max(np.abs(b).max(), 1e-30), l
+        if comps[l].nindices:
+            assert np.abs(eng.get_indices(l) - orc.indices(l)).max() <= 1e-12, l
+
+
+def test_masked_index_sums_are_cached_until_a_map_changes(built):
+    """dangx_index_masked_sums (write_stats_to_term's index means, src/dang_data_mod.f90:540-567, asked for after EVERY phase):
+    answered from the host while nothing has written the maps -- an amplitude phase does not -- and recomputed after a sweep, a
+    host push or a new mask."""
+    case = make_case("C2", nside=8, start="truth")
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+    entries = [(l, j, k) for l, c in enumerate(comps) for j in range(c.nindices) for k in ((1,) if c.cg_group == 1 else (2, 3))]
+    def want():
+        m = np.asarray(ddata.masks)[0] != 0
+        return [float(eng.get_indices(l)[j, k - 1][m].sum()) for l, j, k in entries]
+    s0, c0 = eng.index_masked_sums(entries)
+    assert np.allclose(s0, want(), rtol=1e-13)
+    eng.profile(True)
+    eng.amp_sample(1, L.FLAG_T, "sample", dpar.seed, 5)
+    s1, c1 = eng.index_masked_sums(entries)                  # nothing wrote an index map: no launch
+    assert np.array_equal(s0, s1) and np.array_equal(c0, c1)
+    n_before = sum(v["launches"] for v in eng.profile_get().values())
+    eng.index_sample(1, 0, 1, 5, "sample", dpar.seed, 7)     # synchrotron beta on T moves
+    n_sweep = sum(v["launches"] for v in eng.profile_get().values())
+    s2, _ = eng.index_masked_sums(entries)
+    assert np.allclose(s2, want(), rtol=1e-13) and s2[entries.index((1, 0, 1))] != s1[entries.index((1, 0, 1))]
+    new = eng.get_indices(2).copy()
+    new[0, 0] += 0.25
+    eng.put_indices(2, new)                                  # a host push
+    s3, _ = eng.index_masked_sums(entries)
+    assert np.allclose(s3, want(), rtol=1e-13) and s3[entries.index((2, 0, 1))] != s2[entries.index((2, 0, 1))]
+    eng.profile(False)
+    assert n_sweep > n_before

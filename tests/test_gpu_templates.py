@@ -256,7 +256,9 @@ def test_T_cmb_sampling_per_pixel_and_full_sky(built):
     eng.pull_state()
     ref, _ = O.Oracle(bands, comps, ddata, tcmb=T).chisq(ddata.pol_type[0], ddata.pol_type[-1], ddata.nump)
     assert abs(ddata.chisq - ref) <= 1e-10 * abs(ref), (ddata.chisq, ref)
-    assert eng.chisq_cached(1, 1, 1) is None                 # invalidated by dangx_set_tcmb
+    # (dangx_set_tcmb invalidated the sweep's sum; compute_chisq then evaluated the plane again and left ITS value in the cache)
+    cached = sum(eng.chisq_cached(1, k, k) for k in range(ddata.pol_type[0], ddata.pol_type[-1] + 1))
+    assert abs(cached / meta["nbands"] / ddata.nump - ref) <= 1e-10 * abs(ref)
 
 
 def test_gibbs_iterations_with_a_fitted_template(built):
