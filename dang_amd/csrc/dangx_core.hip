@@ -1843,7 +1843,7 @@ int dangx_amp_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solve
     // model (delta bands, the group's members the only components on the planes, reference fluctuation term) the statistics need
     // no pass of their own over the maps.  DANGX_AMP_CHI=0: the stand-alone amplitude kernel (A/B timing).
     static const bool with_chi = [] { const char* e = getenv("DANGX_AMP_CHI"); return !(e && e[0] == '0'); }();
-    if (with_chi && ctx->hm.all_delta != 0 && (ml_mode == DANGX_ML_OPTIMIZE || fluct_mode == DANGX_FLUCT_REFERENCE) && planeset_group(ctx, a)) {
+    if (with_chi && (ml_mode == DANGX_ML_OPTIMIZE || fluct_mode == DANGX_FLUCT_REFERENCE) && planeset_group(ctx, a)) {
         SweepList sl;
         std::memset(&sl, 0, sizeof(sl));
         sl.s1 = (flag & DANGX_FLAG_QU) ? 2 : (flag & DANGX_FLAG_T) ? 1 : (flag & DANGX_FLAG_Q) ? 2 : 3;
@@ -2297,7 +2297,7 @@ static bool planeset_items(dangx_ctx* ctx, const GroupArgs& g, int map_n, int ns
 static bool planeset_group(dangx_ctx* ctx, const GroupArgs& g) {
     if (!(g.nt == 0 && g.no == 0 && g.nuc == 0)) return false;
     for (int l = 0; l < ctx->hm.ncomp; ++l)
-        if (ctx->desc[l].type == DANGX_TCMB) return false;
+        if (ctx->desc[l].type == DANGX_TCMB || is_global_type(ctx->desc[l].type)) return false;
     return true;
 }
 
@@ -2321,7 +2321,7 @@ int dangx_plane_set_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int
     if (n_not_spd) *n_not_spd = 0;
     static const bool enabled = [] { const char* e = getenv("DANGX_FUSE"); return !(e && e[0] == '0'); }();
     // ---- does the one-launch form cover this?  (the conditions of dangx_amp_index_sample, for every sweep of the list)
-    bool can = enabled && nsweeps <= 2 * DX_MAX_SWEEPS && solver == DANGX_SOLVER_DIRECT && ctx->hm.all_delta != 0 &&
+    bool can = enabled && nsweeps <= 2 * DX_MAX_SWEEPS && solver == DANGX_SOLVER_DIRECT &&
                (ml_mode == DANGX_ML_OPTIMIZE || fluct_mode == DANGX_FLUCT_REFERENCE) &&
                (ml_mode == DANGX_ML_SAMPLE || ml_mode == DANGX_ML_OPTIMIZE);
     GroupArgs g;
@@ -2378,7 +2378,7 @@ int dangx_plane_sweeps_sample(dangx_ctx* ctx, int flag, int nsweeps, const int32
     for (int s = 0; s < nsweeps; ++s)
         if (check_comp(ctx, comp[s]) || nind[s] < 0 || nind[s] >= ctx->desc[comp[s]].nindices) return fail(ctx, "sweep list: component / index out of range");
     static const bool enabled = [] { const char* e = getenv("DANGX_FUSE"); return !(e && e[0] == '0'); }();
-    bool can = enabled && nsweeps <= 2 * DX_MAX_SWEEPS && ctx->hm.all_delta != 0 && (ml_mode == DANGX_ML_SAMPLE || ml_mode == DANGX_ML_OPTIMIZE);
+    bool can = enabled && nsweeps <= 2 * DX_MAX_SWEEPS && (ml_mode == DANGX_ML_SAMPLE || ml_mode == DANGX_ML_OPTIMIZE);
     const int group = ctx->desc[comp[0]].cg_group;
     for (int s = 0; can && s < nsweeps; ++s) can = ctx->desc[comp[s]].cg_group == group && ctx->desc[comp[s]].sample_amplitude;
     GroupArgs g;

@@ -17,13 +17,20 @@ static size_t planeset_lds(int ng, int nb, int nv, int lanes, int Sp) {
 static void item_codes(const SweepList& sl, int code[4]) {
     for (int q = 0; q < 4; ++q) code[q] = (q < sl.n) ? sl.s[q].mode + 8 * sl.s[q].pair : 0;
 }
-static std::string planeset_name(int Sp, int nb, int ng, int lanes, int solve, const SweepList& sl) {
+static std::string planeset_name(int Sp, int nb, int ng, int lanes, int solve, const SweepList& sl, int bp) {
     int c[4];
     item_codes(sl, c);
     std::string s = "dxk::k_plane_set<" + std::to_string(Sp) + ", " + std::to_string(nb) + ", " + std::to_string(ng) + ", " + std::to_string(lanes) +
                     ", " + std::to_string(solve);
     for (int q = 0; q < 4; ++q) s += ", " + std::to_string(c[q]);
-    return s + ">";
+    return s + ", " + std::to_string(bp) + ">";
+}
+
+// bandpass-integrated bands in the model: the BP form of the kernel (one lane per pixel; power-law / mbb chains)
+static int planeset_bp(dangx_ctx* ctx) {
+    for (int j = 0; j < ctx->hm.nbands; ++j)
+        if (ctx->hm.band[j].n != 0) return 1;
+    return 0;
 }
 
 // the BASELINE shapes: C5 (20 bands, 6 members, lane pairs; sweeps synchrotron beta | dust beta + T | AME nu_p) and C3 / C2 / C1
@@ -97,13 +104,20 @@ int dx_planeset_lanes(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl, 
     }
     FusedArgs fa;
     if (!planeset_args(ctx, ga, sl, fa)) return 0;
+    const int bp = planeset_bp(ctx);
+    if (bp) {  // sample loops exist for the power-law and mbb chains, in the one-lane form
+        for (int q = 0; q < sl.n; ++q)
+            if (sl.s[q].mode > CH_MBB_T) return 0;
+        if (!(small_too && nb <= cap && planeset_lds(ga.ng, nb, fa.nv, 1, Sp) <= 80u * 1024u)) return 0;
+        return dx_rtc_get(ctx, "dx_kern_planeset.h", planeset_name(Sp, nb, ga.ng, 1, solve, sl, 1)) ? 1 : 0;
+    }
     // one lane where registers (cap) and the members' SED columns (two blocks per CU: 80 KB each) allow it, else lane pairs
     int lanes = 0;
     if (small_too && nb <= cap && planeset_lds(ga.ng, nb, fa.nv, 1, Sp) <= 80u * 1024u) lanes = 1;
     else if (nb > 12 && nb % 2 == 0 && nb / 2 <= cap && planeset_lds(ga.ng, nb, fa.nv, 2, Sp) <= 80u * 1024u) lanes = 2;
     if (!lanes) return 0;
     if (planeset_builtin(nb, ga.ng, lanes, solve, sl)) return lanes;
-    return dx_rtc_get(ctx, "dx_kern_planeset.h", planeset_name(Sp, nb, ga.ng, lanes, solve, sl)) ? lanes : 0;
+    return dx_rtc_get(ctx, "dx_kern_planeset.h", planeset_name(Sp, nb, ga.ng, lanes, solve, sl, 0)) ? lanes : 0;
 }
 
 // accp: per-sweep counters (sum over items of 1 + pair entries) or null
@@ -112,7 +126,8 @@ bool dx_launch_planeset(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl
     if (lanes < 1 || lanes > 2 || !planeset_args(ctx, ga, sl, fa)) return false;
     const int nb = ctx->hm.nbands, ng = ga.ng, Sp = sl.s2 - sl.s1 + 1;
     const size_t ldsz = planeset_lds(ng, nb, fa.nv, lanes, Sp);
-    if (planeset_builtin(nb, ng, lanes, solve, sl)) {
+    const int bp = planeset_bp(ctx);
+    if (!bp && planeset_builtin(nb, ng, lanes, solve, sl)) {
         if (nb == 20) launch_builtin<20, 6, 2, 1, CH_POW, CH_MBB_BETA + 8, CH_LOGN_NUP>(ctx, ga, fa, sl, Sp, nblk, ldsz, accp);
         else if (nb == 10 && sl.n == 0) launch_builtin<10, 4, 1, 1, 0, 0, 0>(ctx, ga, fa, sl, Sp, nblk, ldsz, accp);
         else if (nb == 10 && !solve) launch_builtin<10, 4, 1, 0, CH_POW, CH_MBB_BETA + 8, 0>(ctx, ga, fa, sl, Sp, nblk, ldsz, accp);
@@ -121,7 +136,7 @@ bool dx_launch_planeset(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl
         else launch_builtin<3, 2, 1, 1, CH_POW, CH_MBB_BETA + 8, 0>(ctx, ga, fa, sl, Sp, nblk, ldsz, accp);
         return true;
     }
-    hipFunction_t fn = dx_rtc_get(ctx, "dx_kern_planeset.h", planeset_name(Sp, nb, ng, lanes, solve, sl));
+    hipFunction_t fn = dx_rtc_get(ctx, "dx_kern_planeset.h", planeset_name(Sp, nb, ng, lanes, solve, sl, bp));
     if (!fn) return false;
     const Model* dm = ctx->dm;
     GroupArgs gg = ga;

@@ -72,9 +72,17 @@ struct BandPick {
 
 // KT: a lane pair's per-band constants are read from a table in LDS (kt1 / kt2 point at the lane's first band) instead of being
 // held in 2*NB registers -- for kernels that have the block's constant table anyway (k_plane_set)
-template <int MODE, int SP, int NB, int LP, bool KT = false>
+// BP (LP == 1 only): some bands are bandpass-integrated (bp%id /= 'delta', src/dang_component_mod.f90:909-913, 949-954): such a
+// band's SED is the tau-weighted sum over its samples in sample order, evaluated by a run-time loop around the same per-sample
+// expressions -- sample tables (nu0, tau0, log(nu0/nu_ref)) through scalar loads, the reciprocal of the Planck denominator as in
+// the delta form.  What is chain invariant per SAMPLE (the other index's exponential of a modified blackbody) has nowhere to
+// live (85 values per pixel in bench.py --bandpass 16) and is evaluated again in every proposal: two exponentials per sample
+// instead of one for the mbb sweeps.
+template <int MODE, int SP, int NB, int LP, bool KT = false, bool BP = false>
 struct RegChain {
+    static constexpr bool kBP = BP;
     double D[SP][NB], F[NB], ISr[SP][NB];  // cleaned data, chain-invariant SED factor, 1/rms  (scaled form: d/rms, amp/rms)
+    double bpa, bpb;                       // BP: CH_MBB_BETA: z = h/(k T), exp(z nu_ref) - 1; CH_MBB_T: beta + 1
     double K1[(LP > 1 && !KT) ? NB : 1], K2[(LP > 1 && !KT) ? NB : 1];  // LP > 1: the lane's per-band constants (see k1 / k2)
     const double *kt1, *kt2;
     double amp[SP];
@@ -127,10 +135,31 @@ struct RegChain {
         const double rs1 = (MODE == CH_LOGN_NUP || MODE == CH_LOGN_W) ? fast_rcp(s1) : 0.0;
 #endif
         // bands in tiles of TT: TT independent exp chains interleave, then accumulate in band order
-        constexpr int TT = (NB % 5 == 0) ? 5 : (NB % 4 == 0) ? 4 : (NB % 3 == 0) ? 3 : 1;
+        // (BP: one band at a time -- a bandpass-integrated band interleaves its own samples)
+        constexpr int TT = BP ? 1 : (NB % 5 == 0) ? 5 : (NB % 4 == 0) ? 4 : (NB % 3 == 0) ? 3 : 1;
+        static_assert(!BP || (LP == 1 && (MODE == CH_POW || MODE == CH_MBB_BETA || MODE == CH_MBB_T)), "bandpass chains: one lane, power law / mbb");
 #pragma unroll
         for (int j0 = 0; j0 < NB; j0 += TT) {
             double s[TT];
+            if (BP && M.band[j0].n != 0) {   // wave-uniform: LP == 1, j0 is the band number
+                const Band& b = M.band[j0];
+                const kptr nu = as_const(M.bp_nu0 + b.off);
+                const kptr tau = as_const(M.bp_tau0 + b.off);
+                const kptr lnr = as_const(c.bp_lnr + b.off);
+                const int n = b.n;
+                double sj = 0.0;
+                if (MODE == CH_POW) {               // :909-913
+#pragma unroll 4
+                    for (int q = 0; q < n; ++q) sj = sj + tau[q] * CEXP(s0 * lnr[q]);
+                } else if (MODE == CH_MBB_BETA) {   // :949-954, T fixed: tau * A / (e^{z nu} - 1) * (nu/nu_ref)^(beta+1)
+#pragma unroll 4
+                    for (int q = 0; q < n; ++q) sj = sj + (tau[q] * bpb) * fast_rcp(CEXP(bpa * nu[q]) - 1.0) * CEXP(s0 * lnr[q]);
+                } else {                            // CH_MBB_T, beta fixed
+#pragma unroll 4
+                    for (int q = 0; q < n; ++q) sj = sj + (tau[q] * s1) * fast_rcp(CEXP(s0 * nu[q]) - 1.0) * CEXP(bpa * lnr[q]);
+                }
+                s[0] = sj;
+            } else
             if (MODE == CH_MBB_T && TT > 1 && BATCH) {
                 // one reciprocal for the tile's TT Planck denominators (prefix products, invert the last, peel backwards):
                 // 3(TT-1) multiplications and one v_rcp_f64 + Newton instead of TT of them (v_rcp_f64 issues at a quarter of
@@ -322,9 +351,11 @@ __device__ __forceinline__ unsigned long long chain_finish(const Model& M, const
         const double A = CEXP(z * c.nu_ref) - 1.0;
 #pragma unroll
         for (int j = 0; j < NB; ++j) R.F[j] = CDIV(A, CEXP(z * pick.nu_c(M, j, NB)) - 1.0);
+        if (RC::kBP) { R.bpa = z; R.bpb = A; }   // bandpass-integrated bands: the same two numbers per SAMPLE (RegChain::lnl)
     } else if (MODE == CH_MBB_T) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) R.F[j] = CEXP((sample0 + 1.0) * pick(c.lnr, j, NB));
+        if (RC::kBP) R.bpa = sample0 + 1.0;
     } else if (MODE == CH_LOGN_W) {
         {
             const double lp = log_pos(sample0);
@@ -398,7 +429,7 @@ __device__ __forceinline__ unsigned long long chain_finish(const Model& M, const
 #ifdef DX_CHAIN_NO_BATCH_RCP
     chain(BoolTag<false>{});
 #else
-    if (MODE == CH_MBB_T) {
+    if (MODE == CH_MBB_T && !RC::kBP) {
         // The chain evaluates the SED at its starting temperature and at proposals inside the hard bounds (:415) only.  If the
         // lowest of those keeps the sum of h nu / (k T) over a tile of five bands below 700, no product of five Planck
         // denominators can overflow and the whole chain takes the batched form; otherwise (T < 0.3 K at 857 GHz, T <= 0) the

@@ -68,6 +68,15 @@ __device__ __forceinline__ void sed_column(int type, const double* __restrict__ 
     }
 }
 
+// the same with bandpass-integrated bands (one lane per pixel: band j of the lane IS band j of the model): such a band's value is
+// eval_sed's tau-weighted sum over its samples (dx_sed.h: sed_bandpass), the delta bands as above one at a time
+template <int NBL>
+__device__ __forceinline__ void sed_column_bp(const Model& M, const Comp& c2, const double* __restrict__ tab, int NB, int NG, int g,
+                                              const Prep& p, double* __restrict__ colg) {
+#pragma unroll 1
+    for (int j = 0; j < NBL; ++j) colg[j * BLOCK] = (M.band[j].n != 0) ? sed_bandpass(M, c2, j, p) : sed_eval_tab(c2.type, tab, NB, NG, g, j, p);
+}
+
 // LP = 2: the bands of a pixel over two adjacent lanes (lane h owns bands [h*NB/2, (h+1)*NB/2)), as the chain's lane-pair form
 // (dx_chain.h).  Each lane evaluates the SED columns of its bands and accumulates its part of the normal equations; one
 // cross-lane add per entry joins them (a + b on one lane, b + a on the other: the same value), both lanes factorise the same

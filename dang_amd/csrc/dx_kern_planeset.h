@@ -42,7 +42,7 @@ template <bool V> struct ItemFlag { static constexpr bool value = V; };
 // one item of the sweep list for member it.gmember: chain (and the paired chain of index nind + 1, as index_chain_pair does);
 // R0.D holds the full residual / rms of the lane's bands, rows 0 .. SP*NBL-1 of the lane's LDS column hold 1 / rms.  Leaves the
 // member's two index values in sample0 / sample1.  LAST: nothing follows, the residual need not be restored.
-template <int MODE, int PAIR, int SP, int NBL, int LP, int NG, bool FIRST, bool LAST, typename RFirst>
+template <int MODE, int PAIR, int SP, int NBL, int LP, int NG, bool FIRST, bool LAST, bool BP, typename RFirst>
 __device__ __forceinline__ void ps_item(const Model& M, const SweepList& sl, const SweepItem& it, RFirst& R0, int i, int half,
                                         int jb, int NB, const double* __restrict__ tab, const double* __restrict__ col,
                                         double& sample0, double& sample1, double chi_first[4],
@@ -53,7 +53,7 @@ __device__ __forceinline__ void ps_item(const Model& M, const SweepList& sl, con
     IndexArgs a;
     a.comp = it.comp; a.nind = it.nind; a.s1 = sl.s1; a.s2 = sl.s2; a.nsample = sl.nsample; a.ml_mode = sl.ml_mode; a.mode = MODE;
     a.bp = 0; a.others = 0u; a.seed = sl.seed; a.stream = it.stream;
-    RegChain<MODE, SP, NBL, LP, true> R;   // per-band constants from the block's table in LDS
+    RegChain<MODE, SP, NBL, LP, true, BP> R;   // per-band constants from the block's table in LDS
     R.set_kt(tab, NB, NG, it.gmember, jb);
 #pragma unroll
     for (int kk = 0; kk < SP; ++kk) {
@@ -69,7 +69,7 @@ __device__ __forceinline__ void ps_item(const Model& M, const SweepList& sl, con
     unsigned long long nb_ = 0ull;
     if (PAIR) {
         constexpr int MODEB = (MODE == CH_MBB_BETA || MODE == CH_LOGN_NUP) ? MODE + 1 : MODE;  // only those two modes have a pair
-        RegChain<MODEB, SP, NBL, LP, true> RB;
+        RegChain<MODEB, SP, NBL, LP, true, BP> RB;
         RB.set_kt(tab, NB, NG, it.gmember, jb);
 #pragma unroll
         for (int kk = 0; kk < SP; ++kk) {
@@ -107,7 +107,9 @@ __device__ __forceinline__ void ps_item(const Model& M, const SweepList& sl, con
 // the modes inside one kernel costs the register allocator ~200 spills (three inlined chains share one frame); a model's
 // sweep sequence is fixed for a run, so it is part of the specialisation: C5 = <POW, MBB_BETA + 8, LOGN_NUP> is built in, any
 // other sequence is compiled on first use (dangx_rtc.hip).
-template <int SP, int NB, int NG, int LP, int SOLVE, int C0, int C1, int C2, int C3>
+// BP: some bands are bandpass-integrated (LP == 1): the members' columns take eval_sed's sample sums, the chains loop over the
+// samples (RegChain<.., BP>); delta-only models keep BP = 0 and their instruction count.
+template <int SP, int NB, int NG, int LP, int SOLVE, int C0, int C1, int C2, int C3, int BP = 0>
 __global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP, SOLVE, C0)) void k_plane_set(const Model* __restrict__ Mp, GroupArgs ga, FusedArgs fa, SweepList sl,
                                                         unsigned long long* __restrict__ not_spd, unsigned long long* __restrict__ accepted,
                                                         double* __restrict__ chi_partial) {
@@ -147,7 +149,8 @@ __global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP, SOLVE, C0)) void k_p
             const Comp& c2 = M.comp[ga.gc[fa.vcomp[v]]];
             double t0v, t1v;
             load_theta(M, c2, i, sl.s1, t0v, t1v);
-            sed_column<NBL>(fa.vtype[v], tab, NB, NG, fa.vcomp[v], jb, sed_prep(c2, t0v, t1v), col + (v * NBL) * BLOCK);
+            if (BP) sed_column_bp<NBL>(M, c2, tab, NB, NG, fa.vcomp[v], sed_prep(c2, t0v, t1v), col + (v * NBL) * BLOCK);
+            else sed_column<NBL>(fa.vtype[v], tab, NB, NG, fa.vcomp[v], jb, sed_prep(c2, t0v, t1v), col + (v * NBL) * BLOCK);
         }
         RegChain<CH_POW, SP, NBL, LP> R0;  // storage for the maps of the plane set: d and 1/sigma, then the residual
 #pragma unroll
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP, SOLVE, C0)) void k_p
                 double sample0, sample1, unused[4];
                 // a component's sweeps are consecutive and travel in ONE item: no lane reads here what its partner wrote
                 load_theta(M, c, i, sl.s1, sample0, sample1);
-                ps_item<(CODE & 7), (CODE >> 3), SP, NBL, LP, NG, FIRST, LAST>(M, sl, it, R0, i, half, jb, NB, tab, col, sample0, sample1,
+                ps_item<(CODE & 7), (CODE >> 3), SP, NBL, LP, NG, FIRST, LAST, (BP != 0)>(M, sl, it, R0, i, half, jb, NB, tab, col, sample0, sample1,
                                                                               FIRST ? chi : unused, chi, accepted, slot);
                 slot += 1 + (CODE >> 3);
             }

@@ -161,3 +161,56 @@ def test_masked_index_sums_are_cached_until_a_map_changes(built):
     assert np.allclose(s3, want(), rtol=1e-13) and s3[entries.index((2, 0, 1))] != s2[entries.index((2, 0, 1))]
     eng.profile(False)
     assert n_sweep > n_before
+
+
+@pytest.mark.parametrize("config,nside,ml_mode", [("C3", 8, "sample"), ("C2", 8, "sample"), ("C3", 4, "optimize")])
+def test_bandpass_integrated_bands_run_the_plane_set_kernel(built, config, nside, ml_mode):
+    """bp%id /= 'delta' on every second band (src/dang_component_mod.f90:909-913, 949-954; one empty bandpass row, which the
+    reference skips): the whole iteration of each plane set is still ONE launch -- the register chain with a run-time sample loop
+    (k_plane_set<.., BP = 1>, specialised on first use) -- and three iterations match the oracle's loop in the reference's order:
+    amplitudes 1e-9, indices 1e-12, accepted counts through the index maps, chi^2 1e-9; the two-call halves
+    (dangx_amp_sample / dangx_plane_sweeps_sample) run the same kernel family."""
+    def tweak(dpar, ddata, bands, comps):
+        rng = np.random.default_rng(4)
+        for b in bands[1::2]:
+            nu = b.nu_c * 1e9 * np.linspace(0.9, 1.1, 9)
+            tau = rng.uniform(0.2, 1.0, nu.size)
+            nu[3] = 0.0
+            b.id, b.nu0, b.tau0 = "bp", nu, tau / tau.sum()
+        dpar.ml_mode = ml_mode
+    case = make_case(config, nside=nside, start="truth", tweak=tweak)
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+    nb, ng = meta["nbands"], len(meta["phys"])
+    for it in (2, 3, 4):
+        if it < 4:
+            eng.profile(True)
+            da.gibbs_iteration(dpar, ddata, it)
+            prof = eng.profile_get()
+            eng.profile(False)
+            assert set(prof) <= {"k_amp_index", "k_reduce"} and prof["k_amp_index"]["launches"] == 2, prof
+        else:   # the two-call halves
+            for g in dpar.cg_groups:
+                eng.amp_sample(g.cg_group, g.pol_flag[0], ml_mode, dpar.seed, da.stream_id(it, 0, g.cg_group, 0, g.pol_flag[0]))
+            for g in dpar.cg_groups:
+                eng.plane_sweeps_sample(g.pol_flag[0], _plane_sweep_list(comps, g.cg_group, g.pol_flag[0], it), dpar.nsample, ml_mode, dpar.seed)
+            da.compute_chisq(ddata)
+        for g in dpar.cg_groups:
+            orc.amp_sample_direct(g.cg_group, g.pol_flag[0], ml_mode, dpar.seed, da.stream_id(it, 0, g.cg_group, 0, g.pol_flag[0]), "reference")
+        for l, c in enumerate(comps):
+            for j in range(c.nindices):
+                if c.sample_index[j]:
+                    f = c.pol_flag[j][0]
+                    orc.sample_index_mh(l, j, MAPN[f], dpar.nsample, ml_mode, dpar.seed, da.stream_id(it, 1, l, j, f))
+        ochisq, _ = orc.chisq(1, 3, ddata.nump)
+        assert abs(ddata.chisq - ochisq) <= 1e-9 * ochisq, (it, ddata.chisq, ochisq)
+    names = eng.rtc_kernels()
+    for sp in (1, 2):
+        assert "dxk::k_plane_set<%d, %d, %d, 1, 1, 1, 10, 0, 0, 1>" % (sp, nb, ng) in names, names    # iteration
+        assert "dxk::k_plane_set<%d, %d, %d, 1, 1, 0, 0, 0, 0, 1>" % (sp, nb, ng) in names, names     # the solve alone
+        assert "dxk::k_plane_set<%d, %d, %d, 1, 0, 1, 10, 0, 0, 1>" % (sp, nb, ng) in names, names    # the sweeps alone
+    for l in range(len(comps)):
+        a, b = eng.get_amplitude(l), orc.amplitude(l)
+        assert np.abs(a - b).max() <= 1e-9 * max(np.abs(b).max(), 1e-30), l
+        if comps[l].nindices:
+            assert np.abs(eng.get_indices(l) - orc.indices(l)).max() <= 1e-12, l

@@ -46,7 +46,7 @@ def test_unlisted_band_counts_run_the_specialised_kernels(built, config, nbands,
     # both plane sets: the group's solve and every sweep on its planes (synchrotron beta | dust beta + T) in one launch; the first
     # iteration's stand-alone sweeps (no solve to go with) are register-chain launches, specialised too
     for sp in (1, 2):
-        assert "dxk::k_plane_set<%d, %d, %d, 1, 1, 1, 10, 0, 0>" % (sp, nbands, ng) in names, names
+        assert "dxk::k_plane_set<%d, %d, %d, 1, 1, 1, 10, 0, 0, 0>" % (sp, nbands, ng) in names, names
     # nothing went through the LDS-column form: every sweep of the run was a register-chain launch
     assert all(n.startswith("dxk::") for n in names)
 
@@ -105,9 +105,9 @@ def test_thirteen_and_fifteen_bands(built, nbands):
     # (three iterations: the index maps start spatially constant, which the first sweeps end)
     eng = _run_and_compare(make_case("C3", nside=4, nbands=nbands), niter=3)
     names = eng.rtc_kernels()
-    assert "dxk::k_plane_set<1, %d, 4, 1, 1, 1, 10, 0, 0>" % nbands in names, names
+    assert "dxk::k_plane_set<1, %d, 4, 1, 1, 1, 10, 0, 0, 0>" % nbands in names, names
     if nbands == 13:
-        assert "dxk::k_plane_set<2, 13, 4, 1, 1, 1, 10, 0, 0>" in names, names
+        assert "dxk::k_plane_set<2, 13, 4, 1, 1, 1, 10, 0, 0, 0>" in names, names
     else:
         assert not any(n.startswith("dxk::k_plane_set<2,") for n in names), names
         assert any(n.startswith("dxk::k_index_mh_") and n.endswith(", 2, 15, 1>") for n in names), names
