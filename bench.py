@@ -34,7 +34,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9
 VALU_SUSTAINED_FMA = 30.9e12
 # rocprofv3 --pmc summaries of the SAME command (tools/profile_round.sh): FETCH_SIZE / WRITE_SIZE and the SQ_* pass
-PROFILE_TAG = {"C3": ["r03_z", "r02_z"], "C5": ["r03_c5z", "r02_c5z"]}   # newest committed profile of the configuration first
+PROFILE_TAG = {"C3": ["r04_z", "r03_z", "r02_z"], "C5": ["r04_c5z", "r03_c5z", "r02_c5z"]}   # newest committed profile of the configuration first
 
 
 def _profile_json(config, kind):
@@ -75,6 +75,50 @@ def measured_valu(config, kernel, avg_launch_s):
                 "source": os.path.relpath(_profile_json(config, "valu"), ROOT)}
     except Exception:
         return None
+
+
+def kernel_instances(config, prof_pl, meta, comps, nmaps):
+    """roofline.kernels: one entry per kernel INSTANCE of the plane-set family, by the name rocprof prints -- the T and the Q+U
+    launch are different code objects with different costs.  avg_ms: THIS run's HIP events (library buckets by plane count);
+    lane-ops / busy / HBM bytes per launch: the committed SQ and FETCH/WRITE passes of the same command; algorithmic bytes:
+    SURVEY 8d's per-iteration bytes of the instance's planes.  valu_frac counts every issued vector instruction as one 4-cycle
+    slot (issue-slot UTILISATION, not efficiency: the compiler's instructions count as useful; the static mix of the proposal
+    loops averages `cycles_per_instr` cycles -- 32-bit ops issue in 2, fp64 reciprocals in 16: profiles/r04_isa_audit.json)."""
+    try:
+        vj = json.load(open(_profile_json(config, "valu")))
+        tj = json.load(open(_profile_json(config, "traffic")))
+        if vj.get("config") != config or "instances" not in vj:
+            return None
+    except Exception:
+        return None
+    try:
+        audit = json.load(open(os.path.join(ROOT, "profiles", "r04_isa_audit.json")))
+    except Exception:
+        audit = {}
+    nphys = len(meta["phys"])
+    nb = meta["nbands"]
+    nidx = sum(c.nindices for c in comps[:nphys])
+    nidx_s = sum(1 for c in comps[:nphys] for j in range(c.nindices) if c.sample_index[j])
+    per_unit = 8.0 * ((2 * nb + nidx + 1 + nphys) + (2 * nb + nphys + nidx + 1 + nidx_s))
+    out = {}
+    for name, v in vj["instances"].items():
+        if v.get("family") != "k_amp_index" or not v.get("planes"):
+            continue
+        live = prof_pl.get(("k_amp_index", v["planes"]))
+        if not live:
+            continue
+        t = live["avg_ms"] * 1e-3
+        alg = per_unit * meta["npix"] * v["planes"]
+        hbm = (tj.get("instances", {}).get(name) or {}).get("hbm_bytes_per_launch")
+        a = audit.get(name, {})
+        out[name] = {"planes": v["planes"], "avg_ms": round(live["avg_ms"], 4), "launches": live["launches"],
+                     "valu_frac": v["valu_lane_ops_per_launch"] / t / VALU_PEAK_LANE_OPS, "busy": v["valu_issue_busy"],
+                     "lane_ops_per_launch": v["valu_lane_ops_per_launch"], "cycles_per_instr": a.get("proposal_cycles_per_instr"),
+                     "spilled_vgprs": a.get("vgpr_spill"), "spilled_sgprs": a.get("sgpr_spill"),
+                     "lane_ops_in_proposal_loops_from_sgpr_spills": a.get("proposal_lane_ops"),
+                     "hbm_frac": alg / t / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg, "traffic": hbm,
+                     "traffic_ratio": (hbm / alg) if hbm else None}
+    return out or None
 
 
 def algorithmic_bytes(meta, comps, kernel, units):
@@ -408,8 +452,11 @@ def main():
     elapsed = time.perf_counter() - t0
     log("timed region: %.3f s" % elapsed)
     prof = eng.profile_get()
+    prof_pl = eng.profile_get(by_planes=True)
     eng.profile(False)
     if two:
+        for k, v in engP.profile_get(by_planes=True).items():
+            prof_pl.setdefault(k, v)      # Q+U launches live on the side context
         for k, v in engP.profile_get().items():
             if k in prof:
                 t = prof[k]
@@ -512,6 +559,23 @@ def main():
             "kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"],
                             "ms_per_step": round(v["total_ms"] / args.steps, 4)} for k, v in prof.items()},
         }
+        inst = kernel_instances(args.config, prof_pl, meta, comps, nmaps) if standard else None
+        if inst:
+            # per instance, and the headline keys from the LONGER one (never an average over the T and Q+U launches)
+            longest = max(inst, key=lambda n: inst[n]["avg_ms"])
+            r = out["roofline"]
+            r["kernels"] = inst
+            r["kernel"] = longest
+            r["avg_launch_ms"] = inst[longest]["avg_ms"]
+            r["achieved"] = inst[longest]["lane_ops_per_launch"] / (inst[longest]["avg_ms"] * 1e-3) / 1e12
+            r["frac"] = inst[longest]["valu_frac"]
+            r["hbm_frac"] = inst[longest]["hbm_frac"]
+            r["hbm_achieved"] = inst[longest]["algorithmic_bytes"] / (inst[longest]["avg_ms"] * 1e-3) / 1e9
+            r["bytes_per_launch"] = inst[longest]["algorithmic_bytes"]
+            r["traffic"] = inst[longest]["traffic"]
+            r["note"] = ("fp64 VALU issue bound; frac = issue-slot UTILISATION of the longer of the two plane-set launches (every issued "
+                         "vector instruction = one 4-cycle slot; kernels[*].cycles_per_instr gives the static mix); hbm_* = SURVEY 8d's "
+                         "algorithmic bytes of that launch / its duration; traffic = counter-measured HBM bytes per launch")
         if gathered is not None:
             out["gather"] = gathered
         if world == 1 and not args.no_cpu_baseline:

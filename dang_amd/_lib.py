@@ -138,6 +138,7 @@ SYMBOLS = {
     "dangx_profile_enable": (C.c_int, [_P, C.c_int]),
     "dangx_profile_reset": (C.c_int, [_P]),
     "dangx_profile_get": (C.c_int, [_P, C.c_int, _D, C.POINTER(C.c_int64)]),
+    "dangx_profile_get_planes": (C.c_int, [_P, C.c_int, C.c_int, _D, C.POINTER(C.c_int64)]),
 }
 
 _lib = None

@@ -586,13 +586,19 @@ class Engine:
         self._chk(self.lib.dangx_profile_enable(self.h, 1 if on else 0))
         self._chk(self.lib.dangx_profile_reset(self.h))
 
-    def profile_get(self):
+    def profile_get(self, by_planes=False):
+        """{kernel family: total_ms, launches, avg_ms}; by_planes: keys (family, planes) for the launches whose plane count the
+        library records (1 = T / Q / U alone, 2 = Q+U): the T and Q+U instances of a kernel are different code objects."""
         out = {}
         for kid, name in L.KERNEL_NAMES.items():
-            ms, n = C.c_double(0.0), C.c_int64(0)
-            self._chk(self.lib.dangx_profile_get(self.h, kid, C.byref(ms), C.byref(n)))
-            if n.value:
-                out[name] = {"total_ms": ms.value, "launches": n.value, "avg_ms": ms.value / n.value}
+            for pl in ((1, 2) if by_planes else (0,)):
+                ms, n = C.c_double(0.0), C.c_int64(0)
+                if pl:
+                    self._chk(self.lib.dangx_profile_get_planes(self.h, kid, pl, C.byref(ms), C.byref(n)))
+                else:
+                    self._chk(self.lib.dangx_profile_get(self.h, kid, C.byref(ms), C.byref(n)))
+                if n.value:
+                    out[(name, pl) if pl else name] = {"total_ms": ms.value, "launches": n.value, "avg_ms": ms.value / n.value}
         return out
 
 

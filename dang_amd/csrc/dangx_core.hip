@@ -7,7 +7,32 @@
 // Cholesky) and the index phase a single pass with the Metropolis chain held in
 // LDS/registers.  All map arrays are pixel-major, so a wavefront's 64 lanes read 64
 // consecutive doubles (512 B) per load.  Everything is fp64.
+#include <dlfcn.h>
+
 #include "dx_host.h"
+
+DxRoctx::DxRoctx() {
+    const char* e = getenv("DANGX_ROCTX");
+    if (!(e && e[0] == '1')) return;
+    for (const char* lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+        void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) continue;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (push && pop) return;
+        push = nullptr; pop = nullptr;
+    }
+}
+const DxRoctx& dx_roctx() {
+    static const DxRoctx r;
+    return r;
+}
+const char* dx_kernel_family(int kid) {
+    static const char* const names[DANGX_K_COUNT] = {"dangx:amplitude_solve", "dangx:index_sweep", "dangx:sky_chisq", "dangx:reduce",
+                                                     "dangx:cg_Ax", "dangx:cg_vec", "dangx:solve+sweeps", "dangx:other"};
+    return (kid >= 0 && kid < DANGX_K_COUNT) ? names[kid] : "dangx:?";
+}
+
 
 // ======================================================================= kernels
 
@@ -988,6 +1013,8 @@ int prof_collect(dangx_ctx* ctx) {
         HIPCHK(ctx, hipEventElapsedTime(&ms, e.a, e.b));
         ctx->prof_ms[e.kid] += ms;
         ctx->prof_n[e.kid] += 1;
+        ctx->prof_ms_pl[e.kid][e.planes] += ms;
+        ctx->prof_n_pl[e.kid][e.planes] += 1;
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
     }
@@ -1806,6 +1833,7 @@ static bool planeset_group(dangx_ctx* ctx, const GroupArgs& g);
 
 int dangx_amp_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed,
                      uint64_t stream, int i_max, double converge, int* cg_iters, int64_t* n_not_spd) {
+    DxRange rg_("dangx_amp_sample");
     if (!ctx) return 1;
     (void)hipSetDevice(ctx->device);
     if (ml_mode != DANGX_ML_SAMPLE && ml_mode != DANGX_ML_OPTIMIZE) return fail(ctx, "bad ml_mode");
@@ -1868,6 +1896,7 @@ int dangx_amp_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solve
 // work is enqueued on every device before the first result is awaited; a coupled group shares its Schur rows.
 int dangx_sky_amp_sample(dangx_ctx* const* ctxs, int nctx, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed,
                          uint64_t stream, int i_max, double converge, int* cg_iters, int64_t* n_not_spd) {
+    DxRange rg_("dangx_sky_amp_sample");
     if (!ctxs || nctx < 1) return 1;
     for (int r = 0; r < nctx; ++r) if (!ctxs[r]) return 1;
     dangx_ctx* c0 = ctxs[0];
@@ -1991,6 +2020,7 @@ int dangx_amp_residual(dangx_ctx* ctx, int group, int flag, int ml_mode, uint64_
 
 int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed,
                        uint64_t stream, int64_t* accepted) {
+    DxRange rg_("dangx_index_sample");
     if (!ctx || check_comp(ctx, comp)) return 1;
     (void)hipSetDevice(ctx->device);
     {   // this sweep makes the component's index map pixel dependent on the touched planes
@@ -2062,7 +2092,7 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
         ctx->have_pending = false;
         unsigned long long* accp = accepted ? ctx->counters + 1 : nullptr;
         if (fused_lanes) {
-            Timed t(ctx, DANGX_K_AMP_INDEX);
+            Timed t(ctx, DANGX_K_AMP_INDEX, Sp);
             fused = dx_launch_fused(ctx, ctx->pending, a, Sp, fused_lanes, nblk, accp);
         }
         if (!fused) {
@@ -2079,13 +2109,13 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
             const bool ok_b = d.lnl_type[nind + 1] == DANGX_LNL_CHISQ && d.prior_type[nind + 1] != DANGX_PRIOR_JEFFREYS;
             unsigned long long* accp = accepted ? ctx->counters + 1 : nullptr;  // counters[1], counters[2]
             if (ok_b) {
-                Timed t(ctx, DANGX_K_INDEX_MH);
+                Timed t(ctx, DANGX_K_INDEX_MH, Sp);
                 fused = ctx->pair_done = dx_launch_mh_pair(ctx, a, b, Sp, nblk, accp);
             }
         }
     }
     if (!fused) {
-        Timed t(ctx, DANGX_K_INDEX_MH);
+        Timed t(ctx, DANGX_K_INDEX_MH, Sp);
         unsigned long long* accp = accepted ? ctx->counters + 1 : nullptr;
         const bool fast = d.lnl_type[nind] == DANGX_LNL_CHISQ &&
                           (a.mode == CH_POW || a.mode == CH_MBB_BETA || a.mode == CH_MBB_T);
@@ -2120,6 +2150,7 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
 // calls, which everything else takes.
 int dangx_index_sample_pair(dangx_ctx* ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed,
                             uint64_t stream_first, uint64_t stream_second, int64_t* accepted_first, int64_t* accepted_second) {
+    DxRange rg_("dangx_index_sample_pair");
     if (!ctx || check_comp(ctx, comp)) return 1;
     static const bool enabled = [] { const char* e = getenv("DANGX_FUSE"); return !(e && e[0] == '0'); }();
     const bool want_counts = accepted_first || accepted_second;
@@ -2153,6 +2184,7 @@ int dangx_index_sample_pair(dangx_ctx* ctx, int comp, int nind, int map_n, int n
 int dangx_amp_index_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed_amp,
                            uint64_t stream_amp, int i_max, double converge, int comp, int nind, int map_n, int nsample,
                            uint64_t seed_index, uint64_t stream_index, int* cg_iters, int64_t* n_not_spd, int64_t* accepted) {
+    DxRange rg_("dangx_amp_index_sample");
     if (!ctx || check_comp(ctx, comp)) return 1;
     if (cg_iters) *cg_iters = 0;
     static const bool enabled = [] { const char* e = getenv("DANGX_FUSE"); return !(e && e[0] == '0'); }();  // A/B switch
@@ -2235,7 +2267,7 @@ static int planeset_launch(dangx_ctx* ctx, const GroupArgs& g, const SweepList& 
         ctx->partial = chi_buf;
         bool ok;
         {
-            Timed t(ctx, !solve ? DANGX_K_INDEX_MH : sl.n ? DANGX_K_AMP_INDEX : DANGX_K_AMP_DIRECT);
+            Timed t(ctx, !solve ? DANGX_K_INDEX_MH : sl.n ? DANGX_K_AMP_INDEX : DANGX_K_AMP_DIRECT, sl.s2 - sl.s1 + 1);
             ok = dx_launch_planeset(ctx, g, sl, lanes, solve, nblk, accepted ? ctx->counters + 4 : nullptr);
         }
         ctx->partial = saved;
@@ -2310,6 +2342,7 @@ static bool planeset_group(dangx_ctx* ctx, const GroupArgs& g) {
 int dangx_plane_set_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed_amp, uint64_t stream_amp,
                            int i_max, double converge, int nsweeps, const int32_t* comp, const int32_t* nind, const uint64_t* stream,
                            int nsample, uint64_t seed_index, int* cg_iters, int64_t* n_not_spd, int64_t* accepted) {
+    DxRange rg_("dangx_plane_set_sample");
     if (!ctx || nsweeps < 1 || !comp || !nind || !stream) return 1;
     (void)hipSetDevice(ctx->device);
     if (sync_model(ctx)) return 1;
@@ -2370,6 +2403,7 @@ int dangx_plane_set_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int
 // consecutive indices of a component through dangx_index_sample_pair.
 int dangx_plane_sweeps_sample(dangx_ctx* ctx, int flag, int nsweeps, const int32_t* comp, const int32_t* nind, const uint64_t* stream,
                               int nsample, int ml_mode, uint64_t seed, int64_t* accepted) {
+    DxRange rg_("dangx_plane_sweeps_sample");
     if (!ctx || nsweeps < 1 || !comp || !nind || !stream) return 1;
     (void)hipSetDevice(ctx->device);
     if (sync_model(ctx)) return 1;
@@ -2443,6 +2477,7 @@ static int sky_chisq_launch(dangx_ctx* ctx, int pol_lo, int pol_hi, double* sky_
 // every other plane gets one explicit update_sky_model + compute_chisq pass over THAT plane, whose result is cached too (the
 // two-call form of the main loop asks after every CG group: only the group's own planes have changed since the last answer)
 int dangx_chisq_current(dangx_ctx* ctx, int pol_lo, int pol_hi, double* chisq_sum) {
+    DxRange rg_("dangx_chisq_current");
     if (!ctx || !chisq_sum) return 1;
     (void)hipSetDevice(ctx->device);
     if (pol_lo < 1 || pol_hi > ctx->dims.nmaps || pol_lo > pol_hi) return fail(ctx, "bad pol_type range");
@@ -2511,6 +2546,7 @@ int dangx_sky_model_chisq_dev(dangx_ctx* ctx, int pol_lo, int pol_hi, double* ch
 }
 
 int dangx_sky_model_chisq(dangx_ctx* ctx, int pol_lo, int pol_hi, double* chisq_sum, double* sky, double* res, double* chi_map) {
+    DxRange rg_("dangx_sky_model_chisq");
     if (!ctx) return 1;
     (void)hipSetDevice(ctx->device);
     if (sync_model(ctx)) return 1;
@@ -2875,6 +2911,7 @@ int dangx_fullsky_prepare_coarse(dangx_ctx* ctx, int comp, int map_n, int nside,
 
 int dangx_index_sample_coarse(dangx_ctx* ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed,
                               uint64_t stream, int nside, int sample_nside, int64_t* accepted) {
+    DxRange rg_("dangx_index_sample_coarse");
     if (!ctx || check_comp(ctx, comp)) return 1;
     (void)hipSetDevice(ctx->device);
     const long long npix = ctx->dims.npix;
@@ -3180,7 +3217,10 @@ int dangx_profile_enable(dangx_ctx* ctx, int on) {
 int dangx_profile_reset(dangx_ctx* ctx) {
     if (!ctx) return 1;
     if (prof_collect(ctx)) return 1;
-    for (int k = 0; k < DANGX_K_COUNT; ++k) { ctx->prof_ms[k] = 0.0; ctx->prof_n[k] = 0; }
+    for (int k = 0; k < DANGX_K_COUNT; ++k) {
+        ctx->prof_ms[k] = 0.0; ctx->prof_n[k] = 0;
+        for (int p = 0; p < 3; ++p) { ctx->prof_ms_pl[k][p] = 0.0; ctx->prof_n_pl[k][p] = 0; }
+    }
     return 0;
 }
 int dangx_profile_get(dangx_ctx* ctx, int kid, double* total_ms, int64_t* launches) {
@@ -3188,6 +3228,13 @@ int dangx_profile_get(dangx_ctx* ctx, int kid, double* total_ms, int64_t* launch
     if (prof_collect(ctx)) return 1;
     if (total_ms) *total_ms = ctx->prof_ms[kid];
     if (launches) *launches = ctx->prof_n[kid];
+    return 0;
+}
+int dangx_profile_get_planes(dangx_ctx* ctx, int kid, int nplanes, double* total_ms, int64_t* launches) {
+    if (!ctx || kid < 0 || kid >= DANGX_K_COUNT || nplanes < 1 || nplanes > 2) return 1;
+    if (prof_collect(ctx)) return 1;
+    if (total_ms) *total_ms = ctx->prof_ms_pl[kid][nplanes];
+    if (launches) *launches = ctx->prof_n_pl[kid][nplanes];
     return 0;
 }
 

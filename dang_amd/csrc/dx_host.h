@@ -100,11 +100,31 @@ struct dangx_ctx {
     std::vector<std::string> rtc_failed;
     // profiling
     bool prof = false;
-    struct Ev { hipEvent_t a, b; int kid; };
+    struct Ev { hipEvent_t a, b; int kid, planes; };
     std::vector<Ev> events;
     double prof_ms[DANGX_K_COUNT] = {};
     long long prof_n[DANGX_K_COUNT] = {};
+    double prof_ms_pl[DANGX_K_COUNT][3] = {};      // the same by the number of planes the launch worked on (0: not recorded)
+    long long prof_n_pl[DANGX_K_COUNT][3] = {};
 };
+
+// roctx ranges around every timed launch group and the entry points that issue them ("rocprof/roctx ranges
+// inside the library"): DANGX_ROCTX=1 loads the ROCm marker library at run time (no link-time dependency; `rocprofv3
+// --marker-trace` then shows the ranges), otherwise the two calls are no-ops.
+struct DxRoctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    DxRoctx();
+};
+const DxRoctx& dx_roctx();
+struct DxRange {
+    bool on;
+    explicit DxRange(const char* name) : on(dx_roctx().push != nullptr) { if (on) (void)dx_roctx().push(name); }
+    ~DxRange() { if (on) (void)dx_roctx().pop(); }
+    DxRange(const DxRange&) = delete;
+    DxRange& operator=(const DxRange&) = delete;
+};
+const char* dx_kernel_family(int kid);
 
 #define HIPCHK(ctx, call)                                                                         \
     do {                                                                                          \
@@ -138,9 +158,10 @@ struct Timed {
     dangx_ctx* ctx;
     dangx_ctx::Ev ev{};
     bool on;
-    Timed(dangx_ctx* c, int kid) : ctx(c), on(c->prof) {
+    DxRange range;
+    Timed(dangx_ctx* c, int kid, int planes = 0) : ctx(c), on(c->prof), range(dx_kernel_family(kid)) {
         if (!on) return;
-        ev.kid = kid;
+        ev.kid = kid; ev.planes = (planes >= 0 && planes <= 2) ? planes : 0;
         (void)hipEventCreate(&ev.a);
         (void)hipEventCreate(&ev.b);
         (void)hipEventRecord(ev.a, ctx->stream);

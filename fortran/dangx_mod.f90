@@ -489,6 +489,13 @@ module dangx_mod
        real(c_double), intent(out) :: total_ms
        integer(c_int64_t), intent(out) :: launches
      end function
+     integer(c_int) function dangx_profile_get_planes(ctx, kernel_id, nplanes, total_ms, launches) bind(C, name='dangx_profile_get_planes')
+       import :: c_int, c_ptr, c_double, c_int64_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: kernel_id, nplanes
+       real(c_double), intent(out) :: total_ms
+       integer(c_int64_t), intent(out) :: launches
+     end function
      integer(c_int) function dangx_sky_model_chisq(ctx, pol_lo, pol_hi, chisq_sum, sky, res, chi_map) &
           bind(C, name='dangx_sky_model_chisq')
        import :: c_int, c_ptr, c_double

@@ -258,10 +258,18 @@ contains
   subroutine write_stats_gpu(ddata)
     type(dang_data) :: ddata
     type(dang_comps), pointer :: cc
-    integer(c_int32_t) :: lc(16), ln(16), lk(16)
-    character(len=48)  :: what(16)
-    real(c_double)     :: avg(16)
+    integer(c_int32_t), allocatable :: lc(:), ln(:), lk(:)
+    character(len=48), allocatable  :: what(:)
+    real(c_double), allocatable     :: avg(:)
     integer :: i, j, k, n, f
+    n = 0
+    do i = 1, ncomp                                       ! one entry per sampled (index, flag): sized from the model
+       cc => component_list(i)%p
+       do j = 1, cc%nindices
+          if (cc%sample_index(j)) n = n + cc%nflag(j)
+       end do
+    end do
+    allocate(lc(n), ln(n), lk(n), what(n), avg(n))
     n = 0
     do i = 1, ncomp
        cc => component_list(i)%p
@@ -269,7 +277,7 @@ contains
           if (.not. cc%sample_index(j)) cycle
           do k = 1, cc%nflag(j)
              f = cc%pol_flag(j,k)
-             if (iand(f, 15) == 0 .or. n == 16) cycle
+             if (iand(f, 15) == 0) cycle
              n = n + 1
              lc(n) = i-1; ln(n) = j-1
              if (iand(f,1) .ne. 0) then
@@ -301,15 +309,19 @@ contains
     real(c_double), intent(out) :: avg(n)
     real(c_double) :: s(n)
     integer(c_int64_t) :: cnt(n)
-    integer :: e
-    if (numprocs == 1) then
-       call dangx_sky_index_means(gpu_sky, n, comp0, nind0, map_n, avg)
-    else
-       call dangx_check(gpu_sky%ctx(1), dangx_index_masked_sums(gpu_sky%ctx(1), n, comp0, nind0, map_n, s, cnt), 'index_masked_sums')
-       do e = 1, n
-          avg(e) = rank_sum(s(e))/rank_sum(real(cnt(e), dp))
-       end do
-    end if
+    integer :: e, b0, nb
+    do b0 = 1, n, 16                    ! dangx_index_masked_sums takes at most 16 maps per call: any number, in batches
+       nb = min(16, n - b0 + 1)
+       if (numprocs == 1) then
+          call dangx_sky_index_means(gpu_sky, nb, comp0(b0:b0+nb-1), nind0(b0:b0+nb-1), map_n(b0:b0+nb-1), avg(b0:b0+nb-1))
+       else
+          call dangx_check(gpu_sky%ctx(1), dangx_index_masked_sums(gpu_sky%ctx(1), nb, comp0(b0:b0+nb-1), nind0(b0:b0+nb-1), &
+               map_n(b0:b0+nb-1), s(b0:b0+nb-1), cnt(b0:b0+nb-1)), 'index_masked_sums')
+          do e = b0, b0 + nb - 1
+             avg(e) = rank_sum(s(e))/rank_sum(real(cnt(e), dp))
+          end do
+       end if
+    end do
   end subroutine gpu_index_means
 
   integer(i4b) function map_of_flag(flag)
@@ -692,18 +704,23 @@ contains
     character(len=80)         :: stokes
     character(len=16)         :: nb_edit, it5
     integer(i4b)              :: j, n, u, nl
-    integer(c_int32_t)        :: lc(16), ln(16), lk(16)
-    real(c_double)            :: la(16)
+    integer(c_int32_t), allocatable :: lc(:), ln(:), lk(:)
+    real(c_double), allocatable     :: la(:)
     logical                   :: created
 
     call gpu_chisq(ddata, .false.)
     call pull_template_amplitudes(ddata_offset_only=.false.)
     allocate(avg(2, ncomp)); avg = 0.d0                  ! sky-wide sums: every rank takes part, the master writes
     nl = 0
+    do n = 1, ncomp                                       ! every sampled index of the model: sized from it
+       nl = nl + count(component_list(n)%p%sample_index(1:component_list(n)%p%nindices))
+    end do
+    allocate(lc(nl), ln(nl), lk(nl), la(nl))
+    nl = 0
     do n = 1, ncomp
        cc => component_list(n)%p
        do j = 1, cc%nindices
-          if (cc%sample_index(j) .and. nl < 16) then
+          if (cc%sample_index(j)) then
              nl = nl + 1; lc(nl) = n-1; ln(nl) = j-1; lk(nl) = map_n
           end if
        end do

@@ -66,7 +66,7 @@ enum { DANGX_SOLVER_DIRECT = 0, DANGX_SOLVER_CG = 1 };
  * component offset); CORRECT draws the textbook sum_nu T^t N^-1/2 eta_nu. */
 enum { DANGX_FLUCT_CORRECT = 0, DANGX_FLUCT_REFERENCE = 1 };
 
-/* kernel ids for dangx_profile_get */
+/* kernel ids for dangx_profile_get / dangx_profile_get_planes */
 enum {
     DANGX_K_AMP_DIRECT = 0, DANGX_K_INDEX_MH = 1, DANGX_K_SKY_CHISQ = 2, DANGX_K_REDUCE = 3,
     DANGX_K_CG_AX = 4, DANGX_K_CG_VEC = 5, DANGX_K_AMP_INDEX = 6, DANGX_K_COUNT = 8
@@ -435,6 +435,11 @@ int dangx_rtc_compile(const char *header, const char *name_expr, char *log, int 
 int dangx_profile_enable(dangx_ctx *ctx, int on);
 int dangx_profile_reset(dangx_ctx *ctx);
 int dangx_profile_get(dangx_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
+/* the same restricted to the launches of that family that worked on `nplanes` (1: T, Q or U alone; 2: Q+U) planes: the T and
+ * Q+U instances of a kernel are different code objects with different costs (bench.py's per-kernel roofline entries).
+ * DANGX_ROCTX=1 in the environment additionally wraps every timed launch group in a roctx range named after its family
+ * (the ROCm marker library is loaded at run time; `rocprofv3 --marker-trace` shows the ranges). */
+int dangx_profile_get_planes(dangx_ctx *ctx, int kernel_id, int nplanes, double *total_ms, int64_t *launches);
 
 #ifdef __cplusplus
 }

@@ -65,9 +65,13 @@ def test_five_rank_rehearsal_of_the_sharded_path_on_one_gpu(built):
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         assert len(lines) == 1, r.stdout
         return json.loads(lines[0])
-    five = run("--gpus", "5", "--backend", "gloo", "--streams", "2")
-    one = run("--gpus", "1")
+    five = run("--gpus", "5", "--backend", "gloo", "--streams", "2", "--gather")
+    one = run("--gpus", "1", "--gather")
     assert five["n_gpus"] == 5 and five["ranks_seen"] == 5 and five["backend"] == "gloo"
+    # north_star's "gather for map output" with the run's (work-balanced, unequal) shard boundaries: the maps reassembled on rank 0
+    # are the one-rank maps bit for bit
+    assert five["gather"]["bounds"] == "work-balanced" and five["gather"]["npix"] == one["gather"]["npix"] == 12 * 256 * 256
+    assert five["gather"]["checksum"] == one["gather"]["checksum"], (five["gather"], one["gather"])
     assert "5 rank(s) (contiguous RING ranges of equal unmasked-pixel count), 2 stream(s) per rank" in five["config"]["workload"]
     for k in ("chisq_after_amp", "chisq_after_index"):
         assert abs(five["config"][k] - one["config"][k]) <= 1e-12 * abs(one["config"][k]), k

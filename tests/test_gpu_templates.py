@@ -350,7 +350,8 @@ def test_T_cmb_as_an_amplitude_sampled_group_member(built):
     assert abs(it_g - it_o) <= 1
 
 
-@pytest.mark.parametrize("which,group,flag", [(("template",), 2, L.FLAG_QU), (("monopole",), 1, L.FLAG_T), (("monopole", "hi_fit"), 1, L.FLAG_T)])
+@pytest.mark.parametrize("which,group,flag", [(("template",), 2, L.FLAG_QU), (("monopole",), 1, L.FLAG_T), (("hi_fit",), 1, L.FLAG_T),
+                                              (("monopole", "hi_fit"), 1, L.FLAG_T)])
 def test_schur_passes_on_the_amplitude_schedule_are_the_run_time_typed_ones(built, which, group, flag):
     """Groups whose global members are templates / monopoles / hi_fit components run the passes of the Schur solve on the amplitude
     kernel's schedule (dangx_ampreg.hip: k_schur_pass1_reg, k_amp_reg<.., true>, k_schur_resid_reg); DANGX_SCHUR_FAST=0 keeps the
@@ -386,7 +387,9 @@ def test_schur_passes_on_the_amplitude_schedule_are_the_run_time_typed_ones(buil
     same_bits = True
     # a monopole beside hi_fit is a near-degenerate pair (condition ~1e8, cf. test_direct_solve_with_global_components...):
     # its residual floor and the agreement of two roundings of the same solve are correspondingly looser
-    tol = 1e-6 if "hi_fit" in which else 1e-9
+    # (the hi_fit passes -- compile units of their own with the Planck factor -- are held to 1e-9 on the hi_fit-only group, which is
+    # well conditioned; only the monopole + hi_fit PAIR gets the loose bound)
+    tol = 1e-6 if ("hi_fit" in which and "monopole" in which) else 1e-9
     for ml in ("optimize", "sample"):
         a, b = res["1"][ml], res["0"][ml]
         assert a["it"] == b["it"] and a["bad"] == b["bad"] == 0

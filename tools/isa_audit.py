@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--asm", help="use an existing device .s instead of compiling")
     ap.add_argument("--min-loop", type=int, default=40, help="hide loops with fewer instructions")
     ap.add_argument("-o", "--out")
+    ap.add_argument("--json", help="merge {kernel name as rocprof prints it: spills, proposal-loop mix} into this file (bench.py reads it)")
     ap.add_argument("--title", default=None)
     a = ap.parse_args()
     with tempfile.TemporaryDirectory() as tmp:
@@ -177,6 +178,23 @@ def main():
             L.append("| %d-%d | %d | %d | %d | %d | %d | %d | %d | %d | %d | %d |" % (
                 b, e, s["n"], s["valu"], s["cyc"], s["philox"], s["lane"], s["scratch"], s["lds"], s["mem"], s["sload"], s["mov64"]))
         L.append("")
+    if a.json:
+        import json
+        J = {}
+        if os.path.exists(a.json):
+            J = json.load(open(a.json))
+        for (name, meta, loops, allins), dn in zip(res, names):
+            # proposal loops = loops with Philox products that no other such loop contains
+            pl = [(b, e, ins) for (b, e, ins) in loops if stats(ins)["philox"] >= 8]
+            outer = [x for x in pl if not any(y is not x and y[0] <= x[0] and x[1] <= y[1] for y in pl)]
+            st = [stats(ins) for (_, _, ins) in outer]
+            nv, nc = sum(x["valu"] for x in st), sum(x["cyc"] for x in st)
+            J[dn] = {"unit": a.unit, "vgpr": meta.get("vgpr_count"), "sgpr": meta.get("sgpr_count"), "vgpr_spill": meta.get("vgpr_spill_count"),
+                     "sgpr_spill": meta.get("sgpr_spill_count"), "scratch_bytes": meta.get("private_segment_fixed_size"),
+                     "proposal_loops": len(outer), "proposal_valu_per_trip": [x["valu"] for x in st],
+                     "proposal_cycles_per_instr": (nc / nv) if nv else None,
+                     "proposal_lane_ops": sum(x["lane"] for x in st), "proposal_scratch_ops": sum(x["scratch"] for x in st)}
+        json.dump(J, open(a.json, "w"), indent=1, sort_keys=True)
     txt = "\n".join(L) + "\n"
     if a.out:
         with open(a.out, "w") as f:

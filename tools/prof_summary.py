@@ -23,6 +23,22 @@ def short(name):
     return (m.group(1) if m else name)[:70]
 
 
+def planes_of(s):
+    """number of map planes a launch of this kernel works on, from its template arguments (None: not a per-plane kernel)"""
+    m = re.match(r"(k_[a-z_]+)<([^>]*)>", s)
+    if not m:
+        return None
+    args = [x.strip() for x in m.group(2).split(",")]
+    try:
+        if m.group(1) in ("k_plane_set", "k_index_mh_pair"):
+            return int(args[0])
+        if m.group(1) in ("k_amp_index", "k_index_mh_reg"):
+            return int(args[1])
+    except (ValueError, IndexError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stats")
@@ -148,6 +164,13 @@ def main():
                                  "valu_lane_ops_per_launch": sum(o * w for o, w in zip(e["lane_ops"], e["wt"])) / W,
                                  "valu_lane_ops_per_s": (e["ops_total"] / e["time_total"]) if e["time_total"] > 0 else None,
                                  "dispatches": e["n"]}
+        # ... and every kernel by the name rocprof prints: the T and Q+U instances of a family are different code objects
+        out["instances"] = {}
+        for (k, name), e in byname.items():
+            calls, dur = trace.get(name, (float(len(e["busy"])), 0.0))
+            out["instances"][name] = {"family": k, "planes": planes_of(name), "calls_in_trace": calls, "avg_ms_in_trace": dur * 1e3,
+                                      "valu_issue_busy": sum(e["busy"]) / len(e["busy"]),
+                                      "valu_lane_ops_per_launch": sum(e["lane_ops"]) / len(e["lane_ops"])}
         json.dump(out, open(a.valu_json, "w"), indent=1)
     if a.traffic_json:
         import json
@@ -182,11 +205,17 @@ def main():
                          "k_cg_vec calibration factor %.3f; kernels of a family weighted by their calls in the kernel-trace pass)"
                          % (os.path.join("profiles", os.path.basename(a.out)), a.fetch_factor),
                "config": a.config, "fetch_correction": a.fetch_factor, "kernels": {}}
+        out["instances"] = {}
         for k, v in fam.items():
             fr = wmean(v.get("FETCH_SIZE", {}))
             wr = wmean(v.get("WRITE_SIZE", {}))
             out["kernels"][k] = {"fetch_raw_bytes": fr, "fetch_corrected_bytes": fr * a.fetch_factor, "write_bytes": wr,
                                  "hbm_bytes_per_launch": fr * a.fetch_factor + wr}
+            for name in set(v.get("FETCH_SIZE", {})) | set(v.get("WRITE_SIZE", {})):   # per kernel name (never averaged over T / Q+U)
+                f1 = v.get("FETCH_SIZE", {}).get(name, [0.0]); w1 = v.get("WRITE_SIZE", {}).get(name, [0.0])
+                fb, wb = sum(f1) / len(f1), sum(w1) / len(w1)
+                out["instances"][name] = {"family": k, "planes": planes_of(name), "fetch_corrected_bytes": fb * a.fetch_factor,
+                                          "write_bytes": wb, "hbm_bytes_per_launch": fb * a.fetch_factor + wb}
         json.dump(out, open(a.traffic_json, "w"), indent=1)
     open(a.out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
