@@ -204,10 +204,12 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_chi(const double* __restrict__
 }
 
 // the same two stages for up to CHI_RING sweeps at once, in launch order (identical sums: same chunks, same trees)
+constexpr int CHI_ROWS = 4 + DX_MAX_IDXSUM;   // rows of a stage entry: the four chi^2 sums + the index sums of a plane-set launch
 struct ChiBatch {
     const double* buf[dangx_ctx::CHI_RING];
     long long nblk[dangx_ctx::CHI_RING];
-    int s1[dangx_ctx::CHI_RING], s2[dangx_ctx::CHI_RING], wb[dangx_ctx::CHI_RING];
+    int s1[dangx_ctx::CHI_RING], s2[dangx_ctx::CHI_RING], wb[dangx_ctx::CHI_RING], ns[dangx_ctx::CHI_RING];
+    int slot[dangx_ctx::CHI_RING][DX_MAX_IDXSUM];
     int n;
 };
 __global__ __launch_bounds__(BLOCK) void k_reduce_rows_batch(ChiBatch b, double* __restrict__ stage) {
@@ -215,10 +217,10 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_rows_batch(ChiBatch b, double*
     const int e = blockIdx.y;
     const double* in = b.buf[e];
     const long long n = b.nblk[e];
-    double* out = stage + (long long)e * 4 * gridDim.x;
+    double* out = stage + (long long)e * CHI_ROWS * gridDim.x;
     const long long chunk = (n + gridDim.x - 1) / gridDim.x;
     const long long lo = (long long)blockIdx.x * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 4 + b.ns[e]; ++q) {
         double s = 0.0;
         for (long long t = lo + threadIdx.x; t < hi; t += BLOCK) s += in[(long long)q * n + t];
         sh[threadIdx.x] = s;
@@ -235,8 +237,8 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_chi_batch(ChiBatch b, const do
                                                             double* __restrict__ cache) {
     __shared__ double sh[BLOCK];
     for (int e = 0; e < b.n; ++e) {
-        const double* partial = stage + (long long)e * 4 * n;
-        for (int q = 0; q < 4; ++q) {
+        const double* partial = stage + (long long)e * CHI_ROWS * n;
+        for (int q = 0; q < 4 + b.ns[e]; ++q) {
             double s = 0.0;
             for (long long t = threadIdx.x; t < n; t += BLOCK) s += partial[(long long)q * n + t];
             sh[threadIdx.x] = s;
@@ -246,9 +248,13 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_chi_batch(ChiBatch b, const do
                 __syncthreads();
             }
             if (threadIdx.x == 0) {
-                const int plane = (q & 1) ? b.s2[e] : b.s1[e];
-                const bool after = q >= 2;
-                if (!((q & 1) && b.s1[e] == b.s2[e]) && (after || b.wb[e])) cache[(after ? 3 : 0) + plane - 1] = sh[0];
+                if (q >= 4) {   // masked sum of an index map the launch swept: the same value on every plane it wrote (:465)
+                    for (int k = b.s1[e]; k <= b.s2[e]; ++k) cache[b.slot[e][q - 4] + (k - b.s1[e])] = sh[0];
+                } else {
+                    const int plane = (q & 1) ? b.s2[e] : b.s1[e];
+                    const bool after = q >= 2;
+                    if (!((q & 1) && b.s1[e] == b.s2[e]) && (after || b.wb[e])) cache[(after ? 3 : 0) + plane - 1] = sh[0];
+                }
             }
             __syncthreads();
         }
@@ -1045,9 +1051,13 @@ int chi_flush(dangx_ctx* ctx) {
     b.n = ctx->chi_npend;
     for (int e = 0; e < b.n; ++e) {
         const auto& p = ctx->chi_pend[e];
-        b.buf[e] = p.buf; b.nblk[e] = p.nblk; b.s1[e] = p.s1; b.s2[e] = p.s2; b.wb[e] = p.wb;
+        b.buf[e] = p.buf; b.nblk[e] = p.nblk; b.s1[e] = p.s1; b.s2[e] = p.s2; b.wb[e] = p.wb; b.ns[e] = p.ns;
+        for (int q = 0; q < DX_MAX_IDXSUM; ++q) b.slot[e][q] = p.slot[q];
     }
-    for (int e = b.n; e < dangx_ctx::CHI_RING; ++e) { b.buf[e] = nullptr; b.nblk[e] = 0; b.s1[e] = b.s2[e] = 1; b.wb[e] = 0; }
+    for (int e = b.n; e < dangx_ctx::CHI_RING; ++e) {
+        b.buf[e] = nullptr; b.nblk[e] = 0; b.s1[e] = b.s2[e] = 1; b.wb[e] = 0; b.ns[e] = 0;
+        for (int q = 0; q < DX_MAX_IDXSUM; ++q) b.slot[e][q] = 0;
+    }
     {
         Timed t(ctx, DANGX_K_REDUCE);
         hipLaunchKernelGGL(k_reduce_rows_batch, dim3(CHI_RSTAGE, b.n), dim3(BLOCK), 0, ctx->stream, b, ctx->chi_stage);
@@ -1061,11 +1071,12 @@ int chi_flush(dangx_ctx* ctx) {
 int chi_next(dangx_ctx* ctx, long long nblk, double** buf) {
     if (ctx->chi_npend == dangx_ctx::CHI_RING && chi_flush(ctx)) return 1;
     auto& p = ctx->chi_pend[ctx->chi_npend];
-    if (p.cap < 4 * nblk) {
+    if (p.cap < CHI_ROWS * nblk) {
         if (p.buf) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(p.buf); p.buf = nullptr; p.cap = 0; }
-        HIPCHK(ctx, hipMalloc(&p.buf, sizeof(double) * (size_t)(4 * nblk)));
-        p.cap = 4 * nblk;
+        HIPCHK(ctx, hipMalloc(&p.buf, sizeof(double) * (size_t)(CHI_ROWS * nblk)));
+        p.cap = CHI_ROWS * nblk;
     }
+    p.ns = 0;
     *buf = p.buf;
     return 0;
 }
@@ -1516,8 +1527,8 @@ int dangx_create(dangx_ctx** out, const dangx_dims* dims) {
     M.pix0 = dims->pix0; M.tcmb = 2.7255;  // src/dang_util_mod.f90:15
     for (int j = 0; j < MAXB; ++j) { M.gain[j] = 1.0; M.offset[j] = 0.0; }  // src/dang_data_mod.f90:127-128
     if (hipMalloc(&ctx->dm, sizeof(Model)) != hipSuccess || hipMalloc(&ctx->scalars, 8 * sizeof(double)) != hipSuccess ||
-        hipMalloc(&ctx->chi_cache, 6 * sizeof(double)) != hipSuccess ||
-        hipMalloc(&ctx->chi_stage, sizeof(double) * dangx_ctx::CHI_RING * 4 * CHI_RSTAGE) != hipSuccess ||
+        hipMalloc(&ctx->chi_cache, CHI_CACHE_DOUBLES * sizeof(double)) != hipSuccess ||
+        hipMalloc(&ctx->chi_stage, sizeof(double) * dangx_ctx::CHI_RING * CHI_ROWS * CHI_RSTAGE) != hipSuccess ||
         hipMalloc(&ctx->rows_out, (4 * MAXB + 8) * sizeof(double)) != hipSuccess ||
         hipMalloc(&ctx->counters, 16 * sizeof(unsigned long long)) != hipSuccess) {
         delete ctx;
@@ -2277,6 +2288,12 @@ static int planeset_launch(dangx_ctx* ctx, const GroupArgs& g, const SweepList& 
     {
         auto& pend = ctx->chi_pend[ctx->chi_npend++];
         pend.nblk = nblk; pend.s1 = sl.s1; pend.s2 = sl.s2; pend.wb = wb ? 1 : 0;
+        pend.ns = 0;
+        for (int q = 0; q < sl.n; ++q)   // the masked sums of the swept index maps ride along (rows 4 ..), in the items' order
+            for (int e = 0; e <= sl.s[q].pair; ++e) {
+                pend.slot[pend.ns++] = idx_slot(sl.s[q].comp, sl.s[q].nind + e, sl.s1);
+                for (int k = sl.s1; k <= sl.s2; ++k) ctx->idxsum_dev[sl.s[q].comp][sl.s[q].nind + e][k - 1] = !ctx->idx_ext[sl.s[q].comp];
+            }
         for (int k = sl.s1; k <= sl.s2; ++k) {
             if (wb) ctx->chi_before_valid[k - 1] = true;
             ctx->chi_after_valid[k - 1] = true;
@@ -3005,11 +3022,29 @@ int dangx_index_masked_sums(dangx_ctx* ctx, int n, const int32_t* comp, const in
         ml.comp[e] = comp[e]; ml.nind[e] = nind[e]; ml.k[e] = map_n[e];
     }
     // what is still valid from an earlier call (nothing has written these maps or the mask since) is answered from the host:
-    // the statistics after an amplitude phase (src/dang_cg_mod.f90:173) repeat the index means of the phase before
-    bool all_cached = true;
-    for (int e = 0; e < n; ++e)
-        if (ctx->idx_ext[comp[e]] || !ctx->idxsum_ok[comp[e]][nind[e]][map_n[e] - 1]) all_cached = false;
-    if (all_cached) {
+    // the statistics after an amplitude phase (src/dang_cg_mod.f90:173) repeat the index means of the phase before; what the
+    // last plane-set launch left on the device beside its chi^2 sums (the sums of the maps it swept) costs one small copy
+    bool all_known = true, need_copy = false;
+    for (int e = 0; e < n; ++e) {
+        const int l = comp[e], q = nind[e], k = map_n[e] - 1;
+        if (ctx->idx_ext[l] || (!ctx->idxsum_ok[l][q][k] && !(ctx->idxsum_dev[l][q][k] && ctx->mask_count >= 0))) all_known = false;
+        else if (!ctx->idxsum_ok[l][q][k]) need_copy = true;
+    }
+    if (all_known && need_copy) {
+        if (chi_flush(ctx)) return 1;
+        double host[CHI_CACHE_DOUBLES];
+        HIPCHK(ctx, hipMemcpyAsync(host, ctx->chi_cache, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int l = 0; l < ctx->hm.ncomp; ++l)
+            for (int q = 0; q < MAXI; ++q)
+                for (int k = 0; k < 3; ++k)
+                    if (ctx->idxsum_dev[l][q][k] && !ctx->idxsum_ok[l][q][k]) {
+                        ctx->idxsum[l][q][k] = host[idx_slot(l, q, k + 1)];
+                        ctx->idxcnt[l][q][k] = ctx->mask_count;
+                        ctx->idxsum_ok[l][q][k] = true;
+                    }
+    }
+    if (all_known) {
         for (int e = 0; e < n; ++e) { sums[e] = ctx->idxsum[comp[e]][nind[e]][map_n[e] - 1]; counts[e] = ctx->idxcnt[comp[e]][nind[e]][map_n[e] - 1]; }
         return 0;
     }
@@ -3028,6 +3063,7 @@ int dangx_index_masked_sums(dangx_ctx* ctx, int n, const int32_t* comp, const in
         ctx->idxsum[comp[e]][nind[e]][map_n[e] - 1] = sums[e]; ctx->idxcnt[comp[e]][nind[e]][map_n[e] - 1] = counts[e];
         ctx->idxsum_ok[comp[e]][nind[e]][map_n[e] - 1] = !ctx->idx_ext[comp[e]];
     }
+    ctx->mask_count = counts[0];   // unmasked pixels of masks(:,1): the same for every map
     return 0;
 }
 

@@ -56,6 +56,7 @@ struct SweepItem {
     unsigned long long stream, stream2;  // random streams of the sweep (and of the paired one)
 };
 constexpr int DX_MAX_SWEEPS = 6;
+constexpr int DX_MAX_IDXSUM = 8;   // index maps one plane-set launch can sweep (4 items, each with its component's next index)
 struct SweepList {
     int n, nsample, ml_mode, s1, s2, pad;
     unsigned long long seed;

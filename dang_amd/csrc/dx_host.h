@@ -48,6 +48,10 @@ struct dangx_ctx {
     double idxsum[MAXC][MAXI][3] = {};
     long long idxcnt[MAXC][MAXI][3] = {};
     bool idx_ext[MAXC] = {};       // the maps live in a buffer of the caller's (dangx_adopt_device_state): never cached
+    // ... and the plane-set launches leave the sums of the maps they swept on the DEVICE (chi_cache, after the six chi^2 slots),
+    // as by-products like chi^2: valid until the map is written again; the count of unmasked pixels is a property of the mask
+    bool idxsum_dev[MAXC][MAXI][3] = {};
+    long long mask_count = -1;
     std::vector<double> bp_nu0, bp_tau0;
     double *d_bp_nu0 = nullptr, *d_bp_tau0 = nullptr, *d_bp_lnr = nullptr;  // lnr: [ncomp][samples]
     bool bp_dirty = true;  // bandpass samples or component reference frequencies changed since the last upload
@@ -60,7 +64,9 @@ struct dangx_ctx {
     // is full: ONE pair of reduction launches then serves every sweep since the last one (in launch order), instead of
     // two small launches behind every sweep -- 6 % of a rank's iteration at the 8-rank shard size
     static constexpr int CHI_RING = 8;
-    struct ChiPend { double* buf = nullptr; long long cap = 0, nblk = 0; int s1 = 0, s2 = 0, wb = 0; } chi_pend[CHI_RING];
+    // ns > 0: rows 4 .. 4+ns-1 of the buffer are block partials of the masked sums of the index maps the launch swept;
+    // slot[q] = their place in chi_cache (idx_slot)
+    struct ChiPend { double* buf = nullptr; long long cap = 0, nblk = 0; int s1 = 0, s2 = 0, wb = 0, ns = 0; int slot[DX_MAX_IDXSUM] = {}; } chi_pend[CHI_RING];
     int chi_npend = 0;
     double* chi_stage = nullptr;
     bool chi_before_valid[3] = {}, chi_after_valid[3] = {}, touched_since_amp[3] = {};
@@ -146,8 +152,12 @@ inline void invalidate_chi(dangx_ctx* ctx) {
 inline void idx_written(dangx_ctx* ctx, int comp) {
     for (int l = 0; l < MAXC; ++l)
         if (comp < 0 || l == comp)
-            for (int q = 0; q < MAXI; ++q) for (int k = 0; k < 3; ++k) ctx->idxsum_ok[l][q][k] = false;
+            for (int q = 0; q < MAXI; ++q) for (int k = 0; k < 3; ++k) ctx->idxsum_ok[l][q][k] = ctx->idxsum_dev[l][q][k] = false;
+    if (comp < 0) ctx->mask_count = -1;
 }
+// place of the masked sum of c%indices(:, plane, nind) of component comp in chi_cache
+inline int idx_slot(int comp, int nind, int plane) { return 6 + (comp * MAXI + nind) * 3 + (plane - 1); }
+constexpr int CHI_CACHE_DOUBLES = 6 + MAXC * MAXI * 3;
 
 inline int fail(dangx_ctx* ctx, const std::string& msg) {
     ctx->err = msg;

@@ -128,6 +128,10 @@ __global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP, SOLVE, C0)) void k_p
     sed_table_build(M, tab, tid, BLOCK, ga.gc, NG);
     __syncthreads();
     double chi[4] = {0.0, 0.0, 0.0, 0.0};
+    // masked sums of the index maps the launch sweeps (mask_avg's numerator, src/dang_util_mod.f90:186-206: what write_stats_to_term
+    // prints after the phase): the value each chain ends on, by-products like chi^2 -- rows 4 .. of chi_partial
+    constexpr int NS0 = C0 ? 1 + (C0 >> 3) : 0, NS1 = C1 ? 1 + (C1 >> 3) : 0, NS2 = C2 ? 1 + (C2 >> 3) : 0, NS3 = C3 ? 1 + (C3 >> 3) : 0;
+    constexpr int NS = NS0 + NS1 + NS2 + NS3;
     const bool live = in_range && !is_masked(mk);
     if (in_range && !live && half == 0) {  // masked: x stays (:695); every swept index map gets a zero (:223, :480-483)
         for (int q = 0; q < sl.n; ++q) {
@@ -328,15 +332,31 @@ __global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP, SOLVE, C0)) void k_p
         run(ItemCode<C3>{}, ItemFlag<false>{}, ItemFlag<true>{}, 3);
     }
     if (chi_partial) {
-        __shared__ double sh[4][BLOCK / 64];
+        // (the values the chains ended on are read back from the index maps -- this lane's own stores -- rather than carried in
+        // registers across the chains: the two-plane kernels have none to spare)
+        double isum[NS > 0 ? NS : 1];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            double v = chi[q];
+        for (int q = 0; q < (NS > 0 ? NS : 1); ++q) isum[q] = 0.0;
+        if (live && half == 0) {
+            constexpr int code[4] = {C0, C1, C2, C3};
+            constexpr int first[4] = {0, NS0, NS0 + NS1, NS0 + NS1 + NS2};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (code[q] != 0) {
+                    const double* at = M.comp[sl.s[q].comp].idx + ((long long)sl.s[q].nind * M.nmaps + (sl.s1 - 1)) * npix + i;
+                    isum[first[q]] = at[0];
+                    if ((code[q] >> 3) != 0) isum[first[q] + 1] = at[(long long)M.nmaps * npix];
+                }
+        }
+        __shared__ double sh[4 + NS][BLOCK / 64];
+#pragma unroll
+        for (int q = 0; q < 4 + NS; ++q) {
+            double v = (q < 4) ? chi[q < 4 ? q : 0] : isum[q >= 4 ? q - 4 : 0];
             for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
             if ((tid & 63) == 0) sh[q][tid >> 6] = v;
         }
         __syncthreads();
-        if (tid < 4) {
+        if (tid < 4 + NS) {
             double s = 0.0;
             for (int w = 0; w < BLOCK / 64; ++w) s += sh[tid][w];
             chi_partial[(long long)tid * gridDim.x + blockIdx.x] = s;

@@ -161,6 +161,23 @@ def test_masked_index_sums_are_cached_until_a_map_changes(built):
     assert np.allclose(s3, want(), rtol=1e-13) and s3[entries.index((2, 0, 1))] != s2[entries.index((2, 0, 1))]
     eng.profile(False)
     assert n_sweep > n_before
+    # the plane-set launches leave the sums of the maps they swept beside their chi^2 sums (by-products of the launch): the next
+    # request is answered from them -- same sums to rounding, the mask's pixel count
+    ddata.engine = eng
+    da.gibbs_iteration(dpar, ddata, 3)
+    s4, c4 = eng.index_masked_sums(entries)
+    assert np.allclose(s4, want(), rtol=1e-13) and np.array_equal(c4, c0) and not np.array_equal(s4, s3)
+    for g in dpar.cg_groups:    # ... the sweeps-only launch too
+        eng.plane_sweeps_sample(g.pol_flag[0], _plane_sweep_list(comps, g.cg_group, g.pol_flag[0], 4), dpar.nsample, "sample", dpar.seed)
+    s5, c5 = eng.index_masked_sums(entries)
+    assert np.allclose(s5, want(), rtol=1e-13) and np.array_equal(c5, c0) and not np.array_equal(s5, s4)
+    # a context that has never counted the mask's pixels takes the explicit pass and gets the same numbers
+    eng2, _ = pair(case)
+    for l in range(len(comps)):
+        if comps[l].nindices:
+            eng2.put_indices(l, eng.get_indices(l))
+    s6, c6 = eng2.index_masked_sums(entries)
+    assert np.allclose(s6, s5, rtol=1e-13) and np.array_equal(c6, c0)
 
 
 @pytest.mark.parametrize("config,nside,ml_mode", [("C3", 8, "sample"), ("C2", 8, "sample"), ("C3", 4, "optimize")])
