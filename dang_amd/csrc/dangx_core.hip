@@ -220,44 +220,43 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_rows_batch(ChiBatch b, double*
     double* out = stage + (long long)e * CHI_ROWS * gridDim.x;
     const long long chunk = (n + gridDim.x - 1) / gridDim.x;
     const long long lo = (long long)blockIdx.x * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
-    for (int q = 0; q < 4 + b.ns[e]; ++q) {
+    const int q = blockIdx.z;   // one row per block: the rows of an entry reduce side by side
+    if (q >= 4 + b.ns[e]) return;
+    double s = 0.0;
+    for (long long t = lo + threadIdx.x; t < hi; t += BLOCK) s += in[(long long)q * n + t];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = BLOCK / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(long long)q * gridDim.x + blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(BLOCK) void k_reduce_chi_batch(ChiBatch b, const double* __restrict__ stage, long long n,
+                                                            double* __restrict__ cache) {
+    __shared__ double sh[BLOCK];
+    const int q = blockIdx.x;   // one row per block; the entries in launch order (a later launch overwrites an earlier one's slot)
+    for (int e = 0; e < b.n; ++e) {
+        if (q >= 4 + b.ns[e]) continue;   // (block-uniform)
+        const double* partial = stage + (long long)e * CHI_ROWS * n;
         double s = 0.0;
-        for (long long t = lo + threadIdx.x; t < hi; t += BLOCK) s += in[(long long)q * n + t];
+        for (long long t = threadIdx.x; t < n; t += BLOCK) s += partial[(long long)q * n + t];
         sh[threadIdx.x] = s;
         __syncthreads();
         for (int o = BLOCK / 2; o > 0; o >>= 1) {
             if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
             __syncthreads();
         }
-        if (threadIdx.x == 0) out[(long long)q * gridDim.x + blockIdx.x] = sh[0];
-        __syncthreads();
-    }
-}
-__global__ __launch_bounds__(BLOCK) void k_reduce_chi_batch(ChiBatch b, const double* __restrict__ stage, long long n,
-                                                            double* __restrict__ cache) {
-    __shared__ double sh[BLOCK];
-    for (int e = 0; e < b.n; ++e) {
-        const double* partial = stage + (long long)e * CHI_ROWS * n;
-        for (int q = 0; q < 4 + b.ns[e]; ++q) {
-            double s = 0.0;
-            for (long long t = threadIdx.x; t < n; t += BLOCK) s += partial[(long long)q * n + t];
-            sh[threadIdx.x] = s;
-            __syncthreads();
-            for (int o = BLOCK / 2; o > 0; o >>= 1) {
-                if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-                __syncthreads();
+        if (threadIdx.x == 0) {
+            if (q >= 4) {   // masked sum of an index map the launch swept: the same value on every plane it wrote (:465)
+                for (int k = b.s1[e]; k <= b.s2[e]; ++k) cache[b.slot[e][q - 4] + (k - b.s1[e])] = sh[0];
+            } else {
+                const int plane = (q & 1) ? b.s2[e] : b.s1[e];
+                const bool after = q >= 2;
+                if (!((q & 1) && b.s1[e] == b.s2[e]) && (after || b.wb[e])) cache[(after ? 3 : 0) + plane - 1] = sh[0];
             }
-            if (threadIdx.x == 0) {
-                if (q >= 4) {   // masked sum of an index map the launch swept: the same value on every plane it wrote (:465)
-                    for (int k = b.s1[e]; k <= b.s2[e]; ++k) cache[b.slot[e][q - 4] + (k - b.s1[e])] = sh[0];
-                } else {
-                    const int plane = (q & 1) ? b.s2[e] : b.s1[e];
-                    const bool after = q >= 2;
-                    if (!((q & 1) && b.s1[e] == b.s2[e]) && (after || b.wb[e])) cache[(after ? 3 : 0) + plane - 1] = sh[0];
-                }
-            }
-            __syncthreads();
         }
+        __syncthreads();
     }
 }
 
@@ -1060,8 +1059,10 @@ int chi_flush(dangx_ctx* ctx) {
     }
     {
         Timed t(ctx, DANGX_K_REDUCE);
-        hipLaunchKernelGGL(k_reduce_rows_batch, dim3(CHI_RSTAGE, b.n), dim3(BLOCK), 0, ctx->stream, b, ctx->chi_stage);
-        hipLaunchKernelGGL(k_reduce_chi_batch, dim3(1), dim3(BLOCK), 0, ctx->stream, b, ctx->chi_stage, (long long)CHI_RSTAGE, ctx->chi_cache);
+        int rows = 4;
+        for (int e = 0; e < b.n; ++e) rows = std::max(rows, 4 + b.ns[e]);
+        hipLaunchKernelGGL(k_reduce_rows_batch, dim3(CHI_RSTAGE, b.n, rows), dim3(BLOCK), 0, ctx->stream, b, ctx->chi_stage);
+        hipLaunchKernelGGL(k_reduce_chi_batch, dim3(rows), dim3(BLOCK), 0, ctx->stream, b, ctx->chi_stage, (long long)CHI_RSTAGE, ctx->chi_cache);
     }
     ctx->chi_npend = 0;
     HIPCHK(ctx, hipGetLastError());

@@ -53,7 +53,9 @@ __device__ __forceinline__ void ps_item(const Model& M, const SweepList& sl, con
     IndexArgs a;
     a.comp = it.comp; a.nind = it.nind; a.s1 = sl.s1; a.s2 = sl.s2; a.nsample = sl.nsample; a.ml_mode = sl.ml_mode; a.mode = MODE;
     a.bp = 0; a.others = 0u; a.seed = sl.seed; a.stream = it.stream;
-    RegChain<MODE, SP, NBL, LP, true, BP> R;   // per-band constants from the block's table in LDS
+    // per-band constants from the block's table in LDS, in the one-lane form too (as scalar operands from the model instead: 86.4
+    // against 87.1 it/s at C3 on one device -- the scalar registers are what the kernel is short of)
+    RegChain<MODE, SP, NBL, LP, true, BP> R;
     R.set_kt(tab, NB, NG, it.gmember, jb);
 #pragma unroll
     for (int kk = 0; kk < SP; ++kk) {
