@@ -145,6 +145,10 @@ const char* dx_kernel_family(int kid);
 // model (T_CMB, calibration, host pushes of state, new data, new descriptors) calls this
 inline void invalidate_chi(dangx_ctx* ctx) {
     for (int k = 0; k < 3; ++k) ctx->chi_before_valid[k] = ctx->chi_after_valid[k] = false;
+    if (ctx->chi_npend) {   // the dropped entries carry the index sums of their launches too: those fall back to the explicit pass
+        for (int l = 0; l < MAXC; ++l)
+            for (int q = 0; q < MAXI; ++q) for (int k = 0; k < 3; ++k) ctx->idxsum_dev[l][q][k] = false;
+    }
     ctx->chi_npend = 0;  // block partials still waiting in the ring belong to that model too: nobody may read them
 }
 

@@ -171,6 +171,13 @@ def test_masked_index_sums_are_cached_until_a_map_changes(built):
         eng.plane_sweeps_sample(g.pol_flag[0], _plane_sweep_list(comps, g.cg_group, g.pol_flag[0], 4), dpar.nsample, "sample", dpar.seed)
     s5, c5 = eng.index_masked_sums(entries)
     assert np.allclose(s5, want(), rtol=1e-13) and np.array_equal(c5, c0) and not np.array_equal(s5, s4)
+    # a model change between the launch and the request (band calibration here) drops the launch's pending partials -- chi^2 and
+    # index sums alike: the request must not read a stale slot
+    da.gibbs_iteration(dpar, ddata, 5)
+    eng.set_calibration(np.ones(meta["nbands"]), np.zeros(meta["nbands"]))
+    s5b, c5b = eng.index_masked_sums(entries)
+    assert np.allclose(s5b, want(), rtol=1e-13) and np.array_equal(c5b, c0) and not np.array_equal(s5b, s5)
+    s5 = s5b
     # a context that has never counted the mask's pixels takes the explicit pass and gets the same numbers
     eng2, _ = pair(case)
     for l in range(len(comps)):
