@@ -203,7 +203,7 @@ __global__ __launch_bounds__(BLOCK, NG <= 4 ? 4 : 3) void k_amp_reg(const Model*
 
 // update_sky_model + compute_chisq (src/dang_data_mod.f90:339-396, 494-526) of ONE plane on the same schedule: the plane's
 // components with a non-zero amplitude play the group (sky = sum of amplitude * SED in component order), the residual replaces
-// the normal equations.  The run-time-typed kernel of dangx_core.hip (k_sky_chisq) spends 1.36 ms per C3 plane on the same
+// the normal equations.  The run-time-typed kernel of dangx_entry.hip (k_sky_chisq) spends 1.36 ms per C3 plane on the same
 // numbers; this one is bound by the 2 nb map loads like k_amp_reg.  Block partials -> partial[blockIdx.x].
 template <int NG, int TB>
 __global__ __launch_bounds__(BLOCK, NG <= 4 ? 4 : 3) void k_chisq_reg(const Model* __restrict__ Mp, GroupArgs a, AmpRegArgs ra,

@@ -1,12 +1,14 @@
-// dangx.hip -- libdangx.so: hand-written HIP (gfx950 / CDNA4) kernels for dang's
-// Gibbs inner loop and the C ABI declared in include/dangx.h.
+// dangx_core.hip -- the context behind the C ABI of include/dangx.h: creation, the host mirror of the model and its device copy
+// (sync_model: band constants, host-evaluated SEDs of spatially constant index maps, bandpass tables), the resident state maps,
+// the chi^2 / index-sum ring the sweeps leave their by-products in (chi_next / chi_flush), the CG group descriptors
+// (make_group), the host solvers of the parity and template paths (device_cg, device_schur), the small reduction / statistics /
+// unit-conversion entry points and the launch profile.  The sampling entry points live in dangx_entry.hip, the full-sky / coarse-
+// Nside device side in dangx_coarse.hip, the sky-wide chains in dangx_sky.hip, the kernels next to their launchers.
 //
-// Design: one thread owns one (pixel, Stokes plane) unit -- the
-// reference's global CG system is block diagonal for diffuse components, so the
-// amplitude phase is a single streaming pass (mixing rows -> normal equations ->
-// Cholesky) and the index phase a single pass with the Metropolis chain held in
-// LDS/registers.  All map arrays are pixel-major, so a wavefront's 64 lanes read 64
-// consecutive doubles (512 B) per load.  Everything is fp64.
+// Design: one thread owns one (pixel, Stokes plane) unit -- the reference's global CG system is block diagonal
+// for diffuse components, so the amplitude phase is a single streaming pass (mixing rows -> normal equations -> Cholesky) and
+// the index phase a single pass with the Metropolis chain held in registers.  All map arrays are pixel-major, so a wavefront's
+// 64 lanes read 64 consecutive doubles (512 B) per load.  Everything is fp64.
 #include <dlfcn.h>
 
 #include "dx_host.h"
@@ -260,171 +262,6 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_chi_batch(ChiBatch b, const do
     }
 }
 
-// out[0] = sum over planes pol_lo..pol_hi of cache[which*3 + plane-1]
-__global__ void k_chi_from_cache(const double* __restrict__ cache, int which, int pol_lo, int pol_hi, double* __restrict__ out) {
-    double s = 0.0;
-    for (int k = pol_lo; k <= pol_hi; ++k) s += cache[which * 3 + k - 1];
-    out[0] = s;
-}
-
-
-// ---------------------------------------------------------------------------
-// update_sky_model + compute_chisq (src/dang_data_mod.f90:339-396, 494-526), one thread per
-// pixel.  sky(i,k,j) is accumulated over components in component_list order in an LDS column;
-// the residual and chi^2 follow the reference's expressions.  Block partials of
-// sum_k sum_j res^2/rms^2 go to `partial` (second stage: k_reduce).
-// (4 waves/SIMD asked for: the kernel streams 2 nb maps per plane against a few SED evaluations, and left to itself the register
-// allocator drifts to 130 registers = 3 waves with any small change of the SED helpers: 1.36 -> 1.70 ms per plane at C3)
-__global__ __launch_bounds__(BLOCK, 4) void k_sky_chisq(const Model* __restrict__ Mp, int pol_lo, int pol_hi, double* __restrict__ sky,
-                            double* __restrict__ res, double* __restrict__ chi_map, double* __restrict__ partial) {
-    extern __shared__ double lds[];  // [nb][BS]
-    const Model& M = *Mp;
-    const int BS = blockDim.x, tid = threadIdx.x;
-    const int npix = M.npix, nb = M.nbands;
-    const int i = blockIdx.x * BS + tid;
-    double chi_sum = 0.0;
-    if (i < npix) {
-        const bool msk = is_masked(M.mask[i]);
-        const bool want_maps = (sky != nullptr) || (res != nullptr);
-        if (!msk || want_maps) {
-            for (int k = 1; k <= M.nmaps; ++k) {
-                const bool in_pol = (k >= pol_lo && k <= pol_hi);
-                if (!want_maps && !in_pol) continue;
-                for (int j = 0; j < nb; ++j) lds[j * BS + tid] = 0.0;
-                for (int l = 0; l < M.ncomp; ++l) {
-                    const Comp& c = M.comp[l];
-                    const double amp = c.amp[(long long)(k - 1) * npix + i];
-                    if (c.type == DANGX_MONOPOLE) continue;  // sets the band offsets instead (src/dang_data_mod.f90:357-361)
-                    if (amp == 0.0 && !want_maps && c.type != DANGX_TCMB && !is_global_type(c.type)) continue;
-                    double t0, t1;
-                    load_theta(M, c, i, k, t0, t1);
-                    const Prep pr = sed_prep(c, t0, t1);
-                    for (int j = 0; j < nb; ++j) lds[j * BS + tid] = lds[j * BS + tid] + comp_signal(M, c, i, k, j, amp, pr);
-                }
-                double chi = 0.0;
-                for (int j = 0; j < nb; ++j) {
-                    const long long q = ((long long)j * M.nmaps + (k - 1)) * npix + i;
-                    const double s = lds[j * BS + tid];
-                    const double r = (k == 1) ? (M.sig[q] - M.offset[j]) / M.gain[j] - s : M.sig[q] - s;
-                    if (sky) sky[q] = s;
-                    if (res) res[q] = r;
-                    if (!msk && in_pol) {
-                        const double rms = M.rms[q];
-                        chi = chi + (r * r) / (rms * rms);
-                    }
-                }
-                if (!msk && in_pol) {
-                    chi_sum += chi;
-                    if (chi_map) chi_map[(long long)(k - 1) * npix + i] = chi / nb;
-                }
-            }
-        }
-    }
-    __shared__ double sh[16];
-    for (int o = 32; o > 0; o >>= 1) chi_sum += __shfl_down(chi_sum, o, 64);
-    if ((tid & 63) == 0) sh[tid >> 6] = chi_sum;
-    __syncthreads();
-    if (tid == 0) {
-        double s = 0.0;
-        for (int w = 0; w < BS / 64; ++w) s += sh[w];
-        partial[blockIdx.x] = s;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Full-sky index mode (index_mode == 1, src/dang_sample_mod.f90:229-329), the tuner (:623-717) and the
-// band-gain fit (:570-621).  With one spectral index for the whole sky the model's SED is pixel
-// independent, so each Metropolis step is ONE memory-bound pass that produces a few global sums; the
-// chain itself (proposal, prior, accept) runs on the host between the all-reduces (dang_amd/api.py).
-
-// data_raw minus every other component for planes s1..s2 (:173-196, all pixels) -> out[(kk*nb + j)*npix + i]
-__global__ __launch_bounds__(BLOCK) void k_fullsky_prepare(const Model* __restrict__ Mp, int comp, int s1, int s2,
-                                                           unsigned others, double* __restrict__ out) {
-    const Model& M = *Mp;
-    const int npix = M.npix, nb = M.nbands;
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= npix) return;
-    for (int k = s1; k <= s2; ++k)
-        for (int j = 0; j < nb; ++j) {
-            double d = M.sig[((long long)j * M.nmaps + (k - 1)) * npix + i];
-            if (k == 1) d = (d - M.offset[j]) / M.gain[j];
-            for (unsigned om = others; om; om &= om - 1) {
-                const Comp& c2 = M.comp[__builtin_ctz(om)];
-                double t0, t1;
-                load_theta(M, c2, i, k, t0, t1);
-                d = d - comp_signal(M, c2, i, k, j, c2.amp[(long long)(k - 1) * npix + i], sed_prep(c2, t0, t1));
-            }
-            out[((long long)(k - s1) * nb + j) * npix + i] = d;
-        }
-}
-
-// row sums for one evaluation at theta: what = 0: evaluate_lnL (1 row: -1/2 sum ((d-m)/rms)^2, unmasked);
-// what = 1: evaluate_marginal_lnL (2*nb*Sp rows: TNd(j,k), TNT(j,k), all pixels); what = 2: jeffreys (1 row).
-// partial[row][gridDim.x]
-// With sample_nside /= nside (crms /= nullptr) the sums run over the npix_c pixels of the DEGRADED data / rms / mask
-// ([kk][j][npix_c] and [npix_c]) while eval_signal reads c%amplitude at the coarse pixel number in the full-resolution
-// array, as the reference does (src/dang_sample_mod.f90:199-217, 548-563).
-__global__ __launch_bounds__(BLOCK) void k_fullsky_rows(const Model* __restrict__ Mp, int comp, int s1, int s2, int what,
-                                                        double th0, double th1, const double* __restrict__ data,
-                                                        const double* __restrict__ crms, const double* __restrict__ cmask,
-                                                        long long npix_c, double* __restrict__ partial) {
-    __shared__ double sh[BLOCK / 64];
-    const Model& M = *Mp;
-    const Comp& c = M.comp[comp];
-    const int nb = M.nbands, Sp = s2 - s1 + 1;
-    const bool coarse = crms != nullptr;
-    const int npix = coarse ? (int)npix_c : M.npix;
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    // coarse: i is a coarse pixel number; the degraded maps are whole-sky on every shard, the amplitude of "pixel i" lives on
-    // the shard that holds full-resolution pixel i -- each coarse pixel is summed by exactly one shard
-    const long long il = coarse ? (long long)i - M.pix0 : i;
-    const bool in = i < npix && il >= 0 && il < M.npix;
-    const bool msk = in ? is_masked(coarse ? cmask[i] : M.mask[i]) : true;
-    const Prep pr = sed_prep(c, th0, th1);
-    const int nrows = (what == 1) ? 2 * nb * Sp : 1;
-    double amp[2] = {0.0, 0.0};
-    if (in) for (int kk = 0; kk < Sp; ++kk) amp[kk] = c.amp[(long long)(s1 + kk - 1) * M.npix + il];
-    auto rms_at = [&](int kk, int j) -> double {
-        return coarse ? crms[((long long)kk * nb + j) * npix + i] : M.rms[((long long)j * M.nmaps + (s1 + kk - 1)) * npix + i];
-    };
-    for (int row = 0; row < nrows; ++row) {
-        double v = 0.0;
-        if (in) {
-            if (what == 0 && !msk) {
-                for (int kk = 0; kk < Sp; ++kk)
-                    for (int j = 0; j < nb; ++j) {
-                        const double m = signal_of(c, amp[kk], sed_eval(M, c, j, pr));
-                        const double t = (data[((long long)kk * nb + j) * npix + i] - m) / rms_at(kk, j);
-                        v = v - 0.5 * (t * t);
-                    }
-            } else if (what == 1) {
-                const int q = row >> 1, j = q / Sp, kk = q - j * Sp;  // (j outer, k inner) as the reference sums
-                const double m = signal_of(c, amp[kk], sed_eval(M, c, j, pr));
-                const double rms = rms_at(kk, j);
-                const double TN = m / (rms * rms);
-                v = (row & 1) ? TN * m : TN * data[((long long)kk * nb + j) * npix + i];
-            } else if (what == 2 && !msk && c.is_synch) {
-                for (int kk = 0; kk < Sp; ++kk)
-                    for (int j = 0; j < nb; ++j) {
-                        const double ss = signal_of(c, amp[kk], sed_eval(M, c, j, pr));
-                        const double rr = 1.0 / rms_at(kk, j);
-                        const double t = (rr * rr) * (ss / amp[kk]) * c.lnr[j];
-                        v = v + t * t;
-                    }
-            }
-        }
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double t = 0.0;
-            for (int w = 0; w < BLOCK / 64; ++w) t += sh[w];
-            partial[(long long)row * gridDim.x + blockIdx.x] = t;
-        }
-        __syncthreads();
-    }
-}
-
 // fit_band_gain sums (src/dang_sample_mod.f90:590-607): rows 0: sum map2*N_inv*map1, 1: sum map1*N_inv*map1
 __global__ __launch_bounds__(BLOCK) void k_gain_rows(const Model* __restrict__ Mp, int band, double* __restrict__ partial) {
     __shared__ double sh[2][BLOCK / 64];
@@ -475,197 +312,6 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_rows_final(const double* __res
         if (threadIdx.x == 0) out[q] = sh[0];
         __syncthreads();
     }
-}
-
-
-// ---------------------------------------------------------------------------
-// Coarse-Nside index sampling (src/dang_sample_mod.f90:199-217, 332-483).  HEALPix is an external library of the
-// reference (absent from its tree); nest2ring and udgrade_ring are restated from the published algorithm
-// (Gorski et al. 2005, ApJ 622, 759; HEALPix pix_tools::nest2ring, udgrade_nr::udgrade_ring -> sub_udgrade_nest).
-
-// udgrade of one RING map per blockIdx.y: out pixel o (RING) -> NEST -> children (degrade: mean of the good ones, in
-// NEST child order; upgrade: the parent's value) -> RING.  mode 0: udgrade_ring; 1: udgrade_rms (input squared,
-// sqrt(mean)*nside_out/nside_in, src/dang_util_mod.f90:341-356); 2: udgrade_mask (mean < 0.5 -> 0 else 1 when
-// degrading, :358-376).  layout 0: plane q at q*npix_in; layout 1: plane q = kk*nb + j of M.rms ((j*nmaps + s1+kk-1)*npix_in)
-__global__ __launch_bounds__(BLOCK) void k_udgrade(const double* __restrict__ in, double* __restrict__ out,
-                                                   const int* __restrict__ n2r_in, const int* __restrict__ r2n_out,
-                                                   long long npix_in, long long npix_out, int ratio, int degrade, int mode,
-                                                   double scale, int layout, int nb, int nmaps, int s1) {
-    const long long o = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    if (o >= npix_out) return;
-    const int q = blockIdx.y;
-    const double* src = in + (layout == 0 ? (long long)q * npix_in
-                                          : ((long long)(q % nb) * nmaps + (s1 + q / nb - 1)) * npix_in);
-    const long long nest = r2n_out[o];
-    double v;
-    if (degrade) {
-        double total = 0.0;
-        int nobs = 0;
-        for (int ip = 0; ip < ratio; ++ip) {
-            double x = src[n2r_in[nest * ratio + ip]];
-            if (mode == 1) x = x * x;
-            if (fabs(x - MISSVAL) > fabs(1e-5 * MISSVAL)) { total = total + x; ++nobs; }  // bad pixels do not enter the mean
-        }
-        v = nobs ? total / nobs : MISSVAL;
-    } else {
-        v = src[n2r_in[nest / ratio]];
-        if (mode == 1) v = v * v;
-    }
-    if (mode == 1) v = sqrt(v) * scale;
-    if (mode == 2 && degrade) v = (v < 0.5) ? 0.0 : 1.0;
-    out[(long long)q * npix_out + o] = v;
-}
-
-// Pixel-sharded form of the degrade step: coarse pixel o collects, in NEST child order, only those of its children whose
-// RING index lies in this shard [pix0, pix0 + npix_loc); it emits the sum of the good ones and their number.  The sums
-// of all shards (added by the caller) are finished by k_udgrade_finish -- with one shard that is k_udgrade bit for bit.
-__global__ __launch_bounds__(BLOCK) void k_udgrade_part(const double* __restrict__ in, double* __restrict__ tot, double* __restrict__ cnt,
-                                                        const int* __restrict__ n2r_in, const int* __restrict__ r2n_out,
-                                                        long long pix0, long long npix_loc, long long npix_out, int ratio, int mode,
-                                                        int layout, int nb, int nmaps, int s1) {
-    const long long o = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    if (o >= npix_out) return;
-    const int q = blockIdx.y;
-    const double* src = in + (layout == 0 ? (long long)q * npix_loc
-                                          : ((long long)(q % nb) * nmaps + (s1 + q / nb - 1)) * npix_loc);
-    const long long nest = r2n_out[o];
-    double total = 0.0;
-    int nobs = 0;
-    for (int ip = 0; ip < ratio; ++ip) {
-        const long long ring = n2r_in[nest * ratio + ip];
-        if (ring < pix0 || ring >= pix0 + npix_loc) continue;
-        double x = src[ring - pix0];
-        if (mode == 1) x = x * x;
-        if (fabs(x - MISSVAL) > fabs(1e-5 * MISSVAL)) { total = total + x; ++nobs; }
-    }
-    tot[(long long)q * npix_out + o] = total;
-    cnt[(long long)q * npix_out + o] = (double)nobs;
-}
-__global__ __launch_bounds__(BLOCK) void k_udgrade_finish(const double* __restrict__ tot, const double* __restrict__ cnt,
-                                                          double* __restrict__ out, long long n, int mode, double scale) {
-    const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    if (t >= n) return;
-    const double nobs = cnt[t];
-    double v = (nobs > 0.0) ? tot[t] / nobs : MISSVAL;
-    if (mode == 1) v = sqrt(v) * scale;
-    if (mode == 2) v = (v < 0.5) ? 0.0 : 1.0;
-    out[t] = v;
-}
-
-// One Metropolis chain per COARSE pixel i, literally as the reference runs it: ddata%masks(i,1), c%indices(i,..) and
-// eval_signal's c%amplitude(i,k) are the FULL-resolution arrays read at the coarse index (:362, :372-377, :548-553);
-// data / rms / mask(:,1) are the degraded maps.  evaluate_lnL sums k outer, j inner with ((d-m)/rms)**2 (:171-177),
-// evaluate_marginal_lnL j outer, k inner (:113-122).  index_map(i) -> idxmap[i] (0 where the chain is skipped, :223).
-// On a pixel shard the chain of coarse pixel i runs where the full-resolution pixel i lives (M.pix0 <= i < M.pix0 + npix);
-// the other shards leave idxmap[i] = 0 and the caller adds the maps.
-__global__ __launch_bounds__(BLOCK) void k_index_mh_coarse(const Model* __restrict__ Mp, IndexArgs a, long long npix_c,
-                                                           const double* __restrict__ cdata, const double* __restrict__ crms,
-                                                           const double* __restrict__ cmask, double* __restrict__ idxmap,
-                                                           unsigned long long* __restrict__ accepted) {
-    const Model& M = *Mp;
-    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    unsigned long long nacc = 0;
-    if (i < npix_c) {
-        idxmap[i] = 0.0;
-        const long long il = i - M.pix0;  // index of full-resolution pixel i in this shard's arrays
-        if (il >= 0 && il < M.npix && !is_masked(M.mask[il])) {
-            const Comp& c = M.comp[a.comp];
-            const int nb = M.nbands, Sp = a.s2 - a.s1 + 1, q = a.nind;
-            double sample0, sample1;
-            load_theta(M, c, (int)il, a.s1, sample0, sample1);
-            const bool first = (q == 0);
-            const double other = first ? sample1 : sample0;
-            double amp[2] = {0.0, 0.0};
-            for (int kk = 0; kk < Sp; ++kk) amp[kk] = c.amp[(long long)(a.s1 + kk - 1) * M.npix + il];
-            const int lnl_type = c.lnl_type[q];
-            const bool cmasked = is_masked(cmask[i]);
-            auto lnl_of = [&](double th) -> double {
-                if (lnl_type == DANGX_LNL_PRIOR) return 0.0;
-                const Prep pr = sed_prep(c, first ? th : other, first ? other : th);
-                double lnL = 0.0;
-                if (lnl_type == DANGX_LNL_CHISQ) {
-                    if (cmasked) return 0.0;  // evaluate_lnL cycles on the (degraded) mask, :169
-                    for (int kk = 0; kk < Sp; ++kk)
-                        for (int j = 0; j < nb; ++j) {
-                            const double m = signal_of(c, amp[kk], sed_eval(M, c, j, pr));
-                            const long long e = ((long long)kk * nb + j) * npix_c + i;
-                            const double t = (cdata[e] - m) / crms[e];
-                            lnL = lnL - 0.5 * (t * t);
-                        }
-                } else {
-                    for (int j = 0; j < nb; ++j)
-                        for (int kk = 0; kk < Sp; ++kk) {
-                            const double m = signal_of(c, amp[kk], sed_eval(M, c, j, pr));
-                            const long long e = ((long long)kk * nb + j) * npix_c + i;
-                            const double TN = m / (crms[e] * crms[e]);
-                            const double TNd = TN * cdata[e], TNT = TN * m;
-                            lnL = lnL - 0.5 * TNd * (1.0 / TNT) * TNd;
-                        }
-                }
-                return lnL;
-            };
-            auto prior = [&](double v) -> double {
-                if (c.prior_type[q] == DANGX_PRIOR_JEFFREYS) {
-                    // eval_jeffreys_prior(c, data, rms, model, map_inds, i, mask(:,1), val), src/dang_lnl_mod.f90:242-304:
-                    // the DEGRADED rms and mask, eval_signal / c%amplitude at the coarse pixel number, theta = (val, -)
-                    double sum = 0.0;
-                    if (c.is_synch && !cmasked) {
-                        const Prep pr = sed_prep(c, v, 0.0);
-                        for (int kk = 0; kk < Sp; ++kk)
-                            for (int j = 0; j < nb; ++j) {
-                                const double ss = signal_of(c, amp[kk], sed_eval(M, c, j, pr));
-                                const double rr = 1.0 / crms[((long long)kk * nb + j) * npix_c + i];
-                                const double tt = (rr * rr) * (ss / amp[kk]) * c.lnr[j];
-                                sum = sum + tt * tt;
-                            }
-                    }
-                    return log(sqrt(sum));
-                }
-                if (c.prior_type[q] != DANGX_PRIOR_GAUSSIAN) return 0.0;
-                const double arg = ((v - c.gauss[q][0]) * (v - c.gauss[q][0])) / (2 * (c.gauss[q][1] * c.gauss[q][1]));
-                return (arg > 745.0) ? -INFINITY : -arg - c.lgden[q];
-            };
-            double cur = first ? sample0 : sample1;
-            double lnl = lnl_of(cur);
-            bool sample_it = true;
-            if (lnl_type == DANGX_LNL_PRIOR) {  // :389-392
-                double u1, u2;
-                sample_it = false;
-                uniform2(a.seed, a.stream, (unsigned long long)i, 0u, u1, u2);
-                cur = rand_normal(c.gauss[q][0], c.gauss[q][1], u1, u2);
-            }
-            double lnl_old = lnl + prior(cur);
-            if (sample_it) {
-                const double step = c.step[q], lo = c.uni[q][0], hi = c.uni[q][1];
-                for (int l = 1; l <= a.nsample; ++l) {
-                    double u1, u2, u3;
-                    uniform3(a.seed, a.stream, (unsigned long long)i, (uint32_t)l, u1, u2, u3);
-                    const double prop = cur + rand_normal(0.0, step, u1, u2);
-                    if (prop < lo || prop > hi) continue;
-                    const double lnl_new = lnl_of(prop) + prior(prop);
-                    const double diff = lnl_new - lnl_old;
-                    const bool acc = (a.ml_mode == DANGX_ML_OPTIMIZE) ? (diff > 0.0) : ((diff >= 0.0) || (exp_sat(diff) > u3));
-                    if (acc) { cur = prop; lnl_old = lnl_new; ++nacc; }
-                }
-            }
-            idxmap[i] = cur;  // :465
-        }
-    }
-    if (accepted) {
-        for (int o = 32; o > 0; o >>= 1) nacc += __shfl_down(nacc, o, 64);
-        if ((threadIdx.x & 63) == 0 && nacc) atomicAdd(accepted, nacc);
-    }
-}
-
-// udgrade_ring(index_map, sample_nside -> nside) + c%indices(:, s1:s2, nind) = index_full_res(:, s1:s2) (:480-483)
-__global__ __launch_bounds__(BLOCK) void k_coarse_writeback(const Model* __restrict__ Mp, int comp, int nind, int s1, int s2,
-                                                            const double* __restrict__ idxmap, const int* __restrict__ r2n_f,
-                                                            const int* __restrict__ n2r_c, int ratio) {
-    const Model& M = *Mp;
-    const int p = blockIdx.x * BLOCK + threadIdx.x;
-    if (p >= M.npix) return;
-    const double v = idxmap[n2r_c[r2n_f[M.pix0 + p] / ratio]];
-    for (int k = s1; k <= s2; ++k) M.comp[comp].idx[((long long)nind * M.nmaps + (k - 1)) * M.npix + p] = v;
 }
 
 
@@ -820,6 +466,10 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sed(const Model* __restrict__ Mp
 
 // ======================================================================= host side
 
+void dx_reduce_two_stage(dangx_ctx* ctx, const double* partial, long long n, double* stage, double* out_dev) {
+    hipLaunchKernelGGL(k_reduce_rows, dim3(DX_RSTAGE), dim3(BLOCK), 0, ctx->stream, partial, n, 1, stage);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(BLOCK), 0, ctx->stream, stage, (long long)DX_RSTAGE, out_dev);
+}
 void dx_reduce_rows_to(dangx_ctx* ctx, const double* partial, unsigned nblk, int rows, double* out_dev) {
     if (rows <= 0) return;
     hipLaunchKernelGGL(k_reduce_rows_final, dim3(rows < 1024 ? rows : 1024), dim3(BLOCK), 0, ctx->stream, partial, (long long)nblk, rows, out_dev);
@@ -914,7 +564,9 @@ double host_sed(const Comp& c, double nu, double cmb_cst, double th0, double th1
     }
 }
 
-int ensure_state(dangx_ctx* ctx, int comp);
+}  // namespace
+
+// ---- host helpers shared with dangx_entry.hip / dangx_coarse.hip / dangx_sky.hip (declared in dx_host.h)
 
 int sync_model(dangx_ctx* ctx) {
     if (!ctx->dirty) return 0;
@@ -1496,8 +1148,6 @@ int ensure_state(dangx_ctx* ctx, int comp) {
     return 0;
 }
 
-}  // namespace
-
 // ======================================================================= C ABI
 
 static int seam_common(dangx_ctx* ctx, int group, int flag, GroupArgs& a, long long& SN, long long& n);
@@ -1840,130 +1490,6 @@ int64_t dangx_group_size(dangx_ctx* ctx, int group, int flag) {
     return (int64_t)a.ng * flag_planes_h(flag) * ctx->hm.npix + a.nglob;
 }
 
-static int planeset_launch(dangx_ctx* ctx, const GroupArgs& g, const SweepList& sl, int lanes, int solve, int64_t* n_not_spd, int64_t* accepted);
-static bool planeset_group(dangx_ctx* ctx, const GroupArgs& g);
-
-int dangx_amp_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed,
-                     uint64_t stream, int i_max, double converge, int* cg_iters, int64_t* n_not_spd) {
-    DxRange rg_("dangx_amp_sample");
-    if (!ctx) return 1;
-    (void)hipSetDevice(ctx->device);
-    if (ml_mode != DANGX_ML_SAMPLE && ml_mode != DANGX_ML_OPTIMIZE) return fail(ctx, "bad ml_mode");
-    GroupArgs a;
-    if (make_group(ctx, group, flag, a) || sync_model(ctx)) return 1;
-    a.ml_mode = ml_mode; a.fluct = fluct_mode; a.seed = seed; a.stream = stream;
-    const long long SN = (long long)flag_planes_h(flag) * ctx->hm.npix;
-    for (int pl = 0; pl < flag_planes_h(flag); ++pl) {  // the planes' cached chi^2 is stale now
-        const int k = (flag & DANGX_FLAG_QU) ? 2 + pl : (flag & DANGX_FLAG_T) ? 1 : (flag & DANGX_FLAG_Q) ? 2 : 3;
-        ctx->chi_before_valid[k - 1] = ctx->chi_after_valid[k - 1] = ctx->touched_since_amp[k - 1] = false;
-        for (int g = 0; g < a.ng; ++g) ctx->plane_nz[a.gc[g]] |= 1u << (k - 1);  // about to be written
-    }
-    if (cg_iters) *cg_iters = 0;
-    if (n_not_spd) *n_not_spd = 0;
-    if (a.nt > 0 && solver != DANGX_SOLVER_CG) {
-        if (fluct_mode != DANGX_FLUCT_REFERENCE && ml_mode == DANGX_ML_SAMPLE)
-            return fail(ctx, "groups with template / monopole / hi_fit members reproduce the reference's fluctuation term only");
-        int nullity = 0;
-        dangx_ctx* one[1] = {ctx};
-        if (device_schur(one, 1, &a, &SN, n_not_spd, &nullity)) return 1;
-        if (cg_iters) *cg_iters = -nullity;  // 0: regular system; -k: k directions of the global amplitudes left at their current value
-        return 0;
-    }
-    if (solver == DANGX_SOLVER_CG) {
-        if (fluct_mode != DANGX_FLUCT_REFERENCE && ml_mode == DANGX_ML_SAMPLE)
-            return fail(ctx, "the CG solver reproduces the reference's fluctuation term only");
-        return device_cg(ctx, a, i_max, converge, cg_iters);
-    }
-    if (ctx->defer_amp) {  // dangx_amp_index_sample: the launch waits for the index sweep it is fused with
-        ctx->pending = a; ctx->pending_SN = SN; ctx->have_pending = true;
-        return 0;
-    }
-    // The amplitude phase with chi^2 of the state it leaves as a by-product (src/dang_cg_mod.f90:172-173 asks for it after every
-    // group): the plane-set kernel without sweep items forms the residual of the new amplitudes anyway -- where it covers the
-    // model (delta bands, the group's members the only components on the planes, reference fluctuation term) the statistics need
-    // no pass of their own over the maps.  DANGX_AMP_CHI=0: the stand-alone amplitude kernel (A/B timing).
-    static const bool with_chi = [] { const char* e = getenv("DANGX_AMP_CHI"); return !(e && e[0] == '0'); }();
-    if (with_chi && (ml_mode == DANGX_ML_OPTIMIZE || fluct_mode == DANGX_FLUCT_REFERENCE) && planeset_group(ctx, a)) {
-        SweepList sl;
-        std::memset(&sl, 0, sizeof(sl));
-        sl.s1 = (flag & DANGX_FLAG_QU) ? 2 : (flag & DANGX_FLAG_T) ? 1 : (flag & DANGX_FLAG_Q) ? 2 : 3;
-        sl.s2 = (flag & DANGX_FLAG_QU) ? 3 : sl.s1;
-        sl.ml_mode = ml_mode;
-        const int lanes = dx_planeset_lanes(ctx, a, sl, 1);
-        if (lanes) return planeset_launch(ctx, a, sl, lanes, 1, n_not_spd, nullptr);
-    }
-    if (n_not_spd) HIPCHK(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));
-    if (dx_launch_amp(ctx, a, SN)) return 1;
-    HIPCHK(ctx, hipGetLastError());
-    if (n_not_spd) {
-        unsigned long long v = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&v, ctx->counters, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        *n_not_spd = (int64_t)v;
-    }
-    return 0;
-}
-
-// One (group, flag) pass of sample_cg_groups over several contexts of ONE process (include/dangx.h).  Independent per-pixel
-// work is enqueued on every device before the first result is awaited; a coupled group shares its Schur rows.
-int dangx_sky_amp_sample(dangx_ctx* const* ctxs, int nctx, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed,
-                         uint64_t stream, int i_max, double converge, int* cg_iters, int64_t* n_not_spd) {
-    DxRange rg_("dangx_sky_amp_sample");
-    if (!ctxs || nctx < 1) return 1;
-    for (int r = 0; r < nctx; ++r) if (!ctxs[r]) return 1;
-    dangx_ctx* c0 = ctxs[0];
-    if (nctx == 1) return dangx_amp_sample(c0, group, flag, ml_mode, solver, fluct_mode, seed, stream, i_max, converge, cg_iters, n_not_spd);
-    if (nctx > 64) return fail(c0, "too many contexts");
-    auto bubble = [&](dangx_ctx* who) { if (who != c0) c0->err = who->err; return 1; };
-    if (ml_mode != DANGX_ML_SAMPLE && ml_mode != DANGX_ML_OPTIMIZE) return fail(c0, "bad ml_mode");
-    GroupArgs probe;
-    if (make_group(c0, group, flag, probe)) return 1;
-    if (cg_iters) *cg_iters = 0;
-    if (n_not_spd) *n_not_spd = 0;
-    if (probe.nt == 0 && solver != DANGX_SOLVER_CG) {  // block diagonal: every shard on its own
-        for (int r = 0; r < nctx; ++r) {
-            if (n_not_spd) {  // the amplitude kernels add to counters[0]: each context starts its launch from zero, on its own stream
-                (void)hipSetDevice(ctxs[r]->device);
-                HIPCHK(c0, hipMemsetAsync(ctxs[r]->counters, 0, sizeof(unsigned long long), ctxs[r]->stream));
-            }
-            if (dangx_amp_sample(ctxs[r], group, flag, ml_mode, solver, fluct_mode, seed, stream, i_max, converge, nullptr, nullptr))
-                return bubble(ctxs[r]);
-        }
-        if (n_not_spd)   // the counters are read after every device has its launch
-            for (int r = 0; r < nctx; ++r) {
-                unsigned long long v = 0;
-                (void)hipSetDevice(ctxs[r]->device);
-                HIPCHK(c0, hipMemcpyAsync(&v, ctxs[r]->counters, sizeof(v), hipMemcpyDeviceToHost, ctxs[r]->stream));
-                HIPCHK(c0, hipStreamSynchronize(ctxs[r]->stream));
-                *n_not_spd += (int64_t)v;
-            }
-        return 0;
-    }
-    if (solver == DANGX_SOLVER_CG)
-        return fail(c0, "the device CG (DANGX_SOLVER_CG) iterates on ONE context per process: use DANGX_SOLVER_DIRECT, or one process per GPU with dangx_set_allreduce");
-    if (fluct_mode != DANGX_FLUCT_REFERENCE && ml_mode == DANGX_ML_SAMPLE)
-        return fail(c0, "groups with template / monopole / hi_fit members reproduce the reference's fluctuation term only");
-    std::vector<GroupArgs> as((size_t)nctx);
-    std::vector<long long> SNs((size_t)nctx);
-    for (int r = 0; r < nctx; ++r) {
-        dangx_ctx* c = ctxs[r];
-        (void)hipSetDevice(c->device);
-        if (make_group(c, group, flag, as[r]) || sync_model(c)) return bubble(c);
-        as[r].ml_mode = ml_mode; as[r].fluct = fluct_mode; as[r].seed = seed; as[r].stream = stream;
-        SNs[r] = (long long)flag_planes_h(flag) * c->hm.npix;
-        for (int pl = 0; pl < flag_planes_h(flag); ++pl) {
-            const int k = (flag & DANGX_FLAG_QU) ? 2 + pl : (flag & DANGX_FLAG_T) ? 1 : (flag & DANGX_FLAG_Q) ? 2 : 3;
-            c->chi_before_valid[k - 1] = c->chi_after_valid[k - 1] = c->touched_since_amp[k - 1] = false;
-            for (int g = 0; g < as[r].ng; ++g) c->plane_nz[as[r].gc[g]] |= 1u << (k - 1);
-        }
-        if (as[r].nglob != as[0].nglob || as[r].nt != as[0].nt) return fail(c0, "the contexts disagree on the group's global-amplitude members");
-    }
-    int nullity = 0;
-    if (device_schur(ctxs, nctx, as.data(), SNs.data(), n_not_spd, &nullity)) return 1;
-    if (cg_iters) *cg_iters = -nullity;
-    return 0;
-}
-
 int dangx_schur_info(dangx_ctx* ctx, double* rel_residual, int* refinements) {
     if (!ctx) return 1;
     if (rel_residual) { rel_residual[0] = ctx->schur_resid; rel_residual[1] = ctx->schur_backward; }
@@ -2029,964 +1555,6 @@ int dangx_amp_residual(dangx_ctx* ctx, int group, int flag, int ml_mode, uint64_
     out[1] = worst;
     return 0;
 }
-
-int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed,
-                       uint64_t stream, int64_t* accepted) {
-    DxRange rg_("dangx_index_sample");
-    if (!ctx || check_comp(ctx, comp)) return 1;
-    (void)hipSetDevice(ctx->device);
-    {   // this sweep makes the component's index map pixel dependent on the touched planes
-        unsigned touched = 0;
-        if (map_n == -1) touched = 6u; else if (map_n >= 1 && map_n <= 3) touched = 1u << (map_n - 1);
-        if (ctx->idx_const[comp] & touched) { ctx->idx_const[comp] &= ~touched; ctx->dirty = true; }
-        idx_written(ctx, comp);
-        if (nind >= 0 && nind < DANGX_MAX_IND) {  // a Q+U sweep writes one value to both planes (:465); a Q or U sweep to one
-            if (map_n == -1) ctx->qu_equal[comp] |= 1u << nind;
-            else if (map_n == 2 || map_n == 3) ctx->qu_equal[comp] &= ~(1u << nind);
-        }
-    }
-    if (sync_model(ctx)) return 1;
-    const dangx_comp_desc& d = ctx->desc[comp];
-    if (nind < 0 || nind >= d.nindices) return fail(ctx, "index number out of range");
-    IndexArgs a;
-    a.comp = comp; a.nind = nind; a.nsample = nsample; a.ml_mode = ml_mode; a.seed = seed; a.stream = stream;
-    if (map_n == -1) { a.s1 = 2; a.s2 = 3; }                       // src/dang_sample_mod.f90:157-163
-    else if (map_n >= 1 && map_n <= 3) { a.s1 = a.s2 = map_n; }
-    else return fail(ctx, "There is something wrong with the poltype flag (map_n must be 1,2,3 or -1)");
-    if (a.s2 > ctx->dims.nmaps) return fail(ctx, "map_n exceeds nmaps");
-    if (d.lnl_type[nind] < DANGX_LNL_CHISQ || d.lnl_type[nind] > DANGX_LNL_PRIOR) return fail(ctx, "bad lnl_type");
-    if (ml_mode != DANGX_ML_SAMPLE && ml_mode != DANGX_ML_OPTIMIZE) return fail(ctx, "bad ml_mode");
-    const int Sp = a.s2 - a.s1 + 1;
-    a.others = 0;
-    for (int l = 0; l < ctx->hm.ncomp; ++l)
-        if (l != comp && ((ctx->plane_nz[l] & ((1u << (a.s1 - 1)) | (1u << (a.s2 - 1)))) || ctx->desc[l].type == DANGX_TCMB ||
-                          is_global_type(ctx->desc[l].type)))
-            a.others |= 1u << l;
-    // chain mode: factorised SED when every band is a delta bandpass
-    const bool all_delta = ctx->hm.all_delta != 0;
-    a.mode = CH_GENERIC;
-    a.bp = all_delta ? 0 : 1;
-    if (d.type == DANGX_POWERLAW) a.mode = CH_POW;
-    else if (d.type == DANGX_MBB) a.mode = nind == 0 ? CH_MBB_BETA : CH_MBB_T;
-    else if (d.type == DANGX_LOGNORMAL && all_delta) a.mode = nind == 0 ? CH_LOGN_NUP : CH_LOGN_W;
-    // with bandpass-integrated bands (or T_cmb / template-type components present) the compile-time modes exist for the
-    // chisq likelihood with a gaussian / uniform prior only; everything else takes the run-time generic chain
-    if (a.bp && (d.lnl_type[nind] != DANGX_LNL_CHISQ || d.prior_type[nind] == DANGX_PRIOR_JEFFREYS)) a.mode = CH_GENERIC;
-    // LDS columns: (2*Sp+1)*nb doubles per thread; pick the block so that >= 2 blocks fit in 160 KiB
-    const size_t per_thread = (size_t)(2 * Sp + 1) * ctx->hm.nbands * sizeof(double);
-    const size_t tabsz = (size_t)(TROWS * ctx->hm.ncomp + 3) * ctx->hm.nbands * sizeof(double);
-    int bs = 256;
-    while (bs > 64 && tabsz + per_thread * bs > 76 * 1024) bs >>= 1;
-    const size_t lds = tabsz + per_thread * bs;
-    const bool reg_ok = !a.bp && d.lnl_type[nind] == DANGX_LNL_CHISQ && d.prior_type[nind] != DANGX_PRIOR_JEFFREYS &&
-                        a.mode != CH_GENERIC && dx_mh_reg_supported(ctx, a.mode, ctx->hm.nbands, Sp);
-    if (reg_ok) bs = BLOCK;  // register-resident form: no LDS columns
-    // lanes per pixel: of the chain's register form, or of the fused launch when a solve on these planes is waiting for this
-    // sweep and the model takes the one-launch form (decided now: the grid and the chi^2 buffers are sized by it)
-    int lanes = reg_ok ? dx_mh_reg_lanes(ctx->hm.nbands, Sp) : 1;
-    const int fused_lanes = (ctx->have_pending && reg_ok) ? dx_fused_lanes(ctx, ctx->pending, a, Sp) : 0;
-    if (fused_lanes) lanes = fused_lanes;
-    const unsigned nblk = nblocks((long long)ctx->hm.npix * lanes, bs);
-    constexpr int RSTAGE = 128;  // blocks of the first reduction stage
-    double* chi_buf = nullptr;
-    if (chi_next(ctx, nblk, &chi_buf)) return 1;
-    // the sweep kernels take their [4][nblk] chi^2 partial buffer from ctx->partial: lend them the ring's, give the
-    // context's own back on every way out of the launch section
-    struct Lend {
-        dangx_ctx* c; double* saved;
-        Lend(dangx_ctx* c_, double* b) : c(c_), saved(c_->partial) { c->partial = b; }
-        void back() { if (c) { c->partial = saved; c = nullptr; } }
-        ~Lend() { back(); }
-    } lend(ctx, chi_buf);
-    if (accepted) HIPCHK(ctx, hipMemsetAsync(ctx->counters + 1, 0, 2 * sizeof(unsigned long long), ctx->stream));
-    bool fused = false;
-    if (ctx->have_pending) {  // an amplitude solve on these planes is waiting: one launch for both, or the solve first
-        ctx->have_pending = false;
-        unsigned long long* accp = accepted ? ctx->counters + 1 : nullptr;
-        if (fused_lanes) {
-            Timed t(ctx, DANGX_K_AMP_INDEX, Sp);
-            fused = dx_launch_fused(ctx, ctx->pending, a, Sp, fused_lanes, nblk, accp);
-        }
-        if (!fused) {
-            if (fused_lanes) return fail(ctx, "the fused solve + sweep launch failed after its kernel was prepared");
-            if (dx_launch_amp(ctx, ctx->pending, ctx->pending_SN)) return 1;
-        }
-    }
-    if (!fused && ctx->pair_on) {  // dangx_index_sample_pair: this sweep and the sweep of index nind + 1 in one launch
-        ctx->pair_on = false;
-        if (reg_ok && nind + 1 < d.nindices) {
-            IndexArgs b = a;
-            b.nind = nind + 1; b.stream = ctx->pair_stream;
-            b.mode = (d.type == DANGX_MBB) ? CH_MBB_T : (d.type == DANGX_LOGNORMAL && all_delta) ? CH_LOGN_W : CH_GENERIC;
-            const bool ok_b = d.lnl_type[nind + 1] == DANGX_LNL_CHISQ && d.prior_type[nind + 1] != DANGX_PRIOR_JEFFREYS;
-            unsigned long long* accp = accepted ? ctx->counters + 1 : nullptr;  // counters[1], counters[2]
-            if (ok_b) {
-                Timed t(ctx, DANGX_K_INDEX_MH, Sp);
-                fused = ctx->pair_done = dx_launch_mh_pair(ctx, a, b, Sp, nblk, accp);
-            }
-        }
-    }
-    if (!fused) {
-        Timed t(ctx, DANGX_K_INDEX_MH, Sp);
-        unsigned long long* accp = accepted ? ctx->counters + 1 : nullptr;
-        const bool fast = d.lnl_type[nind] == DANGX_LNL_CHISQ &&
-                          (a.mode == CH_POW || a.mode == CH_MBB_BETA || a.mode == CH_MBB_T);
-        if (!(reg_ok && dx_launch_mh_reg(ctx, a, Sp, nblk, accp))) dx_launch_mh_lds(ctx, a, fast, Sp, nblk, bs, lds, accp);
-    }
-    lend.back();
-    HIPCHK(ctx, hipGetLastError());  // a failed launch must not leave a pending entry over partials nobody wrote
-    {   // fused chi^2 of the touched planes (before = state left by the amplitude phase, after = new state): the block
-        // partials wait in the ring (chi_flush) until a value is asked for
-        const bool wb = !ctx->touched_since_amp[a.s1 - 1];
-        auto& pend = ctx->chi_pend[ctx->chi_npend++];
-        pend.nblk = nblk; pend.s1 = a.s1; pend.s2 = a.s2; pend.wb = wb ? 1 : 0;
-        for (int k = a.s1; k <= a.s2; ++k) {
-            if (wb) ctx->chi_before_valid[k - 1] = true;
-            ctx->chi_after_valid[k - 1] = true;
-            ctx->touched_since_amp[k - 1] = true;
-        }
-    }
-    if (accepted) {
-        unsigned long long v = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&v, ctx->counters + 1, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        *accepted = (int64_t)v;
-    }
-    return 0;
-}
-
-// dangx_index_sample(comp, nind, ...) followed by dangx_index_sample(comp, nind + 1, ...) on the same planes: two
-// consecutive indices of ONE component (the dust beta and dust T sweeps).  Nothing the second sweep removes from the data
-// has changed in between, so where the register chain covers both (chisq likelihood, gaussian / uniform priors, delta
-// bands; mbb beta -> T, log-normal nu_p -> w) they run in one launch on one staging of the maps -- bit for bit the two
-// calls, which everything else takes.
-int dangx_index_sample_pair(dangx_ctx* ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed,
-                            uint64_t stream_first, uint64_t stream_second, int64_t* accepted_first, int64_t* accepted_second) {
-    DxRange rg_("dangx_index_sample_pair");
-    if (!ctx || check_comp(ctx, comp)) return 1;
-    static const bool enabled = [] { const char* e = getenv("DANGX_FUSE"); return !(e && e[0] == '0'); }();
-    const bool want_counts = accepted_first || accepted_second;
-    int64_t acc1 = 0;
-    ctx->pair_on = enabled; ctx->pair_done = false; ctx->pair_stream = stream_second;
-    int rc = dangx_index_sample(ctx, comp, nind, map_n, nsample, ml_mode, seed, stream_first, want_counts ? &acc1 : nullptr);
-    ctx->pair_on = false;
-    if (rc) return rc;
-    if (accepted_first) *accepted_first = acc1;
-    if (!ctx->pair_done) return dangx_index_sample(ctx, comp, nind + 1, map_n, nsample, ml_mode, seed, stream_second, accepted_second);
-    ctx->pair_done = false;
-    if (nind + 1 < DANGX_MAX_IND) {
-        if (map_n == -1) ctx->qu_equal[comp] |= 1u << (nind + 1);
-        else if (map_n == 2 || map_n == 3) ctx->qu_equal[comp] &= ~(1u << (nind + 1));
-    }
-    if (accepted_second) {
-        unsigned long long v = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&v, ctx->counters + 2, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        *accepted_second = (int64_t)v;
-    }
-    return 0;
-}
-
-// dangx_amp_sample(group, flag, ...) followed by dangx_index_sample(comp, nind, map_n, ...) -- the amplitude solve of a CG
-// group and the first index sweep on the same planes, which is how sample_cg_groups / sample_spectral_parameters follow
-// each other plane set by plane set (src/dang.f90 main loop) -- with ONE kernel launch when the model allows it
-// (dangx_fused.hip: delta bands, diffuse members only, direct solver, reference fluctuation term, chisq likelihood,
-// gaussian / uniform prior, the sampled component a member of the group whose other members are the only other
-// components on these planes).  Results are those of the two calls, bit for bit; every other configuration IS the two calls.
-int dangx_amp_index_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed_amp,
-                           uint64_t stream_amp, int i_max, double converge, int comp, int nind, int map_n, int nsample,
-                           uint64_t seed_index, uint64_t stream_index, int* cg_iters, int64_t* n_not_spd, int64_t* accepted) {
-    DxRange rg_("dangx_amp_index_sample");
-    if (!ctx || check_comp(ctx, comp)) return 1;
-    if (cg_iters) *cg_iters = 0;
-    static const bool enabled = [] { const char* e = getenv("DANGX_FUSE"); return !(e && e[0] == '0'); }();  // A/B switch
-    (void)hipSetDevice(ctx->device);
-    if (sync_model(ctx)) return 1;  // all_delta and the constant-plane flags the decision below reads are set there
-    bool can = enabled && solver == DANGX_SOLVER_DIRECT && ctx->hm.all_delta != 0 &&
-               (ml_mode == DANGX_ML_OPTIMIZE || fluct_mode == DANGX_FLUCT_REFERENCE);
-    // the planes of the sweep are the planes of the solve
-    const int want = (flag == DANGX_FLAG_T) ? 1 : (flag == DANGX_FLAG_Q) ? 2 : (flag == DANGX_FLAG_U) ? 3 : (flag == DANGX_FLAG_QU) ? -1 : 0;
-    can = can && want != 0 && want == map_n;
-    if (can) {
-        const dangx_comp_desc& d = ctx->desc[comp];
-        const unsigned touched = (map_n == -1) ? 6u : 1u << (map_n - 1);
-        // a sweep that turns a spatially constant index map into a varying one changes which SED route the SOLVE takes
-        // (host-evaluated row against per-pixel evaluation) if it is launched after the descriptor update: first sweeps
-        // on constant maps go the two-call way
-        can = nind >= 0 && nind < d.nindices && !(ctx->idx_const[comp] & touched) && d.cg_group == group && d.sample_amplitude &&
-              d.lnl_type[nind] == DANGX_LNL_CHISQ && d.prior_type[nind] != DANGX_PRIOR_JEFFREYS &&
-              (d.type == DANGX_POWERLAW || d.type == DANGX_MBB);
-    }
-    if (can) {
-        GroupArgs g;
-        if (make_group(ctx, group, flag, g)) return 1;
-        can = g.nt == 0 && g.no == 0 && g.nuc == 0 &&
-              dx_fused_supported(ctx->desc[comp].type == DANGX_POWERLAW ? CH_POW : (nind == 0 ? CH_MBB_BETA : CH_MBB_T), ctx->hm.nbands, g.ng);
-        for (int l = 0; can && l < ctx->hm.ncomp; ++l)  // a T_cmb component is an "other" of every sweep and never a diffuse member
-            if (ctx->desc[l].type == DANGX_TCMB) can = false;
-    }
-    if (!can) {
-        const int rc = dangx_amp_sample(ctx, group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, i_max, converge, cg_iters, n_not_spd);
-        return rc ? rc : dangx_index_sample(ctx, comp, nind, map_n, nsample, ml_mode, seed_index, stream_index, accepted);
-    }
-    if (n_not_spd) HIPCHK(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));
-    ctx->defer_amp = true;
-    int rc = dangx_amp_sample(ctx, group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, i_max, converge, nullptr, nullptr);
-    ctx->defer_amp = false;
-    if (rc) { ctx->have_pending = false; return rc; }
-    rc = dangx_index_sample(ctx, comp, nind, map_n, nsample, ml_mode, seed_index, stream_index, accepted);
-    if (ctx->have_pending) {  // the sweep failed before its launch site: the solve still happens, as with the two calls
-        ctx->have_pending = false;
-        if (dx_launch_amp(ctx, ctx->pending, ctx->pending_SN)) return 1;
-    }
-    if (rc) return rc;
-    if (n_not_spd) {
-        unsigned long long v = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&v, ctx->counters, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        *n_not_spd = (int64_t)v;
-    }
-    return 0;
-}
-
-// One k_plane_set launch (dx_kern_planeset.h) with its bookkeeping: solve = 1 starts with the group's amplitude solve (what
-// dangx_amp_sample records: the planes' cached chi^2 is stale, the members' amplitudes are about to be written), sl.n sweep items
-// follow (what dangx_index_sample records per sweep).  The chi^2 by-products go to the ring: with a solve "before" = the state the
-// solve leaves and "after" = the last sweep's (both the same value without sweeps); without, as for any sweep.
-static int planeset_launch(dangx_ctx* ctx, const GroupArgs& g, const SweepList& sl, int lanes, int solve, int64_t* n_not_spd, int64_t* accepted) {
-    const bool qu = sl.s2 > sl.s1;
-    bool wb = true;
-    if (solve) {
-        for (int k = sl.s1; k <= sl.s2; ++k) {
-            ctx->chi_before_valid[k - 1] = ctx->chi_after_valid[k - 1] = ctx->touched_since_amp[k - 1] = false;
-            for (int q = 0; q < g.ng; ++q) ctx->plane_nz[g.gc[q]] |= 1u << (k - 1);
-        }
-    } else {
-        wb = !ctx->touched_since_amp[sl.s1 - 1];
-    }
-    for (int q = 0; q < sl.n; ++q)
-        for (int e = 0; e <= sl.s[q].pair; ++e) {
-            idx_written(ctx, sl.s[q].comp);
-            if (qu) ctx->qu_equal[sl.s[q].comp] |= 1u << (sl.s[q].nind + e);
-            else if (sl.s1 == 2 || sl.s1 == 3) ctx->qu_equal[sl.s[q].comp] &= ~(1u << (sl.s[q].nind + e));
-        }
-    const unsigned nblk = nblocks((long long)ctx->hm.npix * lanes, BLOCK);
-    double* chi_buf = nullptr;
-    if (chi_next(ctx, nblk, &chi_buf)) return 1;
-    HIPCHK(ctx, hipMemsetAsync(ctx->counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
-    {
-        double* saved = ctx->partial;
-        ctx->partial = chi_buf;
-        bool ok;
-        {
-            Timed t(ctx, !solve ? DANGX_K_INDEX_MH : sl.n ? DANGX_K_AMP_INDEX : DANGX_K_AMP_DIRECT, sl.s2 - sl.s1 + 1);
-            ok = dx_launch_planeset(ctx, g, sl, lanes, solve, nblk, accepted ? ctx->counters + 4 : nullptr);
-        }
-        ctx->partial = saved;
-        if (!ok) return fail(ctx, "the plane-set launch failed after its kernel was prepared");
-    }
-    HIPCHK(ctx, hipGetLastError());
-    {
-        auto& pend = ctx->chi_pend[ctx->chi_npend++];
-        pend.nblk = nblk; pend.s1 = sl.s1; pend.s2 = sl.s2; pend.wb = wb ? 1 : 0;
-        pend.ns = 0;
-        for (int q = 0; q < sl.n; ++q)   // the masked sums of the swept index maps ride along (rows 4 ..), in the items' order
-            for (int e = 0; e <= sl.s[q].pair; ++e) {
-                pend.slot[pend.ns++] = idx_slot(sl.s[q].comp, sl.s[q].nind + e, sl.s1);
-                for (int k = sl.s1; k <= sl.s2; ++k) ctx->idxsum_dev[sl.s[q].comp][sl.s[q].nind + e][k - 1] = !ctx->idx_ext[sl.s[q].comp];
-            }
-        for (int k = sl.s1; k <= sl.s2; ++k) {
-            if (wb) ctx->chi_before_valid[k - 1] = true;
-            ctx->chi_after_valid[k - 1] = true;
-            ctx->touched_since_amp[k - 1] = sl.n > 0 || (!solve && ctx->touched_since_amp[k - 1]);
-        }
-    }
-    if (n_not_spd || accepted) {
-        unsigned long long v[16];
-        HIPCHK(ctx, hipMemcpyAsync(v, ctx->counters, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        if (n_not_spd) *n_not_spd = (int64_t)v[0];
-        if (accepted) {   // the kernel counts per item (1 + pair entries each); the items follow the list's order
-            int slot = 4, s = 0;
-            for (int q = 0; q < sl.n; ++q)
-                for (int e = 0; e <= sl.s[q].pair; ++e) accepted[s++] = (int64_t)v[slot++];
-        }
-    }
-    return 0;
-}
-
-// the sweeps (comp[s], nind[s]), s = 0 .. nsweeps-1, as the items of a plane-set launch over group g's members: consecutive
-// indices of a component travel in one item.  false: some sweep has no register-chain form, or the list is too long
-static bool planeset_items(dangx_ctx* ctx, const GroupArgs& g, int map_n, int nsweeps, const int32_t* comp, const int32_t* nind,
-                           const uint64_t* stream, SweepList& sl) {
-    const unsigned touched = (map_n == -1) ? 6u : 1u << (map_n - 1);
-    std::memset(&sl, 0, sizeof(sl));
-    for (int s = 0; s < nsweeps; ++s) {
-        const dangx_comp_desc& d = ctx->desc[comp[s]];
-        int gm = -1;
-        for (int q = 0; q < g.ng; ++q) if (g.gc[q] == comp[s]) gm = q;
-        if (!(gm >= 0 && !(ctx->idx_const[comp[s]] & touched) && d.lnl_type[nind[s]] == DANGX_LNL_CHISQ &&
-              d.prior_type[nind[s]] != DANGX_PRIOR_JEFFREYS && (d.type == DANGX_POWERLAW || d.type == DANGX_MBB || d.type == DANGX_LOGNORMAL)))
-            return false;
-        const int mode = (d.type == DANGX_POWERLAW) ? CH_POW : (d.type == DANGX_MBB) ? (nind[s] == 0 ? CH_MBB_BETA : CH_MBB_T) : (nind[s] == 0 ? CH_LOGN_NUP : CH_LOGN_W);
-        if (sl.n > 0 && sl.s[sl.n - 1].comp == comp[s] && !sl.s[sl.n - 1].pair && sl.s[sl.n - 1].nind + 1 == nind[s] &&
-            (sl.s[sl.n - 1].mode == CH_MBB_BETA || sl.s[sl.n - 1].mode == CH_LOGN_NUP)) {
-            sl.s[sl.n - 1].pair = 1; sl.s[sl.n - 1].stream2 = stream[s];   // index nind + 1 of the same component: one item
-            continue;
-        }
-        for (int q = 0; q < sl.n; ++q) if (sl.s[q].comp == comp[s]) return false;  // a component's sweeps must be consecutive
-        if (sl.n == DX_MAX_SWEEPS) return false;
-        SweepItem& it = sl.s[sl.n++];
-        it.comp = comp[s]; it.nind = nind[s]; it.mode = mode; it.pair = 0; it.gmember = gm; it.stream = stream[s]; it.stream2 = 0;
-    }
-    sl.s1 = (map_n == -1) ? 2 : map_n; sl.s2 = (map_n == -1) ? 3 : map_n;
-    return true;
-}
-
-// a group whose members are the only components with a signal on the planes of the flag: what every plane-set launch needs
-static bool planeset_group(dangx_ctx* ctx, const GroupArgs& g) {
-    if (!(g.nt == 0 && g.no == 0 && g.nuc == 0)) return false;
-    for (int l = 0; l < ctx->hm.ncomp; ++l)
-        if (ctx->desc[l].type == DANGX_TCMB || is_global_type(ctx->desc[l].type)) return false;
-    return true;
-}
-
-// dangx_amp_sample(group, flag, ...) followed by dangx_index_sample(comp[s], nind[s], map_n of the flag, ...) for s = 0 ..
-// nsweeps-1 -- everything one iteration of the main loop does on ONE plane set of a CG group: the solve of sample_cg_groups
-// (src/dang_cg_mod.f90:166-171) and the passes of sample_spectral_parameters that touch these planes (src/dang_sample_mod.f90:
-// 40-75), in the reference's order.  Where k_plane_set covers the model (dx_kern_planeset.h: many bands and members, every swept
-// component a member of the group) all of it is ONE launch with the members' SED columns kept in LDS; everything else IS those
-// calls (through dangx_amp_index_sample / dangx_index_sample_pair where they apply).
-int dangx_plane_set_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed_amp, uint64_t stream_amp,
-                           int i_max, double converge, int nsweeps, const int32_t* comp, const int32_t* nind, const uint64_t* stream,
-                           int nsample, uint64_t seed_index, int* cg_iters, int64_t* n_not_spd, int64_t* accepted) {
-    DxRange rg_("dangx_plane_set_sample");
-    if (!ctx || nsweeps < 1 || !comp || !nind || !stream) return 1;
-    (void)hipSetDevice(ctx->device);
-    if (sync_model(ctx)) return 1;
-    const int map_n = (flag == DANGX_FLAG_T) ? 1 : (flag == DANGX_FLAG_Q) ? 2 : (flag == DANGX_FLAG_U) ? 3 : (flag == DANGX_FLAG_QU) ? -1 : 0;
-    if (map_n == 0) return fail(ctx, "flag must be exactly one of T(1), Q(2), U(4), Q+U(8)");
-    for (int s = 0; s < nsweeps; ++s)
-        if (check_comp(ctx, comp[s]) || nind[s] < 0 || nind[s] >= ctx->desc[comp[s]].nindices) return fail(ctx, "sweep list: component / index out of range");
-    if (cg_iters) *cg_iters = 0;
-    if (n_not_spd) *n_not_spd = 0;
-    static const bool enabled = [] { const char* e = getenv("DANGX_FUSE"); return !(e && e[0] == '0'); }();
-    // ---- does the one-launch form cover this?  (the conditions of dangx_amp_index_sample, for every sweep of the list)
-    bool can = enabled && nsweeps <= 2 * DX_MAX_SWEEPS && solver == DANGX_SOLVER_DIRECT &&
-               (ml_mode == DANGX_ML_OPTIMIZE || fluct_mode == DANGX_FLUCT_REFERENCE) &&
-               (ml_mode == DANGX_ML_SAMPLE || ml_mode == DANGX_ML_OPTIMIZE);
-    GroupArgs g;
-    SweepList sl;
-    std::memset(&sl, 0, sizeof(sl));
-    if (can) {
-        if (make_group(ctx, group, flag, g)) return 1;
-        can = planeset_group(ctx, g) && planeset_items(ctx, g, map_n, nsweeps, comp, nind, stream, sl);
-    }
-    int lanes = 0;
-    if (can) {
-        sl.nsample = nsample; sl.ml_mode = ml_mode; sl.seed = seed_index;
-        g.ml_mode = ml_mode; g.fluct = fluct_mode; g.seed = seed_amp; g.stream = stream_amp;
-        lanes = dx_planeset_lanes(ctx, g, sl, 1);
-    }
-    if (!lanes) {  // the calls this entry point stands for, through the two-step fusions where they apply
-        int s = 0;
-        int64_t acc = 0, acc2 = 0;
-        int rc = dangx_amp_index_sample(ctx, group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, i_max, converge, comp[0], nind[0],
-                                        map_n, nsample, seed_index, stream[0], cg_iters, n_not_spd, accepted ? &acc : nullptr);
-        if (rc) return rc;
-        if (accepted) accepted[0] = acc;
-        for (s = 1; s < nsweeps; ++s) {
-            if (s + 1 < nsweeps && comp[s + 1] == comp[s] && nind[s + 1] == nind[s] + 1) {
-                rc = dangx_index_sample_pair(ctx, comp[s], nind[s], map_n, nsample, ml_mode, seed_index, stream[s], stream[s + 1],
-                                             accepted ? &acc : nullptr, accepted ? &acc2 : nullptr);
-                if (rc) return rc;
-                if (accepted) { accepted[s] = acc; accepted[s + 1] = acc2; }
-                ++s;
-            } else {
-                rc = dangx_index_sample(ctx, comp[s], nind[s], map_n, nsample, ml_mode, seed_index, stream[s], accepted ? &acc : nullptr);
-                if (rc) return rc;
-                if (accepted) accepted[s] = acc;
-            }
-        }
-        return 0;
-    }
-    return planeset_launch(ctx, g, sl, lanes, 1, n_not_spd, accepted);
-}
-
-// dangx_index_sample(comp[s], nind[s], map_n of the flag, ...) for s = 0 .. nsweeps-1: the passes of sample_spectral_parameters
-// (src/dang_sample_mod.f90:40-75) that touch ONE plane set, in the reference's order -- what the two-call seam issues after
-// sample_cg_groups has returned.  Where k_plane_set covers the model (every swept component an amplitude-sampled member of ONE CG
-// group whose members are the only components on these planes, register-chain modes) the sweeps are one launch on the amplitudes
-// in memory (SOLVE = 0: one staging of the maps, the residual kept between the sweeps); everything else IS those calls, with
-// consecutive indices of a component through dangx_index_sample_pair.
-int dangx_plane_sweeps_sample(dangx_ctx* ctx, int flag, int nsweeps, const int32_t* comp, const int32_t* nind, const uint64_t* stream,
-                              int nsample, int ml_mode, uint64_t seed, int64_t* accepted) {
-    DxRange rg_("dangx_plane_sweeps_sample");
-    if (!ctx || nsweeps < 1 || !comp || !nind || !stream) return 1;
-    (void)hipSetDevice(ctx->device);
-    if (sync_model(ctx)) return 1;
-    const int map_n = (flag == DANGX_FLAG_T) ? 1 : (flag == DANGX_FLAG_Q) ? 2 : (flag == DANGX_FLAG_U) ? 3 : (flag == DANGX_FLAG_QU) ? -1 : 0;
-    if (map_n == 0) return fail(ctx, "flag must be exactly one of T(1), Q(2), U(4), Q+U(8)");
-    for (int s = 0; s < nsweeps; ++s)
-        if (check_comp(ctx, comp[s]) || nind[s] < 0 || nind[s] >= ctx->desc[comp[s]].nindices) return fail(ctx, "sweep list: component / index out of range");
-    static const bool enabled = [] { const char* e = getenv("DANGX_FUSE"); return !(e && e[0] == '0'); }();
-    bool can = enabled && nsweeps <= 2 * DX_MAX_SWEEPS && (ml_mode == DANGX_ML_SAMPLE || ml_mode == DANGX_ML_OPTIMIZE);
-    const int group = ctx->desc[comp[0]].cg_group;
-    for (int s = 0; can && s < nsweeps; ++s) can = ctx->desc[comp[s]].cg_group == group && ctx->desc[comp[s]].sample_amplitude;
-    GroupArgs g;
-    SweepList sl;
-    int lanes = 0;
-    if (can) {
-        if (make_group(ctx, group, flag, g)) return 1;
-        if (planeset_group(ctx, g) && planeset_items(ctx, g, map_n, nsweeps, comp, nind, stream, sl)) {
-            sl.nsample = nsample; sl.ml_mode = ml_mode; sl.seed = seed;
-            g.ml_mode = ml_mode; g.fluct = DANGX_FLUCT_REFERENCE; g.seed = 0; g.stream = 0;
-            lanes = dx_planeset_lanes(ctx, g, sl, 0);
-        }
-    }
-    if (lanes) return planeset_launch(ctx, g, sl, lanes, 0, nullptr, accepted);
-    int64_t acc = 0, acc2 = 0;
-    for (int s = 0; s < nsweeps; ++s) {
-        if (s + 1 < nsweeps && comp[s + 1] == comp[s] && nind[s + 1] == nind[s] + 1) {
-            const int rc = dangx_index_sample_pair(ctx, comp[s], nind[s], map_n, nsample, ml_mode, seed, stream[s], stream[s + 1],
-                                                   accepted ? &acc : nullptr, accepted ? &acc2 : nullptr);
-            if (rc) return rc;
-            if (accepted) { accepted[s] = acc; accepted[s + 1] = acc2; }
-            ++s;
-        } else {
-            const int rc = dangx_index_sample(ctx, comp[s], nind[s], map_n, nsample, ml_mode, seed, stream[s], accepted ? &acc : nullptr);
-            if (rc) return rc;
-            if (accepted) accepted[s] = acc;
-        }
-    }
-    return 0;
-}
-
-// chi^2 of planes pol_lo..pol_hi from the values fused into the index sweeps: which = 0 -> the state the
-// amplitude phase left (captured by the first sweep on each plane), 1 -> the current state.  Fails (status 2)
-// if some plane has not been covered by a sweep since its last amplitude update: use dangx_sky_model_chisq.
-int dangx_chisq_cached_dev(dangx_ctx* ctx, int which, int pol_lo, int pol_hi, double* out_dev) {
-    if (!ctx || !out_dev || (which != 0 && which != 1)) return 1;
-    (void)hipSetDevice(ctx->device);
-    if (pol_lo < 1 || pol_hi > ctx->dims.nmaps || pol_lo > pol_hi) return fail(ctx, "bad pol_type range");
-    for (int k = pol_lo; k <= pol_hi; ++k)
-        if (!(which ? ctx->chi_after_valid[k - 1] : ctx->chi_before_valid[k - 1])) {
-            ctx->err = "cached chi^2 not available for plane " + std::to_string(k);
-            return 2;
-        }
-    if (chi_flush(ctx)) return 1;
-    hipLaunchKernelGGL(k_chi_from_cache, dim3(1), dim3(1), 0, ctx->stream, ctx->chi_cache, which, pol_lo, pol_hi, out_dev);
-    HIPCHK(ctx, hipGetLastError());
-    return 0;
-}
-
-int dangx_chisq_cached(dangx_ctx* ctx, int which, int pol_lo, int pol_hi, double* chisq_sum) {
-    if (!ctx || !chisq_sum) return 1;
-    const int rc = dangx_chisq_cached_dev(ctx, which, pol_lo, pol_hi, ctx->scalars + 1);
-    if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(chisq_sum, ctx->scalars + 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
-}
-
-static int sky_chisq_launch(dangx_ctx* ctx, int pol_lo, int pol_hi, double* sky_d, double* res_d, double* chi_d, double* out_dev);
-
-// ddata%chisq's sum for the CURRENT state at the least cost: planes whose sum the last sweeps left behind come from the cache,
-// every other plane gets one explicit update_sky_model + compute_chisq pass over THAT plane, whose result is cached too (the
-// two-call form of the main loop asks after every CG group: only the group's own planes have changed since the last answer)
-int dangx_chisq_current(dangx_ctx* ctx, int pol_lo, int pol_hi, double* chisq_sum) {
-    DxRange rg_("dangx_chisq_current");
-    if (!ctx || !chisq_sum) return 1;
-    (void)hipSetDevice(ctx->device);
-    if (pol_lo < 1 || pol_hi > ctx->dims.nmaps || pol_lo > pol_hi) return fail(ctx, "bad pol_type range");
-    if (sync_model(ctx) || chi_flush(ctx)) return 1;
-    for (int k = pol_lo; k <= pol_hi; ++k)
-        if (!ctx->chi_after_valid[k - 1]) {
-            if (sky_chisq_launch(ctx, k, k, nullptr, nullptr, nullptr, ctx->chi_cache + 3 + (k - 1))) return 1;
-            ctx->chi_after_valid[k - 1] = true;
-        }
-    double v[3] = {0.0, 0.0, 0.0};
-    HIPCHK(ctx, hipMemcpyAsync(v, ctx->chi_cache + 3, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    double s = 0.0;
-    for (int k = pol_lo; k <= pol_hi; ++k) s += v[k - 1];
-    *chisq_sum = s;
-    return 0;
-}
-
-static int sky_chisq_launch(dangx_ctx* ctx, int pol_lo, int pol_hi, double* sky_d, double* res_d, double* chi_d, double* out_dev) {
-    if (pol_lo < 1 || pol_hi > ctx->dims.nmaps || pol_lo > pol_hi) return fail(ctx, "bad pol_type range");
-    int bs = 256;
-    while (bs > 64 && (size_t)ctx->hm.nbands * bs * sizeof(double) > 32 * 1024) bs >>= 1;
-    const unsigned nblk = nblocks(ctx->hm.npix, bs);
-    constexpr int RSTAGE = 128;
-    // delta bandpasses, diffuse components, no maps asked for: one launch per plane on the amplitude kernel's schedule
-    // (k_chisq_reg, dangx_ampreg.hip), the planes' block partials side by side and summed together
-    if (!sky_d && !res_d && !chi_d && ctx->hm.all_delta) {
-        const unsigned nb256 = nblocks(ctx->hm.npix);
-        const int npl = pol_hi - pol_lo + 1;
-        if (ensure_partial(ctx, (long long)npl * nb256 + RSTAGE)) return 1;
-        bool all = true;
-        {
-            Timed t(ctx, DANGX_K_SKY_CHISQ);
-            for (int k = pol_lo; k <= pol_hi && all; ++k) all = dx_launch_chisq_reg(ctx, k, ctx->partial + (long long)(k - pol_lo) * nb256) == 0;
-        }
-        if (all) {
-            Timed t(ctx, DANGX_K_REDUCE);
-            double* stage = ctx->partial + (long long)npl * nb256;
-            hipLaunchKernelGGL(k_reduce_rows, dim3(RSTAGE), dim3(BLOCK), 0, ctx->stream, ctx->partial, (long long)npl * nb256, 1, stage);
-            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(BLOCK), 0, ctx->stream, stage, (long long)RSTAGE, out_dev);
-            HIPCHK(ctx, hipGetLastError());
-            return 0;
-        }
-    }
-    if (ensure_partial(ctx, (long long)nblk + RSTAGE)) return 1;
-    {
-        Timed t(ctx, DANGX_K_SKY_CHISQ);
-        hipLaunchKernelGGL(k_sky_chisq, dim3(nblk), dim3(bs), (size_t)ctx->hm.nbands * bs * sizeof(double), ctx->stream,
-                           ctx->dm, pol_lo, pol_hi, sky_d, res_d, chi_d, ctx->partial);
-    }
-    {
-        Timed t(ctx, DANGX_K_REDUCE);
-        double* stage = ctx->partial + nblk;
-        hipLaunchKernelGGL(k_reduce_rows, dim3(RSTAGE), dim3(BLOCK), 0, ctx->stream, ctx->partial, (long long)nblk, 1, stage);
-        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(BLOCK), 0, ctx->stream, stage, (long long)RSTAGE, out_dev);
-    }
-    HIPCHK(ctx, hipGetLastError());
-    return 0;
-}
-
-int dangx_sky_model_chisq_dev(dangx_ctx* ctx, int pol_lo, int pol_hi, double* chisq_sum_dev) {
-    if (!ctx || !chisq_sum_dev) return 1;
-    (void)hipSetDevice(ctx->device);
-    if (sync_model(ctx)) return 1;
-    return sky_chisq_launch(ctx, pol_lo, pol_hi, nullptr, nullptr, nullptr, chisq_sum_dev);
-}
-
-int dangx_sky_model_chisq(dangx_ctx* ctx, int pol_lo, int pol_hi, double* chisq_sum, double* sky, double* res, double* chi_map) {
-    DxRange rg_("dangx_sky_model_chisq");
-    if (!ctx) return 1;
-    (void)hipSetDevice(ctx->device);
-    if (sync_model(ctx)) return 1;
-    const size_t nmap = (size_t)ctx->dims.npix * ctx->dims.nmaps * sizeof(double);
-    const size_t nall = nmap * ctx->dims.nbands;
-    double *sky_d = nullptr, *res_d = nullptr, *chi_d = nullptr;
-    int rc = 0;
-    if (sky) HIPCHK(ctx, hipMalloc(&sky_d, nall));
-    if (res) HIPCHK(ctx, hipMalloc(&res_d, nall));
-    if (chi_map) { HIPCHK(ctx, hipMalloc(&chi_d, nmap)); HIPCHK(ctx, hipMemsetAsync(chi_d, 0, nmap, ctx->stream)); }
-    rc = sky_chisq_launch(ctx, pol_lo, pol_hi, sky_d, res_d, chi_d, ctx->scalars);
-    if (!rc) {
-        double v = 0.0;
-        const size_t nplanes = (size_t)ctx->dims.nmaps * ctx->dims.nbands;
-        if (hipMemcpyAsync(&v, ctx->scalars, sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = 1;
-        if (sky && copy_planes(ctx, sky, sky_d, nplanes, false)) rc = 1;
-        if (res && copy_planes(ctx, res, res_d, nplanes, false)) rc = 1;
-        if (chi_map && copy_planes(ctx, chi_map, chi_d, (size_t)ctx->dims.nmaps, false)) rc = 1;
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = 1;
-        if (rc) ctx->err = "copy-back failed in dangx_sky_model_chisq";
-        if (chisq_sum) *chisq_sum = v;
-    }
-    if (sky_d) (void)hipFree(sky_d);
-    if (res_d) (void)hipFree(res_d);
-    if (chi_d) (void)hipFree(chi_d);
-    return rc;
-}
-
-
-// ---- full-sky index mode / tuner / gain fit primitives ---------------------------------------------
-
-static int map_planes(dangx_ctx* ctx, int map_n, int& s1, int& s2) {
-    if (map_n == -1) { s1 = 2; s2 = 3; }
-    else if (map_n >= 1 && map_n <= 3) { s1 = s2 = map_n; }
-    else return fail(ctx, "There is something wrong with the poltype flag (map_n must be 1,2,3 or -1)");
-    if (s2 > ctx->dims.nmaps) return fail(ctx, "map_n exceeds nmaps");
-    return 0;
-}
-
-int dangx_fullsky_prepare(dangx_ctx* ctx, int comp, int map_n) {
-    if (!ctx || check_comp(ctx, comp)) return 1;
-    (void)hipSetDevice(ctx->device);
-    int s1, s2;
-    if (map_planes(ctx, map_n, s1, s2) || sync_model(ctx)) return 1;
-    const long long need = (long long)(s2 - s1 + 1) * ctx->hm.nbands * ctx->hm.npix;
-    if (need > ctx->fs_cap) {
-        if (ctx->fs_data) (void)hipFree(ctx->fs_data);
-        ctx->fs_data = nullptr;
-        HIPCHK(ctx, hipMalloc(&ctx->fs_data, sizeof(double) * (size_t)need));
-        ctx->fs_cap = need;
-    }
-    unsigned others = 0;
-    for (int l = 0; l < ctx->hm.ncomp; ++l)
-        if (l != comp && ((ctx->plane_nz[l] & ((1u << (s1 - 1)) | (1u << (s2 - 1)))) || ctx->desc[l].type == DANGX_TCMB || is_global_type(ctx->desc[l].type))) others |= 1u << l;
-    hipLaunchKernelGGL(k_fullsky_prepare, dim3(nblocks(ctx->hm.npix)), dim3(BLOCK), 0, ctx->stream, ctx->dm, comp, s1, s2, others, ctx->fs_data);
-    HIPCHK(ctx, hipGetLastError());
-    ctx->fs_comp = comp; ctx->fs_s1 = s1; ctx->fs_s2 = s2; ctx->fs_npc = 0;
-    return 0;
-}
-
-// what = 0 chisq lnL (1 value), 1 marginal (2*nb*Sp values: TNd(j,k), TNT(j,k) interleaved, j outer / k inner),
-// 2 jeffreys sum (1 value).  Local (this shard's) sums; the caller all-reduces and combines.
-int dangx_fullsky_sums(dangx_ctx* ctx, int what, const double* theta, double* out, int nout) {
-    if (!ctx || !theta || !out) return 1;
-    (void)hipSetDevice(ctx->device);
-    if (ctx->fs_comp < 0) return fail(ctx, "dangx_fullsky_prepare has not been called");
-    if (what < 0 || what > 2) return fail(ctx, "bad sum selector");
-    if (sync_model(ctx)) return 1;
-    const int Sp = ctx->fs_s2 - ctx->fs_s1 + 1;
-    const int rows = (what == 1) ? 2 * ctx->hm.nbands * Sp : 1;
-    if (nout < rows) return fail(ctx, "output buffer too small");
-    const bool coarse = ctx->fs_npc > 0;
-    const unsigned nblk = nblocks(coarse ? ctx->fs_npc : ctx->hm.npix);
-    if (ensure_partial(ctx, (long long)rows * nblk)) return 1;
-    hipLaunchKernelGGL(k_fullsky_rows, dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->dm, ctx->fs_comp, ctx->fs_s1, ctx->fs_s2, what,
-                       theta[0], theta[1], coarse ? ctx->cs_data : ctx->fs_data, coarse ? ctx->cs_rms : (const double*)nullptr,
-                       coarse ? ctx->cs_mask : (const double*)nullptr, coarse ? ctx->fs_npc : 0ll, ctx->partial);
-    hipLaunchKernelGGL(k_reduce_rows_final, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->partial, (long long)nblk, rows, ctx->rows_out);
-    HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(out, ctx->rows_out, sizeof(double) * rows, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
-}
-
-
-// ---- HEALPix index maps on the host (published algorithm; see k_udgrade) ------------------------------------------
-// nest2ring: face f = ipnest / nside^2, (ix, iy) = the even / odd bits of the in-face index, ring jr counted from the
-// north pole, position jp in the ring.
-static void hp_nest2ring_table(int nside, std::vector<int>& n2r) {
-    static const int jrll[12] = {2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4}, jpll[12] = {1, 3, 5, 7, 0, 2, 4, 6, 1, 3, 5, 7};
-    const long long ns2 = (long long)nside * nside, npix = 12 * ns2, ncap = 2LL * nside * (nside - 1);
-    n2r.resize((size_t)npix);
-    for (long long ip = 0; ip < npix; ++ip) {
-        const int face = (int)(ip / ns2);
-        const long long ipf = ip % ns2;
-        int ix = 0, iy = 0;
-        for (int b = 0; b < 16; ++b) { ix |= (int)((ipf >> (2 * b)) & 1) << b; iy |= (int)((ipf >> (2 * b + 1)) & 1) << b; }
-        const long long jr = (long long)jrll[face] * nside - ix - iy - 1;
-        long long nr, n_before;
-        int kshift;
-        if (jr < nside) { nr = jr; n_before = 2 * nr * (nr - 1); kshift = 0; }
-        else if (jr > 3LL * nside) { nr = 4LL * nside - jr; n_before = npix - 2 * (nr + 1) * nr; kshift = 0; }
-        else { nr = nside; n_before = ncap + (jr - nside) * 4LL * nside; kshift = (int)((jr - nside) & 1); }
-        long long jp = ((long long)jpll[face] * nr + ix - iy + 1 + kshift) / 2;
-        if (jp > 4 * nr) jp -= 4 * nr;
-        if (jp < 1) jp += 4 * nr;
-        n2r[(size_t)ip] = (int)(n_before + jp - 1);
-    }
-}
-
-static bool hp_valid_nside(int n) { return n >= 1 && n <= 8192 && (n & (n - 1)) == 0; }
-
-static int hp_upload(dangx_ctx* ctx, int nside, int** n2r_dev, int** r2n_dev) {
-    std::vector<int> n2r, r2n;
-    hp_nest2ring_table(nside, n2r);
-    r2n.resize(n2r.size());
-    for (size_t p = 0; p < n2r.size(); ++p) r2n[(size_t)n2r[p]] = (int)p;
-    if (*n2r_dev) { (void)hipFree(*n2r_dev); (void)hipFree(*r2n_dev); *n2r_dev = *r2n_dev = nullptr; }
-    HIPCHK(ctx, hipMalloc(n2r_dev, n2r.size() * sizeof(int)));
-    HIPCHK(ctx, hipMalloc(r2n_dev, n2r.size() * sizeof(int)));
-    HIPCHK(ctx, hipMemcpy(*n2r_dev, n2r.data(), n2r.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(*r2n_dev, r2n.data(), n2r.size() * sizeof(int), hipMemcpyHostToDevice));
-    return 0;
-}
-
-// RING<->NEST maps of the two resolutions, cached in the context
-static int hp_tables(dangx_ctx* ctx, int nside_f, int nside_c) {
-    if (!hp_valid_nside(nside_f) || !hp_valid_nside(nside_c)) return fail(ctx, "nside must be a power of two in 1..8192");
-    if (ctx->hp_nside != nside_f) { if (hp_upload(ctx, nside_f, &ctx->hp_n2r_f, &ctx->hp_r2n_f)) return 1; ctx->hp_nside = nside_f; }
-    if (ctx->hp_cnside != nside_c) { if (hp_upload(ctx, nside_c, &ctx->hp_n2r_c, &ctx->hp_r2n_c)) return 1; ctx->hp_cnside = nside_c; }
-    return 0;
-}
-
-int dangx_udgrade(dangx_ctx* ctx, int mode, const double* map_in, int nside_in, double* map_out, int nside_out) {
-    if (!ctx || !map_in || !map_out) return 1;
-    (void)hipSetDevice(ctx->device);
-    if (mode < 0 || mode > 2) return fail(ctx, "udgrade mode must be 0 (ring), 1 (rms) or 2 (mask)");
-    if (nside_in == nside_out) return fail(ctx, "udgrade: nside_in == nside_out (the reference copies the maps, src/dang_sample_mod.f90:204-207)");
-    const bool degrade = nside_in > nside_out;
-    if (hp_tables(ctx, degrade ? nside_in : nside_out, degrade ? nside_out : nside_in)) return 1;
-    const long long npi = 12LL * nside_in * nside_in, npo = 12LL * nside_out * nside_out;
-    const int r1 = degrade ? nside_in / nside_out : nside_out / nside_in;
-    double *din = nullptr, *dout = nullptr;
-    HIPCHK(ctx, hipMalloc(&din, sizeof(double) * npi));
-    HIPCHK(ctx, hipMalloc(&dout, sizeof(double) * npo));
-    HIPCHK(ctx, hipMemcpyAsync(din, map_in, sizeof(double) * npi, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_udgrade, dim3(nblocks(npo), 1), dim3(BLOCK), 0, ctx->stream, din, dout,
-                       degrade ? ctx->hp_n2r_f : ctx->hp_n2r_c, degrade ? ctx->hp_r2n_c : ctx->hp_r2n_f, npi, npo, r1 * r1,
-                       degrade ? 1 : 0, mode, (double)nside_out * 1.0 / nside_in, 0, 1, 1, 1);
-    HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(map_out, dout, sizeof(double) * npo, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(din); (void)hipFree(dout);
-    return 0;
-}
-
-// data_raw minus every other component at full resolution (:173-196, the full-sky mode's staging kernel), degraded with
-// udgrade_ring; the rms with udgrade_rms, the mask with udgrade_mask (:199-217) -> cs_data / cs_rms / cs_mask
-static int coarse_stage(dangx_ctx* ctx, int comp, int map_n, int nside, int sample_nside) {
-    const long long npix = ctx->dims.npix;
-    if (hp_tables(ctx, nside, sample_nside)) return 1;
-    if (dangx_fullsky_prepare(ctx, comp, map_n)) return 1;
-    const int s1 = ctx->fs_s1, s2 = ctx->fs_s2, Sp = s2 - s1 + 1, nb = ctx->hm.nbands;
-    ctx->fs_comp = -1;  // the staging buffer is ours now
-    const long long npc = 12LL * sample_nside * sample_nside;
-    const int r1 = nside / sample_nside, ratio = r1 * r1;
-    const long long need = (long long)Sp * nb * npc;
-    if (need > ctx->cs_cap) {
-        for (double** b : {&ctx->cs_data, &ctx->cs_rms, &ctx->cs_mask, &ctx->cs_index}) { if (*b) (void)hipFree(*b); *b = nullptr; }
-        HIPCHK(ctx, hipMalloc(&ctx->cs_data, sizeof(double) * need));
-        HIPCHK(ctx, hipMalloc(&ctx->cs_rms, sizeof(double) * need));
-        HIPCHK(ctx, hipMalloc(&ctx->cs_mask, sizeof(double) * npc));
-        HIPCHK(ctx, hipMalloc(&ctx->cs_index, sizeof(double) * npc));
-        ctx->cs_cap = need;
-    }
-    const dim3 gq(nblocks(npc), Sp * nb), g1(nblocks(npc), 1);
-    const double scale = (double)sample_nside * 1.0 / nside;
-    hipLaunchKernelGGL(k_udgrade, gq, dim3(BLOCK), 0, ctx->stream, ctx->fs_data, ctx->cs_data, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
-                       ratio, 1, 0, scale, 0, nb, ctx->hm.nmaps, s1);
-    hipLaunchKernelGGL(k_udgrade, gq, dim3(BLOCK), 0, ctx->stream, ctx->rms, ctx->cs_rms, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
-                       ratio, 1, 1, scale, 1, nb, ctx->hm.nmaps, s1);
-    hipLaunchKernelGGL(k_udgrade, g1, dim3(BLOCK), 0, ctx->stream, ctx->mask, ctx->cs_mask, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
-                       ratio, 1, 2, scale, 0, nb, ctx->hm.nmaps, s1);
-    HIPCHK(ctx, hipGetLastError());
-    return 0;
-}
-
-// ---- coarse-Nside sampling on a PIXEL SHARD, in three phases with a sum over the shards between them (the children of
-// a coarse pixel are scattered over the RING ranges).  A: every shard degrades what it holds -- per coarse pixel and
-// plane the sum of its own good children and their number (data, rms^2, mask); B: with the sums of all shards the coarse
-// data / rms / mask are finished, and each shard runs the chains of the coarse pixels i whose full-resolution pixel i
-// it holds (the reference reads masks(i), indices(i), amplitude(i) there), leaving 0 elsewhere; C: with the summed
-// coarse index map every shard writes its own pixels.  dangx_index_sample_coarse runs A, B, C through the
-// dangx_set_allreduce callback; a single-process driver with several contexts calls them itself and adds the buffers.
-static long long coarse_partials_len(const dangx_ctx* ctx, int Sp, long long npc) { return 2 * (2ll * Sp * ctx->hm.nbands + 1) * npc; }
-
-static int coarse_check(dangx_ctx* ctx, int comp, int nside, int sample_nside) {
-    if (check_comp(ctx, comp)) return 1;
-    if (ctx->dims.npix_global != 12LL * nside * nside) return fail(ctx, "npix_global is not 12*nside^2");
-    if (!(sample_nside < nside)) return fail(ctx, "sample_nside must be smaller than nside");
-    if (ctx->desc[comp].type > DANGX_TCMB) return fail(ctx, "coarse-Nside sampling is built for the diffuse component types and T_cmb");
-    return 0;
-}
-
-int dangx_coarse_sizes(dangx_ctx* ctx, int map_n, int sample_nside, int64_t* n_partials, int64_t* n_index) {
-    if (!ctx || !n_partials || !n_index) return 1;
-    int s1, s2;
-    if (map_planes(ctx, map_n, s1, s2)) return 1;
-    const long long npc = 12LL * sample_nside * sample_nside;
-    *n_partials = coarse_partials_len(ctx, s2 - s1 + 1, npc);
-    *n_index = npc + 1;
-    return 0;
-}
-
-static int coarse_alloc(dangx_ctx* ctx, int Sp, long long npc) {
-    const long long need = (long long)Sp * ctx->hm.nbands * npc;
-    if (need > ctx->cs_cap) {
-        for (double** b : {&ctx->cs_data, &ctx->cs_rms, &ctx->cs_mask, &ctx->cs_index}) { if (*b) (void)hipFree(*b); *b = nullptr; }
-        HIPCHK(ctx, hipMalloc(&ctx->cs_data, sizeof(double) * need));
-        HIPCHK(ctx, hipMalloc(&ctx->cs_rms, sizeof(double) * need));
-        HIPCHK(ctx, hipMalloc(&ctx->cs_mask, sizeof(double) * npc));
-        HIPCHK(ctx, hipMalloc(&ctx->cs_index, sizeof(double) * npc));
-        ctx->cs_cap = need;
-    }
-    const long long np = coarse_partials_len(ctx, Sp, npc);
-    if (np > ctx->cs_part_cap) {
-        if (ctx->cs_part) (void)hipFree(ctx->cs_part);
-        ctx->cs_part = nullptr;
-        HIPCHK(ctx, hipMalloc(&ctx->cs_part, sizeof(double) * np));
-        ctx->cs_part_cap = np;
-    }
-    return 0;
-}
-
-int dangx_coarse_partials(dangx_ctx* ctx, int comp, int map_n, int nside, int sample_nside, double* buf) {
-    if (!ctx || !buf || coarse_check(ctx, comp, nside, sample_nside)) return 1;
-    (void)hipSetDevice(ctx->device);
-    if (hp_tables(ctx, nside, sample_nside)) return 1;
-    if (dangx_fullsky_prepare(ctx, comp, map_n)) return 1;   // data_raw minus every other component, this shard's pixels
-    const int s1 = ctx->fs_s1, s2 = ctx->fs_s2, Sp = s2 - s1 + 1, nb = ctx->hm.nbands;
-    ctx->fs_comp = -1;
-    const long long npc = 12LL * sample_nside * sample_nside, npl = ctx->dims.npix, p0 = ctx->dims.pix0;
-    const int r1 = nside / sample_nside, ratio = r1 * r1;
-    if (coarse_alloc(ctx, Sp, npc)) return 1;
-    const long long nq = (long long)Sp * nb * npc;
-    double *dt = ctx->cs_part, *dc = dt + nq, *rt = dc + nq, *rc = rt + nq, *mt = rc + nq, *mc = mt + npc;
-    const dim3 gq(nblocks(npc), Sp * nb), g1(nblocks(npc), 1);
-    hipLaunchKernelGGL(k_udgrade_part, gq, dim3(BLOCK), 0, ctx->stream, ctx->fs_data, dt, dc, ctx->hp_n2r_f, ctx->hp_r2n_c, p0, npl, npc,
-                       ratio, 0, 0, nb, ctx->hm.nmaps, s1);
-    hipLaunchKernelGGL(k_udgrade_part, gq, dim3(BLOCK), 0, ctx->stream, ctx->rms, rt, rc, ctx->hp_n2r_f, ctx->hp_r2n_c, p0, npl, npc,
-                       ratio, 1, 1, nb, ctx->hm.nmaps, s1);
-    hipLaunchKernelGGL(k_udgrade_part, g1, dim3(BLOCK), 0, ctx->stream, ctx->mask, mt, mc, ctx->hp_n2r_f, ctx->hp_r2n_c, p0, npl, npc,
-                       ratio, 2, 0, nb, ctx->hm.nmaps, s1);
-    HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(buf, ctx->cs_part, sizeof(double) * coarse_partials_len(ctx, Sp, npc), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
-}
-
-// finish the degraded data / rms / mask from the child sums of ALL shards (phase B's first half) -> cs_data / cs_rms / cs_mask
-static int coarse_finish(dangx_ctx* ctx, int Sp, long long npc, int nside, int sample_nside, const double* partials_sum) {
-    const long long nq = (long long)Sp * ctx->hm.nbands * npc;
-    if (coarse_alloc(ctx, Sp, npc)) return 1;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->cs_part, partials_sum, sizeof(double) * coarse_partials_len(ctx, Sp, npc), hipMemcpyHostToDevice, ctx->stream));
-    const double *dt = ctx->cs_part, *dc = dt + nq, *rt = dc + nq, *rc = rt + nq, *mt = rc + nq, *mc = mt + npc;
-    const double scale = (double)sample_nside * 1.0 / nside;
-    hipLaunchKernelGGL(k_udgrade_finish, dim3(nblocks(nq)), dim3(BLOCK), 0, ctx->stream, dt, dc, ctx->cs_data, nq, 0, scale);
-    hipLaunchKernelGGL(k_udgrade_finish, dim3(nblocks(nq)), dim3(BLOCK), 0, ctx->stream, rt, rc, ctx->cs_rms, nq, 1, scale);
-    hipLaunchKernelGGL(k_udgrade_finish, dim3(nblocks(npc)), dim3(BLOCK), 0, ctx->stream, mt, mc, ctx->cs_mask, npc, 2, scale);
-    HIPCHK(ctx, hipGetLastError());
-    return 0;
-}
-
-// full-sky index mode at a coarser Nside ON A PIXEL SHARD: dangx_coarse_partials of every shard, added, then this call on
-// every shard -- the degraded maps are then whole-sky on each of them and dangx_fullsky_sums adds, per shard, the coarse
-// pixels i whose full-resolution pixel i the shard holds
-int dangx_fullsky_finish_coarse(dangx_ctx* ctx, int comp, int map_n, int nside, int sample_nside, const double* partials_sum) {
-    if (!ctx || !partials_sum || coarse_check(ctx, comp, nside, sample_nside)) return 1;
-    (void)hipSetDevice(ctx->device);
-    int s1, s2;
-    if (map_planes(ctx, map_n, s1, s2) || sync_model(ctx)) return 1;
-    const long long npc = 12LL * sample_nside * sample_nside;
-    if (coarse_finish(ctx, s2 - s1 + 1, npc, nside, sample_nside, partials_sum)) return 1;
-    ctx->fs_comp = comp; ctx->fs_s1 = s1; ctx->fs_s2 = s2; ctx->fs_npc = npc;
-    return 0;
-}
-
-int dangx_coarse_chains(dangx_ctx* ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed, uint64_t stream,
-                        int nside, int sample_nside, const double* partials_sum, double* index_out) {
-    if (!ctx || !partials_sum || !index_out || coarse_check(ctx, comp, nside, sample_nside)) return 1;
-    (void)hipSetDevice(ctx->device);
-    const dangx_comp_desc& d = ctx->desc[comp];
-    if (nind < 0 || nind >= d.nindices) return fail(ctx, "index number out of range");
-    if (d.lnl_type[nind] < DANGX_LNL_CHISQ || d.lnl_type[nind] > DANGX_LNL_PRIOR) return fail(ctx, "bad lnl_type");
-    if (ml_mode != DANGX_ML_SAMPLE && ml_mode != DANGX_ML_OPTIMIZE) return fail(ctx, "bad ml_mode");
-    int s1, s2;
-    if (map_planes(ctx, map_n, s1, s2) || sync_model(ctx)) return 1;
-    const int Sp = s2 - s1 + 1, nb = ctx->hm.nbands;
-    const long long npc = 12LL * sample_nside * sample_nside, nq = (long long)Sp * nb * npc;
-    if (coarse_finish(ctx, Sp, npc, nside, sample_nside, partials_sum)) return 1;
-    (void)nq;
-    IndexArgs a{};
-    a.comp = comp; a.nind = nind; a.nsample = nsample; a.ml_mode = ml_mode; a.seed = seed; a.stream = stream;
-    a.s1 = s1; a.s2 = s2; a.mode = CH_GENERIC;
-    HIPCHK(ctx, hipMemsetAsync(ctx->counters + 1, 0, sizeof(unsigned long long), ctx->stream));
-    {
-        Timed t(ctx, DANGX_K_INDEX_MH);
-        hipLaunchKernelGGL(k_index_mh_coarse, dim3(nblocks(npc)), dim3(BLOCK), 0, ctx->stream, ctx->dm, a, npc, ctx->cs_data, ctx->cs_rms,
-                           ctx->cs_mask, ctx->cs_index, ctx->counters + 1);
-    }
-    HIPCHK(ctx, hipGetLastError());
-    unsigned long long v = 0;
-    HIPCHK(ctx, hipMemcpyAsync(index_out, ctx->cs_index, sizeof(double) * npc, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(&v, ctx->counters + 1, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    index_out[npc] = (double)v;  // accepted proposals of this shard's chains
-    return 0;
-}
-
-int dangx_coarse_writeback(dangx_ctx* ctx, int comp, int nind, int map_n, int nside, int sample_nside, const double* index_sum) {
-    if (!ctx || !index_sum || coarse_check(ctx, comp, nside, sample_nside)) return 1;
-    (void)hipSetDevice(ctx->device);
-    if (nind < 0 || nind >= ctx->desc[comp].nindices) return fail(ctx, "index number out of range");
-    int s1, s2;
-    if (map_planes(ctx, map_n, s1, s2) || hp_tables(ctx, nside, sample_nside) || sync_model(ctx)) return 1;
-    const long long npc = 12LL * sample_nside * sample_nside;
-    const int r1 = nside / sample_nside, ratio = r1 * r1;
-    if (coarse_alloc(ctx, s2 - s1 + 1, npc)) return 1;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->cs_index, index_sum, sizeof(double) * npc, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_coarse_writeback, dim3(nblocks(ctx->dims.npix)), dim3(BLOCK), 0, ctx->stream, ctx->dm, comp, nind, s1, s2, ctx->cs_index,
-                       ctx->hp_r2n_f, ctx->hp_n2r_c, ratio);
-    HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    for (int k = s1; k <= s2; ++k) {
-        ctx->chi_before_valid[k - 1] = ctx->chi_after_valid[k - 1] = false;
-        ctx->touched_since_amp[k - 1] = true;
-        ctx->idx_const[comp] &= ~(1u << (k - 1));
-    }
-    idx_written(ctx, comp);
-    if (map_n == -1) ctx->qu_equal[comp] |= 1u << nind;
-    else if (map_n == 2 || map_n == 3) ctx->qu_equal[comp] &= ~(1u << nind);
-    ctx->dirty = true;
-    return 0;
-}
-
-// full-sky index mode with sample_nside /= nside (src/dang_sample_mod.f90:199-217, 229-329): the chain's sky-wide sums run
-// over the degraded maps.  After this call dangx_fullsky_sums evaluates on them; the chain ends with dangx_fill_index
-// (udgrade_ring of a constant coarse map is that constant everywhere, :480-483).
-int dangx_fullsky_prepare_coarse(dangx_ctx* ctx, int comp, int map_n, int nside, int sample_nside) {
-    if (!ctx || check_comp(ctx, comp)) return 1;
-    (void)hipSetDevice(ctx->device);
-    const long long npix = ctx->dims.npix;
-    if (ctx->dims.pix0 != 0 || npix != 12LL * nside * nside || ctx->dims.npix_global != npix)
-        return fail(ctx, "coarse-Nside sampling needs ONE whole-sky context (npix = 12*nside^2): the children of a coarse pixel are scattered over the RING ranges of a sharded run");
-    if (!(sample_nside < nside)) return fail(ctx, "sample_nside must be smaller than nside (equal: dangx_fullsky_prepare)");
-    if (ctx->desc[comp].type > DANGX_TCMB) return fail(ctx, "coarse-Nside sampling is built for the diffuse component types and T_cmb");
-    if (coarse_stage(ctx, comp, map_n, nside, sample_nside)) return 1;
-    ctx->fs_comp = comp;
-    ctx->fs_npc = 12LL * sample_nside * sample_nside;
-    return 0;
-}
-
-int dangx_index_sample_coarse(dangx_ctx* ctx, int comp, int nind, int map_n, int nsample, int ml_mode, uint64_t seed,
-                              uint64_t stream, int nside, int sample_nside, int64_t* accepted) {
-    DxRange rg_("dangx_index_sample_coarse");
-    if (!ctx || check_comp(ctx, comp)) return 1;
-    (void)hipSetDevice(ctx->device);
-    const long long npix = ctx->dims.npix;
-    if (ctx->dims.pix0 != 0 || npix != 12LL * nside * nside || ctx->dims.npix_global != npix) {
-        // a pixel shard: the three phases, with the sum over the ranks between them
-        if (!ctx->allreduce)
-            return fail(ctx, "coarse-Nside sampling on a pixel shard needs the sum over the shards: register dangx_set_allreduce (one process per GPU), or call dangx_coarse_partials / _chains / _writeback and add the buffers (several contexts in one process)");
-        int64_t np = 0, ni = 0;
-        if (dangx_coarse_sizes(ctx, map_n, sample_nside, &np, &ni)) return 1;
-        std::vector<double> part((size_t)np), idx((size_t)ni);
-        if (dangx_coarse_partials(ctx, comp, map_n, nside, sample_nside, part.data()) || rank_sum(ctx, part.data(), np)) return 1;
-        if (dangx_coarse_chains(ctx, comp, nind, map_n, nsample, ml_mode, seed, stream, nside, sample_nside, part.data(), idx.data()) ||
-            rank_sum(ctx, idx.data(), ni))
-            return 1;
-        if (accepted) *accepted = (int64_t)idx[(size_t)ni - 1];   // all ranks' chains
-        return dangx_coarse_writeback(ctx, comp, nind, map_n, nside, sample_nside, idx.data());
-    }
-    if (!(sample_nside < nside)) return fail(ctx, "sample_nside must be smaller than nside (equal: dangx_index_sample)");
-    const dangx_comp_desc& d = ctx->desc[comp];
-    if (nind < 0 || nind >= d.nindices) return fail(ctx, "index number out of range");
-    if (d.type > DANGX_TCMB) return fail(ctx, "coarse-Nside sampling is built for the diffuse component types and T_cmb");
-    if (d.lnl_type[nind] < DANGX_LNL_CHISQ || d.lnl_type[nind] > DANGX_LNL_PRIOR) return fail(ctx, "bad lnl_type");
-    if (ml_mode != DANGX_ML_SAMPLE && ml_mode != DANGX_ML_OPTIMIZE) return fail(ctx, "bad ml_mode");
-    if (coarse_stage(ctx, comp, map_n, nside, sample_nside)) return 1;
-    const int s1 = ctx->fs_s1, s2 = ctx->fs_s2;
-    const long long npc = 12LL * sample_nside * sample_nside;
-    const int r1 = nside / sample_nside, ratio = r1 * r1;
-    IndexArgs a{};
-    a.comp = comp; a.nind = nind; a.nsample = nsample; a.ml_mode = ml_mode; a.seed = seed; a.stream = stream;
-    a.s1 = s1; a.s2 = s2; a.mode = CH_GENERIC;
-    if (accepted) HIPCHK(ctx, hipMemsetAsync(ctx->counters + 1, 0, sizeof(unsigned long long), ctx->stream));
-    {
-        Timed t(ctx, DANGX_K_INDEX_MH);
-        hipLaunchKernelGGL(k_index_mh_coarse, dim3(nblocks(npc)), dim3(BLOCK), 0, ctx->stream, ctx->dm, a, npc, ctx->cs_data, ctx->cs_rms,
-                           ctx->cs_mask, ctx->cs_index, accepted ? ctx->counters + 1 : nullptr);
-    }
-    hipLaunchKernelGGL(k_coarse_writeback, dim3(nblocks(npix)), dim3(BLOCK), 0, ctx->stream, ctx->dm, comp, nind, s1, s2, ctx->cs_index,
-                       ctx->hp_r2n_f, ctx->hp_n2r_c, ratio);
-    HIPCHK(ctx, hipGetLastError());
-    for (int k = s1; k <= s2; ++k) {  // the planes changed: cached chi^2 and constant-index bookkeeping are stale
-        ctx->chi_before_valid[k - 1] = ctx->chi_after_valid[k - 1] = false;
-        ctx->touched_since_amp[k - 1] = true;
-        ctx->idx_const[comp] &= ~(1u << (k - 1));
-    }
-    idx_written(ctx, comp);
-    if (map_n == -1) ctx->qu_equal[comp] |= 1u << nind;
-    else if (map_n == 2 || map_n == 3) ctx->qu_equal[comp] &= ~(1u << nind);
-    ctx->dirty = true;
-    if (accepted) {
-        unsigned long long v = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&v, ctx->counters + 1, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        *accepted = (int64_t)v;
-    }
-    return 0;
-}
-
 
 // local (this shard's) sum of c%indices(:, map_n, nind) over unmasked pixels and their number: mask_avg = sum / count
 int dangx_index_masked_sum(dangx_ctx* ctx, int comp, int nind, int map_n, double* sum, int64_t* count) {

@@ -4,7 +4,7 @@
 // sample_spectral_parameters (:75-78).
 //
 // In these steps one number describes the whole sky, so a Metropolis step is a pass over the maps that leaves a few sums
-// (the kernels of dangx_core.hip: k_fullsky_rows, k_gain_rows, k_index_plain_sum) and a few scalar operations between two
+// (the kernels of dangx_coarse.hip / dangx_core.hip: k_fullsky_rows, k_gain_rows, k_index_plain_sum) and a few scalar operations between two
 // such passes.  The scalar part lives HERE, once, for every host language: the Python mirror (dang_amd/api.py), the Fortran
 // layers (fortran/dangx_multi_mod.f90, fortran/reference_side/dang_gpu_mod.f90) and a C driver all make the same call.
 //

@@ -1,5 +1,6 @@
 // dx_host.h -- host-side context and launch-argument structs shared by the translation units of libdangx.so
-// (dangx_core.hip: context, C ABI, small kernels; dangx_amp.hip: amplitude kernels of diffuse groups; dangx_mixed.hip /
+// (dangx_core.hip: context, model, chi^2 ring, host solvers, small kernels; dangx_entry.hip: the sampling entry points;
+// dangx_coarse.hip: full-sky / coarse-Nside device side; dangx_amp.hip: amplitude kernels of diffuse groups; dangx_mixed.hip /
 // dangx_schur.hip: groups with template-type members (mixed CG operators / direct Schur solve); dangx_mh.hip: LDS-form
 // Metropolis kernels; dangx_mhreg.hip: register-resident Metropolis kernels, compiled once per chain mode).
 #pragma once
@@ -202,6 +203,32 @@ inline unsigned nblocks(long long n, int bs = BLOCK) { return (unsigned)((n + bs
 
 // out[row] = sum(partial[row][0..nblk)) for rows 0..rows-1 (deterministic; defined in dangx_core.hip)
 void dx_reduce_rows_to(dangx_ctx* ctx, const double* partial, unsigned nblk, int rows, double* out_dev);
+// out_dev[0] = sum(partial[0..n)) in two deterministic stages; stage: DX_RSTAGE doubles of scratch behind the partials
+constexpr int DX_RSTAGE = 128;
+void dx_reduce_two_stage(dangx_ctx* ctx, const double* partial, long long n, double* stage, double* out_dev);
+
+// ---- host helpers of dangx_core.hip used by the other translation units of the ABI
+int sync_model(dangx_ctx* ctx);                 // host model -> device copy when something changed (constant-index rows, bandpass tables)
+int prof_collect(dangx_ctx* ctx);
+int ensure_work(dangx_ctx* ctx, long long n);
+int ensure_state(dangx_ctx* ctx, int comp);     // allocate a component's maps on first use
+int check_comp(dangx_ctx* ctx, int comp);
+int copy_planes(dangx_ctx* ctx, void* dst, const void* src, size_t planes, bool to_device);
+int make_group(dangx_ctx* ctx, int group, int flag, GroupArgs& a);
+int chi_flush(dangx_ctx* ctx);                  // reduce every pending launch's chi^2 / index-sum partials into chi_cache
+int chi_next(dangx_ctx* ctx, long long nblk, double** buf);
+int reduce_to_host(dangx_ctx* ctx, long long nblk, double* out);
+int rank_sum(dangx_ctx* ctx, double* buf, int64_t n);
+int device_cg(dangx_ctx* ctx, const GroupArgs& a, int i_max, double converge, int* iters);
+int device_schur(dangx_ctx* const* cs, int nc, const GroupArgs* as, const long long* SNs, int64_t* n_not_spd, int* nullity);
+// map_n of sample_index_mh (src/dang_sample_mod.f90:53-64) -> first and last map plane
+inline int map_planes(dangx_ctx* ctx, int map_n, int& s1, int& s2) {
+    if (map_n == -1) { s1 = 2; s2 = 3; }
+    else if (map_n >= 1 && map_n <= 3) { s1 = s2 = map_n; }
+    else return fail(ctx, "There is something wrong with the poltype flag (map_n must be 1,2,3 or -1)");
+    if (s2 > ctx->dims.nmaps) return fail(ctx, "map_n exceeds nmaps");
+    return 0;
+}
 
 // run-time specialisation (dangx_rtc.hip): the kernel named by a template-id of `header`, or nullptr (+ ctx->err)
 bool dx_rtc_enabled();
