@@ -340,7 +340,11 @@ __device__ __forceinline__ void subtract_other_pair(const Model& M, const Comp& 
 template <int MODE, int SP, int NB, int LP, bool SCALE = true, bool ADD = false, bool SUB = false, class RC>
 __device__ __forceinline__ unsigned long long chain_finish(const Model& M, const IndexArgs& a, const Comp& c, RC& R,
                                                            const BandPick<LP>& pick, double sample0, double sample1, int i, int half,
-                                                           double chi[4], double* final_value = nullptr) {
+                                                           double chi[4], double* final_value = nullptr,
+                                                           const double* acc_in = nullptr, double* acc_out = nullptr) {
+    // acc_in (k_plane_set, second chain of a component's pair): the likelihood sums of the state this chain starts from, as the
+    // chain before it left them -- the same state, the same SED (another factorisation of it): no first evaluation.
+    // acc_out: the sums of the state the chain ends on.
     const int npix = M.npix;
     double* out = c.idx + ((long long)a.nind * M.nmaps) * npix + i;
     const bool first = (a.nind == 0);
@@ -387,7 +391,9 @@ __device__ __forceinline__ unsigned long long chain_finish(const Model& M, const
     const double step = c.step[q], lo = c.uni[q][0], hi = c.uni[q][1];
     auto chain = [&](auto batch_tag) {
         constexpr bool B = decltype(batch_tag)::value;
-        double lnl = R.template lnl<B, ADD ? 1 : 0>(M, c, cur, other, a0, a1);
+        double lnl;
+        if (acc_in) { a0 = acc_in[0]; a1 = acc_in[1]; lnl = a0 + a1; }
+        else lnl = R.template lnl<B, ADD ? 1 : 0>(M, c, cur, other, a0, a1);
         chi[0] = -2.0 * a0; chi[1] = -2.0 * a1;
         double lnl_old = lnl + prior(cur);
         if (LP == 1 || DX_CHAIN_PAIR_RNG == 0) {
@@ -452,6 +458,7 @@ __device__ __forceinline__ unsigned long long chain_finish(const Model& M, const
     }
 #endif
     if (final_value) *final_value = cur;
+    if (acc_out) { acc_out[0] = a0; acc_out[1] = a1; }
     if (half != 0) {  // the pair's second lane carries the same chain: its sums and counts are the first lane's
         chi[0] = chi[1] = 0.0;
         return 0ull;

@@ -46,7 +46,7 @@ template <int MODE, int PAIR, int SP, int NBL, int LP, int NG, bool FIRST, bool 
 __device__ __forceinline__ void ps_item(const Model& M, const SweepList& sl, const SweepItem& it, RFirst& R0, int i, int half,
                                         int jb, int NB, const double* __restrict__ tab, const double* __restrict__ col,
                                         double& sample0, double& sample1, double chi_first[4],
-                                        double chi_last[4], unsigned long long* __restrict__ accepted, int slot) {
+                                        double chi_last[4], unsigned long long* __restrict__ accepted, int slot, const double* first_acc) {
     const Comp& c = M.comp[it.comp];
     const BandPick<LP> pick = {half};
     const int npix = M.npix;
@@ -63,8 +63,12 @@ __device__ __forceinline__ void ps_item(const Model& M, const SweepList& sl, con
 #pragma unroll
         for (int j = 0; j < NBL; ++j) { R.D[kk][j] = R0.D[kk][j]; R.ISr[kk][j] = col[(kk * NBL + j) * BLOCK] * R.amp[kk]; }
     }
-    double chia[4] = {0.0, 0.0, 0.0, 0.0}, va;
-    unsigned long long na = chain_finish<MODE, SP, NBL, LP, false, true, (!PAIR && !LAST)>(M, a, c, R, pick, sample0, sample1, i, half, chia, &va);
+    double chia[4] = {0.0, 0.0, 0.0, 0.0}, va, acc[2];
+    // FIRST: the kernel has put this member's signal back already, from its SED column of the solve (R0.D is the cleaned data and
+    // first_acc the likelihood sums of the state the solve left): no evaluation before the first proposal.  Later items: the
+    // chain's first evaluation adds the signal back (LNL_ADD)
+    unsigned long long na = chain_finish<MODE, SP, NBL, LP, false, !FIRST, (!PAIR && !LAST)>(M, a, c, R, pick, sample0, sample1, i, half, chia, &va,
+                                                                                            FIRST ? first_acc : nullptr, acc);
     if (it.nind == 0) sample0 = va; else sample1 = va;
     if (FIRST) { chi_first[0] = chia[0]; chi_first[1] = chia[1]; }
     chi_last[2] = chia[2]; chi_last[3] = chia[3];
@@ -82,7 +86,8 @@ __device__ __forceinline__ void ps_item(const Model& M, const SweepList& sl, con
         IndexArgs b = a;
         b.nind = it.nind + 1; b.stream = it.stream2; b.mode = MODEB;
         double chib[4] = {0.0, 0.0, 0.0, 0.0}, vb;
-        nb_ = chain_finish<MODEB, SP, NBL, LP, false, false, !LAST>(M, b, c, RB, pick, sample0, sample1, i, half, chib, &vb);
+        // (the second chain starts from the state the first one ended on: its likelihood sums are that chain's, not evaluated again)
+        nb_ = chain_finish<MODEB, SP, NBL, LP, false, false, !LAST>(M, b, c, RB, pick, sample0, sample1, i, half, chib, &vb, acc);
         if (b.nind == 0) sample0 = vb; else sample1 = vb;
         chi_last[2] = chib[2]; chi_last[3] = chib[3];
         if (!LAST) {
@@ -294,6 +299,7 @@ __global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP, SOLVE, C0)) void k_p
                 asm volatile("" : "+v"(R0.D[kk][j]));
             }
         }
+        double first_acc[2] = {0.0, 0.0};
         if (C0 == 0) {  // no sweep follows: chi^2 of the state the solve leaves is the residual's (both the "before" and "after" slots)
 #pragma unroll
             for (int kk = 0; kk < SP; ++kk) {
@@ -304,6 +310,25 @@ __global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP, SOLVE, C0)) void k_p
                 if (half == 0) { chi[kk] = acc; chi[2 + kk] = acc; }
             }
         } else {
+            // the first sweep's cleaned data: residual + the swept member's own signal, from its SED column of the solve (the index
+            // values have not moved since), and the likelihood sums of the state the solve left = the residual's
+            {
+                const SweepItem it0 = sl.s[0];
+                const double* m = col + (fa.vslot[it0.gmember] * NBL) * BLOCK;
+#pragma unroll
+                for (int kk = 0; kk < SP; ++kk) {
+                    const double a0 = M.comp[it0.comp].amp[(long long)(sl.s1 + kk - 1) * npix + i];
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NBL; ++j) {
+                        const double r = R0.D[kk][j];
+                        acc = fma(r, r, acc);
+                        R0.D[kk][j] = fma(a0 * R0.ISr[kk][j], m[j * BLOCK], r);
+                    }
+                    if (LP > 1) acc += __shfl_xor(acc, 1, 64);
+                    first_acc[kk] = -0.5 * acc;
+                }
+            }
             // 1 / rms of the lane's bands -> its LDS column (the SED columns are dead from here on)
 #pragma unroll
             for (int kk = 0; kk < SP; ++kk)
@@ -324,7 +349,7 @@ __global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP, SOLVE, C0)) void k_p
                 // a component's sweeps are consecutive and travel in ONE item: no lane reads here what its partner wrote
                 load_theta(M, c, i, sl.s1, sample0, sample1);
                 ps_item<(CODE & 7), (CODE >> 3), SP, NBL, LP, NG, FIRST, LAST, (BP != 0)>(M, sl, it, R0, i, half, jb, NB, tab, col, sample0, sample1,
-                                                                              FIRST ? chi : unused, chi, accepted, slot);
+                                                                              FIRST ? chi : unused, chi, accepted, slot, first_acc);
                 slot += 1 + (CODE >> 3);
             }
         };
