@@ -782,7 +782,8 @@ def plan_plane_sets(dpar, eng):
     return out
 
 
-def sample_cg_groups(dpar: DangParams, ddata: DangData, it=1, verbose=False, defer_chisq=False, fuse_first=None, it_index=None):
+def sample_cg_groups(dpar: DangParams, ddata: DangData, it=1, verbose=False, defer_chisq=False, fuse_first=None, it_index=None,
+                     want_counts=True):
     """sample_cg_groups(dpar, ddata), src/dang_cg_mod.f90:142-177.
 
     defer_chisq=True skips the chi^2 pass after the amplitude phase; sample_spectral_parameters then
@@ -808,14 +809,15 @@ def sample_cg_groups(dpar: DangParams, ddata: DangData, it=1, verbose=False, def
                 iti = it if it_index is None else it_index
                 bad, accs = eng.plane_set_sample(g.cg_group, f, dpar.ml_mode, dpar.seed, stream_id(it, 0, g.cg_group, 0, f),
                                                  [(l, j, stream_id(iti, 1, l, j, f)) for l, j in same], dpar.nsample, dpar.seed,
-                                                 solver=dpar.solver, fluct_mode=dpar.fluct_mode, i_max=g.i_max, converge=g.converge)
+                                                 solver=dpar.solver, fluct_mode=dpar.fluct_mode, i_max=g.i_max, converge=g.converge,
+                                                 want_counts=want_counts)
                 for l, j in same:
                     fuse_first.add((l, j, f))
                 info.append((g.cg_group, f, 0, bad))
                 continue
             cg_it, bad = eng.amp_sample(g.cg_group, f, dpar.ml_mode, dpar.seed, stream_id(it, 0, g.cg_group, 0, f),
                                         solver=dpar.solver, fluct_mode=dpar.fluct_mode,
-                                        i_max=g.i_max, converge=g.converge)
+                                        i_max=g.i_max, converge=g.converge, want_counts=want_counts or dpar.solver == "cg")
             info.append((g.cg_group, f, cg_it, bad))
         if has_global:  # update_sky_model: self%offset = c%template_amplitudes(:,1) of a monopole (src/dang_data_mod.f90:357-361)
             for l, c in enumerate(eng.component_list):
@@ -831,51 +833,57 @@ def sample_cg_groups(dpar: DangParams, ddata: DangData, it=1, verbose=False, def
 _MAPN = {L.FLAG_T: 1, L.FLAG_Q: 2, L.FLAG_U: 3, L.FLAG_QU: -1}  # src/dang_sample_mod.f90:53-64
 
 
-def sample_spectral_parameters(dpar: DangParams, ddata: DangData, it=2, verbose=False, skip=()):
+def sample_spectral_parameters(dpar: DangParams, ddata: DangData, it=2, verbose=False, skip=(), want_counts=True):
     """sample_spectral_parameters(dpar, ddata), src/dang_sample_mod.f90:21-86 (per-pixel index_mode).
 
-    Two consecutive plain sweeps of one component on the same planes (dust beta, dust T) go through
-    Engine.index_sample_pair (one launch, bit for bit the two sweeps).  skip: (component, index, flag) sweeps already done
-    together with their group's solve (sample_cg_groups(fuse_first=...))."""
+    Consecutive plain per-pixel sweeps of one plane set go through Engine.plane_sweeps_sample (one launch where the model
+    allows it; inside it two consecutive indices of one component -- dust beta, dust T -- travel together).  skip: (component,
+    index, flag) sweeps already done together with their group's solve (sample_cg_groups(fuse_first=...))."""
     eng = ddata.engine
     sampled = False
     info = []
-    for l, c in enumerate(eng.component_list):
-        if c.nindices == 0 or not any(c.sample_index):
-            continue
+    comps = eng.component_list
+    # the sweeps of the iteration as a flat list in the loop's order (component, index, flag): consecutive plain per-pixel sweeps
+    # with ONE flag whose components belong to one CG group go through Engine.plane_sweeps_sample -- one launch on the plane set
+    # where the model allows it (sweeps on disjoint planes are independent, so collecting a plane set's sweeps changes nothing)
+    entries = [(l, j, f) for l, c in enumerate(comps) for j in range(c.nindices) if c.sample_index[j] for f in c.pol_flag[j]]
+    plain = [(f in _MAPN and _plain_sweep(eng, comps[l], j) and comps[l].sample_amplitude and (l, j, f) not in skip) for l, j, f in entries]
+    done = set()
+    for e, (l, j, f) in enumerate(entries):
+        c = comps[l]
         sampled = True
-        paired = set()
-        for j in range(c.nindices):
-            if not c.sample_index[j]:
+        if (l, j, f) in skip or e in done:
+            continue
+        if plain[e]:
+            n = 1
+            while e + n < len(entries) and plain[e + n] and entries[e + n][2] == f and comps[entries[e + n][0]].cg_group == c.cg_group:
+                n += 1
+            if n >= 2:
+                run = entries[e:e + n]
+                accs = eng.plane_sweeps_sample(f, [(l2, j2, stream_id(it, 1, l2, j2, f)) for l2, j2, _ in run], dpar.nsample, dpar.ml_mode, dpar.seed,
+                                               want_counts=want_counts)
+                info += [(l2, j2, f, a) for (l2, j2, _), a in zip(run, accs)]
+                done.update(range(e + 1, e + n))
                 continue
-            for f in c.pol_flag[j]:
-                if (l, j, f) in skip or (j, f) in paired:
-                    continue
-                if (f in _MAPN and j + 1 < c.nindices and _plain_sweep(eng, c, j) and _plain_sweep(eng, c, j + 1)
-                        and f in c.pol_flag[j + 1] and (l, j + 1, f) not in skip):
-                    a1, a2 = eng.index_sample_pair(l, j, _MAPN[f], dpar.nsample, dpar.ml_mode, dpar.seed,
-                                                   stream_id(it, 1, l, j, f), stream_id(it, 1, l, j + 1, f))
-                    info.append((l, j, f, a1)); info.append((l, j + 1, f, a2))
-                    paired.add((j + 1, f))
-                    continue
-                if f not in _MAPN:
-                    raise DangxError("There is something wrong with the poltype flag for component " + c.label)
-                coarse = c.sample_nside[j] if c.sample_nside else 0
-                if c.index_mode and c.index_mode[j] == 1:
-                    acc = sample_index_mh_fullsky(dpar, ddata, l, j, _MAPN[f], stream_id(it, 1, l, j, f),
-                                                  sample_nside=coarse if (coarse and coarse != eng.nside) else None)
-                elif coarse and coarse != eng.nside:
-                    if c.tuned and not c.tuned[j]:
-                        raise DangxError("step-size tuning with sample_nside /= nside is not built")
-                    acc = eng.index_sample_coarse(l, j, _MAPN[f], dpar.nsample, dpar.ml_mode, dpar.seed,
-                                                  stream_id(it, 1, l, j, f), coarse)
-                else:
-                    if c.tuned and not c.tuned[j]:       # 'Tuning!', src/dang_sample_mod.f90:341-346
-                        tune_perpixel(dpar, ddata, l, j, _MAPN[f], stream_id(it, 1, l, j, f))
-                    acc = eng.index_sample(l, j, _MAPN[f], dpar.nsample, dpar.ml_mode, dpar.seed,
-                                           stream_id(it, 1, l, j, f))
-                info.append((l, j, f, acc))
-        if c.type == "T_cmb":  # "Update the global variable T_CMB": T_CMB = c%indices(0,1,1), :75-78 (it enters a2t of 'cmb')
+        if f not in _MAPN:
+            raise DangxError("There is something wrong with the poltype flag for component " + c.label)
+        coarse = c.sample_nside[j] if c.sample_nside else 0
+        if c.index_mode and c.index_mode[j] == 1:
+            acc = sample_index_mh_fullsky(dpar, ddata, l, j, _MAPN[f], stream_id(it, 1, l, j, f),
+                                          sample_nside=coarse if (coarse and coarse != eng.nside) else None)
+        elif coarse and coarse != eng.nside:
+            if c.tuned and not c.tuned[j]:
+                raise DangxError("step-size tuning with sample_nside /= nside is not built")
+            acc = eng.index_sample_coarse(l, j, _MAPN[f], dpar.nsample, dpar.ml_mode, dpar.seed,
+                                          stream_id(it, 1, l, j, f), coarse)
+        else:
+            if c.tuned and not c.tuned[j]:       # 'Tuning!', src/dang_sample_mod.f90:341-346
+                tune_perpixel(dpar, ddata, l, j, _MAPN[f], stream_id(it, 1, l, j, f))
+            acc = eng.index_sample(l, j, _MAPN[f], dpar.nsample, dpar.ml_mode, dpar.seed,
+                                   stream_id(it, 1, l, j, f))
+        info.append((l, j, f, acc))
+        # "Update the global variable T_CMB": T_CMB = c%indices(0,1,1), :75-78 (it enters a2t of 'cmb'), after the component's last sweep
+        if c.type == "T_cmb" and not any(l2 == l for l2, _, _ in entries[e + 1:]):
             arr, n = _ctx_array([eng])
             eng._chk(eng.lib.dangx_update_tcmb(arr, n, l, None))
     if sampled:
@@ -892,14 +900,16 @@ def sample_spectral_parameters(dpar: DangParams, ddata: DangData, it=2, verbose=
     return info
 
 
-def gibbs_iteration(dpar: DangParams, ddata: DangData, it, verbose=False):
+def gibbs_iteration(dpar: DangParams, ddata: DangData, it, verbose=False, want_counts=True):
     """sample_cg_groups followed by sample_spectral_parameters (one pass of the main loop, src/dang.f90:87-126, for
     iterations in which both run) with every group's solve issued together with the first sweep on its planes: the same
     state, bit for bit, as the two calls with the same `it`, in fewer kernel launches.  chi^2 after the amplitude phase
-    comes from the sweeps' by-product (ddata.chisq_after_amp)."""
+    comes from the sweeps' by-product (ddata.chisq_after_amp).
+    want_counts=False: the plane-set launches do not count accepted proposals / non-SPD blocks (the reference reports neither;
+    reading them back makes the host wait for every launch and costs the kernel ~4 %) -- the info lists carry zeros there."""
     done = set()
-    a = sample_cg_groups(dpar, ddata, it=it, verbose=False, defer_chisq=True, fuse_first=done, it_index=it)
-    b = sample_spectral_parameters(dpar, ddata, it=it, verbose=verbose, skip=done)
+    a = sample_cg_groups(dpar, ddata, it=it, verbose=False, defer_chisq=True, fuse_first=done, it_index=it, want_counts=want_counts)
+    b = sample_spectral_parameters(dpar, ddata, it=it, verbose=verbose, skip=done, want_counts=want_counts)
     return a, b
 
 

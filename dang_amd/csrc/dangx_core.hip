@@ -1403,6 +1403,10 @@ int dangx_set_template(dangx_ctx* ctx, int comp, const double* tmpl, const int32
     const size_t bytes = (size_t)ctx->dims.npix * ctx->dims.nmaps * sizeof(double);
     if (!ctx->tmpl[comp]) HIPCHK(ctx, hipMalloc(&ctx->tmpl[comp], bytes));
     if (copy_planes(ctx, ctx->tmpl[comp], tmpl, (size_t)ctx->dims.nmaps, true)) return 1;
+    ctx->tmpl_nz[comp] = 0;   // planes on which the template is identically zero carry none of its signal (a Q/U template on T)
+    for (int k = 0; k < ctx->dims.nmaps; ++k)
+        for (long long t = 0; t < ctx->dims.npix; ++t)
+            if (host_at(ctx, tmpl, k, t) != 0.0) { ctx->tmpl_nz[comp] |= 1u << k; break; }
     ctx->corr_mask[comp] = mask; ctx->nfit[comp] = nfit;
     ctx->dirty = true;
     invalidate_chi(ctx);

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_sky_chisq(const Model* __restrict_
 extern "C" {
 
 static int planeset_launch(dangx_ctx* ctx, const GroupArgs& g, const SweepList& sl, int lanes, int solve, int64_t* n_not_spd, int64_t* accepted);
-static bool planeset_group(dangx_ctx* ctx, const GroupArgs& g);
+static bool planeset_group(dangx_ctx* ctx, GroupArgs& g, int s1, int s2, int solve);
 
 int dangx_amp_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed,
                      uint64_t stream, int i_max, double converge, int* cg_iters, int64_t* n_not_spd) {
@@ -127,14 +127,17 @@ int dangx_amp_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solve
     // model (delta bands, the group's members the only components on the planes, reference fluctuation term) the statistics need
     // no pass of their own over the maps.  DANGX_AMP_CHI=0: the stand-alone amplitude kernel (A/B timing).
     static const bool with_chi = [] { const char* e = getenv("DANGX_AMP_CHI"); return !(e && e[0] == '0'); }();
-    if (with_chi && (ml_mode == DANGX_ML_OPTIMIZE || fluct_mode == DANGX_FLUCT_REFERENCE) && planeset_group(ctx, a)) {
+    if (with_chi && (ml_mode == DANGX_ML_OPTIMIZE || fluct_mode == DANGX_FLUCT_REFERENCE)) {
         SweepList sl;
         std::memset(&sl, 0, sizeof(sl));
         sl.s1 = (flag & DANGX_FLAG_QU) ? 2 : (flag & DANGX_FLAG_T) ? 1 : (flag & DANGX_FLAG_Q) ? 2 : 3;
         sl.s2 = (flag & DANGX_FLAG_QU) ? 3 : sl.s1;
         sl.ml_mode = ml_mode;
-        const int lanes = dx_planeset_lanes(ctx, a, sl, 1);
-        if (lanes) return planeset_launch(ctx, a, sl, lanes, 1, n_not_spd, nullptr);
+        GroupArgs ps = a;
+        if (planeset_group(ctx, ps, sl.s1, sl.s2, 1)) {
+            const int lanes = dx_planeset_lanes(ctx, ps, sl, 1);
+            if (lanes) return planeset_launch(ctx, ps, sl, lanes, 1, n_not_spd, nullptr);
+        }
     }
     if (n_not_spd) HIPCHK(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));
     if (dx_launch_amp(ctx, a, SN)) return 1;
@@ -521,11 +524,29 @@ static bool planeset_items(dangx_ctx* ctx, const GroupArgs& g, int map_n, int ns
     return true;
 }
 
-// a group whose members are the only components with a signal on the planes of the flag: what every plane-set launch needs
-static bool planeset_group(dangx_ctx* ctx, const GroupArgs& g) {
-    if (!(g.nt == 0 && g.no == 0 && g.nuc == 0)) return false;
-    for (int l = 0; l < ctx->hm.ncomp; ++l)
-        if (ctx->desc[l].type == DANGX_TCMB || is_global_type(ctx->desc[l].type)) return false;
+// What every plane-set launch needs: the group's diffuse members are the only components with a signal on planes s1..s2 --
+// except, for the sweeps alone (solve = 0), `template` components: their signal template_amplitudes(band, map) * template(pix, map)
+// (eval_signal, src/dang_component_mod.f90:754-776) is one more term of "every other component" and is removed when the residual
+// is formed; g.uc / g.nuc become the list of those (at most 4).  A global-amplitude component whose template map is identically
+// zero on these planes (a Q/U dust template seen from the T plane set) has no signal there and is ignored -- also by the solve,
+// whose compute_rhs would remove tamp * 0 on its unfitted bands (:445-460).  Monopoles (also the band offset, quirk 6), hi_fit
+// (a per-pixel Planck factor) and T_cmb components with a signal on the planes keep the run-time-typed kernels.
+static bool planeset_group(dangx_ctx* ctx, GroupArgs& g, int s1, int s2, int solve) {
+    unsigned planes = 0;
+    for (int k = s1; k <= s2; ++k) planes |= 1u << (k - 1);
+    int ntg = 0, tg[MAXC];
+    for (int l = 0; l < ctx->hm.ncomp; ++l) {
+        const int t = ctx->desc[l].type;
+        if (t == DANGX_TCMB) return false;
+        if (!is_global_type(t) || !(ctx->tmpl_nz[l] & planes)) continue;
+        if (solve || t != DANGX_TEMPLATE || ntg == 4) return false;
+        tg[ntg++] = l;
+    }
+    if (solve && g.nt != 0) return false;               // a coupled solve is the Schur path
+    for (int o = 0; o < g.no; ++o)                      // any other diffuse component with a signal on the planes
+        if (!is_global_type(ctx->desc[g.oc[o]].type)) return false;
+    g.nuc = ntg;
+    for (int t = 0; t < ntg; ++t) g.uc[t] = tg[t];
     return true;
 }
 
@@ -558,7 +579,7 @@ int dangx_plane_set_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int
     std::memset(&sl, 0, sizeof(sl));
     if (can) {
         if (make_group(ctx, group, flag, g)) return 1;
-        can = planeset_group(ctx, g) && planeset_items(ctx, g, map_n, nsweeps, comp, nind, stream, sl);
+        can = planeset_group(ctx, g, (map_n == -1) ? 2 : map_n, (map_n == -1) ? 3 : map_n, 1) && planeset_items(ctx, g, map_n, nsweeps, comp, nind, stream, sl);
     }
     int lanes = 0;
     if (can) {
@@ -567,6 +588,15 @@ int dangx_plane_set_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int
         lanes = dx_planeset_lanes(ctx, g, sl, 1);
     }
     if (!lanes) {  // the calls this entry point stands for, through the two-step fusions where they apply
+        {   // template / monopole / hi_fit components in the model: the solve is the Schur path (or sees them as other components),
+            // and the sweeps beside them go together where the sweeps-only launch covers them (dangx_plane_sweeps_sample)
+            GroupArgs gq;
+            if (make_group(ctx, group, flag, gq)) return 1;
+            if (gq.nt != 0 || gq.nuc != 0) {
+                const int rc = dangx_amp_sample(ctx, group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, i_max, converge, cg_iters, n_not_spd);
+                return rc ? rc : dangx_plane_sweeps_sample(ctx, flag, nsweeps, comp, nind, stream, nsample, ml_mode, seed_index, accepted);
+            }
+        }
         int s = 0;
         int64_t acc = 0, acc2 = 0;
         int rc = dangx_amp_index_sample(ctx, group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, i_max, converge, comp[0], nind[0],
@@ -616,7 +646,7 @@ int dangx_plane_sweeps_sample(dangx_ctx* ctx, int flag, int nsweeps, const int32
     int lanes = 0;
     if (can) {
         if (make_group(ctx, group, flag, g)) return 1;
-        if (planeset_group(ctx, g) && planeset_items(ctx, g, map_n, nsweeps, comp, nind, stream, sl)) {
+        if (planeset_group(ctx, g, (map_n == -1) ? 2 : map_n, (map_n == -1) ? 3 : map_n, 0) && planeset_items(ctx, g, map_n, nsweeps, comp, nind, stream, sl)) {
             sl.nsample = nsample; sl.ml_mode = ml_mode; sl.seed = seed;
             g.ml_mode = ml_mode; g.fluct = DANGX_FLUCT_REFERENCE; g.seed = 0; g.stream = 0;
             lanes = dx_planeset_lanes(ctx, g, sl, 0);

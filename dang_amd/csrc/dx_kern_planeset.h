@@ -46,7 +46,7 @@ template <int MODE, int PAIR, int SP, int NBL, int LP, int NG, bool FIRST, bool 
 __device__ __forceinline__ void ps_item(const Model& M, const SweepList& sl, const SweepItem& it, RFirst& R0, int i, int half,
                                         int jb, int NB, const double* __restrict__ tab, const double* __restrict__ col,
                                         double& sample0, double& sample1, double chi_first[4],
-                                        double chi_last[4], unsigned long long* __restrict__ accepted, int slot, const double* first_acc) {
+                                        double chi_last[4], unsigned int* __restrict__ accepted, int slot, const double* first_acc) {
     const Comp& c = M.comp[it.comp];
     const BandPick<LP> pick = {half};
     const int npix = M.npix;
@@ -102,10 +102,11 @@ __device__ __forceinline__ void ps_item(const Model& M, const SweepList& sl, con
 #pragma unroll
             for (int j = 0; j < NBL; ++j) R0.D[kk][j] = R.D[kk][j];
     }
-    if (accepted) {  // per-sweep counters ([slot], [slot + 1] for the paired sweep): a diagnostic output, so one atomic per lane that
-        // accepted something (this code runs inside the pixel's live branch: no cross-lane reduction here)
-        if (na) atomicAdd(accepted + slot, na);
-        if (nb_) atomicAdd(accepted + slot + 1, nb_);
+    if (accepted) {  // per-sweep counters ([slot], [slot + 1] for the paired sweep), a diagnostic output: summed over the block in LDS
+        // (this code runs inside the pixel's live branch: no cross-lane reduction here), one global atomic per block and counter at
+        // the kernel's end -- one per lane straight to memory queued ~20 M same-address atomics behind the launch, +35 % on its time
+        if (na) atomicAdd(accepted + slot, (unsigned int)na);
+        if (nb_) atomicAdd(accepted + slot + 1, (unsigned int)nb_);
     }
 }
 
@@ -133,6 +134,8 @@ __global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP, SOLVE, C0)) void k_p
     const int i = in_range ? (int)u : 0;
     const double mk = M.mask[i];
     sed_table_build(M, tab, tid, BLOCK, ga.gc, NG);
+    __shared__ unsigned int acc_blk[DX_MAX_IDXSUM];   // accepted proposals of the block, per counter of the sweep list
+    if (tid < DX_MAX_IDXSUM) acc_blk[tid] = 0u;
     __syncthreads();
     double chi[4] = {0.0, 0.0, 0.0, 0.0};
     // masked sums of the index maps the launch sweeps (mask_avg's numerator, src/dang_util_mod.f90:186-206: what write_stats_to_term
@@ -291,6 +294,15 @@ __global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP, SOLVE, C0)) void k_p
                     for (int j = 0; j < NBL; ++j) R0.D[kk][j] -= amp2 * m[j];
                 }
             }
+            // `template` components with a signal on these planes (sweeps alone; the launcher's list ga.uc): eval_signal =
+            // template_amplitudes(band, map) * template(pix, map) (src/dang_component_mod.f90:754-776), one more "other component"
+#pragma unroll 1
+            for (int t = 0; t < ga.nuc; ++t) {
+                const Comp& ct = M.comp[ga.uc[t]];
+                const double tv = ct.tmpl[(long long)(k - 1) * npix + i];
+#pragma unroll
+                for (int j = 0; j < NBL; ++j) R0.D[kk][j] -= ct.tamp[k - 1][jb + j] * tv;
+            }
 #pragma unroll
             for (int j = 0; j < NBL; ++j) {
                 R0.D[kk][j] *= R0.ISr[kk][j];
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP, SOLVE, C0)) void k_p
                 // a component's sweeps are consecutive and travel in ONE item: no lane reads here what its partner wrote
                 load_theta(M, c, i, sl.s1, sample0, sample1);
                 ps_item<(CODE & 7), (CODE >> 3), SP, NBL, LP, NG, FIRST, LAST, (BP != 0)>(M, sl, it, R0, i, half, jb, NB, tab, col, sample0, sample1,
-                                                                              FIRST ? chi : unused, chi, accepted, slot, first_acc);
+                                                                              FIRST ? chi : unused, chi, accepted ? acc_blk : nullptr, slot, first_acc);
                 slot += 1 + (CODE >> 3);
             }
         };
@@ -357,6 +369,10 @@ __global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP, SOLVE, C0)) void k_p
         run(ItemCode<C1>{}, ItemFlag<false>{}, ItemFlag<C2 == 0>{}, 1);
         run(ItemCode<C2>{}, ItemFlag<false>{}, ItemFlag<C3 == 0>{}, 2);
         run(ItemCode<C3>{}, ItemFlag<false>{}, ItemFlag<true>{}, 3);
+    }
+    if (accepted && NS > 0) {
+        __syncthreads();
+        if (tid < NS && acc_blk[tid] != 0u) atomicAdd(accepted + tid, (unsigned long long)acc_blk[tid]);
     }
     if (chi_partial) {
         // (the values the chains ended on are read back from the index maps -- this lane's own stores -- rather than carried in

@@ -238,3 +238,95 @@ def test_bandpass_integrated_bands_run_the_plane_set_kernel(built, config, nside
         assert np.abs(a - b).max() <= 1e-9 * max(np.abs(b).max(), 1e-30), l
         if comps[l].nindices:
             assert np.abs(eng.get_indices(l) - orc.indices(l)).max() <= 1e-12, l
+
+
+def _template_case(config, nside):
+    from test_oracle_templates_cpu import add_globals
+
+    def tweak(dpar, ddata, bands, comps):
+        nb = ddata.sig_map.shape[0]
+        add_globals(dpar, ddata, bands, comps, ("template",), 2, fit_bands=[nb - 2, nb - 1])
+    return make_case(config, nside=nside, start="truth", tweak=tweak)
+
+
+def _copy_group_state(eng, orc, comps, group):
+    """The state the GPU's Schur solve left -> the oracle (whose direct solve covers per-pixel members only)."""
+    for l, c in enumerate(comps):
+        if c.cg_group != group:
+            continue
+        if c.type == "template":
+            orc.template_amplitudes(l)[:] = eng.get_template_amplitudes(l)
+        else:
+            orc.amplitude(l)[:] = eng.get_amplitude(l)
+
+
+@pytest.mark.parametrize("config,nside", [("C3", 8), ("C2", 8)])
+def test_sweeps_beside_a_fitted_template_run_the_plane_set_kernels(built, config, nside):
+    """SURVEY 8f rank 1's model shape: diffuse components and a Q/U template whose per-band amplitudes are fitted in the Q+U group.
+    The template has no signal on T (its T plane is zero), so the T group keeps its plane-set launches; on Q+U the coupled solve is
+    the Schur one and the sweeps that follow are ONE launch that takes the template's signal out of the data like any other
+    component outside the sweep (src/dang_sample_mod.f90:331-352).  Sweeps against the oracle on the same state: indices 1e-12,
+    accepted counts equal, chi^2 1e-10; the profile shows one sweep launch per plane set and no stand-alone chi^2 pass."""
+    case = _template_case(config, nside)
+    dpar, ddata, bands, comps, meta = case
+    eng, orc = pair(case)
+    nmaps = meta["nmaps"]
+    tl = len(comps) - 1
+    for it in (2, 3):
+        for g in dpar.cg_groups:
+            f = g.pol_flag[0]
+            s = da.stream_id(it, 0, g.cg_group, 0, f)
+            _, bad = eng.amp_sample(g.cg_group, f, "sample", dpar.seed, s)
+            assert bad == 0
+            if g.cg_group == 2:
+                _copy_group_state(eng, orc, comps, 2)
+            else:
+                orc.amp_sample_direct(g.cg_group, f, "sample", dpar.seed, s, "reference")
+        assert np.abs(eng.get_template_amplitudes(tl)[1]).max() > 0.0
+        eng.profile(True)
+        counts = {}
+        for g in dpar.cg_groups:
+            f = g.pol_flag[0]
+            sw = _plane_sweep_list(comps, g.cg_group, f, it)
+            for (l, j, st), a in zip(sw, eng.plane_sweeps_sample(f, sw, dpar.nsample, "sample", dpar.seed)):
+                counts[(l, j, f)] = a
+        after = eng.chisq_cached(1, 1, nmaps)
+        prof = eng.profile_get()
+        eng.profile(False)
+        assert prof["k_index_mh"]["launches"] == len(dpar.cg_groups) and "k_sky_chisq" not in prof, prof
+        for (l, j, f), a in counts.items():
+            assert a == orc.sample_index_mh(l, j, MAPN[f], dpar.nsample, "sample", dpar.seed, da.stream_id(it, 1, l, j, f)), (it, l, j)
+        for l in range(len(comps)):
+            if comps[l].nindices:
+                assert np.abs(eng.get_indices(l) - orc.indices(l)).max() <= 1e-12, (it, l)
+        ochi, _ = orc.chisq(1, nmaps, 1.0)
+        assert after is not None and abs(after / meta["nbands"] - ochi) <= 1e-10 * ochi
+        assert abs(eng.sky_model_chisq(1, nmaps) - after) <= 1e-10 * after
+
+
+@pytest.mark.parametrize("config,nside", [("C3", 8), ("C2", 8)])
+def test_one_call_form_beside_a_fitted_template(built, config, nside):
+    """dangx_plane_set_sample on the same model: the T group (the template carries nothing there) is one launch, solve and sweeps;
+    the Q+U group is the Schur solve followed by the sweeps-only launch -- bit for bit what the two calls give, and the driver's
+    iteration (sample_cg_groups + sample_spectral_parameters) lands on the same maps."""
+    case = _template_case(config, nside)
+    dpar, ddata, bands, comps, meta = case
+    one, two = da.Engine(bands, comps, ddata, npix_global=meta["npix_global"], device=0), da.Engine(bands, comps, ddata, npix_global=meta["npix_global"], device=0)
+    it = 2
+    one.profile(True)
+    for g in dpar.cg_groups:
+        f = g.pol_flag[0]
+        s = da.stream_id(it, 0, g.cg_group, 0, f)
+        sw = _plane_sweep_list(comps, g.cg_group, f, it)
+        bad1, acc1 = one.plane_set_sample(g.cg_group, f, "sample", dpar.seed, s, sw, dpar.nsample, dpar.seed)
+        _, bad2 = two.amp_sample(g.cg_group, f, "sample", dpar.seed, s)
+        acc2 = two.plane_sweeps_sample(f, sw, dpar.nsample, "sample", dpar.seed)
+        assert bad1 == bad2 == 0 and acc1 == acc2, (g.cg_group, acc1, acc2)
+    prof = one.profile_get()
+    one.profile(False)
+    assert prof["k_amp_index"]["launches"] == 1 and prof["k_index_mh"]["launches"] == 1, prof      # T: one launch; Q+U: the sweeps
+    for l in range(len(comps)):
+        assert np.array_equal(one.get_amplitude(l), two.get_amplitude(l)), l
+        if comps[l].nindices:
+            assert np.array_equal(one.get_indices(l), two.get_indices(l)), l
+    assert np.array_equal(one.get_template_amplitudes(len(comps) - 1), two.get_template_amplitudes(len(comps) - 1))

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Whole Gibbs iterations of the C3 model WITH a fitted polarisation template in the Q+U group (the shape of the
+runs dang was written for -- diffuse components beside a dust template whose per-band amplitudes are fitted): the Schur solve of
+the coupled group, the T group's plane-set launch and the Q+U sweeps beside a template.  Prints ms per iteration and the launch
+profile by kernel family."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dang_amd as da  # noqa: E402
+from dang_amd import synth  # noqa: E402
+from dang_amd.api import DangComps  # noqa: E402
+
+nside = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+plain = len(sys.argv) > 3 and sys.argv[3] == "plain"      # the same sky without the template: what the template costs
+start = sys.argv[4] if len(sys.argv) > 4 else "truth"
+counts = len(sys.argv) > 5 and sys.argv[5] == "counts"   # read the accepted-proposal counts back after every launch (a diagnostic)
+dev = torch.device("cuda", 0)
+dpar, ddata, bands, comps, meta = synth.make_sky("C3", nside=nside, device=dev, as_numpy=False, start=start)
+npix, nb = meta["npix"], meta["nbands"]
+g = torch.Generator(device="cpu").manual_seed(3)
+tmpl = torch.zeros(3, npix, dtype=torch.float64)
+tmpl[1:] = torch.randn(2, npix, generator=g, dtype=torch.float64)
+corr = [j in (7, 8, 9) for j in range(nb)]
+truth = np.zeros((3, nb)); truth[1:, 7:] = [2.0, -1.5, 0.7]
+for k in (1, 2):
+    for j in range(nb):
+        if not plain:
+            ddata.sig_map[j, k] += truth[k, j] * tmpl[k].to(dev)
+if not plain:
+  comps.append(DangComps(label="tmpl", type="template", nu_ref=100.0, cg_group=2, nindices=0, nfit=3, corr=corr,
+                         template=tmpl.numpy(), template_amplitudes=np.zeros((3, nb)),
+                         amplitude=torch.zeros(3, npix, dtype=torch.float64, device=dev)))
+eng = da.initialize(bands, comps, ddata, npix_global=meta["npix_global"], device=0)
+for it in (1, 2):
+    da.gibbs_iteration(dpar, ddata, it, want_counts=counts)
+eng.profile(True)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for it in range(3, 3 + steps):
+    da.gibbs_iteration(dpar, ddata, it, want_counts=counts)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / steps
+prof = eng.profile_get()
+print("template model: %.2f ms per Gibbs iteration (%.1f it/s); chisq %.6f; template amplitudes %s"
+      % (1e3 * dt, 1.0 / dt, ddata.chisq, "-" if plain else np.round(eng.get_template_amplitudes(len(comps) - 1)[1, 7:], 4)))
+for k, v in prof.items():
+    print("  %-14s %3d launches per iteration, %8.3f ms per iteration" % (k, v["launches"] // steps, v["total_ms"] / steps))
