@@ -103,6 +103,8 @@ SYMBOLS = {
     "dangx_plane_set_sample": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_double,
                                          C.c_int, _P, _P, _P, C.c_int, C.c_uint64, C.POINTER(C.c_int), C.POINTER(C.c_int64), _P]),
     "dangx_plane_sweeps_sample": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_uint64, _P]),
+    "dangx_sky_plane_set_sample": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int,
+                                             C.c_double, C.c_int, _P, _P, _P, C.c_int, C.c_uint64, C.POINTER(C.c_int), C.POINTER(C.c_int64), _P]),
     "dangx_sky_model_chisq": (C.c_int, [_P, C.c_int, C.c_int, _D, _P, _P, _P]),
     "dangx_sky_model_chisq_dev": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "dangx_chisq_cached": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _D]),

@@ -721,6 +721,25 @@ def sky_amp_sample(engines, group, flag, ml_mode, seed, stream, solver="direct",
     return it.value, bad.value
 
 
+def sky_plane_set_sample(engines, group, flag, ml_mode, seed_amp, stream_amp, sweeps, nsample, seed_index, solver="direct",
+                         fluct_mode="reference", i_max=100, converge=1e-8, want_counts=True):
+    """Engine.plane_set_sample over several pixel-shard contexts of ONE process (dangx_sky_plane_set_sample): a group with template
+    members shares its Schur rows over the contexts, and where the plane-set kernel covers the model its back-substitution runs in
+    the launch that does the sweeps.  Returns (cg_iters, n_not_spd, [accepted proposals per sweep])."""
+    arr, n = _ctx_array(engines)
+    ns = len(sweeps)
+    comp = np.ascontiguousarray([s[0] for s in sweeps], dtype=np.int32)
+    nind = np.ascontiguousarray([s[1] for s in sweeps], dtype=np.int32)
+    strm = np.ascontiguousarray([s[2] for s in sweeps], dtype=np.uint64)
+    it, bad, acc = C.c_int(0), C.c_int64(0), np.zeros(ns, dtype=np.int64)
+    engines[0]._chk(engines[0].lib.dangx_sky_plane_set_sample(
+        arr, n, group, flag, L.ML_CODES[ml_mode], L.SOLVER_CG if solver == "cg" else L.SOLVER_DIRECT,
+        L.FLUCT_REFERENCE if fluct_mode == "reference" else L.FLUCT_CORRECT, seed_amp, stream_amp, i_max, converge,
+        ns, comp.ctypes.data, nind.ctypes.data, strm.ctypes.data, nsample, seed_index, C.byref(it),
+        C.byref(bad) if want_counts else None, acc.ctypes.data if want_counts else None))
+    return it.value, bad.value, [int(a) for a in acc]
+
+
 def compute_chisq(ddata):
     """update_sky_model + compute_chisq (src/dang_data_mod.f90:339-396, 494-526); all-reduced over shards."""
     eng = ddata.engine

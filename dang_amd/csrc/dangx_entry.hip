@@ -86,6 +86,7 @@ extern "C" {
 
 static int planeset_launch(dangx_ctx* ctx, const GroupArgs& g, const SweepList& sl, int lanes, int solve, int64_t* n_not_spd, int64_t* accepted);
 static bool planeset_group(dangx_ctx* ctx, GroupArgs& g, int s1, int s2, int solve);
+static bool planeset_items(dangx_ctx* ctx, const GroupArgs& g, int map_n, int nsweeps, const int32_t* comp, const int32_t* nind, const uint64_t* stream, SweepList& sl);
 
 int dangx_amp_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed,
                      uint64_t stream, int i_max, double converge, int* cg_iters, int64_t* n_not_spd) {
@@ -531,6 +532,9 @@ static bool planeset_items(dangx_ctx* ctx, const GroupArgs& g, int map_n, int ns
 // zero on these planes (a Q/U dust template seen from the T plane set) has no signal there and is ignored -- also by the solve,
 // whose compute_rhs would remove tamp * 0 on its unfitted bands (:445-460).  Monopoles (also the band offset, quirk 6), hi_fit
 // (a per-pixel Planck factor) and T_cmb components with a signal on the planes keep the run-time-typed kernels.
+// solve = 2: the back-substitution of a template group's Schur solve (dangx_sky_plane_set_sample) followed by the sweeps: every
+// template with a signal on the planes must then be a global member of THIS group (its new amplitudes, on every band, are what pass 2
+// removes from the data: dx_ampreg.h, HT form), and the group has no monopole / hi_fit member.
 static bool planeset_group(dangx_ctx* ctx, GroupArgs& g, int s1, int s2, int solve) {
     unsigned planes = 0;
     for (int k = s1; k <= s2; ++k) planes |= 1u << (k - 1);
@@ -539,10 +543,16 @@ static bool planeset_group(dangx_ctx* ctx, GroupArgs& g, int s1, int s2, int sol
         const int t = ctx->desc[l].type;
         if (t == DANGX_TCMB) return false;
         if (!is_global_type(t) || !(ctx->tmpl_nz[l] & planes)) continue;
-        if (solve || t != DANGX_TEMPLATE || ntg == 4) return false;
+        if (solve == 1 || t != DANGX_TEMPLATE || ntg == 4) return false;
+        if (solve == 2) {
+            bool member = false;
+            for (int q = 0; q < g.nt; ++q) member = member || g.tc[q] == l;
+            if (!member) return false;
+        }
         tg[ntg++] = l;
     }
-    if (solve && g.nt != 0) return false;               // a coupled solve is the Schur path
+    if (solve == 1 && g.nt != 0) return false;          // a coupled solve is the Schur path
+    if (solve == 2 && g.nt != ntg) return false;        // a global member without a signal here, or of another type
     for (int o = 0; o < g.no; ++o)                      // any other diffuse component with a signal on the planes
         if (!is_global_type(ctx->desc[g.oc[o]].type)) return false;
     g.nuc = ntg;
@@ -592,6 +602,11 @@ int dangx_plane_set_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int
             // and the sweeps beside them go together where the sweeps-only launch covers them (dangx_plane_sweeps_sample)
             GroupArgs gq;
             if (make_group(ctx, group, flag, gq)) return 1;
+            if (gq.nt != 0 && solver == DANGX_SOLVER_DIRECT) {   // a coupled group: the Schur solve, its back-substitution with the sweeps
+                dangx_ctx* one[1] = {ctx};
+                return dangx_sky_plane_set_sample(one, 1, group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, i_max, converge, nsweeps,
+                                                  comp, nind, stream, nsample, seed_index, cg_iters, n_not_spd, accepted);
+            }
             if (gq.nt != 0 || gq.nuc != 0) {
                 const int rc = dangx_amp_sample(ctx, group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, i_max, converge, cg_iters, n_not_spd);
                 return rc ? rc : dangx_plane_sweeps_sample(ctx, flag, nsweeps, comp, nind, stream, nsample, ml_mode, seed_index, accepted);
@@ -619,6 +634,91 @@ int dangx_plane_set_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int
         return 0;
     }
     return planeset_launch(ctx, g, sl, lanes, 1, n_not_spd, accepted);
+}
+
+// dangx_plane_set_sample over several contexts of ONE process (include/dangx.h).  Diffuse groups: that call on every context.  A
+// group with global-amplitude members couples the contexts through its Schur rows (dangx_sky_amp_sample); where its global members
+// are `template` components and the plane-set kernel covers the model, a well-conditioned solve (device_schur) leaves its
+// back-substitution -- the per-pixel solve on the data minus the templates' NEW signal -- to the launch that runs the sweeps:
+// pass 1, the small host solve, then ONE launch per context instead of pass 2, the residual pass and the sweeps.
+int dangx_sky_plane_set_sample(dangx_ctx* const* ctxs, int nctx, int group, int flag, int ml_mode, int solver, int fluct_mode,
+                               uint64_t seed_amp, uint64_t stream_amp, int i_max, double converge, int nsweeps, const int32_t* comp,
+                               const int32_t* nind, const uint64_t* stream, int nsample, uint64_t seed_index, int* cg_iters,
+                               int64_t* n_not_spd, int64_t* accepted) {
+    DxRange rg_("dangx_sky_plane_set_sample");
+    if (!ctxs || nctx < 1 || nctx > 64 || nsweeps < 1 || !comp || !nind || !stream) return 1;
+    for (int r = 0; r < nctx; ++r) if (!ctxs[r]) return 1;
+    dangx_ctx* c0 = ctxs[0];
+    auto bubble = [&](dangx_ctx* who) { if (who != c0) c0->err = who->err; return 1; };
+    GroupArgs probe;
+    if (make_group(c0, group, flag, probe)) return 1;
+    if (cg_iters) *cg_iters = 0;
+    if (n_not_spd) *n_not_spd = 0;
+    std::vector<int64_t> acc((size_t)nsweeps, 0);
+    if (accepted) for (int s = 0; s < nsweeps; ++s) accepted[s] = 0;
+    auto add_acc = [&]() { if (accepted) for (int s = 0; s < nsweeps; ++s) accepted[s] += acc[(size_t)s]; };
+    if (probe.nt == 0 || solver != DANGX_SOLVER_DIRECT) {
+        if (probe.nt != 0 && nctx > 1)
+            return fail(c0, "the device CG (DANGX_SOLVER_CG) iterates on ONE context per process: use DANGX_SOLVER_DIRECT, or one process per GPU with dangx_set_allreduce");
+        for (int r = 0; r < nctx; ++r) {
+            int64_t bad = 0;
+            if (dangx_plane_set_sample(ctxs[r], group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, i_max, converge, nsweeps, comp, nind,
+                                       stream, nsample, seed_index, r == 0 ? cg_iters : nullptr, n_not_spd ? &bad : nullptr, accepted ? acc.data() : nullptr))
+                return bubble(ctxs[r]);
+            if (n_not_spd) *n_not_spd += bad;
+            add_acc();
+        }
+        return 0;
+    }
+    const int map_n = (flag == DANGX_FLAG_T) ? 1 : (flag == DANGX_FLAG_Q) ? 2 : (flag == DANGX_FLAG_U) ? 3 : (flag == DANGX_FLAG_QU) ? -1 : 0;
+    if (map_n == 0) return fail(c0, "flag must be exactly one of T(1), Q(2), U(4), Q+U(8)");
+    if (ml_mode != DANGX_ML_SAMPLE && ml_mode != DANGX_ML_OPTIMIZE) return fail(c0, "bad ml_mode");
+    if (fluct_mode != DANGX_FLUCT_REFERENCE && ml_mode == DANGX_ML_SAMPLE)
+        return fail(c0, "groups with template / monopole / hi_fit members reproduce the reference's fluctuation term only");
+    static const bool enabled = [] { const char* e = getenv("DANGX_FUSE"); return !(e && e[0] == '0'); }();
+    const int s1 = (map_n == -1) ? 2 : map_n, s2 = (map_n == -1) ? 3 : map_n;
+    std::vector<GroupArgs> as((size_t)nctx), gs((size_t)nctx);
+    std::vector<SweepList> sls((size_t)nctx);
+    std::vector<long long> SNs((size_t)nctx);
+    std::vector<int> lanes((size_t)nctx, 0);
+    bool fuse = enabled && nsweeps <= 2 * DX_MAX_SWEEPS;
+    for (int r = 0; r < nctx; ++r) {
+        dangx_ctx* c = ctxs[r];
+        (void)hipSetDevice(c->device);
+        for (int s = 0; s < nsweeps; ++s)
+            if (check_comp(c, comp[s]) || nind[s] < 0 || nind[s] >= c->desc[comp[s]].nindices) { fail(c, "sweep list: component / index out of range"); return bubble(c); }
+        if (make_group(c, group, flag, as[r]) || sync_model(c)) return bubble(c);
+        as[r].ml_mode = ml_mode; as[r].fluct = fluct_mode; as[r].seed = seed_amp; as[r].stream = stream_amp;
+        SNs[r] = (long long)flag_planes_h(flag) * c->hm.npix;
+        for (int k = s1; k <= s2; ++k) {
+            c->chi_before_valid[k - 1] = c->chi_after_valid[k - 1] = c->touched_since_amp[k - 1] = false;
+            for (int g = 0; g < as[r].ng; ++g) c->plane_nz[as[r].gc[g]] |= 1u << (k - 1);
+        }
+        if (as[r].nglob != as[0].nglob || as[r].nt != as[0].nt) return fail(c0, "the contexts disagree on the group's global-amplitude members");
+        if (fuse) {
+            gs[r] = as[r];
+            std::memset(&sls[r], 0, sizeof(SweepList));
+            fuse = planeset_group(c, gs[r], s1, s2, 2) && planeset_items(c, gs[r], map_n, nsweeps, comp, nind, stream, sls[r]);
+            if (fuse) {
+                sls[r].nsample = nsample; sls[r].ml_mode = ml_mode; sls[r].seed = seed_index;
+                lanes[r] = dx_planeset_lanes(c, gs[r], sls[r], 1);
+                fuse = lanes[r] != 0;
+            }
+        }
+    }
+    int nullity = 0, defer = fuse ? 1 : 0;
+    if (device_schur(ctxs, nctx, as.data(), SNs.data(), n_not_spd, &nullity, &defer)) return 1;
+    if (cg_iters) *cg_iters = -nullity;
+    for (int r = 0; r < nctx; ++r) {
+        dangx_ctx* c = ctxs[r];
+        (void)hipSetDevice(c->device);
+        // (pass 1 has counted the units whose block is not positive definite: the launch's own count of the same units is not read)
+        const int rc = defer ? planeset_launch(c, gs[r], sls[r], lanes[r], 1, nullptr, accepted ? acc.data() : nullptr)
+                             : dangx_plane_sweeps_sample(c, flag, nsweeps, comp, nind, stream, nsample, ml_mode, seed_index, accepted ? acc.data() : nullptr);
+        if (rc) return bubble(c);
+        add_acc();
+    }
+    return 0;
 }
 
 // dangx_index_sample(comp[s], nind[s], map_n of the flag, ...) for s = 0 .. nsweeps-1: the passes of sample_spectral_parameters

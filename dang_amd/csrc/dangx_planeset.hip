@@ -104,6 +104,7 @@ int dx_planeset_lanes(dangx_ctx* ctx, const GroupArgs& ga, const SweepList& sl, 
     }
     FusedArgs fa;
     if (!planeset_args(ctx, ga, sl, fa)) return 0;
+    if (solve && fa.cal && ga.nuc > 0) return 0;   // the kernel removes the templates before the solve's T / gain (no such model yet)
     const int bp = planeset_bp(ctx);
     if (bp) {  // sample loops exist for the power-law and mbb chains, in the one-lane form
         for (int q = 0; q < sl.n; ++q)

@@ -11,6 +11,9 @@
 #ifndef DX_SCHUR_HF
 #define DX_SCHUR_HF 0
 #endif
+#ifndef DX_P1_WAVES        // waves per SIMD pass 1 is compiled for (3 costs it 275 spilled registers)
+#define DX_P1_WAVES 2
+#endif
 #ifndef DX_SCHUR_PART      // 1: pass 1, 2: the residual pass (four units in all)
 #define DX_SCHUR_PART 1
 #endif
@@ -26,7 +29,7 @@ constexpr bool HFV = DX_SCHUR_HF != 0;
 // Cholesky factor the R^2 + 3R row values of the unit and one block reduction for all of them.
 //   rows [0, R^2): S[r][r'] ; [R^2, R^2+R): t[r] ; [R^2+R, R^2+2R): fluctuation sum of natural row r ; [R^2+2R, R^2+3R): G[r][r]
 template <int NG, int TB, int SS, bool HF>
-__global__ __launch_bounds__(BLOCK, 2) void k_schur_pass1_reg(const Model* __restrict__ Mp, GroupArgs a, AmpRegArgs ra, SchurArgs sa,
+__global__ __launch_bounds__(BLOCK, DX_P1_WAVES) void k_schur_pass1_reg(const Model* __restrict__ Mp, GroupArgs a, AmpRegArgs ra, SchurArgs sa,
                                                              double* __restrict__ rowpartial, unsigned long long* __restrict__ not_spd) {
     constexpr int NV = SS * SS + 3 * SS;   // row values of a unit (R <= SS)
     extern __shared__ double lds[];

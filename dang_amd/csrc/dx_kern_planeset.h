@@ -176,6 +176,24 @@ __global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP, SOLVE, C0)) void k_p
 #pragma unroll
                 for (int j = 0; j < NBL; ++j) { R0.D[kk][j] = sigp[(jb + j) * bstride]; R0.ISr[kk][j] = rmsp[(jb + j) * bstride]; }
             }
+            auto cal_transform = [&]() {  // data_raw = (sig - offset) / gain on the temperature plane (:174)
+                const double* gn = tab + (TROWS * NG + 1) * NB + jb;
+#pragma unroll
+                for (int j = 0; j < NBL; ++j) R0.D[kk][j] = (R0.D[kk][j] - gn[NB + j]) / gn[j];
+            };
+            if (!SOLVE && SP == 1 && fa.cal) cal_transform();
+            // `template` components with a signal on these planes (the launcher's list ga.uc): eval_signal = template_amplitudes(band,
+            // map) * template(pix, map) (src/dang_component_mod.f90:754-776), taken out of the data first.  For the sweeps it is one
+            // more "other component"; for a solve (the back-substitution of a template group's Schur solve, dangx_sky_plane_set_sample:
+            // the group's templates with their NEW amplitudes) it is compute_rhs' data minus the global members' share of A x
+            // (k_amp_reg's HT form, dangx_ampreg.hip) -- the same data either way
+#pragma unroll 1
+            for (int t = 0; t < ga.nuc; ++t) {
+                const Comp& ct = M.comp[ga.uc[t]];
+                const double tv = ct.tmpl[(long long)(k - 1) * npix + i];
+#pragma unroll
+                for (int j = 0; j < NBL; ++j) R0.D[kk][j] -= ct.tamp[k - 1][jb + j] * tv;
+            }
             double bv[NG];
             if (SOLVE) {
                 // ---- the block solve of unit (i, k) (k_amp_index's), amplitudes stored for the sweeps
@@ -276,11 +294,7 @@ __global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP, SOLVE, C0)) void k_p
             // (:180-196 removes all but the sampled one; its own signal returns in the chain's first evaluation).  Member by member,
             // each through ONE base address and compile-time offsets (a run-time stride costs one address register per load: the
             // solve's band loop above pays that)
-            if (SP == 1 && fa.cal) {  // data_raw = (sig - offset) / gain on the temperature plane (:174)
-                const double* gn = tab + (TROWS * NG + 1) * NB + jb;
-#pragma unroll
-                for (int j = 0; j < NBL; ++j) R0.D[kk][j] = (R0.D[kk][j] - gn[NB + j]) / gn[j];
-            }
+            if (SOLVE && SP == 1 && fa.cal) cal_transform();
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const double amp2 = bv[g];
@@ -293,15 +307,6 @@ __global__ __launch_bounds__(BLOCK, DX_PS_WAVES(SP, NB, LP, SOLVE, C0)) void k_p
 #pragma unroll
                     for (int j = 0; j < NBL; ++j) R0.D[kk][j] -= amp2 * m[j];
                 }
-            }
-            // `template` components with a signal on these planes (sweeps alone; the launcher's list ga.uc): eval_signal =
-            // template_amplitudes(band, map) * template(pix, map) (src/dang_component_mod.f90:754-776), one more "other component"
-#pragma unroll 1
-            for (int t = 0; t < ga.nuc; ++t) {
-                const Comp& ct = M.comp[ga.uc[t]];
-                const double tv = ct.tmpl[(long long)(k - 1) * npix + i];
-#pragma unroll
-                for (int j = 0; j < NBL; ++j) R0.D[kk][j] -= ct.tamp[k - 1][jb + j] * tv;
             }
 #pragma unroll
             for (int j = 0; j < NBL; ++j) {

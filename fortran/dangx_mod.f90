@@ -385,6 +385,20 @@ module dangx_mod
        integer(c_int), intent(out), optional :: cg_iters
        integer(c_int64_t), intent(out), optional :: n_not_spd
      end function
+     integer(c_int) function dangx_sky_plane_set_sample_c(ctxs, nctx, group, flag, ml_mode, solver, fluct_mode, seed_amp, stream_amp, &
+          i_max, converge, nsweeps, comp, nind, stream, nsample, seed_index, cg_iters, n_not_spd, accepted) &
+          bind(C, name='dangx_sky_plane_set_sample')
+       import :: c_int, c_ptr, c_int32_t, c_int64_t, c_double
+       type(c_ptr), intent(in) :: ctxs(*)
+       integer(c_int), value :: nctx, group, flag, ml_mode, solver, fluct_mode, i_max, nsweeps, nsample
+       real(c_double), value :: converge
+       integer(c_int64_t), value :: seed_amp, stream_amp, seed_index
+       integer(c_int32_t), intent(in) :: comp(*), nind(*)          ! 0-based, in sample_spectral_parameters' order
+       integer(c_int64_t), intent(in) :: stream(*)
+       integer(c_int), intent(out), optional :: cg_iters
+       integer(c_int64_t), intent(out), optional :: n_not_spd
+       integer(c_int64_t), intent(out), optional :: accepted(*)
+     end function
      integer(c_int) function dangx_plan_fusion(ctx, npairs, pair_group, pair_flag, nsweeps, sweep_comp, sweep_nind, sweep_flag, &
           sweep_plain, solver, first_sweep) bind(C, name='dangx_plan_fusion')
        import :: c_int, c_ptr, c_int32_t

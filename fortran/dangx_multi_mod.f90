@@ -323,32 +323,30 @@ contains
   end subroutine dangx_sky_amp_index_sample
 
   ! dangx_sky_amp_sample(group, flag, ...) followed by dangx_sky_index_sample(comp(s), nind(s), ...) for every sweep on the group's
-  ! planes, in the reference's order, through dangx_plane_set_sample: ONE launch per context for models with many bands and
-  ! members (the members' SED columns stay in LDS across the sweeps), those calls through the two-step fusions otherwise
+  ! planes, in the reference's order, through dangx_sky_plane_set_sample: ONE launch per context for models with many bands and
+  ! members (the members' SED columns stay in LDS across the sweeps); a group with template members shares its Schur rows over the
+  ! contexts and, where the plane-set kernel covers the model, back-substitutes inside the launch that runs the sweeps
   subroutine dangx_sky_plane_set_sample(sky, group, flag, ml_mode, fluct_mode, seed_amp, stream_amp, nsweeps, comp, nind, stream, &
-       nsample, seed_index, n_not_spd, accepted)
+       nsample, seed_index, n_not_spd, accepted, nullity)
     type(dangx_sky), intent(in) :: sky
     integer, intent(in) :: group, flag, ml_mode, fluct_mode, nsweeps, nsample
     integer(c_int32_t), intent(in) :: comp(nsweeps), nind(nsweeps)      ! 0-based
     integer(c_int64_t), intent(in) :: seed_amp, stream_amp, seed_index, stream(nsweeps)
     integer(c_int64_t), intent(out), optional :: n_not_spd, accepted(nsweeps)
+    integer, intent(out), optional :: nullity
     integer(c_int64_t) :: nbad, nacc(nsweeps)
-    integer :: r
+    integer(c_int) :: iters
+    iters = 0
     if (present(n_not_spd) .or. present(accepted)) then
-       if (present(n_not_spd)) n_not_spd = 0
-       if (present(accepted)) accepted = 0
-       do r = 1, sky%nctx
-          call dangx_check(sky%ctx(r), dangx_plane_set_sample(sky%ctx(r), group, flag, ml_mode, DANGX_SOLVER_DIRECT, fluct_mode, seed_amp, &
-               stream_amp, 0, 0.d0, nsweeps, comp, nind, stream, nsample, seed_index, n_not_spd=nbad, accepted=nacc), 'dangx_plane_set_sample')
-          if (present(n_not_spd)) n_not_spd = n_not_spd + nbad
-          if (present(accepted)) accepted = accepted + nacc
-       end do
+       call dangx_check(sky%ctx(1), dangx_sky_plane_set_sample_c(sky%ctx, sky%nctx, group, flag, ml_mode, DANGX_SOLVER_DIRECT, fluct_mode, &
+            seed_amp, stream_amp, 0, 0.d0, nsweeps, comp, nind, stream, nsample, seed_index, iters, nbad, nacc), 'dangx_sky_plane_set_sample')
+       if (present(n_not_spd)) n_not_spd = nbad
+       if (present(accepted)) accepted = nacc
     else
-       do r = 1, sky%nctx
-          call dangx_check(sky%ctx(r), dangx_plane_set_sample(sky%ctx(r), group, flag, ml_mode, DANGX_SOLVER_DIRECT, fluct_mode, seed_amp, &
-               stream_amp, 0, 0.d0, nsweeps, comp, nind, stream, nsample, seed_index), 'dangx_plane_set_sample')
-       end do
+       call dangx_check(sky%ctx(1), dangx_sky_plane_set_sample_c(sky%ctx, sky%nctx, group, flag, ml_mode, DANGX_SOLVER_DIRECT, fluct_mode, &
+            seed_amp, stream_amp, 0, 0.d0, nsweeps, comp, nind, stream, nsample, seed_index, iters), 'dangx_sky_plane_set_sample')
     end if
+    if (present(nullity)) nullity = -iters
   end subroutine dangx_sky_plane_set_sample
 
   ! dangx_sky_index_sample(comp(s), nind(s), ...) for the sweeps of ONE plane set, in the reference's order, through

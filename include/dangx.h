@@ -193,7 +193,9 @@ int dangx_amp_sample(dangx_ctx *ctx, int group, int flag, int ml_mode, int solve
  * compute_sample_vector / compute_Ax, src/dang_cg_mod.f90:326-1096): rel_residual[0] = the largest |b - A x| over the
  * global rows relative to that row of b; rel_residual[1] = the same relative to the size of the row's terms
  * (sum |b terms| + |A x terms|: rounding alone leaves ~1e-16 sqrt(npix) there, and weakly constrained amplitudes are
- * large, so [0] can sit well above [1]); refinements = steps taken (0: the first solution already met 1e-12). */
+ * large, so [0] can sit well above [1]); refinements = steps taken (0: the first solution already met 1e-12).
+ * A well-conditioned system (every pivot of the equilibrated Schur matrix >= 1e-3) is not measured: both numbers are then the
+ * a-priori bound 16 R eps / (smallest pivot) and refinements = 0; the environment variable DANGX_SCHUR_CHECK=1 measures always. */
 int dangx_schur_info(dangx_ctx *ctx, double *rel_residual /*[2]*/, int *refinements);
 /* Residual of the reference's linear system at the CURRENT amplitudes, through the reference's own operators
  * (dangx_compute_rhs + dangx_compute_sample_vector(eta(seed, stream)) - dangx_compute_Ax(x), vectors kept on the device):
@@ -410,6 +412,20 @@ int dangx_plan_fusion(dangx_ctx *ctx, int npairs, const int32_t *pair_group, con
  * check and the refinement steps are shared the same way.  nctx = 1 IS dangx_amp_sample.  DANGX_SOLVER_CG needs nctx = 1. */
 int dangx_sky_amp_sample(dangx_ctx *const *ctxs, int nctx, int group, int flag, int ml_mode, int solver, int fluct_mode,
                          uint64_t seed, uint64_t stream, int i_max, double converge, int *cg_iters, int64_t *n_not_spd);
+
+/* ---- dangx_plane_set_sample over SEVERAL contexts of one process: dangx_sky_amp_sample(ctxs, nctx, group, flag, ...) followed by
+ * dangx_plane_sweeps_sample(ctxs[r], flag, nsweeps, comp, nind, stream, ...) on every context -- what sample_cg_groups
+ * (src/dang_cg_mod.f90:166-171) and the passes of sample_spectral_parameters on the group's planes (src/dang_sample_mod.f90:40-75)
+ * do for one (group, flag) pair.  Diffuse groups: dangx_plane_set_sample on every context.  Groups with global-amplitude members
+ * (:522-587, :833-893) share their Schur rows over the contexts and ranks as in dangx_sky_amp_sample; when the global members are
+ * `template` components, the plane-set kernel covers the model and the small system is well conditioned (every pivot of the
+ * equilibrated Schur matrix >= 1e-3, which bounds the global rows' residual by ~1e-12 |b| without measuring it), the
+ * back-substitution runs inside the launch that does the sweeps: per context pass 1 and ONE launch.  nctx = 1 IS
+ * dangx_plane_set_sample.  accepted[nsweeps], n_not_spd, cg_iters (= -nullity for a coupled group) nullable. */
+int dangx_sky_plane_set_sample(dangx_ctx *const *ctxs, int nctx, int group, int flag, int ml_mode, int solver, int fluct_mode,
+                               uint64_t seed_amp, uint64_t stream_amp, int i_max, double converge, int nsweeps, const int32_t *comp,
+                               const int32_t *nind, const uint64_t *stream, int nsample, uint64_t seed_index, int *cg_iters,
+                               int64_t *n_not_spd, int64_t *accepted);
 
 /* ---- secondary seams (type-bound procedures of dang_cg_group), host vectors in the
  * reference's packing [c1: plane1(npix), plane2(npix) | c2: ... ] -------------------- */

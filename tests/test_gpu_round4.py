@@ -304,29 +304,95 @@ def test_sweeps_beside_a_fitted_template_run_the_plane_set_kernels(built, config
         assert abs(eng.sky_model_chisq(1, nmaps) - after) <= 1e-10 * after
 
 
+def _close_states(a, b, comps, what):
+    for l in range(len(comps)):
+        x, y = a.get_amplitude(l), b.get_amplitude(l)
+        assert np.abs(x - y).max() <= 1e-10 * max(np.abs(y).max(), 1e-30), (what, l)
+        if comps[l].nindices:
+            assert np.abs(a.get_indices(l) - b.get_indices(l)).max() <= 1e-12, (what, l)
+        if comps[l].type == "template":
+            x, y = a.get_template_amplitudes(l), b.get_template_amplitudes(l)
+            assert np.abs(x - y).max() <= 1e-12 * max(np.abs(y).max(), 1e-30), (what, l)
+
+
 @pytest.mark.parametrize("config,nside", [("C3", 8), ("C2", 8)])
-def test_one_call_form_beside_a_fitted_template(built, config, nside):
-    """dangx_plane_set_sample on the same model: the T group (the template carries nothing there) is one launch, solve and sweeps;
-    the Q+U group is the Schur solve followed by the sweeps-only launch -- bit for bit what the two calls give, and the driver's
-    iteration (sample_cg_groups + sample_spectral_parameters) lands on the same maps."""
+def test_one_call_form_beside_a_fitted_template(built, config, nside, monkeypatch):
+    """dangx_plane_set_sample on the same model.  T group (the template carries nothing there): one launch, solve and sweeps.  Q+U
+    group: pass 1 of the Schur solve, the small host solve, then ONE launch that back-substitutes -- the per-pixel solve on the data
+    minus the template's new signal (dx_ampreg.h, HT form) -- and runs the sweeps; granted because the system is well conditioned
+    (device_schur: every pivot >= 1e-3), for which the residual pass is skipped.  With DANGX_SCHUR_CHECK=1 the residual is measured
+    (<= 1e-12 of b, no refinement step: what the skip assumes) and the launches are pass 2, the residual pass and the sweeps.  Both
+    forms and the two-call seam give the same state (the template's signal leaves the data before / after the members': rounding
+    order, 1e-10 of the amplitudes; indices 1e-12; accepted counts equal)."""
     case = _template_case(config, nside)
     dpar, ddata, bands, comps, meta = case
-    one, two = da.Engine(bands, comps, ddata, npix_global=meta["npix_global"], device=0), da.Engine(bands, comps, ddata, npix_global=meta["npix_global"], device=0)
-    it = 2
-    one.profile(True)
-    for g in dpar.cg_groups:
-        f = g.pol_flag[0]
-        s = da.stream_id(it, 0, g.cg_group, 0, f)
-        sw = _plane_sweep_list(comps, g.cg_group, f, it)
-        bad1, acc1 = one.plane_set_sample(g.cg_group, f, "sample", dpar.seed, s, sw, dpar.nsample, dpar.seed)
-        _, bad2 = two.amp_sample(g.cg_group, f, "sample", dpar.seed, s)
-        acc2 = two.plane_sweeps_sample(f, sw, dpar.nsample, "sample", dpar.seed)
-        assert bad1 == bad2 == 0 and acc1 == acc2, (g.cg_group, acc1, acc2)
-    prof = one.profile_get()
-    one.profile(False)
-    assert prof["k_amp_index"]["launches"] == 1 and prof["k_index_mh"]["launches"] == 1, prof      # T: one launch; Q+U: the sweeps
+    mk = lambda: da.Engine(bands, comps, ddata, npix_global=meta["npix_global"], device=0)
+    one, two, chk = mk(), mk(), mk()
+    for it in (2, 3):
+        for which, eng in (("fused", one), ("checked", chk)):
+            monkeypatch.setenv("DANGX_SCHUR_CHECK", "1" if which == "checked" else "0")
+            eng.profile(True)
+            accs = {}
+            for g in dpar.cg_groups:
+                f = g.pol_flag[0]
+                sw = _plane_sweep_list(comps, g.cg_group, f, it)
+                bad, accs[g.cg_group] = eng.plane_set_sample(g.cg_group, f, "sample", dpar.seed, da.stream_id(it, 0, g.cg_group, 0, f), sw, dpar.nsample, dpar.seed)
+                assert bad == 0
+            prof = eng.profile_get()
+            eng.profile(False)
+            (resid, backward), nref = eng.schur_info()
+            if which == "fused":
+                acc1 = accs
+                # T: one launch; Q+U: one launch after pass 1 -- no stand-alone back-substitution, no stand-alone sweeps
+                assert prof["k_amp_index"]["launches"] == 2 and "k_index_mh" not in prof and "k_amp_direct" not in prof, prof
+                assert nref == 0 and resid <= 1e-12
+            else:
+                assert prof["k_amp_index"]["launches"] == 1 and prof["k_index_mh"]["launches"] == 1 and prof["k_amp_direct"]["launches"] == 1, prof
+                assert nref == 0 and resid <= 1e-12, (resid, backward, nref)     # measured: what the skip assumes
+                assert accs == acc1
+        monkeypatch.setenv("DANGX_SCHUR_CHECK", "0")
+        for g in dpar.cg_groups:
+            f = g.pol_flag[0]
+            sw = _plane_sweep_list(comps, g.cg_group, f, it)
+            _, bad2 = two.amp_sample(g.cg_group, f, "sample", dpar.seed, da.stream_id(it, 0, g.cg_group, 0, f))
+            acc2 = two.plane_sweeps_sample(f, sw, dpar.nsample, "sample", dpar.seed)
+            assert bad2 == 0 and acc2 == acc1[g.cg_group], (g.cg_group, acc1, acc2)
+        _close_states(one, two, comps, "one call / two calls")
+        _close_states(one, chk, comps, "fused / checked")
+        lo, hi = ddata.pol_type[0], ddata.pol_type[-1]
+        assert abs(one.chisq_cached(1, lo, hi) - two.chisq_cached(1, lo, hi)) <= 1e-10 * two.chisq_cached(1, lo, hi)
+
+
+@pytest.mark.parametrize("config,nside", [("C3", 8)])
+def test_template_group_over_three_contexts_in_one_call(built, config, nside):
+    """dangx_sky_plane_set_sample: the Schur rows of the template group are shared over three pixel-shard contexts, every context then
+    back-substitutes and sweeps in one launch -- the state of the one-context call on the whole sky (the rows are summed in another
+    order: 1e-10 of the amplitudes)."""
+    case = _template_case(config, nside)
+    dpar, ddata, bands, comps, meta = case
+    whole = da.Engine(bands, comps, ddata, npix_global=meta["npix_global"], device=0)
+    engs = shard_engines(case, 3)
+    bounds = [e.pix0 for e in engs] + [meta["npix"]]
+    for it in (2, 3):
+        for g in dpar.cg_groups:
+            f = g.pol_flag[0]
+            sw = _plane_sweep_list(comps, g.cg_group, f, it)
+            s = da.stream_id(it, 0, g.cg_group, 0, f)
+            bad, acc = whole.plane_set_sample(g.cg_group, f, "sample", dpar.seed, s, sw, dpar.nsample, dpar.seed)
+            for e in engs:
+                e.profile(True)
+            nul, bad3, acc3 = da.sky_plane_set_sample(engs, g.cg_group, f, "sample", dpar.seed, s, sw, dpar.nsample, dpar.seed)
+            assert (nul, bad3, acc3) == (0, bad, acc), (g.cg_group, acc, acc3)
+            for e in engs:
+                prof = e.profile_get()
+                e.profile(False)
+                assert prof["k_amp_index"]["launches"] == 1 and "k_index_mh" not in prof and "k_amp_direct" not in prof, prof
     for l in range(len(comps)):
-        assert np.array_equal(one.get_amplitude(l), two.get_amplitude(l)), l
-        if comps[l].nindices:
-            assert np.array_equal(one.get_indices(l), two.get_indices(l)), l
-    assert np.array_equal(one.get_template_amplitudes(len(comps) - 1), two.get_template_amplitudes(len(comps) - 1))
+        full = whole.get_amplitude(l)
+        for q, e in enumerate(engs):
+            part = e.get_amplitude(l)
+            assert np.abs(part - full[:, bounds[q]:bounds[q + 1]]).max() <= 1e-10 * max(np.abs(full).max(), 1e-30), (l, q)
+            if comps[l].nindices:
+                assert np.abs(e.get_indices(l) - whole.get_indices(l)[:, :, bounds[q]:bounds[q + 1]]).max() <= 1e-12, (l, q)
+        if comps[l].type == "template":
+            assert np.abs(engs[0].get_template_amplitudes(l) - whole.get_template_amplitudes(l)).max() <= 1e-12 * np.abs(whole.get_template_amplitudes(l)).max()
