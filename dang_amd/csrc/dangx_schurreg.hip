@@ -766,6 +766,7 @@ int launch_pass1_ng(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, co
         }
         const size_t ldsz = ((size_t)(TROWS * NG + 3 + 2 * MAXU) * nb + (size_t)ra.nv * nb * BLOCK) * sizeof(double);
         if (qu && ldsz <= most) {
+            if (nb == 10) return launch_pass1_qu<NG, 10>(ctx, a, ra, sa, SN, rows_dev, ldsz);   // every map of a plane requested at once
             if (nb % 5 == 0) return launch_pass1_qu<NG, 5>(ctx, a, ra, sa, SN, rows_dev, ldsz);
             if (nb % 4 == 0) return launch_pass1_qu<NG, 4>(ctx, a, ra, sa, SN, rows_dev, ldsz);
             if (nb % 2 == 0) return launch_pass1_qu<NG, 2>(ctx, a, ra, sa, SN, rows_dev, ldsz);
