@@ -392,8 +392,16 @@ contains
                 lc(q) = sw_comp(e); ln(q) = sw_nind(e)
                 ls(q) = dangx_stream_id(iter, 1, int(sw_comp(e)), int(sw_nind(e)), flag)
              end do
-             call dangx_sky_plane_set_sample(gpu_sky, i, flag, mode, DANGX_FLUCT_REFERENCE, gpu_seed, dangx_stream_id(iter, 0, i, 0, flag), &
-                  nl, lc, ln, ls, nsample, gpu_seed)
+             if (coupled) then   ! the Schur solve's account, as on the two-call path (the call waits for the small system anyway)
+                call dangx_sky_plane_set_sample(gpu_sky, i, flag, mode, DANGX_FLUCT_REFERENCE, gpu_seed, dangx_stream_id(iter, 0, i, 0, flag), &
+                     nl, lc, ln, ls, nsample, gpu_seed, n_not_spd=nbad, nullity=nullity)
+                if (nbad > 0) write(*,*) 'warning: ', nbad, ' non-SPD pixel blocks left unchanged'
+                call dangx_check(gpu_sky%ctx(1), dangx_schur_info(gpu_sky%ctx(1), resid, refinements), 'schur_info')
+                write(*,fmt='(a,es10.2,a,i2,a)') '  global rows: |b - A x| / |b| = ', resid(1), ' after ', refinements, ' refinement(s)'
+             else
+                call dangx_sky_plane_set_sample(gpu_sky, i, flag, mode, DANGX_FLUCT_REFERENCE, gpu_seed, dangx_stream_id(iter, 0, i, 0, flag), &
+                     nl, lc, ln, ls, nsample, gpu_seed)
+             end if
              deallocate(lc, ln, ls)
           else if (coupled .or. per_group_stats) then     ! with the count: the chi^2 pass below waits for the device anyway
              call dangx_sky_amp_sample(gpu_sky, i, flag, mode, DANGX_FLUCT_REFERENCE, gpu_seed, &

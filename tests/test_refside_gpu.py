@@ -197,6 +197,42 @@ def test_wrapper_runs_a_template_and_monopole_group_over_three_contexts(built, t
     assert np.array_equal(a["offset"], a["tamp"][mono][0])
 
 
+def test_wrapper_runs_a_template_group_with_its_sweeps(built, tmp_path):
+    """A Q/U template fitted beside the diffuse members of the Q+U group, indices sampled: gibbs_iteration_gpu hands the group's
+    solve AND the sweeps on its planes to dangx_sky_plane_set_sample -- pass 1 of the Schur solve on every context, the rows
+    shared, then one launch per context that back-substitutes and sweeps.  The two calls of the reference's loop (Schur solve
+    with pass 2 and the residual pass, then the sweeps) give the same state (1e-9 / 1e-12), on one context and on three."""
+    _need_drive()
+
+    def tweak(dpar, ddata, bands, comps):
+        nb = ddata.sig_map.shape[0]
+        add_globals(dpar, ddata, bands, comps, ("template",), 2, fit_bands=[nb - 2, nb - 1])
+    case = make_case("C2", nside=8, start="truth", tweak=tweak)
+    dpar, ddata, bands, comps, meta = case
+    res = {}
+    for mode, nctx in (("twocall", 1), ("fused", 1), ("fused", 3)):
+        d = tmp_path / ("%s%d" % (mode, nctx))
+        d.mkdir()
+        fin, fout = str(d / "in.bin"), str(d / "out.bin")
+        fdrive.write_problem(fin, dpar, ddata, comps, meta, NITER)
+        out = fdrive.run(fin, fout, nctx=nctx, mode=mode)
+        assert out.count("global rows: |b - A x| / |b| =") == NITER      # the Schur solve's account on either path
+        res[(mode, nctx)] = fdrive.read_result(fout, comps, meta)
+    a = res[("twocall", 1)]
+    tl = [l for l, c in enumerate(comps) if c.type == "template"][0]
+    assert np.abs(a["tamp"][tl][1, -2:]).min() > 0 and np.array_equal(a["tamp"][tl][1], a["tamp"][tl][2])
+    for key in (("fused", 1), ("fused", 3)):
+        b = res[key]
+        for l, c in enumerate(comps):
+            scale = max(np.abs(a["amp"][l]).max(), 1e-30)
+            assert np.abs(a["amp"][l] - b["amp"][l]).max() <= 1e-9 * scale, (key, l)
+            if c.nindices:
+                assert np.abs(a["ind"][l] - b["ind"][l]).max() <= 1e-12, (key, l)
+            if a["tamp"][l] is not None:
+                assert np.abs(a["tamp"][l] - b["tamp"][l]).max() <= 1e-9 * max(np.abs(a["tamp"][l]).max(), 1e-30), (key, l)
+        assert abs(a["chisq"] - b["chisq"]) <= 1e-9 * a["chisq"], key
+
+
 def test_wrapper_runs_fullsky_tuner_and_coarse_sweeps(built, tmp_path):
     """sample_spectral_parameters_gpu's other branches, through the chains behind the ABI: a full-sky index whose step is
     tuned first, a per-pixel index with a pending 'Tuning!' block, and a coarse-Nside sweep -- state, step sizes and tuned
