@@ -396,3 +396,70 @@ def test_template_group_over_three_contexts_in_one_call(built, config, nside):
                 assert np.abs(e.get_indices(l) - whole.get_indices(l)[:, :, bounds[q]:bounds[q + 1]]).max() <= 1e-12, (l, q)
         if comps[l].type == "template":
             assert np.abs(engs[0].get_template_amplitudes(l) - whole.get_template_amplitudes(l)).max() <= 1e-12 * np.abs(whole.get_template_amplitudes(l)).max()
+
+
+def _random_template_case(seed):
+    """A random IQU model with one or two Q/U templates fitted in the Q+U group (at most four global rows)."""
+    from dang_amd.api import DangComps
+    rng = np.random.default_rng(7000 + seed)
+    extra = [c for c in rng.permutation(["cmb", "ff"])[: int(rng.integers(0, 3))]]
+    names = ["synch", "dust"] + extra
+    # (as many bands as diffuse members: the members absorb every global row -- a singular system, the rows keep their values)
+    nb = int(rng.choice([b for b in (4, 5, 6, 8, 10, 12) if b >= len(names) + 2]))
+    ntmpl = int(rng.integers(1, 3))
+    rows = [int(rng.integers(1, 3)) for _ in range(ntmpl)]            # fitted bands per template: 1 or 2 each (R <= 4)
+    info = dict(nb=nb, comps=names, rows=rows, nside=int(rng.choice([2, 4])), nsample=int(rng.choice([3, 10])), seed=seed)
+
+    def tweak(dpar, ddata, bands, comps):
+        nmaps, npix = ddata.sig_map.shape[1:]
+        add = np.zeros_like(ddata.sig_map)
+        for t, nfit in enumerate(rows):
+            fit = sorted(int(j) for j in rng.choice(nb, size=nfit, replace=False))
+            corr = [j in fit for j in range(nb)]
+            tmpl = np.zeros((nmaps, npix))
+            tmpl[1], tmpl[2] = rng.normal(0, 1, npix), rng.normal(0, 1, npix)
+            truth = np.zeros(nb)
+            truth[fit] = rng.normal(0.0, 3.0, nfit)
+            ta = np.zeros((nmaps, nb))
+            ta[1:, :] = rng.normal(0.0, 0.5, nb) * ~np.asarray(corr)     # amplitudes on the UNFITTED bands (removed in every group, :445-460)
+            for k in (1, 2):
+                add[:, k, :] += (truth + ta[k])[:, None] * tmpl[k][None, :]
+            comps.append(DangComps(label="tmpl%d" % t, type="template", nu_ref=100.0, cg_group=2, nindices=0, nfit=nfit, corr=corr,
+                                   template=tmpl, template_amplitudes=ta, amplitude=np.zeros((nmaps, npix))))
+        ddata.sig_map = ddata.sig_map + add
+    case = make_case(None, nside=info["nside"], nbands=nb, comps=names, nmaps=3, tweak=tweak, start="truth", nsample=info["nsample"])
+    return case, info
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_template_models_one_launch_equals_the_separate_passes(built, seed, monkeypatch):
+    """16 random models (4-12 bands, 2-4 diffuse members, one or two Q/U templates with 1-2 fitted bands each and amplitudes on
+    their unfitted bands): two iterations through dangx_plane_set_sample as they run by default -- pass 1 (k_schur_pass1_qu where
+    the shape allows), the host solve, one launch that back-substitutes and sweeps (kernels specialised at run time for most of
+    these shapes) -- against DANGX_SCHUR_CHECK=1: pass 2, the measured residual, the sweeps-only launch.  Same state; the measured
+    residual of every solve the default path did not check is <= 1e-11 of b."""
+    case, info = _random_template_case(seed)
+    dpar, ddata, bands, comps, meta = case
+    mk = lambda: da.Engine(bands, comps, ddata, npix_global=meta["npix_global"], device=0)
+    fused, chk = mk(), mk()
+    for it in (2, 3):
+        accs = {}
+        for which, eng in (("fused", fused), ("checked", chk)):
+            monkeypatch.setenv("DANGX_SCHUR_CHECK", "1" if which == "checked" else "0")
+            for g in dpar.cg_groups:
+                f = g.pol_flag[0]
+                sw = _plane_sweep_list(comps, g.cg_group, f, it)
+                if not sw:
+                    continue
+                bad, acc = eng.plane_set_sample(g.cg_group, f, "sample", dpar.seed, da.stream_id(it, 0, g.cg_group, 0, f), sw, dpar.nsample, dpar.seed)
+                assert bad == 0, (info, which)
+                accs[(which, g.cg_group)] = acc
+                if g.cg_group == 2:
+                    (resid, _), nref = eng.schur_info()
+                    if which == "checked":
+                        assert resid <= 1e-11 or nref > 0, (info, resid, nref)
+        monkeypatch.setenv("DANGX_SCHUR_CHECK", "0")
+        for g in dpar.cg_groups:
+            if ("fused", g.cg_group) in accs:
+                assert accs[("fused", g.cg_group)] == accs[("checked", g.cg_group)], (info, it, g.cg_group)
+        _close_states(fused, chk, comps, info)
