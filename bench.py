@@ -269,6 +269,36 @@ def launch_ranks(n, backend):
     return rc
 
 
+def template_model(config_name, nsample, steps=6, warmup=2):
+    """The same workload with a Q/U template fitted at three bands in the Q+U group (the model class of real dang
+    runs): whole Gibbs iterations through da.gibbs_iteration -- T group one plane-set launch, Q+U group pass 1 of the Schur solve +
+    one launch that back-substitutes and sweeps.  A secondary figure beside the headline, never `value`."""
+    import dang_amd as da
+    from dang_amd import synth
+    dev = torch.device("cuda", 0)
+    dpar, ddata, bands, comps, meta = synth.make_sky(config_name, device=dev, nsample=nsample, as_numpy=False)
+    nb = meta["nbands"]
+    fit = tuple(range(nb - 3, nb))
+    tl = synth.add_qu_template(ddata, comps, meta, fit_bands=fit)
+    eng = da.initialize(bands, comps, ddata, npix_global=meta["npix_global"], device=0)
+    try:
+        for it in range(1, warmup + 1):
+            da.gibbs_iteration(dpar, ddata, it, want_counts=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for it in range(warmup + 1, warmup + 1 + steps):
+            da.gibbs_iteration(dpar, ddata, it, want_counts=False)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        (resid, _), nref = eng.schur_info()
+        ta = eng.get_template_amplitudes(tl)[1, list(fit)]
+        return {"workload": "%s + a Q/U template fitted at bands %s of the Q+U group (injected 2.0, -1.5, 0.7)" % (config_name, list(fit)),
+                "it_per_s": 1.0 / dt, "ms_per_step": 1e3 * dt, "steps": steps, "chisq": float(ddata.chisq),
+                "template_amplitudes": [float(x) for x in ta], "schur_residual_bound": float(resid), "refinements": int(nref)}
+    finally:
+        eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -280,6 +310,7 @@ def main():
     ap.add_argument("--nbands", type=int, default=None, help="diagnostic (not a BASELINE config): the configuration's model on another "
                     "number of bands -- a shape without a built-in kernel instantiation is specialised at run time (hiprtc)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-template-model", action="store_true", help="skip the secondary figure: the workload with a fitted Q/U template")
     ap.add_argument("--no-fortran-seam", action="store_true", help="skip the it/s of the reference-side Fortran wrapper (two-call "
                     "seam and gibbs_iteration_gpu), which bench.py otherwise reports beside the headline value at N=1")
     ap.add_argument("--no-fuse", action="store_true", help="diagnostic: amplitude solve and first index sweep of a plane set as "
@@ -606,6 +637,19 @@ def main():
                 log("fortran_seam done")
             except Exception as e:  # flang absent / driver failed: say so in the line, never break it
                 out["fortran_seam"] = {"error": repr(e)[:500]}
+        if world == 1 and standard and not args.no_template_model:
+            try:
+                log("timing the template model (template_model)")
+                if args.no_fortran_seam:   # (the seam branch above has released the headline's maps already)
+                    eng.close()
+                    if two:
+                        engP.close()
+                    del ddata.sig_map, ddata.rms_map
+                    torch.cuda.empty_cache()
+                out["template_model"] = template_model(args.config, args.nsample)
+                log("template_model done")
+            except Exception as e:
+                out["template_model"] = {"error": repr(e)[:500]}
         print(json.dumps(out))
     if world > 1:
         td.barrier()

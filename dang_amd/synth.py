@@ -201,3 +201,24 @@ def make_sky(config="C1", nside=None, nbands=None, comps=None, nmaps=None, devic
                 ncomp=len(component_list), freqs_ghz=freqs, truth=truth, phys=phys,
                 bounds=bounds)   # shard boundaries (None = equal ranges): what dist.gather_maps needs to reassemble the sky
     return dpar, ddata, bands, component_list, meta
+
+
+def add_qu_template(ddata, comps, meta, fit_bands=(7, 8, 9), amplitudes=(2.0, -1.5, 0.7), cg_group=2, seed=3):
+    """A Q/U template (unit-variance Gaussian maps, zero on T) fitted at `fit_bands` with ONE amplitude per band for Q and U
+    (src/dang_cg_mod.f90:1380-1382), its signal added to the data: the model class of SURVEY 8f rank 1 -- diffuse components beside a
+    dust template -- on top of any make_sky configuration with torch maps.  Appends the component to `comps`; returns its index."""
+    import torch
+    from .api import DangComps
+    npix, nb = meta["npix"], meta["nbands"]
+    dev = ddata.sig_map.device
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    tmpl = torch.zeros(3, npix, dtype=torch.float64)
+    tmpl[1:] = torch.randn(2, npix, generator=g, dtype=torch.float64)
+    corr = [j in tuple(fit_bands) for j in range(nb)]
+    for k in (1, 2):
+        for j, a in zip(fit_bands, amplitudes):
+            ddata.sig_map[j, k] += a * tmpl[k].to(dev)
+    comps.append(DangComps(label="tmpl", type="template", nu_ref=100.0, cg_group=cg_group, nindices=0, nfit=len(tuple(fit_bands)), corr=corr,
+                           template=tmpl.numpy(), template_amplitudes=np.zeros((3, nb)),
+                           amplitude=torch.zeros(3, npix, dtype=torch.float64, device=dev)))
+    return len(comps) - 1

@@ -13,7 +13,6 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dang_amd as da  # noqa: E402
 from dang_amd import synth  # noqa: E402
-from dang_amd.api import DangComps  # noqa: E402
 
 nside = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
@@ -23,19 +22,8 @@ counts = len(sys.argv) > 5 and sys.argv[5] == "counts"   # read the accepted-pro
 dev = torch.device("cuda", 0)
 dpar, ddata, bands, comps, meta = synth.make_sky("C3", nside=nside, device=dev, as_numpy=False, start=start)
 npix, nb = meta["npix"], meta["nbands"]
-g = torch.Generator(device="cpu").manual_seed(3)
-tmpl = torch.zeros(3, npix, dtype=torch.float64)
-tmpl[1:] = torch.randn(2, npix, generator=g, dtype=torch.float64)
-corr = [j in (7, 8, 9) for j in range(nb)]
-truth = np.zeros((3, nb)); truth[1:, 7:] = [2.0, -1.5, 0.7]
-for k in (1, 2):
-    for j in range(nb):
-        if not plain:
-            ddata.sig_map[j, k] += truth[k, j] * tmpl[k].to(dev)
 if not plain:
-  comps.append(DangComps(label="tmpl", type="template", nu_ref=100.0, cg_group=2, nindices=0, nfit=3, corr=corr,
-                         template=tmpl.numpy(), template_amplitudes=np.zeros((3, nb)),
-                         amplitude=torch.zeros(3, npix, dtype=torch.float64, device=dev)))
+    synth.add_qu_template(ddata, comps, meta)
 eng = da.initialize(bands, comps, ddata, npix_global=meta["npix_global"], device=0)
 for it in (1, 2):
     da.gibbs_iteration(dpar, ddata, it, want_counts=counts)
