@@ -88,6 +88,17 @@ static int planeset_launch(dangx_ctx* ctx, const GroupArgs& g, const SweepList& 
 static bool planeset_group(dangx_ctx* ctx, GroupArgs& g, int s1, int s2, int solve);
 static bool planeset_items(dangx_ctx* ctx, const GroupArgs& g, int map_n, int nsweeps, const int32_t* comp, const int32_t* nind, const uint64_t* stream, SweepList& sl);
 
+// The sums of squares a sweep leaves behind are chi^2 of update_sky_model's residual -- unless a monopole has a signal on the planes:
+// the chain removes it as one more component (eval_signal, src/dang_sample_mod.f90:180-196) ON TOP of the band offset it has
+// become (src/dang_data_mod.f90:357-361), while the sky model leaves it out.  Such planes take the explicit pass.
+static bool chi_byproduct_ok(const dangx_ctx* ctx, int s1, int s2) {
+    unsigned planes = 0;
+    for (int k = s1; k <= s2; ++k) planes |= 1u << (k - 1);
+    for (int l = 0; l < ctx->hm.ncomp; ++l)
+        if (ctx->desc[l].type == DANGX_MONOPOLE && (ctx->tmpl_nz[l] & planes)) return false;
+    return true;
+}
+
 int dangx_amp_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed,
                      uint64_t stream, int i_max, double converge, int* cg_iters, int64_t* n_not_spd) {
     DxRange rg_("dangx_amp_sample");
@@ -322,9 +333,10 @@ int dangx_index_sample(dangx_ctx* ctx, int comp, int nind, int map_n, int nsampl
         const bool wb = !ctx->touched_since_amp[a.s1 - 1];
         auto& pend = ctx->chi_pend[ctx->chi_npend++];
         pend.nblk = nblk; pend.s1 = a.s1; pend.s2 = a.s2; pend.wb = wb ? 1 : 0;
+        const bool chi_ok = chi_byproduct_ok(ctx, a.s1, a.s2);
         for (int k = a.s1; k <= a.s2; ++k) {
-            if (wb) ctx->chi_before_valid[k - 1] = true;
-            ctx->chi_after_valid[k - 1] = true;
+            if (wb) ctx->chi_before_valid[k - 1] = chi_ok;
+            ctx->chi_after_valid[k - 1] = chi_ok;
             ctx->touched_since_amp[k - 1] = true;
         }
     }
@@ -477,9 +489,10 @@ static int planeset_launch(dangx_ctx* ctx, const GroupArgs& g, const SweepList& 
                 pend.slot[pend.ns++] = idx_slot(sl.s[q].comp, sl.s[q].nind + e, sl.s1);
                 for (int k = sl.s1; k <= sl.s2; ++k) ctx->idxsum_dev[sl.s[q].comp][sl.s[q].nind + e][k - 1] = !ctx->idx_ext[sl.s[q].comp];
             }
+        const bool chi_ok = chi_byproduct_ok(ctx, sl.s1, sl.s2);
         for (int k = sl.s1; k <= sl.s2; ++k) {
-            if (wb) ctx->chi_before_valid[k - 1] = true;
-            ctx->chi_after_valid[k - 1] = true;
+            if (wb) ctx->chi_before_valid[k - 1] = chi_ok;
+            ctx->chi_after_valid[k - 1] = chi_ok;
             ctx->touched_since_amp[k - 1] = sl.n > 0 || (!solve && ctx->touched_since_amp[k - 1]);
         }
     }
@@ -526,12 +539,12 @@ static bool planeset_items(dangx_ctx* ctx, const GroupArgs& g, int map_n, int ns
 }
 
 // What every plane-set launch needs: the group's diffuse members are the only components with a signal on planes s1..s2 --
-// except, for the sweeps alone (solve = 0), `template` components: their signal template_amplitudes(band, map) * template(pix, map)
+// except, for the sweeps alone (solve = 0), `template` and `monopole` components: their signal template_amplitudes(band, map) * template(pix, map)
 // (eval_signal, src/dang_component_mod.f90:754-776) is one more term of "every other component" and is removed when the residual
 // is formed; g.uc / g.nuc become the list of those (at most 4).  A global-amplitude component whose template map is identically
 // zero on these planes (a Q/U dust template seen from the T plane set) has no signal there and is ignored -- also by the solve,
-// whose compute_rhs would remove tamp * 0 on its unfitted bands (:445-460).  Monopoles (also the band offset, quirk 6), hi_fit
-// (a per-pixel Planck factor) and T_cmb components with a signal on the planes keep the run-time-typed kernels.
+// whose compute_rhs would remove tamp * 0 on its unfitted bands (:445-460).  hi_fit (a per-pixel Planck factor) and T_cmb
+// components with a signal on the planes keep the run-time-typed kernels.
 // solve = 2: the back-substitution of a template group's Schur solve (dangx_sky_plane_set_sample) followed by the sweeps: every
 // template with a signal on the planes must then be a global member of THIS group (its new amplitudes, on every band, are what pass 2
 // removes from the data: dx_ampreg.h, HT form), and the group has no monopole / hi_fit member.
@@ -543,7 +556,9 @@ static bool planeset_group(dangx_ctx* ctx, GroupArgs& g, int s1, int s2, int sol
         const int t = ctx->desc[l].type;
         if (t == DANGX_TCMB) return false;
         if (!is_global_type(t) || !(ctx->tmpl_nz[l] & planes)) continue;
-        if (solve == 1 || t != DANGX_TEMPLATE || ntg == 4) return false;
+        // (a monopole's signal is template_amplitudes(band, map) * template(pix, map) too -- its amplitudes are also the band offsets,
+        // which the T launch reads from the block's table; as the member of a solve it keeps the separate passes)
+        if (solve == 1 || ntg == 4 || !(t == DANGX_TEMPLATE || (t == DANGX_MONOPOLE && solve == 0))) return false;
         if (solve == 2) {
             bool member = false;
             for (int q = 0; q < g.nt; ++q) member = member || g.tc[q] == l;

@@ -80,3 +80,22 @@ def test_five_rank_rehearsal_of_the_sharded_path_on_one_gpu(built):
     assert "equal pixel count" in eq["config"]["workload"]
     for k in ("chisq_after_amp", "chisq_after_index"):
         assert abs(eq["config"][k] - one["config"][k]) <= 1e-12 * abs(one["config"][k]), k
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_the_template_model_figure(built):
+    """The default line (C3 at full size) with its secondary figure: the same workload with a Q/U template fitted in the Q+U group,
+    whole iterations through gibbs_iteration -- the injected amplitudes come back, the Schur solve needed no refinement, and the
+    headline keys are what they were."""
+    r = subprocess.run([sys.executable, BENCH, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-fortran-seam"], env=_env(),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["metric"] and d["n_gpus"] == 1 and d["roofline"]["frac"] > 0 and "C3" in d["config"]["workload"]
+    t = d["template_model"]
+    assert "error" not in t, t
+    assert t["it_per_s"] > 0 and t["refinements"] == 0 and t["schur_residual_bound"] <= 1e-12
+    for got, want in zip(t["template_amplitudes"], (2.0, -1.5, 0.7)):
+        assert abs(got - want) < 0.01, t
