@@ -222,3 +222,20 @@ def add_qu_template(ddata, comps, meta, fit_bands=(7, 8, 9), amplitudes=(2.0, -1
                            template=tmpl.numpy(), template_amplitudes=np.zeros((3, nb)),
                            amplitude=torch.zeros(3, npix, dtype=torch.float64, device=dev)))
     return len(comps) - 1
+
+
+def add_monopole(ddata, comps, meta, fit_bands=(0, 8, 9), amplitudes=(3.0, -2.0, 5.0), cg_group=1):
+    """A monopole (template = 1 on T, src/dang_component_mod.f90:593-595) fitted at `fit_bands` in the T group, its signal added to
+    the data; its amplitudes become the band offsets (update_sky_model, src/dang_data_mod.f90:357-361).  Appends the component."""
+    import torch
+    from .api import DangComps
+    npix, nb = meta["npix"], meta["nbands"]
+    tmpl = np.zeros((3, npix))
+    tmpl[0] = 1.0
+    corr = [j in tuple(fit_bands) for j in range(nb)]
+    for j, a in zip(fit_bands, amplitudes):
+        ddata.sig_map[j, 0] += a
+    comps.append(DangComps(label="mono", type="monopole", nu_ref=100.0, cg_group=cg_group, nindices=0, nfit=len(tuple(fit_bands)), corr=corr,
+                           template=tmpl, template_amplitudes=np.zeros((3, nb)),
+                           amplitude=torch.zeros(3, npix, dtype=torch.float64, device=ddata.sig_map.device)))
+    return len(comps) - 1

@@ -22,7 +22,10 @@ counts = len(sys.argv) > 5 and sys.argv[5] == "counts"   # read the accepted-pro
 dev = torch.device("cuda", 0)
 dpar, ddata, bands, comps, meta = synth.make_sky("C3", nside=nside, device=dev, as_numpy=False, start=start)
 npix, nb = meta["npix"], meta["nbands"]
-if not plain:
+mono = len(sys.argv) > 3 and sys.argv[3] == "mono"       # a monopole fitted in the T group instead
+if mono:
+    synth.add_monopole(ddata, comps, meta)
+elif not plain:
     synth.add_qu_template(ddata, comps, meta)
 eng = da.initialize(bands, comps, ddata, npix_global=meta["npix_global"], device=0)
 for it in (1, 2):
@@ -36,6 +39,6 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 prof = eng.profile_get()
 print("template model: %.2f ms per Gibbs iteration (%.1f it/s); chisq %.6f; template amplitudes %s"
-      % (1e3 * dt, 1.0 / dt, ddata.chisq, "-" if plain else np.round(eng.get_template_amplitudes(len(comps) - 1)[1, 7:], 4)))
+      % (1e3 * dt, 1.0 / dt, ddata.chisq, "-" if plain else np.round(eng.get_template_amplitudes(len(comps) - 1)[0 if mono else 1], 4)))
 for k, v in prof.items():
     print("  %-14s %3d launches per iteration, %8.3f ms per iteration" % (k, v["launches"] // steps, v["total_ms"] / steps))
