@@ -268,227 +268,6 @@ __global__ __launch_bounds__(BLOCK, DX_P1_WAVES) void k_schur_pass1_reg(const Mo
 }
 
 
-#if !DX_SCHUR_HF
-// Pass 1 for a Q+U group whose varying members have the same indices on both planes (as a Q+U sweep leaves them): ONE thread per
-// pixel works through both planes at once.  The members' SED columns are evaluated once, for every band, into the thread's LDS
-// column (the plane-set kernel's layout) instead of once per plane; the band loop accumulates the normal equations of BOTH planes
-// from one tile of maps (half the memory round trips: each map plane is a 100-300 MB stride from the next, and two waves per SIMD
-// hide little of one); the vectors of the global rows' bands are read again after the loop (from the cache the maps just passed
-// through) instead of being picked out of it band by band; and the row values of the two planes are added in registers before
-// the one block reduction.  SS = R, the group's global rows.
-template <int NG, int TB, int SS>
-__global__ __launch_bounds__(BLOCK, 2) void k_schur_pass1_qu(const Model* __restrict__ Mp, GroupArgs a, AmpRegArgs ra, SchurArgs sa,
-                                                            double* __restrict__ rowpartial, unsigned long long* __restrict__ not_spd) {
-    constexpr int NV = SS * SS + 3 * SS, NA = NG * (NG + 1) / 2;
-    extern __shared__ double lds[];
-    __shared__ double wsum[NV][BLOCK / 64];
-    const Model& M = *Mp;
-    const int npix = M.npix, nb = M.nbands, tid = threadIdx.x;
-    double* tab = lds;
-    double* cu = lds + (TROWS * NG + 3) * nb;          // [plane][MAXU templates][band], zero where nothing is removed
-    double* col = lds + (TROWS * NG + 3 + 2 * MAXU) * nb + tid;   // [member slot][band] x BLOCK
-    const long long u = (long long)blockIdx.x * BLOCK + tid;
-    const bool in_range = u < npix;
-    const int i = in_range ? (int)u : 0;
-    const double mk = as_global(M.mask)[i];
-    // plane 2's maps; plane 3's are npix further on.  Tile 0 of both planes is requested before the table and the SED columns
-    const long long bstride = (long long)M.nmaps * npix;
-    const gcptr sig0 = as_global(M.sig) + (long long)npix + i, rms0 = as_global(M.rms) + (long long)npix + i;
-    double dcur[2][TB], rcur[2][TB], tv[2][MAXU], tT[MAXU];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-#pragma unroll
-        for (int t = 0; t < TB; ++t) { dcur[p][t] = sig0[(long long)p * npix + t * bstride]; rcur[p][t] = rms0[(long long)p * npix + t * bstride]; }
-        gl_load(M, ra, i, 2 + p, npix, tv[p], tT);
-    }
-    // (every template slot is read for every band, unconditionally: a test per template and band -- uniform, but compiled as an
-    // exec-masked branch with a full wait on the maps in flight -- costs more than the multiplications by zero)
-    for (int t = tid; t < 2 * MAXU * nb; t += BLOCK) {
-        const int p = t / (MAXU * nb), q = t - p * MAXU * nb, w = q / nb, j = q - w * nb;
-        double v = 0.0;
-        if (w < ra.nu && ((ra.uinuc >> w) & 1u)) {
-            const Comp& c = M.comp[ra.ucomp[w]];
-            if (!((c.corr_mask >> j) & 1)) v = c.tamp[1 + p][j];
-        }
-        cu[t] = v;
-    }
-    sed_table_build(M, tab, tid, BLOCK, a.gc, NG);
-    const bool sample = (a.ml_mode == DANGX_ML_SAMPLE);
-    const bool live = in_range && !is_masked(mk);
-    __syncthreads();
-    double rv[NV];
-#pragma unroll
-    for (int e = 0; e < NV; ++e) rv[e] = 0.0;
-    if (live) {
-        // ---- the SED columns, once (plane 2's index values: equal on plane 3, the launcher has checked)
-#pragma unroll 1
-        for (int v = 0; v < ra.nv; ++v) {
-            const Comp& c = M.comp[a.gc[ra.vcomp[v]]];
-            const gcptr ix = as_global(c.idx) + (long long)npix + i;
-            const double t0 = (c.nind > 0) ? ix[0] : 0.0, t1 = (c.nind > 1) ? ix[(long long)M.nmaps * npix] : 0.0;
-            const Prep pr = sed_prep(c, t0, t1);
-#pragma unroll 1
-            for (int j0 = 0; j0 < nb; j0 += TB) sed_tile<TB>(ra.vtype[v], tab, nb, NG, ra.vcomp[v], j0, pr, col + (v * nb + j0) * BLOCK);
-        }
-        double eta[2] = {0.0, 0.0}, f0[2] = {0.0, 0.0};
-        if (sample) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                double u1, u2;
-                uniform2(a.seed, a.stream, (unsigned long long)(M.pix0 + i), (uint32_t)(2 + p), u1, u2);
-                eta[p] = rand_normal(0.0, 1.0, u1, u2);
-            }
-        }
-        double A[2][NA], bv[2][NG];
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-#pragma unroll
-            for (int q = 0; q < NA; ++q) A[p][q] = 0.0;
-#pragma unroll
-            for (int g = 0; g < NG; ++g) bv[p][g] = 0.0;
-        }
-        // ---- the normal equations of both planes, band tile by band tile
-#pragma unroll 1
-        for (int j0 = 0; j0 < nb; j0 += TB) {
-            if (j0 > 0) {
-#pragma unroll
-                for (int p = 0; p < 2; ++p)
-#pragma unroll
-                    for (int t = 0; t < TB; ++t) {
-                        dcur[p][t] = sig0[(long long)p * npix + (j0 + t) * bstride];
-                        rcur[p][t] = rms0[(long long)p * npix + (j0 + t) * bstride];
-                    }
-            }
-#pragma unroll
-            for (int t = 0; t < TB; ++t) {
-                const int j = j0 + t;
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    double d = dcur[p][t];
-#pragma unroll
-                    for (int w = 0; w < MAXU; ++w) d = d - cu[(p * MAXU + w) * nb + j] * tv[p][w];
-                    const double is = fast_rcp(rcur[p][t]);
-                    const double inv = is * is;
-                    double mrow[NG];
-#pragma unroll
-                    for (int g = 0; g < NG; ++g)
-                        mrow[g] = (ra.vslot[g] >= 0) ? col[(ra.vslot[g] * nb + j) * BLOCK] : tab[(TROWS * g + 4 + p) * nb + j];
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) {
-                        const double t2 = mrow[g] * inv;
-                        bv[p][g] += d * t2;
-#pragma unroll
-                        for (int h = 0; h <= g; ++h) A[p][g * (g + 1) / 2 + h] += t2 * mrow[h];
-                    }
-                    f0[p] += (eta[p] * is) * mrow[NG - 1];
-                }
-            }
-        }
-        // ---- W = M / sigma^2, d / sigma^2, eta / sigma and 1 / sigma^2 of the band of every global row (two rows on one band carry
-        // the same vector twice), then each plane's Cholesky factor and row values
-        double dr[2][SS], rr[2][SS];
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int r = 0; r < SS; ++r) {
-                const int j = __builtin_amdgcn_readfirstlane((int)sa.rj[r]);
-                dr[p][r] = sig0[(long long)p * npix + j * bstride];
-                rr[p][r] = rms0[(long long)p * npix + j * bstride];
-            }
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int k = 2 + p;
-            double Wv[SS][NG], dn[SS], en[SS], iv[SS], ri[NG];
-#pragma unroll
-            for (int r = 0; r < SS; ++r) {
-                const int j = __builtin_amdgcn_readfirstlane((int)sa.rj[r]);
-                double d = dr[p][r];
-#pragma unroll
-                for (int w = 0; w < MAXU; ++w) d = d - cu[(p * MAXU + w) * nb + j] * tv[p][w];
-                const double is = fast_rcp(rr[p][r]);
-                const double inv = is * is;
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    const double m = (ra.vslot[g] >= 0) ? col[(ra.vslot[g] * nb + j) * BLOCK] : tab[(TROWS * g + 2 + k) * nb + j];
-                    Wv[r][g] = m * inv;
-                }
-                dn[r] = d * inv; en[r] = eta[p] * is; iv[r] = inv;
-            }
-            bv[p][0] += f0[p];
-            bool ok = true;
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-#pragma unroll
-                for (int h = 0; h <= g; ++h) {
-                    double sacc = A[p][g * (g + 1) / 2 + h];
-#pragma unroll
-                    for (int t = 0; t < h; ++t) sacc -= A[p][g * (g + 1) / 2 + t] * A[p][h * (h + 1) / 2 + t];
-                    if (h == g) {
-                        if (!(sacc > 0.0) || !(sacc < 1.0e300)) ok = false;
-                        ri[g] = fast_rsqrt(sacc);
-                    } else {
-                        A[p][g * (g + 1) / 2 + h] = sacc * ri[h];
-                    }
-                }
-            }
-            if (!ok) {
-                atomicAdd(not_spd, 1ull);
-            } else {
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    double sacc = bv[p][g];
-#pragma unroll
-                    for (int t = 0; t < g; ++t) sacc -= A[p][g * (g + 1) / 2 + t] * bv[p][t];
-                    bv[p][g] = sacc * ri[g];   // yh
-                }
-#pragma unroll
-                for (int r = 0; r < SS; ++r)
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) {
-                        double sacc = Wv[r][g];
-#pragma unroll
-                        for (int t = 0; t < g; ++t) sacc -= A[p][g * (g + 1) / 2 + t] * Wv[r][t];
-                        Wv[r][g] = sacc * ri[g];   // Q_r
-                    }
-#pragma unroll
-                for (int r = 0; r < SS; ++r) {
-                    double s_r = 0.0, dot = 0.0;
-#pragma unroll
-                    for (int w = 0; w < MAXU; ++w) s_r = (ra.rowu[r] == w) ? tv[p][w] : s_r;
-                    const double w_r = ((ra.rowmono >> r) & 1u) ? 1.0 : s_r;   // :857
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) dot += Wv[r][g] * bv[p][g];
-                    rv[SS * SS + r] += dn[r] * s_r - w_r * dot;            // t[r]
-                    rv[SS * SS + SS + r] += en[r] * w_r;                    // fluctuation sum of natural row r
-                    rv[SS * SS + 2 * SS + r] += w_r * s_r * iv[r];          // G[r][r]
-#pragma unroll
-                    for (int r2 = 0; r2 < SS; ++r2) {
-                        double s2 = 0.0, dot2 = 0.0;
-#pragma unroll
-                        for (int w = 0; w < MAXU; ++w) s2 = (ra.rowu[r2] == w) ? tv[p][w] : s2;
-#pragma unroll
-                        for (int g = 0; g < NG; ++g) dot2 += Wv[r][g] * Wv[r2][g];
-                        rv[r * SS + r2] += ((sa.rj[r] == sa.rj[r2]) ? w_r * s2 * iv[r] : 0.0) - w_r * s2 * dot2;
-                    }
-                }
-            }
-        }
-    }
-    // ---- one block reduction for the row values of both planes (wave tree, then the four wave sums in order)
-#pragma unroll
-    for (int e = 0; e < NV; ++e) {
-        double v = rv[e];
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if ((tid & 63) == 0) wsum[e][tid >> 6] = v;
-    }
-    __syncthreads();
-    if (tid < NV) {   // R = SS: the slots are the rows of the layout the host reads
-        double t = 0.0;
-        for (int w = 0; w < BLOCK / 64; ++w) t += wsum[tid][w];
-        rowpartial[(long long)tid * gridDim.x + blockIdx.x] = t;
-    }
-}
-#endif
 
 #endif
 #if DX_SCHUR_PART == 2
@@ -679,6 +458,9 @@ int dx_schurreg_resid_hf1(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& s
 int dx_schurreg_pass1_hf1(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
 int dx_schurreg_resid_hf0(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
 int dx_schurreg_pass1_hf0(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
+int dx_schurqu_pass1_tb5(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
+int dx_schurqu_pass1_tb4(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
+int dx_schurqu_pass1_tb2(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
 static bool group_has_hifit(dangx_ctx* ctx, const GroupArgs& a) {
     for (int t = 0; t < a.nt; ++t) if (ctx->desc[a.tc[t]].type == DANGX_HIFIT) return true;
     return false;
@@ -732,47 +514,10 @@ int launch_pass1_tb(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, co
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }
-#if !DX_SCHUR_HF
-template <int NG, int TB>
-int launch_pass1_qu(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, const SchurArgs& sa, long long SN, double* rows_dev, size_t ldsz) {
-    const int R = sa.nrows, nrows = R * R + 3 * R;
-    const unsigned gx = nblocks(SN / 2);
-    if (ensure_partial(ctx, (long long)nrows * gx)) return 1;
-    HIPCHK(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));
-    // SS = R, the global rows of the group
-    switch (sa.nrows) {
-    case 1: hipLaunchKernelGGL((k_schur_pass1_qu<NG, TB, 1>), dim3(gx), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial, ctx->counters); break;
-    case 2: hipLaunchKernelGGL((k_schur_pass1_qu<NG, TB, 2>), dim3(gx), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial, ctx->counters); break;
-    case 3: hipLaunchKernelGGL((k_schur_pass1_qu<NG, TB, 3>), dim3(gx), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial, ctx->counters); break;
-    default: hipLaunchKernelGGL((k_schur_pass1_qu<NG, TB, 4>), dim3(gx), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, sa, ctx->partial, ctx->counters); break;
-    }
-    dx_reduce_rows_to(ctx, ctx->partial, gx, nrows, rows_dev);
-    HIPCHK(ctx, hipGetLastError());
-    return 0;
-}
-#endif
 template <int NG>
 int launch_pass1_ng(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, const SchurArgs& sa, long long SN, double* rows_dev) {
     const int nb = ctx->hm.nbands;
     const size_t most = 80u * 1024u;
-#if !DX_SCHUR_HF
-    {   // Q+U with the varying members' indices equal on both planes: one thread per pixel, the SED columns evaluated once
-        static const bool qu_on = [] { const char* e = getenv("DANGX_SCHUR_QU"); return !(e && e[0] == '0'); }();  // A/B switch
-        bool qu = qu_on && a.flag == DANGX_FLAG_QU && ra.uhifit == 0u;
-        for (int v = 0; qu && v < ra.nv; ++v) {
-            const int l = a.gc[ra.vcomp[v]];
-            const unsigned all = (1u << ctx->hm.comp[l].nind) - 1u;
-            qu = (ctx->qu_equal[l] & all) == all;
-        }
-        const size_t ldsz = ((size_t)(TROWS * NG + 3 + 2 * MAXU) * nb + (size_t)ra.nv * nb * BLOCK) * sizeof(double);
-        if (qu && ldsz <= most) {
-            if (nb == 10) return launch_pass1_qu<NG, 10>(ctx, a, ra, sa, SN, rows_dev, ldsz);   // every map of a plane requested at once
-            if (nb % 5 == 0) return launch_pass1_qu<NG, 5>(ctx, a, ra, sa, SN, rows_dev, ldsz);
-            if (nb % 4 == 0) return launch_pass1_qu<NG, 4>(ctx, a, ra, sa, SN, rows_dev, ldsz);
-            if (nb % 2 == 0) return launch_pass1_qu<NG, 2>(ctx, a, ra, sa, SN, rows_dev, ldsz);
-        }
-    }
-#endif
     if (nb % 5 == 0 && amp_reg_lds<5>(NG, nb, ra.nv, ra.nu) <= most) return launch_pass1_tb<NG, 5>(ctx, a, ra, sa, SN, rows_dev);
     if (nb % 4 == 0 && amp_reg_lds<4>(NG, nb, ra.nv, ra.nu) <= most) return launch_pass1_tb<NG, 4>(ctx, a, ra, sa, SN, rows_dev);
     if (nb % 3 == 0 && amp_reg_lds<3>(NG, nb, ra.nv, ra.nu) <= most) return launch_pass1_tb<NG, 3>(ctx, a, ra, sa, SN, rows_dev);
@@ -786,6 +531,14 @@ int launch_pass1_ng(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, co
 // pass 1 of the Schur solve (dangx_schur.hip: k_schur_pass1) on this schedule: 0 launched, 1 error, -1 not covered (more than
 // four global rows or fitted bands, a hi_fit member, bandpass-integrated bands, the textbook fluctuation term ...)
 int DX_PASS1_WORKER(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev) {
+#if !DX_SCHUR_HF
+    if (a.flag == DANGX_FLAG_QU) {   // Q+U template groups: one thread per pixel, up to eight global rows (dangx_schurqu.hip)
+        const int nb = ctx->hm.nbands;
+        const int rc = (nb % 5 == 0) ? dx_schurqu_pass1_tb5(ctx, a, sa, SN, rows_dev) : (nb % 4 == 0) ? dx_schurqu_pass1_tb4(ctx, a, sa, SN, rows_dev)
+                     : (nb % 2 == 0) ? dx_schurqu_pass1_tb2(ctx, a, sa, SN, rows_dev) : -1;
+        if (rc >= 0) return rc;
+    }
+#endif
     AmpRegArgs ra;
     if (sa.nrows < 1 || sa.nrows > 4 || sa.nslots > 4 || !template_group_args(ctx, a, ra)) return -1;
     if ((ra.uhifit != 0u) != HFV) return -1;

@@ -476,3 +476,63 @@ def test_random_template_models_one_launch_equals_the_separate_passes(built, see
             if ("fused", g.cg_group) in accs:
                 assert accs[("fused", g.cg_group)] == accs[("checked", g.cg_group)], (info, it, g.cg_group)
         _close_states(fused, chk, comps, info)
+
+
+@pytest.mark.parametrize("nrows", [2, 5, 6, 8])
+def test_pass1_for_q_u_template_groups_with_up_to_eight_rows(built, nrows):
+    """k_schur_pass1_qu (dangx_schurqu.hip: one thread per pixel, both planes, symmetric row storage; beyond five rows the row values
+    are reduced row by row) against the per-plane passes (DANGX_SCHUR_QU=0: k_schur_pass1_reg up to four rows, the run-time-typed
+    k_schur_pass1 beyond): the solution satisfies the reference's system A x = b + sample vector through the oracle's operators,
+    and the two sets of kernels give the same amplitudes to rounding -- but not bit for bit, which shows that both ran."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "import dang_amd as da\n"
+            "from dang_amd import _lib as L\n"
+            "from util import make_case, pair\n"
+            "from test_oracle_templates_cpu import add_globals\n"
+            "from test_gpu_templates import _packed_x\n"
+            "def tweak(dpar, ddata, bands, comps):\n"
+            "    nb = ddata.sig_map.shape[0]\n"
+            "    add_globals(dpar, ddata, bands, comps, ('template',), 2, fit_bands=list(range(nb - %d, nb)))\n"
+            "case = make_case('C3', nside=8, start='truth', tweak=tweak)\n"
+            "dpar, ddata, bands, comps, meta = case\n"
+            "eng, orc = pair(case)\n"
+            "out = {}\n"
+            "for ml in ('optimize', 'sample'):\n"
+            "    b = orc.compute_rhs(2, L.FLAG_QU)\n"
+            "    if ml == 'sample':\n"
+            "        b = b + orc.compute_sample_vector(2, L.FLAG_QU, orc.draw_eta(L.FLAG_QU, 8, 9))\n"
+            "    it, bad = eng.amp_sample(2, L.FLAG_QU, ml, 8, 9)\n"
+            "    x = _packed_x(eng, comps, ('template',), 2, L.FLAG_QU, meta['nbands'])\n"
+            "    Ax = orc.compute_Ax(2, L.FLAG_QU, x)\n"
+            "    scale = orc.compute_Ax(2, L.FLAG_QU, np.abs(x)) + np.abs(b)\n"
+            "    live = scale > 0\n"
+            "    (rb, rt), steps = eng.schur_info()\n"
+            "    out[ml] = dict(it=it, bad=bad, rb=rb, steps=steps, res=float(np.abs(Ax - b)[live].max() / scale[live].max()),\n"
+            "                   amp=[eng.get_amplitude(l).tolist() for l, c in enumerate(comps) if c.cg_group == 2 and c.type != 'template'],\n"
+            "                   tamp=eng.get_template_amplitudes(len(comps) - 1).tolist())\n"
+            "print('RESULT ' + json.dumps(out))\n") % (root, os.path.join(root, "tests"), nrows)
+    res = {}
+    for qu in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DANGX_SCHUR_QU=qu, DANGX_SCHUR_CHECK="1"), stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=600)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+        assert r.returncode == 0 and lines, r.stdout[-3000:]
+        res[qu] = json.loads(lines[-1][7:])
+    same_bits = True
+    for ml in ("optimize", "sample"):
+        a, b = res["1"][ml], res["0"][ml]
+        assert a["it"] == b["it"] and a["bad"] == b["bad"] == 0
+        assert a["res"] <= 1e-9 and b["res"] <= 1e-9, (ml, a["res"], b["res"])     # A x = b through the reference's operators
+        ta, tb = np.array(a["tamp"]), np.array(b["tamp"])
+        assert np.abs(ta - tb).max() <= 1e-8 * max(np.abs(tb).max(), 1e-30), (ml, np.abs(ta - tb).max())
+        for x, y in zip(a["amp"], b["amp"]):
+            x, y = np.array(x), np.array(y)
+            assert np.abs(x - y).max() <= 1e-8 * max(np.abs(y).max(), 1e-30), ml
+            same_bits = same_bits and np.array_equal(x, y)
+    assert not same_bits

@@ -26,7 +26,9 @@ mono = len(sys.argv) > 3 and sys.argv[3] == "mono"       # a monopole fitted in 
 if mono:
     synth.add_monopole(ddata, comps, meta)
 elif not plain:
-    synth.add_qu_template(ddata, comps, meta)
+    nfit = int(os.environ.get("TEMPLATE_NFIT", "3"))     # bands the template is fitted at (the last nfit)
+    fit = tuple(range(nb - nfit, nb))
+    synth.add_qu_template(ddata, comps, meta, fit_bands=fit, amplitudes=tuple([2.0, -1.5, 0.7, 1.2, -0.8, 0.5, 1.7, -1.1, 0.9, 0.4][:nfit]))
 eng = da.initialize(bands, comps, ddata, npix_global=meta["npix_global"], device=0)
 for it in (1, 2):
     da.gibbs_iteration(dpar, ddata, it, want_counts=counts)
@@ -40,5 +42,7 @@ dt = (time.perf_counter() - t0) / steps
 prof = eng.profile_get()
 print("template model: %.2f ms per Gibbs iteration (%.1f it/s); chisq %.6f; template amplitudes %s"
       % (1e3 * dt, 1.0 / dt, ddata.chisq, "-" if plain else np.round(eng.get_template_amplitudes(len(comps) - 1)[0 if mono else 1], 4)))
+if not plain:
+    print("  Schur: residual %.2e (bound when not measured), refinements %d" % (eng.schur_info()[0][0], eng.schur_info()[1]))
 for k, v in prof.items():
     print("  %-14s %3d launches per iteration, %8.3f ms per iteration" % (k, v["launches"] // steps, v["total_ms"] / steps))
