@@ -1,6 +1,7 @@
 // dangx_schurqu.hip -- pass 1 of the Schur solve of a Q+U template group with one thread per pixel (see the kernel's comment;
 // dangx_schurreg.hip holds the per-plane passes and calls in here first).  Compiled three times (dang_amd/_build.py):
-// -DDX_QU_TB=5 / 4 / 2, the band tile -- 48 kernels per unit (members 1-6 x global rows 1-8) build side by side.
+// -DDX_QU_TB=5 / 2, the band tile (five or more bands / fewer; the nb % TB bands left over are taken one by one) -- 48 kernels
+// per unit (members 1-6 x global rows 1-8) build side by side.
 #include "dx_ampreg.h"
 
 #ifndef DX_QU_TB
@@ -24,7 +25,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_schur_pass1_qu(const Model* __rest
     extern __shared__ double lds[];
     __shared__ double wsum[NV][BLOCK / 64];
     const Model& M = *Mp;
-    const int npix = M.npix, nb = M.nbands, tid = threadIdx.x;
+    const int npix = M.npix, nb = M.nbands, tid = threadIdx.x, nfull = (nb / TB) * TB;   // (the launcher: nb >= TB)
     double* tab = lds;
     double* cu = lds + (TROWS * NG + 3) * nb;          // [plane][MAXU templates][band], zero where nothing is removed
     double* col = lds + (TROWS * NG + 3 + 2 * MAXU) * nb + tid;   // [member slot][band] x BLOCK
@@ -75,7 +76,9 @@ __global__ __launch_bounds__(BLOCK, 2) void k_schur_pass1_qu(const Model* __rest
             const double t0 = (c.nind > 0) ? ix[0] : 0.0, t1 = (c.nind > 1) ? ix[(long long)M.nmaps * npix] : 0.0;
             const Prep pr = sed_prep(c, t0, t1);
 #pragma unroll 1
-            for (int j0 = 0; j0 < nb; j0 += TB) sed_tile<TB>(ra.vtype[v], tab, nb, NG, ra.vcomp[v], j0, pr, col + (v * nb + j0) * BLOCK);
+            for (int j0 = 0; j0 < nfull; j0 += TB) sed_tile<TB>(ra.vtype[v], tab, nb, NG, ra.vcomp[v], j0, pr, col + (v * nb + j0) * BLOCK);
+#pragma unroll 1
+            for (int j = nfull; j < nb; ++j) sed_tile<1>(ra.vtype[v], tab, nb, NG, ra.vcomp[v], j, pr, col + (v * nb + j) * BLOCK);
         }
         if (sample) {
 #pragma unroll
@@ -85,9 +88,27 @@ __global__ __launch_bounds__(BLOCK, 2) void k_schur_pass1_qu(const Model* __rest
                 eta[p] = rand_normal(0.0, 1.0, u1, u2);
             }
         }
-        // ---- the normal equations of both planes, band tile by band tile
+        // ---- the normal equations of both planes, band tile by band tile (then the nb % TB bands left over, one by one)
+        auto accumulate = [&](int p, int j, double d, double rms) {
+#pragma unroll
+            for (int w = 0; w < MAXU; ++w) d = d - cu[(p * MAXU + w) * nb + j] * tv[p][w];
+            const double is = fast_rcp(rms);
+            const double inv = is * is;
+            double mrow[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                mrow[g] = (ra.vslot[g] >= 0) ? col[(ra.vslot[g] * nb + j) * BLOCK] : tab[(TROWS * g + 4 + p) * nb + j];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const double t2 = mrow[g] * inv;
+                bv[p][g] += d * t2;
+#pragma unroll
+                for (int h = 0; h <= g; ++h) A[p][g * (g + 1) / 2 + h] += t2 * mrow[h];
+            }
+            f0[p] += (eta[p] * is) * mrow[NG - 1];
+        };
 #pragma unroll 1
-        for (int j0 = 0; j0 < nb; j0 += TB) {
+        for (int j0 = 0; j0 < nfull; j0 += TB) {
             if (j0 > 0) {
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
@@ -98,29 +119,15 @@ __global__ __launch_bounds__(BLOCK, 2) void k_schur_pass1_qu(const Model* __rest
                     }
             }
 #pragma unroll
-            for (int t = 0; t < TB; ++t) {
-                const int j = j0 + t;
+            for (int t = 0; t < TB; ++t)
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    double d = dcur[p][t];
-#pragma unroll
-                    for (int w = 0; w < MAXU; ++w) d = d - cu[(p * MAXU + w) * nb + j] * tv[p][w];
-                    const double is = fast_rcp(rcur[p][t]);
-                    const double inv = is * is;
-                    double mrow[NG];
-#pragma unroll
-                    for (int g = 0; g < NG; ++g)
-                        mrow[g] = (ra.vslot[g] >= 0) ? col[(ra.vslot[g] * nb + j) * BLOCK] : tab[(TROWS * g + 4 + p) * nb + j];
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) {
-                        const double t2 = mrow[g] * inv;
-                        bv[p][g] += d * t2;
-#pragma unroll
-                        for (int h = 0; h <= g; ++h) A[p][g * (g + 1) / 2 + h] += t2 * mrow[h];
-                    }
-                    f0[p] += (eta[p] * is) * mrow[NG - 1];
-                }
-            }
+                for (int p = 0; p < 2; ++p) accumulate(p, j0 + t, dcur[p][t], rcur[p][t]);
+        }
+#pragma unroll 1
+        for (int j = nfull; j < nb; ++j) {
+            const double d0 = sig0[j * bstride], r0 = rms0[j * bstride], d1 = sig0[(long long)npix + j * bstride], r1 = rms0[(long long)npix + j * bstride];
+            accumulate(0, j, d0, r0);
+            accumulate(1, j, d1, r1);
         }
     }
     // ---- per plane: W = M / sigma^2, d / sigma^2, eta / sigma and 1 / sigma^2 of the band of every global row (two rows on one band
@@ -299,13 +306,13 @@ int launch_qu_ng(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, const
 
 #define DX_QU_CAT2(a, b) a##b
 #define DX_QU_CAT(a, b) DX_QU_CAT2(a, b)
-// 0 launched, 1 error, -1 not covered: the flag is not Q+U, the band count is not a multiple of this unit's tile, more than eight
+// 0 launched, 1 error, -1 not covered: the flag is not Q+U, fewer bands than this unit's tile, more than eight
 // global rows, a global member that is not a template, index maps that differ between Q and U, SED columns beyond 80 KB per block
 int DX_QU_CAT(dx_schurqu_pass1_tb, DX_QU_TB)(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev) {
     static const bool qu_on = [] { const char* e = getenv("DANGX_SCHUR_QU"); return !(e && e[0] == '0'); }();  // A/B switch
     AmpRegArgs ra;
     const int nb = ctx->hm.nbands;
-    if (!qu_on || a.flag != DANGX_FLAG_QU || nb % DX_QU_TB != 0 || sa.nrows < 1 || sa.nrows > 8 || !template_group_args(ctx, a, ra)) return -1;
+    if (!qu_on || a.flag != DANGX_FLAG_QU || nb < DX_QU_TB || sa.nrows < 1 || sa.nrows > 8 || !template_group_args(ctx, a, ra)) return -1;
     if (ra.uhifit != 0u) return -1;
     if (a.ml_mode == DANGX_ML_SAMPLE && a.fluct != DANGX_FLUCT_REFERENCE) return -1;
     for (int t = 0; t < a.nt; ++t)

@@ -459,7 +459,6 @@ int dx_schurreg_pass1_hf1(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& s
 int dx_schurreg_resid_hf0(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
 int dx_schurreg_pass1_hf0(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
 int dx_schurqu_pass1_tb5(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
-int dx_schurqu_pass1_tb4(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
 int dx_schurqu_pass1_tb2(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
 static bool group_has_hifit(dangx_ctx* ctx, const GroupArgs& a) {
     for (int t = 0; t < a.nt; ++t) if (ctx->desc[a.tc[t]].type == DANGX_HIFIT) return true;
@@ -534,8 +533,7 @@ int DX_PASS1_WORKER(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, lon
 #if !DX_SCHUR_HF
     if (a.flag == DANGX_FLAG_QU) {   // Q+U template groups: one thread per pixel, up to eight global rows (dangx_schurqu.hip)
         const int nb = ctx->hm.nbands;
-        const int rc = (nb % 5 == 0) ? dx_schurqu_pass1_tb5(ctx, a, sa, SN, rows_dev) : (nb % 4 == 0) ? dx_schurqu_pass1_tb4(ctx, a, sa, SN, rows_dev)
-                     : (nb % 2 == 0) ? dx_schurqu_pass1_tb2(ctx, a, sa, SN, rows_dev) : -1;
+        const int rc = (nb >= 5) ? dx_schurqu_pass1_tb5(ctx, a, sa, SN, rows_dev) : (nb >= 2) ? dx_schurqu_pass1_tb2(ctx, a, sa, SN, rows_dev) : -1;
         if (rc >= 0) return rc;
     }
 #endif

@@ -418,7 +418,7 @@ def _random_template_case(seed):
     extra = [c for c in rng.permutation(["cmb", "ff"])[: int(rng.integers(0, 3))]]
     names = ["synch", "dust"] + extra
     # (as many bands as diffuse members: the members absorb every global row -- a singular system, the rows keep their values)
-    nb = int(rng.choice([b for b in (4, 5, 6, 8, 10, 12) if b >= len(names) + 2]))
+    nb = int(rng.choice([b for b in (4, 5, 6, 7, 8, 9, 10, 12) if b >= len(names) + 2]))
     ntmpl = int(rng.integers(1, 3))
     rows = [int(rng.integers(1, 3)) for _ in range(ntmpl)]            # fitted bands per template: 1 or 2 each (R <= 4)
     info = dict(nb=nb, comps=names, rows=rows, nside=int(rng.choice([2, 4])), nsample=int(rng.choice([3, 10])), seed=seed)
@@ -446,7 +446,7 @@ def _random_template_case(seed):
 
 @pytest.mark.parametrize("seed", range(16))
 def test_random_template_models_one_launch_equals_the_separate_passes(built, seed, monkeypatch):
-    """16 random models (4-12 bands, 2-4 diffuse members, one or two Q/U templates with 1-2 fitted bands each and amplitudes on
+    """16 random models (4-12 bands, odd counts too, 2-4 diffuse members, one or two Q/U templates with 1-2 fitted bands each and amplitudes on
     their unfitted bands): two iterations through dangx_plane_set_sample as they run by default -- pass 1 (k_schur_pass1_qu where
     the shape allows), the host solve, one launch that back-substitutes and sweeps (kernels specialised at run time for most of
     these shapes) -- against DANGX_SCHUR_CHECK=1: pass 2, the measured residual, the sweeps-only launch.  Same state; the measured
