@@ -1,5 +1,5 @@
 // dangx_schurqu.hip -- pass 1 of the Schur solve of a Q+U template group with one thread per pixel (see the kernel's comment;
-// dangx_schurreg.hip holds the per-plane passes and calls in here first).  Compiled three times (dang_amd/_build.py):
+// dangx_schurreg.hip holds the per-plane passes and calls in here first).  Compiled twice (dang_amd/_build.py):
 // -DDX_QU_TB=5 / 2, the band tile (five or more bands / fewer; the nb % TB bands left over are taken one by one) -- 48 kernels
 // per unit (members 1-6 x global rows 1-8) build side by side.
 #include "dx_ampreg.h"
@@ -16,8 +16,9 @@ namespace {
 // from one tile of maps (half the memory round trips: each map plane is a 100-300 MB stride from the next, and two waves per SIMD
 // hide little of one); the vectors of the global rows' bands are read again after the loop (from the cache the maps just passed
 // through) instead of being picked out of it band by band; and (up to five rows) the row values of the two planes are added in
-// registers before the one block reduction.  SS = R, the group's global rows (up to 8).  A Q/U template's row weight is its template value (a monopole
-// exists on T only), so the Schur matrix of a unit is symmetric: R (R + 1) / 2 + 3 R row values instead of R^2 + 3 R.
+// registers before the one block reduction.  SS = R, the group's global rows (up to 8).  A Q/U template's row weight is its
+// template value (a monopole exists on T only), so the Schur matrix of a unit is symmetric: R (R + 1) / 2 + 3 R row values instead
+// of R^2 + 3 R.
 template <int NG, int TB, int SS>
 __global__ __launch_bounds__(BLOCK, 2) void k_schur_pass1_qu(const Model* __restrict__ Mp, GroupArgs a, AmpRegArgs ra, SchurArgs sa,
                                                             double* __restrict__ rowpartial, unsigned long long* __restrict__ not_spd) {

@@ -24,7 +24,8 @@ dpar, ddata, bands, comps, meta = synth.make_sky("C3", nside=nside, device=dev, 
 npix, nb = meta["npix"], meta["nbands"]
 mono = len(sys.argv) > 3 and sys.argv[3] == "mono"       # a monopole fitted in the T group instead
 if mono:
-    synth.add_monopole(ddata, comps, meta)
+    nfit = int(os.environ.get("TEMPLATE_NFIT", "3"))     # bands the monopole is fitted at (the first nfit)
+    synth.add_monopole(ddata, comps, meta, fit_bands=tuple(range(nfit)), amplitudes=tuple([3.0, -2.0, 5.0, 1.0, -4.0, 2.5, -1.5, 0.5, 3.5, -2.5][:nfit]))
 elif not plain:
     nfit = int(os.environ.get("TEMPLATE_NFIT", "3"))     # bands the template is fitted at (the last nfit)
     fit = tuple(range(nb - nfit, nb))
