@@ -7,6 +7,9 @@
 #ifndef DX_QU_TB
 #define DX_QU_TB 5
 #endif
+#ifndef DX_QU_WAVES   // waves per SIMD the kernel is compiled for, by its number of global rows.  Three (<= 168 registers, possible
+#define DX_QU_WAVES(SS) 2   // with two varying members: 41 KB of SED columns) costs 28-32 spilled registers and gains nothing
+#endif
 
 namespace {
 
@@ -20,7 +23,7 @@ namespace {
 // template value (a monopole exists on T only), so the Schur matrix of a unit is symmetric: R (R + 1) / 2 + 3 R row values instead
 // of R^2 + 3 R.
 template <int NG, int TB, int SS>
-__global__ __launch_bounds__(BLOCK, 2) void k_schur_pass1_qu(const Model* __restrict__ Mp, GroupArgs a, AmpRegArgs ra, SchurArgs sa,
+__global__ __launch_bounds__(BLOCK, DX_QU_WAVES(SS)) void k_schur_pass1_qu(const Model* __restrict__ Mp, GroupArgs a, AmpRegArgs ra, SchurArgs sa,
                                                             double* __restrict__ rowpartial, unsigned long long* __restrict__ not_spd) {
     constexpr int NP = SS * (SS + 1) / 2, NV = NP + 3 * SS, NA = NG * (NG + 1) / 2;
     extern __shared__ double lds[];
