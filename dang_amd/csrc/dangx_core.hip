@@ -1071,7 +1071,15 @@ int device_schur(dangx_ctx* const* cs, int nc, const GroupArgs* as, const long l
     const char* chk = getenv("DANGX_SCHUR_CHECK");
     double minpiv = 1.0;
     for (int c = 0; c < rank; ++c) minpiv = std::min(minpiv, std::fabs(S[(size_t)c * R + c]));
-    const bool well = rank == R && minpiv >= 1e-3 && !(chk && chk[0] == '1');
+    // (Only for `template` members, whose amplitudes are of the size of the data -- tests/test_gpu_round4.py.  The bound is a backward
+    // error: relative to the size of a row's terms.  A monopole + hi_fit pair can sit at 1e-15 of its terms and 2e-9 of b with
+    // pivots of 1e-2, its amplitudes being 1e7 times the data -- seed 243 of a 300-seed run of tests/test_gpu_fuzz.py, where the
+    // measured figure is what the report must carry.  DANGX_SCHUR_SKIP=any extends the skip to every member type, for experiments.)
+    const char* skp = getenv("DANGX_SCHUR_SKIP");
+    bool templates_only = !(skp && skp[0] == 'a');
+    for (int t = 0; templates_only && t < a.nt; ++t) templates_only = ctx->desc[a.tc[t]].type == DANGX_TEMPLATE;
+    if (skp && skp[0] == 'a') templates_only = true;
+    const bool well = rank == R && minpiv >= 1e-3 && templates_only && !(chk && chk[0] == '1');
     const bool deferred = well && defer && *defer;
     if (defer) *defer = deferred ? 1 : 0;
     if (deferred) {

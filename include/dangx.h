@@ -194,7 +194,7 @@ int dangx_amp_sample(dangx_ctx *ctx, int group, int flag, int ml_mode, int solve
  * global rows relative to that row of b; rel_residual[1] = the same relative to the size of the row's terms
  * (sum |b terms| + |A x terms|: rounding alone leaves ~1e-16 sqrt(npix) there, and weakly constrained amplitudes are
  * large, so [0] can sit well above [1]); refinements = steps taken (0: the first solution already met 1e-12).
- * A well-conditioned system (every pivot of the equilibrated Schur matrix >= 1e-3) is not measured: both numbers are then the
+ * A well-conditioned system of `template` members (every pivot of the equilibrated Schur matrix >= 1e-3) is not measured: both numbers are then the
  * a-priori bound 16 R eps / (smallest pivot) and refinements = 0; the environment variable DANGX_SCHUR_CHECK=1 measures always. */
 int dangx_schur_info(dangx_ctx *ctx, double *rel_residual /*[2]*/, int *refinements);
 /* Residual of the reference's linear system at the CURRENT amplitudes, through the reference's own operators

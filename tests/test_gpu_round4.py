@@ -1,5 +1,6 @@
 """Round-4 additions (one test per review item, each against the oracle or an invariant of the path)."""
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -444,7 +445,7 @@ def _random_template_case(seed):
     return case, info
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DANGX_TEMPLATE_FUZZ_SEEDS", "16"))))
 def test_random_template_models_one_launch_equals_the_separate_passes(built, seed, monkeypatch):
     """16 random models (4-12 bands, odd counts too, 2-4 diffuse members, one or two Q/U templates with 1-2 fitted bands each and amplitudes on
     their unfitted bands): two iterations through dangx_plane_set_sample as they run by default -- pass 1 (k_schur_pass1_qu where
