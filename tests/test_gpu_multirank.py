@@ -17,6 +17,9 @@ JOBS = [  # (global members, group, flag, solver, ml_mode)
     (("monopole", "hi_fit"), 1, 1, "direct", "optimize"),
     (("template",), 2, 8, "cg", "sample"),
     ((), 1, 1, "cg", "sample"),
+    # the solve together with the sweeps on its planes (dangx_plane_set_sample): the Schur rows through the callback, then ONE launch
+    # per rank that back-substitutes and sweeps; the swept index maps are gathered and compared too
+    (("template",), 2, 8, "planeset", "sample"),
 ]
 
 
@@ -28,12 +31,14 @@ def _free_port():
     return p
 
 
-def _full_case(which, group):
+def _full_case(which, group, solver=""):
     from test_oracle_templates_cpu import add_globals
     from util import make_case
 
     def tweak(dpar, ddata, bands, comps):
-        if which:
+        if which and solver == "planeset":   # a well-posed fit (two of five bands): the solve that needs no residual pass
+            add_globals(dpar, ddata, bands, comps, which, group, fit_bands=[3, 4])
+        elif which:
             add_globals(dpar, ddata, bands, comps, which, group, skip_band0=True)
     return make_case("C2", nside=4, start="truth", tweak=tweak)
 
@@ -63,8 +68,19 @@ def _run(case, which, group, flag, solver, ml_mode, rank=0, world=1):
     eng = da.Engine(bands, comps, ddata, npix_global=meta["npix_global"], pix0=p0, device=0)
     # few CG iterations: the check is on the mechanics (every sum over the sky complete), before the rounding-level
     # differences of the summation order are amplified along an unconverged trajectory
-    it, _ = eng.amp_sample(group, flag, ml_mode, 8, 9, solver=solver, i_max=6, converge=1e-10)
+    if solver == "planeset":
+        sweeps = [(l, j, da.stream_id(2, 1, l, j, flag)) for l, c in enumerate(comps) for j in range(c.nindices)
+                  if c.cg_group == group and c.sample_index[j] and flag in c.pol_flag[j]]
+        eng.profile(True)
+        bad, _ = eng.plane_set_sample(group, flag, ml_mode, 8, 9, sweeps, 5, 11)
+        prof = eng.profile_get()
+        assert bad == 0 and prof["k_amp_index"]["launches"] == 1 and "k_index_mh" not in prof and "k_amp_direct" not in prof, prof
+        it = 0
+    else:
+        it, _ = eng.amp_sample(group, flag, ml_mode, 8, 9, solver=solver, i_max=6, converge=1e-10)
     amps = [eng.get_amplitude(l) for l in range(len(comps))]
+    if solver == "planeset":   # (index maps as further "amplitude" arrays of the comparison: [nmaps, npix] per index)
+        amps += [eng.get_indices(l)[j] for l, c in enumerate(comps) for j in range(c.nindices) if c.cg_group == group]
     tas = [eng.get_template_amplitudes(l) for l, c in enumerate(comps) if c.type in ("template", "monopole", "hi_fit")]
     return it, amps, tas
 
@@ -124,7 +140,7 @@ def _worker(rank, world, port, out):
     import torch
     res = {}
     for n, (which, group, flag, solver, ml_mode) in enumerate(JOBS):
-        it, amps, tas = _run(_full_case(which, group), which, group, flag, solver, ml_mode, rank, world)
+        it, amps, tas = _run(_full_case(which, group, solver), which, group, flag, solver, ml_mode, rank, world)
         res["it%d" % n] = it
         for l, a in enumerate(amps):
             g = dist.gather_maps(torch.from_numpy(a), 192, dst=0)
@@ -157,7 +173,7 @@ def test_two_ranks_solve_the_same_coupled_systems_as_one(built, tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     got = np.load(out)
     for n, (which, group, flag, solver, ml_mode) in enumerate(JOBS):
-        it, amps, tas = _run(_full_case(which, group), which, group, flag, solver, ml_mode)
+        it, amps, tas = _run(_full_case(which, group, solver), which, group, flag, solver, ml_mode)
         assert int(got["it%d" % n]) == it, (n, int(got["it%d" % n]), it)
         # sums over the sky are formed in a different order (per-rank partials, then the all-reduce)
         tol = 1e-9
