@@ -1445,6 +1445,12 @@ int dangx_set_template(dangx_ctx* ctx, int comp, const double* tmpl, const int32
     for (int k = 0; k < ctx->dims.nmaps; ++k)
         for (long long t = 0; t < ctx->dims.npix; ++t)
             if (host_at(ctx, tmpl, k, t) != 0.0) { ctx->tmpl_nz[comp] |= 1u << k; break; }
+    ctx->tmpl_one[comp] = 0;
+    for (int k = 0; k < ctx->dims.nmaps; ++k) {
+        bool one = true;
+        for (long long t = 0; one && t < ctx->dims.npix; ++t) one = host_at(ctx, tmpl, k, t) == 1.0;
+        if (one) ctx->tmpl_one[comp] |= 1u << k;
+    }
     ctx->corr_mask[comp] = mask; ctx->nfit[comp] = nfit;
     ctx->dirty = true;
     invalidate_chi(ctx);

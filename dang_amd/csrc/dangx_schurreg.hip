@@ -458,8 +458,10 @@ int dx_schurreg_resid_hf1(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& s
 int dx_schurreg_pass1_hf1(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
 int dx_schurreg_resid_hf0(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
 int dx_schurreg_pass1_hf0(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
-int dx_schurqu_pass1_tb5(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
-int dx_schurqu_pass1_tb2(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
+int dx_schurqu2_pass1_tb5(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
+int dx_schurqu2_pass1_tb2(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
+int dx_schurqu1_pass1_tb5(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
+int dx_schurqu1_pass1_tb2(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev);
 static bool group_has_hifit(dangx_ctx* ctx, const GroupArgs& a) {
     for (int t = 0; t < a.nt; ++t) if (ctx->desc[a.tc[t]].type == DANGX_HIFIT) return true;
     return false;
@@ -531,9 +533,13 @@ int launch_pass1_ng(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, co
 // four global rows or fitted bands, a hi_fit member, bandpass-integrated bands, the textbook fluctuation term ...)
 int DX_PASS1_WORKER(dangx_ctx* ctx, const GroupArgs& a, const SchurArgs& sa, long long SN, double* rows_dev) {
 #if !DX_SCHUR_HF
-    if (a.flag == DANGX_FLAG_QU) {   // Q+U template groups: one thread per pixel, up to eight global rows (dangx_schurqu.hip)
+    {   // dangx_schurqu.hip: up to eight global rows (templates, monopoles); Q+U with equal index maps as one thread per pixel,
+        // everything else as one thread per (pixel, plane)
         const int nb = ctx->hm.nbands;
-        const int rc = (nb >= 5) ? dx_schurqu_pass1_tb5(ctx, a, sa, SN, rows_dev) : (nb >= 2) ? dx_schurqu_pass1_tb2(ctx, a, sa, SN, rows_dev) : -1;
+        int rc = -1;
+        if (a.flag == DANGX_FLAG_QU)
+            rc = (nb >= 5) ? dx_schurqu2_pass1_tb5(ctx, a, sa, SN, rows_dev) : (nb >= 2) ? dx_schurqu2_pass1_tb2(ctx, a, sa, SN, rows_dev) : -1;
+        if (rc < 0) rc = (nb >= 5) ? dx_schurqu1_pass1_tb5(ctx, a, sa, SN, rows_dev) : (nb >= 2) ? dx_schurqu1_pass1_tb2(ctx, a, sa, SN, rows_dev) : -1;
         if (rc >= 0) return rc;
     }
 #endif

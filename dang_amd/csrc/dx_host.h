@@ -41,6 +41,7 @@ struct dangx_ctx {
     int corr_mask[MAXC] = {}, nfit[MAXC] = {};
     double tamp[MAXC][3][MAXB] = {};  // c%template_amplitudes, host mirror [map][band]
     unsigned tmpl_nz[MAXC] = {};   // bit k-1: plane k of c%template has a non-zero pixel (a template without one has no signal there)
+    unsigned tmpl_one[MAXC] = {};  // bit k-1: plane k of c%template is identically 1 (a monopole's, src/dang_component_mod.f90:593-595)
     unsigned idx_const[MAXC] = {}; // bit k-1: every index of the component is spatially constant on plane k
     unsigned qu_equal[MAXC] = {};  // bit q: index map q of the component is equal on the Q and U planes for every pixel
     double idx_val[MAXC][3][MAXI] = {};
