@@ -205,7 +205,10 @@ __global__ __launch_bounds__(BLOCK, NG <= 4 ? 4 : 3) void k_amp_reg(const Model*
 // components with a non-zero amplitude play the group (sky = sum of amplitude * SED in component order), the residual replaces
 // the normal equations.  The run-time-typed kernel of dangx_entry.hip (k_sky_chisq) spends 1.36 ms per C3 plane on the same
 // numbers; this one is bound by the 2 nb map loads like k_amp_reg.  Block partials -> partial[blockIdx.x].
-template <int NG, int TB>
+// GT: `template` components with a signal on the plane are part of the sky model too -- template_amplitudes(band, map) * template(pix,
+// map) (eval_signal, src/dang_component_mod.f90:754-776); their coefficients sit behind the table in MAXU zero-padded rows and are
+// read unconditionally.  (A monopole is NOT: update_sky_model turns it into the band offsets, src/dang_data_mod.f90:357-361.)
+template <int NG, int TB, bool GT = false>
 __global__ __launch_bounds__(BLOCK, NG <= 4 ? 4 : 3) void k_chisq_reg(const Model* __restrict__ Mp, GroupArgs a, AmpRegArgs ra,
                                                                      double* __restrict__ partial) {
     extern __shared__ double lds[];  // as k_amp_reg
@@ -213,7 +216,8 @@ __global__ __launch_bounds__(BLOCK, NG <= 4 ? 4 : 3) void k_chisq_reg(const Mode
     const Model& M = *Mp;
     const int npix = M.npix, nb = M.nbands, tid = threadIdx.x;
     double* tab = lds;
-    double* prl = lds + (TROWS * NG + 3) * nb + tid;
+    double* cu = lds + (TROWS * NG + 3) * nb;
+    double* prl = lds + (TROWS * NG + 3 + (GT ? MAXU : 0)) * nb + tid;
     double* col = prl + 3 * ra.nv * BLOCK;
     const long long u = (long long)blockIdx.x * BLOCK + tid;
     const bool in_range = u < npix;
@@ -231,6 +235,15 @@ __global__ __launch_bounds__(BLOCK, NG <= 4 ? 4 : 3) void k_chisq_reg(const Mode
             const gcptr ix = as_global(c.idx) + (long long)(k - 1) * npix + i;
             if (c.nind > 0) th[v][0] = ix[0];
             if (c.nind > 1) th[v][1] = ix[(long long)M.nmaps * npix];
+        }
+    }
+    double tv[MAXU];
+    if (GT) {
+#pragma unroll
+        for (int w = 0; w < MAXU; ++w) tv[w] = (w < ra.nu) ? as_global(M.comp[ra.ucomp[w]].tmpl)[(long long)(k - 1) * npix + i] : 0.0;
+        for (int t = tid; t < MAXU * nb; t += BLOCK) {
+            const int w = t / nb, j = t - w * nb;
+            cu[t] = (w < ra.nu) ? M.comp[ra.ucomp[w]].tamp[k - 1][j] : 0.0;
         }
     }
     sed_table_build(M, tab, tid, BLOCK, a.gc, NG);
@@ -287,6 +300,10 @@ __global__ __launch_bounds__(BLOCK, NG <= 4 ? 4 : 3) void k_chisq_reg(const Mode
                 double sky = 0.0;
 #pragma unroll
                 for (int g = 0; g < NG; ++g) sky = sky + av[g] * mp[g][t * ms[g]];  // component order, :349-356
+                if (GT) {
+#pragma unroll
+                    for (int w = 0; w < MAXU; ++w) sky = sky + cu[w * nb + j0 + t] * tv[w];
+                }
                 const double r = (d - sky) * fast_rcp(rcur[t]);
                 chi = fma(r, r, chi);  // :505-523
             }
@@ -333,21 +350,26 @@ int launch_ng(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, long lon
 
 template <int NG, int TB>
 int launch_chi_tb(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, double* partial) {
-    const size_t ldsz = amp_reg_lds<TB>(NG, ctx->hm.nbands, ra.nv);
-    hipLaunchKernelGGL((k_chisq_reg<NG, TB>), dim3(nblocks(ctx->hm.npix)), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, partial);
+    if (ra.nu > 0) {
+        const size_t ldsz = amp_reg_lds<TB>(NG, ctx->hm.nbands, ra.nv, MAXU);
+        hipLaunchKernelGGL((k_chisq_reg<NG, TB, true>), dim3(nblocks(ctx->hm.npix)), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, partial);
+    } else {
+        const size_t ldsz = amp_reg_lds<TB>(NG, ctx->hm.nbands, ra.nv);
+        hipLaunchKernelGGL((k_chisq_reg<NG, TB>), dim3(nblocks(ctx->hm.npix)), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, a, ra, partial);
+    }
     return 0;
 }
 template <int NG>
 int launch_chi_ng(dangx_ctx* ctx, const GroupArgs& a, const AmpRegArgs& ra, double* partial) {
-    const int nb = ctx->hm.nbands;
+    const int nb = ctx->hm.nbands, nu = ra.nu > 0 ? MAXU : 0;
     const size_t want = (160u * 1024u) / (NG <= 4 ? 4 : 3), most = 80u * 1024u;
     for (const size_t cap : {want, most}) {
-        if (nb % 5 == 0 && amp_reg_lds<5>(NG, nb, ra.nv) <= cap) return launch_chi_tb<NG, 5>(ctx, a, ra, partial);
-        if (nb % 4 == 0 && amp_reg_lds<4>(NG, nb, ra.nv) <= cap) return launch_chi_tb<NG, 4>(ctx, a, ra, partial);
-        if (nb % 3 == 0 && amp_reg_lds<3>(NG, nb, ra.nv) <= cap) return launch_chi_tb<NG, 3>(ctx, a, ra, partial);
+        if (nb % 5 == 0 && amp_reg_lds<5>(NG, nb, ra.nv, nu) <= cap) return launch_chi_tb<NG, 5>(ctx, a, ra, partial);
+        if (nb % 4 == 0 && amp_reg_lds<4>(NG, nb, ra.nv, nu) <= cap) return launch_chi_tb<NG, 4>(ctx, a, ra, partial);
+        if (nb % 3 == 0 && amp_reg_lds<3>(NG, nb, ra.nv, nu) <= cap) return launch_chi_tb<NG, 3>(ctx, a, ra, partial);
         if (nb % 5 && nb % 4 && nb % 3) {
-            if (nb % 2 == 0 && amp_reg_lds<2>(NG, nb, ra.nv) <= cap) return launch_chi_tb<NG, 2>(ctx, a, ra, partial);
-            if (nb % 2 && amp_reg_lds<1>(NG, nb, ra.nv) <= cap) return launch_chi_tb<NG, 1>(ctx, a, ra, partial);
+            if (nb % 2 == 0 && amp_reg_lds<2>(NG, nb, ra.nv, nu) <= cap) return launch_chi_tb<NG, 2>(ctx, a, ra, partial);
+            if (nb % 2 && amp_reg_lds<1>(NG, nb, ra.nv, nu) <= cap) return launch_chi_tb<NG, 1>(ctx, a, ra, partial);
         }
     }
     return -1;
@@ -395,24 +417,38 @@ int dx_launch_amp_reg(dangx_ctx* ctx, const GroupArgs& a, long long SN) {
 }
 
 // chi^2 block partials of plane k (1..nmaps) into partial[0 .. nblocks(npix)): 0 when launched, -1 when the plane needs the
-// run-time-typed kernel (bandpass-integrated bands, global or T_cmb components, more than six components with an amplitude on
-// the plane, none at all)
+// run-time-typed kernel (bandpass-integrated bands, hi_fit or T_cmb components, more than four templates or six components with an
+// amplitude on the plane, none at all)
 int dx_launch_chisq_reg(dangx_ctx* ctx, int k, double* partial) {
     static const bool enabled = [] { const char* e = getenv("DANGX_CHISQ_FAST"); return !(e && e[0] == '0'); }();  // A/B switch
-    if (!enabled || !ctx->hm.all_delta || k < 1 || k > ctx->dims.nmaps) return -1;
+    if (!enabled || k < 1 || k > ctx->dims.nmaps) return -1;
+    for (int j = 0; j < ctx->hm.nbands; ++j)
+        if (ctx->hm.band[j].n != 0) return -1;                   // (hm.all_delta is also 0 when the model holds a global-type component)
     GroupArgs a = {};
     a.ng = 0;
+    AmpRegArgs ra;
+    ra.nv = 0; ra.nu = 0; ra.umember = 0u; ra.rowmono = 0u; ra.uinuc = 0u; ra.uhifit = 0u;
+    for (int w = 0; w < MAXU; ++w) ra.ucomp[w] = 0;
     for (int l = 0; l < ctx->hm.ncomp; ++l) {
         const Comp& c = ctx->hm.comp[l];
-        if (!((ctx->plane_nz[l] >> (k - 1)) & 1u)) continue;  // amplitude 0 everywhere on the plane: 0 * sed
+        if (c.type == DANGX_TCMB) return -1;                     // a signal without an amplitude: the run-time-typed kernel
+        if (c.type == DANGX_MONOPOLE) continue;                  // the band offsets, not a term of the sky model (:357-361)
+        if (c.type == DANGX_TEMPLATE) {                          // template_amplitudes * template: a term wherever the map is not zero
+            if (!((ctx->tmpl_nz[l] >> (k - 1)) & 1u)) continue;
+            if (ra.nu >= MAXU) return -1;
+            ra.ucomp[ra.nu++] = l;
+            continue;
+        }
+        if (c.type == DANGX_HIFIT) {                             // (a per-pixel Planck factor: the run-time-typed kernel where it has a signal)
+            if (!((ctx->tmpl_nz[l] >> (k - 1)) & 1u)) continue;
+            return -1;
+        }
+        if (!((ctx->plane_nz[l] >> (k - 1)) & 1u)) continue;     // amplitude 0 everywhere on the plane: 0 * sed
         if (c.type < DANGX_POWERLAW || c.type > DANGX_CMB || a.ng >= 6) return -1;
         a.gc[a.ng++] = l;
     }
     if (a.ng < 1) return -1;
     a.flag = (k == 1) ? DANGX_FLAG_T : (k == 2) ? DANGX_FLAG_Q : DANGX_FLAG_U;
-    AmpRegArgs ra;
-    ra.nv = 0; ra.nu = 0; ra.umember = 0u; ra.rowmono = 0u; ra.uinuc = 0u; ra.uhifit = 0u;
-    for (int w = 0; w < MAXU; ++w) ra.ucomp[w] = 0;
     for (int r = 0; r < 8; ++r) ra.rowu[r] = -1;
     for (int g = 0; g < MAXG; ++g) { ra.vslot[g] = -1; ra.vcomp[g] = 0; ra.vtype[g] = 0; }
     for (int g = 0; g < a.ng; ++g) {

@@ -845,7 +845,7 @@ static int sky_chisq_launch(dangx_ctx* ctx, int pol_lo, int pol_hi, double* sky_
     constexpr int RSTAGE = 128;
     // delta bandpasses, diffuse components, no maps asked for: one launch per plane on the amplitude kernel's schedule
     // (k_chisq_reg, dangx_ampreg.hip), the planes' block partials side by side and summed together
-    if (!sky_d && !res_d && !chi_d && ctx->hm.all_delta) {
+    if (!sky_d && !res_d && !chi_d) {   // (dx_launch_chisq_reg says -1 for what it does not cover)
         const unsigned nb256 = nblocks(ctx->hm.npix);
         const int npl = pol_hi - pol_lo + 1;
         if (ensure_partial(ctx, (long long)npl * nb256 + RSTAGE)) return 1;
