@@ -57,7 +57,11 @@ __global__ __launch_bounds__(BLOCK) void k_fullsky_rows(const Model* __restrict_
     const bool in = i < npix && il >= 0 && il < M.npix;
     const bool msk = in ? is_masked(coarse ? cmask[i] : M.mask[i]) : true;
     const Prep pr = sed_prep(c, th0, th1);
-    const int nrows = (what == 1) ? 2 * nb * Sp : 1;
+    // one index value for the whole sky: the SED is one number per band -- evaluated once per block, not once per pixel
+    __shared__ double sj[MAXB];
+    if (threadIdx.x < nb) sj[threadIdx.x] = sed_eval(M, c, threadIdx.x, pr);
+    __syncthreads();
+    const int nrows = (what == 1) ? 2 * nb * Sp : (what == 3) ? 3 * nb * Sp : 1;
     double amp[2] = {0.0, 0.0};
     if (in) for (int kk = 0; kk < Sp; ++kk) amp[kk] = c.amp[(long long)(s1 + kk - 1) * M.npix + il];
     auto rms_at = [&](int kk, int j) -> double {
@@ -69,20 +73,29 @@ __global__ __launch_bounds__(BLOCK) void k_fullsky_rows(const Model* __restrict_
             if (what == 0 && !msk) {
                 for (int kk = 0; kk < Sp; ++kk)
                     for (int j = 0; j < nb; ++j) {
-                        const double m = signal_of(c, amp[kk], sed_eval(M, c, j, pr));
+                        const double m = signal_of(c, amp[kk], sj[j]);
                         const double t = (data[((long long)kk * nb + j) * npix + i] - m) / rms_at(kk, j);
                         v = v - 0.5 * (t * t);
                     }
             } else if (what == 1) {
                 const int q = row >> 1, j = q / Sp, kk = q - j * Sp;  // (j outer, k inner) as the reference sums
-                const double m = signal_of(c, amp[kk], sed_eval(M, c, j, pr));
+                const double m = signal_of(c, amp[kk], sj[j]);
                 const double rms = rms_at(kk, j);
                 const double TN = m / (rms * rms);
                 v = (row & 1) ? TN * m : TN * data[((long long)kk * nb + j) * npix + i];
+            } else if (what == 3 && !msk) {
+                // the sufficient statistics of the chisq likelihood about theta (the index is one value for the whole sky, so the SED
+                // is one number per band): with r0 = (d - a s0) / sigma, rows 3q .. 3q+2 = sum r0^2, sum r0 a / sigma, sum a^2 / sigma^2
+                // -- chi^2 at any other theta is sum_q [W0 - 2 (s - s0) U + (s - s0)^2 V] (dangx_sky.hip)
+                const int q = row / 3, t3 = row - 3 * q, j = q / Sp, kk = q - j * Sp;
+                const double rr = 1.0 / rms_at(kk, j);
+                const double ar = amp[kk] * rr;
+                const double r0 = (data[((long long)kk * nb + j) * npix + i] - signal_of(c, amp[kk], sj[j])) * rr;
+                v = (t3 == 0) ? r0 * r0 : (t3 == 1) ? r0 * ar : ar * ar;
             } else if (what == 2 && !msk && c.is_synch) {
                 for (int kk = 0; kk < Sp; ++kk)
                     for (int j = 0; j < nb; ++j) {
-                        const double ss = signal_of(c, amp[kk], sed_eval(M, c, j, pr));
+                        const double ss = signal_of(c, amp[kk], sj[j]);
                         const double rr = 1.0 / rms_at(kk, j);
                         const double t = (rr * rr) * (ss / amp[kk]) * c.lnr[j];
                         v = v + t * t;
@@ -327,10 +340,10 @@ int dangx_fullsky_sums(dangx_ctx* ctx, int what, const double* theta, double* ou
     if (!ctx || !theta || !out) return 1;
     (void)hipSetDevice(ctx->device);
     if (ctx->fs_comp < 0) return fail(ctx, "dangx_fullsky_prepare has not been called");
-    if (what < 0 || what > 2) return fail(ctx, "bad sum selector");
+    if (what < 0 || what > 3) return fail(ctx, "bad sum selector");
     if (sync_model(ctx)) return 1;
     const int Sp = ctx->fs_s2 - ctx->fs_s1 + 1;
-    const int rows = (what == 1) ? 2 * ctx->hm.nbands * Sp : 1;
+    const int rows = (what == 1) ? 2 * ctx->hm.nbands * Sp : (what == 3) ? 3 * ctx->hm.nbands * Sp : 1;
     if (nout < rows) return fail(ctx, "output buffer too small");
     const bool coarse = ctx->fs_npc > 0;
     const unsigned nblk = nblocks(coarse ? ctx->fs_npc : ctx->hm.npix);

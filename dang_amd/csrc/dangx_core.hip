@@ -568,6 +568,18 @@ double host_sed(const Comp& c, double nu, double cmb_cst, double th0, double th1
 
 // ---- host helpers shared with dangx_entry.hip / dangx_coarse.hip / dangx_sky.hip (declared in dx_host.h)
 
+// eval_sed of a diffuse component at band j for index values (t0, t1) on the host: the delta form, or the tau0-weighted sum over
+// the band's samples (the expressions sync_model uses for spatially constant indices)
+double dx_host_band_sed(dangx_ctx* ctx, int comp, int j, double t0, double t1) {
+    const Comp& c = ctx->hm.comp[comp];
+    const Band& b = ctx->hm.band[j];
+    if (b.n == 0 || c.type == DANGX_CMB) return host_sed(c, b.nu_c, c.cst[j], t0, t1);
+    double sum = 0.0;
+    for (int q = 0; q < b.n; ++q)
+        if (ctx->bp_nu0[b.off + q] != 0.0) sum = sum + ctx->bp_tau0[b.off + q] * host_sed(c, ctx->bp_nu0[b.off + q], 0.0, t0, t1);
+    return sum;
+}
+
 int sync_model(dangx_ctx* ctx) {
     if (!ctx->dirty) return 0;
     Model& M = ctx->hm;

@@ -101,10 +101,50 @@ int sky_rows(const Sky& s, int what, const double* theta, double* rows, int nrow
     return sky_ranks(s, rows, nrows);
 }
 
+// The chisq likelihood of a full-sky chain from ONE pass over the maps.  The index is one value for the whole sky, so the model of
+// band j on plane k is a(p) s_j(theta) with a pixel-independent s_j: about the chain's starting point theta0, with r0 = (d - a
+// s_j(theta0)) / sigma,
+//   -2 lnL(theta) = sum_jk [ W0_jk - 2 ds_j U_jk + ds_j^2 V_jk ],  ds_j = s_j(theta) - s_j(theta0),
+//   W0 = sum_p r0^2, U = sum_p r0 a / sigma, V = sum_p a^2 / sigma^2  (unmasked pixels; k_fullsky_rows, selector 3).
+// Exact algebra, no cancellation near theta0 (W0 is chi^2 itself, the other terms are of the size of the change); every proposal of
+// the chain and of the tuner then costs nb SED evaluations on the host instead of a pass over the maps and a sky-wide reduction:
+// NUMSAMPLE + 1 passes per sweep become one.  DANGX_FULLSKY_STATS=0: every evaluation a pass (A/B, and the form the reference has).
+struct SkyStats {
+    bool on = false;
+    int comp = 0, nb = 0, Sp = 0;
+    std::vector<double> s0, rows;   // s_j(theta0); W0, U, V per (band, plane) as the kernel writes them
+};
+int sky_stats(const Sky& s, int comp, int Sp, const double* theta0, SkyStats& st) {
+    static const bool enabled = [] { const char* e = getenv("DANGX_FULLSKY_STATS"); return !(e && e[0] == '0'); }();
+    dangx_ctx* c0 = s.root();
+    const int ty = c0->desc[comp].type;
+    st.on = false;
+    if (!enabled || !(ty == DANGX_POWERLAW || ty == DANGX_MBB || ty == DANGX_FREEFREE || ty == DANGX_LOGNORMAL)) return 0;
+    st.comp = comp; st.nb = c0->dims.nbands; st.Sp = Sp;
+    st.rows.assign((size_t)3 * st.nb * Sp, 0.0);
+    if (sky_rows(s, 3, theta0, st.rows.data(), 3 * st.nb * Sp)) return 1;
+    st.s0.resize((size_t)st.nb);
+    for (int j = 0; j < st.nb; ++j) st.s0[(size_t)j] = dx_host_band_sed(c0, comp, j, theta0[0], theta0[1]);
+    st.on = true;
+    return 0;
+}
+double stats_lnl(const Sky& s, const SkyStats& st, const double* theta) {
+    double chi = 0.0;
+    for (int j = 0; j < st.nb; ++j) {
+        const double ds = dx_host_band_sed(s.root(), st.comp, j, theta[0], theta[1]) - st.s0[(size_t)j];
+        for (int kk = 0; kk < st.Sp; ++kk) {
+            const double* r = &st.rows[(size_t)3 * (j * st.Sp + kk)];
+            chi = chi + (r[0] - 2.0 * ds * r[1] + ds * ds * r[2]);
+        }
+    }
+    return -0.5 * chi;
+}
+
 // evaluate_lnL / evaluate_marginal_lnL over the whole sky (src/dang_lnl_mod.f90:126-182, 47-124)
-int sky_lnl(const Sky& s, int lnl_type, const double* theta, int Sp, double* out) {
+int sky_lnl(const Sky& s, int lnl_type, const double* theta, int Sp, double* out, const SkyStats* st = nullptr) {
     const int nb = s.root()->dims.nbands;
     *out = 0.0;
+    if (lnl_type == DANGX_LNL_CHISQ && st && st->on) { *out = stats_lnl(s, *st, theta); return 0; }
     if (lnl_type == DANGX_LNL_CHISQ) return sky_rows(s, 0, theta, out, 1);
     if (lnl_type == DANGX_LNL_MARGINAL) {
         std::vector<double> rows((size_t)2 * nb * Sp);
@@ -147,14 +187,14 @@ void set_step(const Sky& s, int comp, int nind, double step) {
 // return when nothing is accepted any more (optimize mode at the optimum: the step only ever halves); stopped after 64
 // rounds here, as in the oracle.
 int tune(const Sky& s, int comp, int nind, int Sp, int nsample, int ml_mode, unsigned long long seed, unsigned long long stream,
-         const double* theta_init, uint32_t* draw, int32_t* tuned) {
+         const double* theta_init, uint32_t* draw, int32_t* tuned, const SkyStats* st = nullptr) {
     dangx_ctx* c0 = s.root();
     const dangx_comp_desc& d = c0->desc[comp];
     double sample[2] = {theta_init[0], theta_init[1]}, theta[2] = {theta_init[0], theta_init[1]};
     double lnl = 0.0, lnl_new = 0.0, lnl_old = 0.0;
     const int lt = d.lnl_type[nind], pt = d.prior_type[nind];
     if (lt == DANGX_LNL_CHISQ || lt == DANGX_LNL_MARGINAL) {
-        if (sky_lnl(s, lt, sample, Sp, &lnl)) return 1;
+        if (sky_lnl(s, lt, sample, Sp, &lnl, st)) return 1;
     } else if (lt == DANGX_LNL_PRIOR) {
         double u1, u2;
         h_uniform2(seed, stream, (*draw)++, u1, u2);
@@ -171,7 +211,7 @@ int tune(const Sky& s, int comp, int nind, int Sp, int nsample, int ml_mode, uns
             theta[nind] = sample[nind] + h_rand_normal(0.0, step, u1, u2);
             if (theta[nind] < d.uni_prior[nind][0] || theta[nind] > d.uni_prior[nind][1]) continue;
             if (lt == DANGX_LNL_CHISQ || lt == DANGX_LNL_MARGINAL) {
-                if (sky_lnl(s, lt, theta, Sp, &lnl)) return 1;
+                if (sky_lnl(s, lt, theta, Sp, &lnl, st)) return 1;
             }
             if (pt == DANGX_PRIOR_GAUSSIAN) lnl_new = lnl + h_log_normal_prior(theta[nind], d.gauss_prior[nind][0], d.gauss_prior[nind][1]);
             else if (pt == DANGX_PRIOR_UNIFORM) lnl_new = lnl;
@@ -267,8 +307,10 @@ int dangx_fullsky_sample(dangx_ctx* const* ctxs, int nctx, int comp, int nind, i
     const int lt = d.lnl_type[nind];
     double lnl = 0.0, pr = 0.0;
     bool sample_it = true;
+    SkyStats st;
+    if (lt == DANGX_LNL_CHISQ && sky_stats(s, comp, Sp, first, st)) return 1;
     if (lt == DANGX_LNL_CHISQ || lt == DANGX_LNL_MARGINAL) {
-        if (sky_lnl(s, lt, sample, Sp, &lnl)) return 1;
+        if (sky_lnl(s, lt, sample, Sp, &lnl, &st)) return 1;
     } else {  // 'prior': one draw from the gaussian prior, no chain (:255-257)
         double u1, u2;
         sample_it = false;
@@ -281,7 +323,7 @@ int dangx_fullsky_sample(dangx_ctx* const* ctxs, int nctx, int comp, int nind, i
     if (sample_it) {
         if (!tuned[nind]) {  // :272-275
             uint32_t draw = 1;
-            if (tune(s, comp, nind, Sp, nsample, ml_mode, seed, stream ^ 0x5555555555555555ull, sample, &draw, tuned)) return 1;
+            if (tune(s, comp, nind, Sp, nsample, ml_mode, seed, stream ^ 0x5555555555555555ull, sample, &draw, tuned, &st)) return 1;
         }
         sample[0] = theta[0] = first[0]; sample[1] = theta[1] = first[1];
         const double step = c0->desc[comp].step_size[nind];
@@ -290,7 +332,7 @@ int dangx_fullsky_sample(dangx_ctx* const* ctxs, int nctx, int comp, int nind, i
             h_uniform3(seed, stream, (uint32_t)l, u1, u2, u3);
             theta[nind] = sample[nind] + h_rand_normal(0.0, step, u1, u2);
             if (theta[nind] < d.uni_prior[nind][0] || theta[nind] > d.uni_prior[nind][1]) continue;
-            if (sky_lnl(s, lt, theta, Sp, &lnl) || sky_prior(s, d, nind, theta[nind], &pr)) return 1;
+            if (sky_lnl(s, lt, theta, Sp, &lnl, &st) || sky_prior(s, d, nind, theta[nind], &pr)) return 1;
             const double lnl_new = lnl + pr;
             const double diff = lnl_new - lnl_old, ratio = std::exp(diff);
             if ((ml_mode == DANGX_ML_OPTIMIZE && ratio > 1.0) || (ml_mode == DANGX_ML_SAMPLE && ratio > u3)) {

@@ -222,6 +222,7 @@ int chi_next(dangx_ctx* ctx, long long nblk, double** buf);
 int reduce_to_host(dangx_ctx* ctx, long long nblk, double* out);
 int rank_sum(dangx_ctx* ctx, double* buf, int64_t n);
 int device_cg(dangx_ctx* ctx, const GroupArgs& a, int i_max, double converge, int* iters);
+double dx_host_band_sed(dangx_ctx* ctx, int comp, int j, double t0, double t1);   // eval_sed of a diffuse component, host side
 int device_schur(dangx_ctx* const* cs, int nc, const GroupArgs* as, const long long* SNs, int64_t* n_not_spd, int* nullity, int* defer = nullptr);
 // map_n of sample_index_mh (src/dang_sample_mod.f90:53-64) -> first and last map plane
 inline int map_planes(dangx_ctx* ctx, int map_n, int& s1, int& s2) {
