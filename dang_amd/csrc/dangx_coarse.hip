@@ -114,6 +114,73 @@ __global__ __launch_bounds__(BLOCK) void k_fullsky_rows(const Model* __restrict_
     }
 }
 
+// Selector 3 of dangx_fullsky_sums on its own schedule: every (plane, band) of a pixel in one pass, four bands' maps in flight, the
+// three sums of a (band, plane) reduced over the wave at once and written as the WAVE's partial (row-major [row][block * 4 + wave]:
+// no barrier; dx_reduce_rows_to adds them in that order).  `others` != 0: the data are formed here -- data_raw minus every other
+// component, dangx_fullsky_prepare's expression (:173-196) -- instead of read from its staging buffer, which is then never written.
+__global__ __launch_bounds__(BLOCK) void k_fullsky_stats(const Model* __restrict__ Mp, int comp, int s1, int s2, double th0, double th1,
+                                                         const double* __restrict__ data, unsigned others, int fused,
+                                                         const double* __restrict__ crms, const double* __restrict__ cmask,
+                                                         long long npix_c, double* __restrict__ partial) {
+    const Model& M = *Mp;
+    const Comp& c = M.comp[comp];
+    const int nb = M.nbands, Sp = s2 - s1 + 1;
+    const bool coarse = crms != nullptr;
+    const int npix = coarse ? (int)npix_c : M.npix;
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    const long long il = coarse ? (long long)i - M.pix0 : i;
+    const bool in = i < npix && il >= 0 && il < M.npix;
+    const bool live = in && !is_masked(coarse ? cmask[i] : M.mask[i]);
+    const int ic = in ? i : 0;
+    const Prep pr = sed_prep(c, th0, th1);
+    __shared__ double sj[MAXB];
+    if (threadIdx.x < nb) sj[threadIdx.x] = sed_eval(M, c, threadIdx.x, pr);
+    __syncthreads();
+    const long long nwp = (long long)gridDim.x * (BLOCK / 64), wp = (long long)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    for (int kk = 0; kk < Sp; ++kk) {
+        const int k = s1 + kk;
+        const double amp = in ? c.amp[(long long)(k - 1) * M.npix + il] : 0.0;
+        for (int j0 = 0; j0 < nb; j0 += 4) {
+            double d[4], rm[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int j = (j0 + t < nb) ? j0 + t : nb - 1;
+                rm[t] = coarse ? crms[((long long)kk * nb + j) * npix + ic] : M.rms[((long long)j * M.nmaps + (k - 1)) * npix + ic];
+                d[t] = fused ? M.sig[((long long)j * M.nmaps + (k - 1)) * npix + ic] : data[((long long)kk * nb + j) * npix + ic];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int j = j0 + t;
+                if (j >= nb) break;
+                double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+                if (live) {
+                    double dd = d[t];
+                    if (fused) {
+                        if (k == 1) dd = (dd - M.offset[j]) / M.gain[j];
+                        for (unsigned om = others; om; om &= om - 1) {
+                            const Comp& c2 = M.comp[__builtin_ctz(om)];
+                            double t0, t1;
+                            load_theta(M, c2, i, k, t0, t1);
+                            dd = dd - comp_signal(M, c2, i, k, j, c2.amp[(long long)(k - 1) * npix + i], sed_prep(c2, t0, t1));
+                        }
+                    }
+                    const double rr = 1.0 / rm[t];
+                    const double ar = amp * rr;
+                    const double r0 = (dd - signal_of(c, amp, sj[j])) * rr;
+                    v0 = r0 * r0; v1 = r0 * ar; v2 = ar * ar;
+                }
+                for (int o = 32; o > 0; o >>= 1) { v0 += __shfl_down(v0, o, 64); v1 += __shfl_down(v1, o, 64); v2 += __shfl_down(v2, o, 64); }
+                if ((threadIdx.x & 63) == 0) {
+                    const long long row = 3ll * (j * Sp + kk);
+                    partial[row * nwp + wp] = v0;
+                    partial[(row + 1) * nwp + wp] = v1;
+                    partial[(row + 2) * nwp + wp] = v2;
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Coarse-Nside index sampling (src/dang_sample_mod.f90:199-217, 332-483).  HEALPix is an external library of the
 // reference (absent from its tree); nest2ring and udgrade_ring are restated from the published algorithm
@@ -313,7 +380,7 @@ extern "C" {
 // ---- full-sky index mode / tuner / gain fit primitives ---------------------------------------------
 
 
-int dangx_fullsky_prepare(dangx_ctx* ctx, int comp, int map_n) {
+static int fullsky_prepare_impl(dangx_ctx* ctx, int comp, int map_n, bool lazy) {
     if (!ctx || check_comp(ctx, comp)) return 1;
     (void)hipSetDevice(ctx->device);
     int s1, s2;
@@ -328,11 +395,19 @@ int dangx_fullsky_prepare(dangx_ctx* ctx, int comp, int map_n) {
     unsigned others = 0;
     for (int l = 0; l < ctx->hm.ncomp; ++l)
         if (l != comp && ((ctx->plane_nz[l] & ((1u << (s1 - 1)) | (1u << (s2 - 1)))) || ctx->desc[l].type == DANGX_TCMB || is_global_type(ctx->desc[l].type))) others |= 1u << l;
-    hipLaunchKernelGGL(k_fullsky_prepare, dim3(nblocks(ctx->hm.npix)), dim3(BLOCK), 0, ctx->stream, ctx->dm, comp, s1, s2, others, ctx->fs_data);
+    // lazy (the sky-wide chains, dangx_sky.hip): the staging pass is deferred -- the chisq chain needs the cleaned data once, inside
+    // its statistics pass (k_fullsky_stats forms them itself); any other sum (marginal rows, the Jeffreys sum, selector 0) fills
+    // the buffer first (dangx_fullsky_sums).  DANGX_FULLSKY_LAZY=0: always staged (A/B).
+    static const bool lazy_on = [] { const char* e = getenv("DANGX_FULLSKY_LAZY"); return !(e && e[0] == '0'); }();
+    ctx->fs_others = others;
+    ctx->fs_lazy = lazy && lazy_on;
+    if (!ctx->fs_lazy) hipLaunchKernelGGL(k_fullsky_prepare, dim3(nblocks(ctx->hm.npix)), dim3(BLOCK), 0, ctx->stream, ctx->dm, comp, s1, s2, others, ctx->fs_data);
     HIPCHK(ctx, hipGetLastError());
     ctx->fs_comp = comp; ctx->fs_s1 = s1; ctx->fs_s2 = s2; ctx->fs_npc = 0;
     return 0;
 }
+int dangx_fullsky_prepare(dangx_ctx* ctx, int comp, int map_n) { return fullsky_prepare_impl(ctx, comp, map_n, false); }
+int dx_fullsky_prepare_lazy(dangx_ctx* ctx, int comp, int map_n) { return fullsky_prepare_impl(ctx, comp, map_n, true); }
 
 // what = 0 chisq lnL (1 value), 1 marginal (2*nb*Sp values: TNd(j,k), TNT(j,k) interleaved, j outer / k inner),
 // 2 jeffreys sum (1 value).  Local (this shard's) sums; the caller all-reduces and combines.
@@ -347,6 +422,24 @@ int dangx_fullsky_sums(dangx_ctx* ctx, int what, const double* theta, double* ou
     if (nout < rows) return fail(ctx, "output buffer too small");
     const bool coarse = ctx->fs_npc > 0;
     const unsigned nblk = nblocks(coarse ? ctx->fs_npc : ctx->hm.npix);
+    if (what == 3) {   // the chisq statistics: one pass, the waves' partials
+        const long long nwp = (long long)nblk * (BLOCK / 64);
+        if (ensure_partial(ctx, (long long)rows * nwp)) return 1;
+        hipLaunchKernelGGL(k_fullsky_stats, dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->dm, ctx->fs_comp, ctx->fs_s1, ctx->fs_s2, theta[0], theta[1],
+                           coarse ? ctx->cs_data : ctx->fs_data, ctx->fs_others, (!coarse && ctx->fs_lazy) ? 1 : 0,
+                           coarse ? ctx->cs_rms : (const double*)nullptr, coarse ? ctx->cs_mask : (const double*)nullptr,
+                           coarse ? ctx->fs_npc : 0ll, ctx->partial);
+        dx_reduce_rows_to(ctx, ctx->partial, nwp, rows, ctx->rows_out);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(out, ctx->rows_out, sizeof(double) * rows, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        return 0;
+    }
+    if (ctx->fs_lazy && !coarse) {   // the staging buffer was left unwritten (dangx_fullsky_prepare_lazy): fill it now
+        hipLaunchKernelGGL(k_fullsky_prepare, dim3(nblocks(ctx->hm.npix)), dim3(BLOCK), 0, ctx->stream, ctx->dm, ctx->fs_comp, ctx->fs_s1, ctx->fs_s2,
+                           ctx->fs_others, ctx->fs_data);
+        ctx->fs_lazy = false;
+    }
     if (ensure_partial(ctx, (long long)rows * nblk)) return 1;
     hipLaunchKernelGGL(k_fullsky_rows, dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->dm, ctx->fs_comp, ctx->fs_s1, ctx->fs_s2, what,
                        theta[0], theta[1], coarse ? ctx->cs_data : ctx->fs_data, coarse ? ctx->cs_rms : (const double*)nullptr,

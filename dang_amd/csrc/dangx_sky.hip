@@ -255,7 +255,7 @@ int prepare(const Sky& s, int comp, int map_n, int nside, int sample_nside) {
     dangx_ctx* c0 = s.root();
     if (sample_nside <= 0 || sample_nside == nside) {
         for (int r = 0; r < s.n; ++r)
-            if (dangx_fullsky_prepare(s.c[r], comp, map_n)) return sky_err(s, s.c[r]);
+            if (dx_fullsky_prepare_lazy(s.c[r], comp, map_n)) return sky_err(s, s.c[r]);
         return 0;
     }
     const bool whole = s.n == 1 && c0->dims.pix0 == 0 && c0->dims.npix == c0->dims.npix_global && !c0->allreduce;

@@ -82,6 +82,8 @@ struct dangx_ctx {
     double* fs_data = nullptr;              // full-sky mode: cleaned data [Sp][nb][npix]
     long long fs_cap = 0;
     int fs_comp = -1, fs_s1 = 0, fs_s2 = 0;
+    unsigned fs_others = 0;                 // components dangx_fullsky_prepare removes from the data
+    bool fs_lazy = false;                   // fs_data not written yet (dx_fullsky_prepare_lazy): dangx_fullsky_sums fills it when a sum needs it
     long long fs_npc = 0;                   // > 0: the full-sky sums run over the degraded maps (cs_*) of that many pixels
     double* rows_out = nullptr;             // device [2*MAXB*2 + 8] row sums
     // coarse-Nside index sampling: HEALPix RING<->NEST maps of both resolutions + degraded data / rms / mask
@@ -222,6 +224,7 @@ int chi_next(dangx_ctx* ctx, long long nblk, double** buf);
 int reduce_to_host(dangx_ctx* ctx, long long nblk, double* out);
 int rank_sum(dangx_ctx* ctx, double* buf, int64_t n);
 int device_cg(dangx_ctx* ctx, const GroupArgs& a, int i_max, double converge, int* iters);
+extern "C" int dx_fullsky_prepare_lazy(dangx_ctx* ctx, int comp, int map_n);   // dangx_fullsky_prepare without the staging pass (dangx_coarse.hip)
 double dx_host_band_sed(dangx_ctx* ctx, int comp, int j, double t0, double t1);   // eval_sed of a diffuse component, host side
 int device_schur(dangx_ctx* const* cs, int nc, const GroupArgs* as, const long long* SNs, int64_t* n_not_spd, int* nullity, int* defer = nullptr);
 // map_n of sample_index_mh (src/dang_sample_mod.f90:53-64) -> first and last map plane
