@@ -114,17 +114,21 @@ __global__ __launch_bounds__(BLOCK) void k_fullsky_rows(const Model* __restrict_
     }
 }
 
-// Selector 3 of dangx_fullsky_sums on its own schedule: every (plane, band) of a pixel in one pass, four bands' maps in flight, the
-// three sums of a (band, plane) reduced over the wave at once and written as the WAVE's partial (row-major [row][block * 4 + wave]:
-// no barrier; dx_reduce_rows_to adds them in that order).  `others` != 0: the data are formed here -- data_raw minus every other
-// component, dangx_fullsky_prepare's expression (:173-196) -- instead of read from its staging buffer, which is then never written.
+// Selector 3 of dangx_fullsky_sums on its own schedule: every (plane, band) of a pixel in one pass, the three sums of a (band,
+// plane) reduced over the wave at once, the block's four wave sums added in order after ONE barrier.  `fused`: the data are formed
+// here -- data_raw minus every other component in dangx_fullsky_prepare's order (:173-196), a plane's bands in the thread's LDS
+// column, each other component's index values / amplitude read once per plane -- instead of read from the staging buffer, which is
+// then never written.  Dynamic LDS: nb * BLOCK doubles (the column) + 3 * nb * Sp * (BLOCK / 64) (the wave sums).
 __global__ __launch_bounds__(BLOCK) void k_fullsky_stats(const Model* __restrict__ Mp, int comp, int s1, int s2, double th0, double th1,
                                                          const double* __restrict__ data, unsigned others, int fused,
                                                          const double* __restrict__ crms, const double* __restrict__ cmask,
                                                          long long npix_c, double* __restrict__ partial) {
+    extern __shared__ double fs_lds[];
     const Model& M = *Mp;
     const Comp& c = M.comp[comp];
-    const int nb = M.nbands, Sp = s2 - s1 + 1;
+    const int nb = M.nbands, Sp = s2 - s1 + 1, nrows = 3 * nb * Sp;
+    double* col = fs_lds + threadIdx.x;                 // [band] x BLOCK
+    double* wsum = fs_lds + (long long)nb * BLOCK;      // [row][wave]
     const bool coarse = crms != nullptr;
     const int npix = coarse ? (int)npix_c : M.npix;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
@@ -136,48 +140,49 @@ __global__ __launch_bounds__(BLOCK) void k_fullsky_stats(const Model* __restrict
     __shared__ double sj[MAXB];
     if (threadIdx.x < nb) sj[threadIdx.x] = sed_eval(M, c, threadIdx.x, pr);
     __syncthreads();
-    const long long nwp = (long long)gridDim.x * (BLOCK / 64), wp = (long long)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const int wave = threadIdx.x >> 6;
     for (int kk = 0; kk < Sp; ++kk) {
         const int k = s1 + kk;
         const double amp = in ? c.amp[(long long)(k - 1) * M.npix + il] : 0.0;
-        for (int j0 = 0; j0 < nb; j0 += 4) {
-            double d[4], rm[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int j = (j0 + t < nb) ? j0 + t : nb - 1;
-                rm[t] = coarse ? crms[((long long)kk * nb + j) * npix + ic] : M.rms[((long long)j * M.nmaps + (k - 1)) * npix + ic];
-                d[t] = fused ? M.sig[((long long)j * M.nmaps + (k - 1)) * npix + ic] : data[((long long)kk * nb + j) * npix + ic];
+        // ---- the plane's cleaned data -> the column
+        for (int j = 0; j < nb; ++j) {
+            double d = fused ? M.sig[((long long)j * M.nmaps + (k - 1)) * npix + ic] : data[((long long)kk * nb + j) * npix + ic];
+            if (fused && k == 1) d = (d - M.offset[j]) / M.gain[j];
+            col[j * BLOCK] = d;
+        }
+        if (fused && live)
+            for (unsigned om = others; om; om &= om - 1) {
+                const Comp& c2 = M.comp[__builtin_ctz(om)];
+                double t0, t1;
+                load_theta(M, c2, i, k, t0, t1);
+                const Prep p2 = sed_prep(c2, t0, t1);
+                const double a2 = c2.amp[(long long)(k - 1) * npix + i];
+                for (int j = 0; j < nb; ++j) col[j * BLOCK] = col[j * BLOCK] - comp_signal(M, c2, i, k, j, a2, p2);
             }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int j = j0 + t;
-                if (j >= nb) break;
-                double v0 = 0.0, v1 = 0.0, v2 = 0.0;
-                if (live) {
-                    double dd = d[t];
-                    if (fused) {
-                        if (k == 1) dd = (dd - M.offset[j]) / M.gain[j];
-                        for (unsigned om = others; om; om &= om - 1) {
-                            const Comp& c2 = M.comp[__builtin_ctz(om)];
-                            double t0, t1;
-                            load_theta(M, c2, i, k, t0, t1);
-                            dd = dd - comp_signal(M, c2, i, k, j, c2.amp[(long long)(k - 1) * npix + i], sed_prep(c2, t0, t1));
-                        }
-                    }
-                    const double rr = 1.0 / rm[t];
-                    const double ar = amp * rr;
-                    const double r0 = (dd - signal_of(c, amp, sj[j])) * rr;
-                    v0 = r0 * r0; v1 = r0 * ar; v2 = ar * ar;
-                }
-                for (int o = 32; o > 0; o >>= 1) { v0 += __shfl_down(v0, o, 64); v1 += __shfl_down(v1, o, 64); v2 += __shfl_down(v2, o, 64); }
-                if ((threadIdx.x & 63) == 0) {
-                    const long long row = 3ll * (j * Sp + kk);
-                    partial[row * nwp + wp] = v0;
-                    partial[(row + 1) * nwp + wp] = v1;
-                    partial[(row + 2) * nwp + wp] = v2;
-                }
+        // ---- the three sums of every band
+        for (int j = 0; j < nb; ++j) {
+            double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+            if (live) {
+                const double rms = coarse ? crms[((long long)kk * nb + j) * npix + i] : M.rms[((long long)j * M.nmaps + (k - 1)) * npix + i];
+                const double rr = 1.0 / rms;
+                const double ar = amp * rr;
+                const double r0 = (col[j * BLOCK] - signal_of(c, amp, sj[j])) * rr;
+                v0 = r0 * r0; v1 = r0 * ar; v2 = ar * ar;
+            }
+            for (int o = 32; o > 0; o >>= 1) { v0 += __shfl_down(v0, o, 64); v1 += __shfl_down(v1, o, 64); v2 += __shfl_down(v2, o, 64); }
+            if ((threadIdx.x & 63) == 0) {
+                const int row = 3 * (j * Sp + kk);
+                wsum[row * (BLOCK / 64) + wave] = v0;
+                wsum[(row + 1) * (BLOCK / 64) + wave] = v1;
+                wsum[(row + 2) * (BLOCK / 64) + wave] = v2;
             }
         }
+    }
+    __syncthreads();
+    for (int row = threadIdx.x; row < nrows; row += BLOCK) {
+        double t = 0.0;
+        for (int w = 0; w < BLOCK / 64; ++w) t += wsum[row * (BLOCK / 64) + w];
+        partial[(long long)row * gridDim.x + blockIdx.x] = t;
     }
 }
 
@@ -422,10 +427,11 @@ int dangx_fullsky_sums(dangx_ctx* ctx, int what, const double* theta, double* ou
     if (nout < rows) return fail(ctx, "output buffer too small");
     const bool coarse = ctx->fs_npc > 0;
     const unsigned nblk = nblocks(coarse ? ctx->fs_npc : ctx->hm.npix);
-    if (what == 3) {   // the chisq statistics: one pass, the waves' partials
-        const long long nwp = (long long)nblk * (BLOCK / 64);
+    if (what == 3) {   // the chisq statistics: one pass
+        const long long nwp = nblk;
+        const size_t ldsz = ((size_t)ctx->hm.nbands * BLOCK + (size_t)rows * (BLOCK / 64)) * sizeof(double);
         if (ensure_partial(ctx, (long long)rows * nwp)) return 1;
-        hipLaunchKernelGGL(k_fullsky_stats, dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->dm, ctx->fs_comp, ctx->fs_s1, ctx->fs_s2, theta[0], theta[1],
+        hipLaunchKernelGGL(k_fullsky_stats, dim3(nblk), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, ctx->fs_comp, ctx->fs_s1, ctx->fs_s2, theta[0], theta[1],
                            coarse ? ctx->cs_data : ctx->fs_data, ctx->fs_others, (!coarse && ctx->fs_lazy) ? 1 : 0,
                            coarse ? ctx->cs_rms : (const double*)nullptr, coarse ? ctx->cs_mask : (const double*)nullptr,
                            coarse ? ctx->fs_npc : 0ll, ctx->partial);
