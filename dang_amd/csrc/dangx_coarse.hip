@@ -145,10 +145,21 @@ __global__ __launch_bounds__(BLOCK) void k_fullsky_stats(const Model* __restrict
         const int k = s1 + kk;
         const double amp = in ? c.amp[(long long)(k - 1) * M.npix + il] : 0.0;
         // ---- the plane's cleaned data -> the column
-        for (int j = 0; j < nb; ++j) {
-            double d = fused ? M.sig[((long long)j * M.nmaps + (k - 1)) * npix + ic] : data[((long long)kk * nb + j) * npix + ic];
-            if (fused && k == 1) d = (d - M.offset[j]) / M.gain[j];
-            col[j * BLOCK] = d;
+        for (int j0 = 0; j0 < nb; j0 += 5) {   // five bands' maps in flight
+            double d[5];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const int j = (j0 + t < nb) ? j0 + t : nb - 1;
+                d[t] = fused ? M.sig[((long long)j * M.nmaps + (k - 1)) * npix + ic] : data[((long long)kk * nb + j) * npix + ic];
+            }
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const int j = j0 + t;
+                if (j < nb) {
+                    if (fused && k == 1) d[t] = (d[t] - M.offset[j]) / M.gain[j];
+                    col[j * BLOCK] = d[t];
+                }
+            }
         }
         if (fused && live)
             for (unsigned om = others; om; om &= om - 1) {
@@ -160,11 +171,20 @@ __global__ __launch_bounds__(BLOCK) void k_fullsky_stats(const Model* __restrict
                 for (int j = 0; j < nb; ++j) col[j * BLOCK] = col[j * BLOCK] - comp_signal(M, c2, i, k, j, a2, p2);
             }
         // ---- the three sums of every band
-        for (int j = 0; j < nb; ++j) {
+        for (int j0 = 0; j0 < nb; j0 += 5) {
+            double rmt[5];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const int j = (j0 + t < nb) ? j0 + t : nb - 1;
+                rmt[t] = coarse ? crms[((long long)kk * nb + j) * npix + ic] : M.rms[((long long)j * M.nmaps + (k - 1)) * npix + ic];
+            }
+#pragma unroll
+          for (int t = 0; t < 5; ++t) {
+            const int j = j0 + t;
+            if (j >= nb) break;
             double v0 = 0.0, v1 = 0.0, v2 = 0.0;
             if (live) {
-                const double rms = coarse ? crms[((long long)kk * nb + j) * npix + i] : M.rms[((long long)j * M.nmaps + (k - 1)) * npix + i];
-                const double rr = 1.0 / rms;
+                const double rr = 1.0 / rmt[t];
                 const double ar = amp * rr;
                 const double r0 = (col[j * BLOCK] - signal_of(c, amp, sj[j])) * rr;
                 v0 = r0 * r0; v1 = r0 * ar; v2 = ar * ar;
@@ -176,6 +196,7 @@ __global__ __launch_bounds__(BLOCK) void k_fullsky_stats(const Model* __restrict
                 wsum[(row + 1) * (BLOCK / 64) + wave] = v1;
                 wsum[(row + 2) * (BLOCK / 64) + wave] = v2;
             }
+          }
         }
     }
     __syncthreads();
