@@ -537,3 +537,49 @@ def test_pass1_for_q_u_template_groups_with_up_to_eight_rows(built, nrows):
             assert np.abs(x - y).max() <= 1e-8 * max(np.abs(y).max(), 1e-30), ml
             same_bits = same_bits and np.array_equal(x, y)
     assert not same_bits
+
+
+def test_fullsky_chain_from_one_pass_equals_the_pass_per_proposal_form(built):
+    """Full-sky index mode (index_mode = 1): the chisq chain and its tuner run on the sufficient statistics of ONE pass over the maps
+    (W0, U, V per band and plane about the starting point; dangx_sky.hip) instead of a pass per proposal (DANGX_FULLSKY_STATS=0, the
+    reference's form).  Same accepted counts, the same index values to 1e-12, the same step sizes, for a tuned and an untuned start,
+    at the map resolution and at a coarser one."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "import dang_amd as da\n"
+            "from test_gpu_fullsky import _fullsky_case\n"
+            "out = {}\n"
+            "for tuned, coarse in ((True, 0), (False, 0), (True, 4)):\n"
+            "    case = _fullsky_case('chisq', 'gaussian', tuned=tuned, config='C2', nside=16)\n"
+            "    dpar, ddata, bands, comps, meta = case\n"
+            "    if not tuned:\n"
+            "        for c in comps: c.step_size = [2.0 * g[1] for g in c.gauss_prior]\n"
+            "    eng = da.initialize(bands, comps, ddata, npix_global=meta['npix_global'], device=0)\n"
+            "    acc, val, step = [], [], []\n"
+            "    for it in (2, 3):\n"
+            "        for l, c in enumerate(comps):\n"
+            "            for j in range(c.nindices):\n"
+            "                if not c.sample_index[j]: continue\n"
+            "                f = c.pol_flag[j][0]\n"
+            "                acc.append(da.sample_index_mh_fullsky(dpar, ddata, l, j, {1: 1, 8: -1}[f], da.stream_id(it, 1, l, j, f),\n"
+            "                                                      sample_nside=coarse or None))\n"
+            "                val.append(float(eng.get_indices(l)[j, 0 if f == 1 else 1, 0])); step.append(float(c.step_size[j]))\n"
+            "    out['%%d_%%d' %% (tuned, coarse)] = dict(acc=acc, val=val, step=step)\n"
+            "print('RESULT ' + json.dumps(out))\n") % (root, os.path.join(root, "tests"))
+    res = {}
+    for stats in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DANGX_FULLSKY_STATS=stats), stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=600)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+        assert r.returncode == 0 and lines, r.stdout[-3000:]
+        res[stats] = json.loads(lines[-1][7:])
+    for key, a in res["1"].items():
+        b = res["0"][key]
+        assert a["acc"] == b["acc"], (key, a["acc"], b["acc"])
+        assert np.abs(np.array(a["val"]) - np.array(b["val"])).max() <= 1e-12, key
+        assert a["step"] == b["step"], key
+        assert sum(a["acc"]) > 0

@@ -35,5 +35,5 @@ for k, v in eng.profile_get().items():
 for l, c in enumerate(comps):
     for j in range(c.nindices):
         if c.sample_index[j]:
-            x = eng.peek_indices(l, 1 if c.pol_flag[j][0] == 1 else 2, j)
-            print("  %-8s %-5s %s" % (c.label, c.ind_label[j], np.round(x[:1], 5)))
+            x = eng.get_indices(l)[j, 0 if c.pol_flag[j][0] == 1 else 1, 0]
+            print("  %-8s %-5s %.5f" % (c.label, c.ind_label[j], x))
