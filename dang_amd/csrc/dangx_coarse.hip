@@ -573,11 +573,36 @@ static int coarse_stage(dangx_ctx* ctx, int comp, int map_n, int nside, int samp
     const double scale = (double)sample_nside * 1.0 / nside;
     hipLaunchKernelGGL(k_udgrade, gq, dim3(BLOCK), 0, ctx->stream, ctx->fs_data, ctx->cs_data, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
                        ratio, 1, 0, scale, 0, nb, ctx->hm.nmaps, s1);
+    // the degraded rms and mask: the kept copy of this plane set if the maps have not changed since, else degraded and kept
+    static const bool keep_on = [] { const char* e = getenv("DANGX_COARSE_KEEP"); return !(e && e[0] == '0'); }();  // A/B switch
+    dangx_ctx::CsKept* hit = nullptr;
+    for (auto& kq : ctx->cs_kept)
+        if (keep_on && kq.rms && kq.gen == ctx->data_gen && kq.s1 == s1 && kq.s2 == s2 && kq.nside == nside && kq.sample_nside == sample_nside) hit = &kq;
+    if (hit) {
+        hit->stamp = ++ctx->cs_stamp;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->cs_rms, hit->rms, sizeof(double) * need, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->cs_mask, hit->mask, sizeof(double) * npc, hipMemcpyDeviceToDevice, ctx->stream));
+        return 0;
+    }
     hipLaunchKernelGGL(k_udgrade, gq, dim3(BLOCK), 0, ctx->stream, ctx->rms, ctx->cs_rms, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
                        ratio, 1, 1, scale, 1, nb, ctx->hm.nmaps, s1);
     hipLaunchKernelGGL(k_udgrade, g1, dim3(BLOCK), 0, ctx->stream, ctx->mask, ctx->cs_mask, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
                        ratio, 1, 2, scale, 0, nb, ctx->hm.nmaps, s1);
     HIPCHK(ctx, hipGetLastError());
+    if (keep_on) {   // into the slot used longest ago
+        dangx_ctx::CsKept& kq = (ctx->cs_kept[0].stamp <= ctx->cs_kept[1].stamp) ? ctx->cs_kept[0] : ctx->cs_kept[1];
+        if (kq.cap < need || kq.capm < npc) {
+            if (kq.rms) (void)hipFree(kq.rms);
+            if (kq.mask) (void)hipFree(kq.mask);
+            kq.rms = kq.mask = nullptr; kq.cap = kq.capm = 0; kq.gen = -1;
+            HIPCHK(ctx, hipMalloc(&kq.rms, sizeof(double) * need));
+            HIPCHK(ctx, hipMalloc(&kq.mask, sizeof(double) * npc));
+            kq.cap = need; kq.capm = npc;
+        }
+        HIPCHK(ctx, hipMemcpyAsync(kq.rms, ctx->cs_rms, sizeof(double) * need, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(kq.mask, ctx->cs_mask, sizeof(double) * npc, hipMemcpyDeviceToDevice, ctx->stream));
+        kq.s1 = s1; kq.s2 = s2; kq.nside = nside; kq.sample_nside = sample_nside; kq.gen = ctx->data_gen; kq.stamp = ++ctx->cs_stamp;
+    }
     return 0;
 }
 

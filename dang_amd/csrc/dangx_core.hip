@@ -1256,6 +1256,7 @@ int dangx_destroy(dangx_ctx* ctx) {
     // HEALPix index tables and the degraded maps of the coarse-Nside sweeps live as long as the context
     for (int** b : {&ctx->hp_n2r_f, &ctx->hp_r2n_f, &ctx->hp_n2r_c, &ctx->hp_r2n_c}) { if (*b) (void)hipFree(*b); *b = nullptr; }
     for (double** b : {&ctx->cs_data, &ctx->cs_rms, &ctx->cs_mask, &ctx->cs_index}) { if (*b) (void)hipFree(*b); *b = nullptr; }
+    for (auto& kq : ctx->cs_kept) { if (kq.rms) (void)hipFree(kq.rms); if (kq.mask) (void)hipFree(kq.mask); kq.rms = kq.mask = nullptr; kq.cap = kq.capm = 0; kq.gen = -1; }
     if (ctx->cs_part) (void)hipFree(ctx->cs_part);
     ctx->cs_part = nullptr; ctx->cs_part_cap = 0;
     ctx->hp_nside = ctx->hp_cnside = 0; ctx->cs_cap = 0;
@@ -1380,6 +1381,7 @@ int dangx_upload_data(dangx_ctx* ctx, const double* sig, const double* rms, cons
         copy_planes(ctx, ctx->mask, mask, (size_t)ctx->dims.nmaps, true))
         return 1;
     ctx->dirty = true;
+    ++ctx->data_gen;
     invalidate_chi(ctx);
     idx_written(ctx, -1);   // a new mask
     return 0;
@@ -1392,6 +1394,7 @@ int dangx_adopt_device_data(dangx_ctx* ctx, const double* sig, const double* rms
     ctx->rms = const_cast<double*>(rms);
     ctx->mask = const_cast<double*>(mask);
     ctx->dirty = true;
+    ++ctx->data_gen;
     invalidate_chi(ctx);
     idx_written(ctx, -1);
     return 0;
@@ -1736,6 +1739,7 @@ int dangx_normalize_bandpass(const double* tau_in, int n, double* tau_out) {
 }
 
 int dangx_convert_maps(dangx_ctx* ctx, const int32_t* unit, const int32_t* cg_map, double* conversion) {
+    if (ctx) ++ctx->data_gen;   // the maps are rescaled in place
     if (!ctx || !unit || !conversion) return 1;
     (void)hipSetDevice(ctx->device);
     if (!ctx->sig || !ctx->rms) return fail(ctx, "map data not uploaded");

@@ -91,6 +91,11 @@ struct dangx_ctx {
     int *hp_n2r_f = nullptr, *hp_r2n_f = nullptr, *hp_n2r_c = nullptr, *hp_r2n_c = nullptr;
     double *cs_data = nullptr, *cs_rms = nullptr, *cs_mask = nullptr, *cs_index = nullptr;
     long long cs_cap = 0;
+    // the degraded rms / mask of a plane set do not change between sweeps (the maps are the run's input): two kept copies, keyed by
+    // (planes, nside, sample_nside, generation of the map data); a hit replaces two degrade passes by two device copies
+    struct CsKept { int s1 = 0, s2 = 0, nside = 0, sample_nside = 0; long long gen = -1, cap = 0, capm = 0, stamp = 0; double *rms = nullptr, *mask = nullptr; };
+    CsKept cs_kept[2];
+    long long data_gen = 0, cs_stamp = 0;   // data_gen: bumped whenever sig / rms / mask are replaced or rescaled
     double* cs_part = nullptr;              // per-shard sums / counts of the degrade step (pixel-sharded coarse sampling)
     long long cs_part_cap = 0;
     long long work_cap = 0;
