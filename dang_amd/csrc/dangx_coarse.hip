@@ -16,22 +16,44 @@ namespace {
 // data_raw minus every other component for planes s1..s2 (:173-196, all pixels) -> out[(kk*nb + j)*npix + i]
 __global__ __launch_bounds__(BLOCK) void k_fullsky_prepare(const Model* __restrict__ Mp, int comp, int s1, int s2,
                                                            unsigned others, double* __restrict__ out) {
+    // a plane's bands in the thread's LDS column (dynamic LDS: nb * BLOCK doubles): five maps in flight, every other component's
+    // index values and amplitude read once per plane; per band the subtractions keep their order (:180-196)
+    extern __shared__ double fp_lds[];
+    double* col = fp_lds + threadIdx.x;
     const Model& M = *Mp;
     const int npix = M.npix, nb = M.nbands;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= npix) return;
-    for (int k = s1; k <= s2; ++k)
-        for (int j = 0; j < nb; ++j) {
-            double d = M.sig[((long long)j * M.nmaps + (k - 1)) * npix + i];
-            if (k == 1) d = (d - M.offset[j]) / M.gain[j];
+    const bool in = i < npix;
+    const int ic = in ? i : 0;
+    for (int k = s1; k <= s2; ++k) {
+        for (int j0 = 0; j0 < nb; j0 += 5) {
+            double d[5];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const int j = (j0 + t < nb) ? j0 + t : nb - 1;
+                d[t] = M.sig[((long long)j * M.nmaps + (k - 1)) * npix + ic];
+            }
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const int j = j0 + t;
+                if (j < nb) {
+                    if (k == 1) d[t] = (d[t] - M.offset[j]) / M.gain[j];
+                    col[j * BLOCK] = d[t];
+                }
+            }
+        }
+        if (in)
             for (unsigned om = others; om; om &= om - 1) {
                 const Comp& c2 = M.comp[__builtin_ctz(om)];
                 double t0, t1;
                 load_theta(M, c2, i, k, t0, t1);
-                d = d - comp_signal(M, c2, i, k, j, c2.amp[(long long)(k - 1) * npix + i], sed_prep(c2, t0, t1));
+                const Prep p2 = sed_prep(c2, t0, t1);
+                const double a2 = c2.amp[(long long)(k - 1) * npix + i];
+                for (int j = 0; j < nb; ++j) col[j * BLOCK] = col[j * BLOCK] - comp_signal(M, c2, i, k, j, a2, p2);
             }
-            out[((long long)(k - s1) * nb + j) * npix + i] = d;
-        }
+        if (in)
+            for (int j = 0; j < nb; ++j) out[((long long)(k - s1) * nb + j) * npix + i] = col[j * BLOCK];
+    }
 }
 
 // row sums for one evaluation at theta: what = 0: evaluate_lnL (1 row: -1/2 sum ((d-m)/rms)^2, unmasked);
@@ -427,7 +449,7 @@ static int fullsky_prepare_impl(dangx_ctx* ctx, int comp, int map_n, bool lazy) 
     static const bool lazy_on = [] { const char* e = getenv("DANGX_FULLSKY_LAZY"); return !(e && e[0] == '0'); }();
     ctx->fs_others = others;
     ctx->fs_lazy = lazy && lazy_on;
-    if (!ctx->fs_lazy) hipLaunchKernelGGL(k_fullsky_prepare, dim3(nblocks(ctx->hm.npix)), dim3(BLOCK), 0, ctx->stream, ctx->dm, comp, s1, s2, others, ctx->fs_data);
+    if (!ctx->fs_lazy) hipLaunchKernelGGL(k_fullsky_prepare, dim3(nblocks(ctx->hm.npix)), dim3(BLOCK), (size_t)ctx->hm.nbands * BLOCK * sizeof(double), ctx->stream, ctx->dm, comp, s1, s2, others, ctx->fs_data);
     HIPCHK(ctx, hipGetLastError());
     ctx->fs_comp = comp; ctx->fs_s1 = s1; ctx->fs_s2 = s2; ctx->fs_npc = 0;
     return 0;
@@ -463,7 +485,7 @@ int dangx_fullsky_sums(dangx_ctx* ctx, int what, const double* theta, double* ou
         return 0;
     }
     if (ctx->fs_lazy && !coarse) {   // the staging buffer was left unwritten (dangx_fullsky_prepare_lazy): fill it now
-        hipLaunchKernelGGL(k_fullsky_prepare, dim3(nblocks(ctx->hm.npix)), dim3(BLOCK), 0, ctx->stream, ctx->dm, ctx->fs_comp, ctx->fs_s1, ctx->fs_s2,
+        hipLaunchKernelGGL(k_fullsky_prepare, dim3(nblocks(ctx->hm.npix)), dim3(BLOCK), (size_t)ctx->hm.nbands * BLOCK * sizeof(double), ctx->stream, ctx->dm, ctx->fs_comp, ctx->fs_s1, ctx->fs_s2,
                            ctx->fs_others, ctx->fs_data);
         ctx->fs_lazy = false;
     }
