@@ -267,6 +267,49 @@ __global__ __launch_bounds__(BLOCK) void k_udgrade(const double* __restrict__ in
     out[(long long)q * npix_out + o] = v;
 }
 
+// k_udgrade's degrade branch for several planes at once: the children's RING numbers are read once per QC planes (they are the
+// same for every plane; one thread reads 64 consecutive ints, 256 B apart from its neighbour's) and QC maps are in flight per
+// child.  Each plane's sum runs over its children in NESTED order as before.
+constexpr int UDG_QC = 10;
+__global__ __launch_bounds__(BLOCK) void k_udgrade_planes(const double* __restrict__ in, double* __restrict__ out,
+                                                          const int* __restrict__ n2r_in, const int* __restrict__ r2n_out,
+                                                          long long npix_in, long long npix_out, int ratio, int mode, double scale,
+                                                          int layout, int nb, int nmaps, int s1, int nplanes) {
+    const long long o = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (o >= npix_out) return;
+    const int q0 = blockIdx.y * UDG_QC;
+    long long off[UDG_QC];
+    double total[UDG_QC];
+    int nobs[UDG_QC];
+#pragma unroll
+    for (int t = 0; t < UDG_QC; ++t) {
+        const int q = (q0 + t < nplanes) ? q0 + t : nplanes - 1;
+        off[t] = (layout == 0) ? (long long)q * npix_in : ((long long)(q % nb) * nmaps + (s1 + q / nb - 1)) * npix_in;
+        total[t] = 0.0; nobs[t] = 0;
+    }
+    const long long nest = r2n_out[o];
+    const int* kids = n2r_in + nest * ratio;
+    for (int ip = 0; ip < ratio; ++ip) {
+        const long long c = kids[ip];
+        double x[UDG_QC];
+#pragma unroll
+        for (int t = 0; t < UDG_QC; ++t) x[t] = in[off[t] + c];
+#pragma unroll
+        for (int t = 0; t < UDG_QC; ++t) {
+            double v = x[t];
+            if (mode == 1) v = v * v;
+            if (fabs(v - MISSVAL) > fabs(1e-5 * MISSVAL)) { total[t] = total[t] + v; ++nobs[t]; }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < UDG_QC; ++t)
+        if (q0 + t < nplanes) {
+            double v = nobs[t] ? total[t] / nobs[t] : MISSVAL;
+            if (mode == 1) v = sqrt(v) * scale;
+            out[(long long)(q0 + t) * npix_out + o] = v;
+        }
+}
+
 // Pixel-sharded form of the degrade step: coarse pixel o collects, in NEST child order, only those of its children whose
 // RING index lies in this shard [pix0, pix0 + npix_loc); it emits the sum of the good ones and their number.  The sums
 // of all shards (added by the caller) are finished by k_udgrade_finish -- with one shard that is k_udgrade bit for bit.
@@ -593,8 +636,9 @@ static int coarse_stage(dangx_ctx* ctx, int comp, int map_n, int nside, int samp
     }
     const dim3 gq(nblocks(npc), Sp * nb), g1(nblocks(npc), 1);
     const double scale = (double)sample_nside * 1.0 / nside;
-    hipLaunchKernelGGL(k_udgrade, gq, dim3(BLOCK), 0, ctx->stream, ctx->fs_data, ctx->cs_data, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
-                       ratio, 1, 0, scale, 0, nb, ctx->hm.nmaps, s1);
+    const dim3 gp(nblocks(npc), (Sp * nb + UDG_QC - 1) / UDG_QC);
+    hipLaunchKernelGGL(k_udgrade_planes, gp, dim3(BLOCK), 0, ctx->stream, ctx->fs_data, ctx->cs_data, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
+                       ratio, 0, scale, 0, nb, ctx->hm.nmaps, s1, Sp * nb);
     // the degraded rms and mask: the kept copy of this plane set if the maps have not changed since, else degraded and kept
     static const bool keep_on = [] { const char* e = getenv("DANGX_COARSE_KEEP"); return !(e && e[0] == '0'); }();  // A/B switch
     dangx_ctx::CsKept* hit = nullptr;
@@ -606,8 +650,8 @@ static int coarse_stage(dangx_ctx* ctx, int comp, int map_n, int nside, int samp
         HIPCHK(ctx, hipMemcpyAsync(ctx->cs_mask, hit->mask, sizeof(double) * npc, hipMemcpyDeviceToDevice, ctx->stream));
         return 0;
     }
-    hipLaunchKernelGGL(k_udgrade, gq, dim3(BLOCK), 0, ctx->stream, ctx->rms, ctx->cs_rms, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
-                       ratio, 1, 1, scale, 1, nb, ctx->hm.nmaps, s1);
+    hipLaunchKernelGGL(k_udgrade_planes, gp, dim3(BLOCK), 0, ctx->stream, ctx->rms, ctx->cs_rms, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
+                       ratio, 1, scale, 1, nb, ctx->hm.nmaps, s1, Sp * nb);
     hipLaunchKernelGGL(k_udgrade, g1, dim3(BLOCK), 0, ctx->stream, ctx->mask, ctx->cs_mask, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
                        ratio, 1, 2, scale, 0, nb, ctx->hm.nmaps, s1);
     HIPCHK(ctx, hipGetLastError());
