@@ -82,6 +82,11 @@ __global__ __launch_bounds__(BLOCK, 4) void k_sky_chisq(const Model* __restrict_
 
 }  // namespace
 
+// chi^2 of plane k as some sweep has just computed it on the host (the full-sky chain's sufficient statistics at the value it ended
+// on): the "after" slot of the cache, as a sweep's launch would leave it.  Pending launches are reduced first (their slots are
+// older).  Not on planes where a monopole has a signal (chi_byproduct_ok).
+int dx_set_chi_after(dangx_ctx* ctx, int k, double chi);
+
 extern "C" {
 
 static int planeset_launch(dangx_ctx* ctx, const GroupArgs& g, const SweepList& sl, int lanes, int solve, int64_t* n_not_spd, int64_t* accepted);
@@ -98,6 +103,18 @@ static bool chi_byproduct_ok(const dangx_ctx* ctx, int s1, int s2) {
         if (ctx->desc[l].type == DANGX_MONOPOLE && (ctx->tmpl_nz[l] & planes)) return false;
     return true;
 }
+
+}  // extern "C"
+int dx_set_chi_after(dangx_ctx* ctx, int k, double chi) {
+    if (k < 1 || k > ctx->dims.nmaps || !chi_byproduct_ok(ctx, k, k)) return 0;
+    (void)hipSetDevice(ctx->device);
+    if (chi_flush(ctx)) return 1;
+    ctx->chi_host[k - 1] = chi;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->chi_cache + 3 + (k - 1), &ctx->chi_host[k - 1], sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ctx->chi_after_valid[k - 1] = true;
+    return 0;
+}
+extern "C" {
 
 int dangx_amp_sample(dangx_ctx* ctx, int group, int flag, int ml_mode, int solver, int fluct_mode, uint64_t seed,
                      uint64_t stream, int i_max, double converge, int* cg_iters, int64_t* n_not_spd) {

@@ -113,6 +113,7 @@ struct SkyStats {
     bool on = false;
     int comp = 0, nb = 0, Sp = 0;
     std::vector<double> s0, rows;   // s_j(theta0); W0, U, V per (band, plane) as the kernel writes them
+    std::vector<std::vector<double>> part;   // the same rows of every context of this process (before the sums over contexts and ranks)
 };
 int sky_stats(const Sky& s, int comp, int Sp, const double* theta0, SkyStats& st) {
     static const bool enabled = [] { const char* e = getenv("DANGX_FULLSKY_STATS"); return !(e && e[0] == '0'); }();
@@ -121,8 +122,14 @@ int sky_stats(const Sky& s, int comp, int Sp, const double* theta0, SkyStats& st
     st.on = false;
     if (!enabled || !(ty == DANGX_POWERLAW || ty == DANGX_MBB || ty == DANGX_FREEFREE || ty == DANGX_LOGNORMAL)) return 0;
     st.comp = comp; st.nb = c0->dims.nbands; st.Sp = Sp;
-    st.rows.assign((size_t)3 * st.nb * Sp, 0.0);
-    if (sky_rows(s, 3, theta0, st.rows.data(), 3 * st.nb * Sp)) return 1;
+    const int nrows = 3 * st.nb * Sp;
+    st.rows.assign((size_t)nrows, 0.0);
+    st.part.assign((size_t)s.n, std::vector<double>((size_t)nrows, 0.0));
+    for (int r = 0; r < s.n; ++r) {   // (sky_rows, keeping every context's own rows: its planes' chi^2 comes from them at the end)
+        if (dangx_fullsky_sums(s.c[r], 3, theta0, st.part[(size_t)r].data(), nrows)) return sky_err(s, s.c[r]);
+        for (int q = 0; q < nrows; ++q) st.rows[(size_t)q] += st.part[(size_t)r][(size_t)q];
+    }
+    if (sky_ranks(s, st.rows.data(), nrows)) return 1;
     st.s0.resize((size_t)st.nb);
     for (int j = 0; j < st.nb; ++j) st.s0[(size_t)j] = dx_host_band_sed(c0, comp, j, theta0[0], theta0[1]);
     st.on = true;
@@ -344,6 +351,22 @@ int dangx_fullsky_sample(dangx_ctx* const* ctxs, int nctx, int comp, int nind, i
     }
     for (int r = 0; r < nctx; ++r)  // :329, :483: every pixel, masked ones too
         if (dangx_fill_index(ctxs[r], comp, nind, map_n, sample[nind])) return sky_err(s, ctxs[r]);
+    // chi^2 of the swept planes at the value the chain ended on, from the statistics: -2 lnL without the prior, per context its own
+    // pixels' share -- what a per-pixel sweep's launch leaves behind, so compute_chisq needs no pass of its own (map resolution only:
+    // the coarse chain's likelihood runs over degraded maps)
+    if (st.on && sample_it && (sample_nside <= 0 || sample_nside == nside)) {
+        std::vector<double> ds((size_t)st.nb);
+        for (int j = 0; j < st.nb; ++j) ds[(size_t)j] = dx_host_band_sed(c0, comp, j, sample[0], sample[1]) - st.s0[(size_t)j];
+        for (int r = 0; r < nctx; ++r)
+            for (int kk = 0; kk < Sp; ++kk) {
+                double chi = 0.0;
+                for (int j = 0; j < st.nb; ++j) {
+                    const double* q = &st.part[(size_t)r][(size_t)3 * (j * Sp + kk)];
+                    chi = chi + (q[0] - 2.0 * ds[(size_t)j] * q[1] + ds[(size_t)j] * ds[(size_t)j] * q[2]);
+                }
+                if (dx_set_chi_after(ctxs[r], s1 + kk, chi)) return sky_err(s, ctxs[r]);
+            }
+    }
     if (step_size) *step_size = c0->desc[comp].step_size[nind];
     if (value) *value = sample[nind];
     if (accepted) *accepted = nacc;

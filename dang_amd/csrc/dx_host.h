@@ -63,6 +63,7 @@ struct dangx_ctx {
     long long partial_cap = 0;
     double* scalars = nullptr;              // device scalars [8]
     double* chi_cache = nullptr;            // device [6]: chi^2 before/after of planes 1..3 (fused in k_index_mh)
+    double chi_host[3] = {0.0, 0.0, 0.0};   // host staging of dx_set_chi_after
     // block partials of the sweeps' chi^2 sums wait here until somebody asks for a value (dangx_chisq_cached) or the ring
     // is full: ONE pair of reduction launches then serves every sweep since the last one (in launch order), instead of
     // two small launches behind every sweep -- 6 % of a rank's iteration at the 8-rank shard size
@@ -224,6 +225,7 @@ int ensure_state(dangx_ctx* ctx, int comp);     // allocate a component's maps o
 int check_comp(dangx_ctx* ctx, int comp);
 int copy_planes(dangx_ctx* ctx, void* dst, const void* src, size_t planes, bool to_device);
 int make_group(dangx_ctx* ctx, int group, int flag, GroupArgs& a);
+int dx_set_chi_after(dangx_ctx* ctx, int k, double chi);   // dangx_entry.hip
 int chi_flush(dangx_ctx* ctx);                  // reduce every pending launch's chi^2 / index-sum partials into chi_cache
 int chi_next(dangx_ctx* ctx, long long nblk, double** buf);
 int reduce_to_host(dangx_ctx* ctx, long long nblk, double* out);
