@@ -299,6 +299,42 @@ def template_model(config_name, nsample, steps=6, warmup=2):
         eng.close()
 
 
+def index_mode_figures(config_name, nsample, steps=4, warmup=2):
+    """Two more secondary figures: whole Gibbs iterations of the workload with every sampled index in FULL-SKY mode (index_mode = 1,
+    SURVEY 8f rank 2: the chains run on the sufficient statistics of one pass per sweep) and with every index sampled per pixel at
+    Nside / 8 (stage, degrade, one chain per coarse pixel).  Never `value`."""
+    import dang_amd as da
+    from dang_amd import synth
+    dev = torch.device("cuda", 0)
+    out = {}
+    for mode in ("fullsky", "coarse"):
+        dpar, ddata, bands, comps, meta = synth.make_sky(config_name, device=dev, nsample=nsample, as_numpy=False)
+        nside = int(round((meta["npix_global"] / 12.0) ** 0.5))
+        for c in comps:
+            if mode == "fullsky":
+                c.index_mode = [1] * c.nindices
+                c.step_size = [0.05 * g[1] for g in c.gauss_prior]
+            else:
+                c.sample_nside = [max(nside // 8, 1)] * c.nindices
+        eng = da.initialize(bands, comps, ddata, npix_global=meta["npix_global"], device=0)
+        try:
+            for it in range(1, warmup + 1):
+                da.gibbs_iteration(dpar, ddata, it, want_counts=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for it in range(warmup + 1, warmup + 1 + steps):
+                da.gibbs_iteration(dpar, ddata, it, want_counts=False)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            out[mode] = {"workload": "%s, every sampled index %s" % (config_name, "in full-sky mode" if mode == "fullsky" else "per pixel at Nside %d of %d" % (max(nside // 8, 1), nside)),
+                         "it_per_s": 1.0 / dt, "ms_per_step": 1e3 * dt, "steps": steps, "chisq": float(ddata.chisq)}
+        finally:
+            eng.close()
+            del ddata.sig_map, ddata.rms_map
+            torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -650,6 +686,12 @@ def main():
                 log("template_model done")
             except Exception as e:
                 out["template_model"] = {"error": repr(e)[:500]}
+            try:
+                log("timing the full-sky and coarse-Nside index modes (index_modes)")
+                out["index_modes"] = index_mode_figures(args.config, args.nsample)
+                log("index_modes done")
+            except Exception as e:
+                out["index_modes"] = {"error": repr(e)[:500]}
         print(json.dumps(out))
     if world > 1:
         td.barrier()

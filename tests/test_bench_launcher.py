@@ -4,6 +4,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -99,3 +100,6 @@ def test_bench_line_carries_the_template_model_figure(built):
     assert t["it_per_s"] > 0 and t["refinements"] == 0 and t["schur_residual_bound"] <= 1e-12
     for got, want in zip(t["template_amplitudes"], (2.0, -1.5, 0.7)):
         assert abs(got - want) < 0.01, t
+    m = d["index_modes"]
+    assert "error" not in m and m["fullsky"]["it_per_s"] > 0 and m["coarse"]["it_per_s"] > 0, m
+    assert np.isfinite(m["fullsky"]["chisq"]) and np.isfinite(m["coarse"]["chisq"])
