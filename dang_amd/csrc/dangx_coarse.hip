@@ -151,6 +151,7 @@ __global__ __launch_bounds__(BLOCK) void k_fullsky_stats(const Model* __restrict
     const int nb = M.nbands, Sp = s2 - s1 + 1, nrows = 3 * nb * Sp;
     double* col = fs_lds + threadIdx.x;                 // [band] x BLOCK
     double* wsum = fs_lds + (long long)nb * BLOCK;      // [row][wave]
+    double* ocs = wsum + nrows * (BLOCK / 64);          // [other][plane][band]: the SED rows of the others whose indices are constant
     const bool coarse = crms != nullptr;
     const int npix = coarse ? (int)npix_c : M.npix;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
@@ -161,6 +162,16 @@ __global__ __launch_bounds__(BLOCK) void k_fullsky_stats(const Model* __restrict
     const Prep pr = sed_prep(c, th0, th1);
     __shared__ double sj[MAXB];
     if (threadIdx.x < nb) sj[threadIdx.x] = sed_eval(M, c, threadIdx.x, pr);
+    if (fused) {   // (a scalar load per other component and band inside the pixel's loop otherwise: in full-sky models every index is constant)
+        int oi = 0;
+        for (unsigned om = others; om; om &= om - 1, ++oi) {
+            const Comp& c2 = M.comp[__builtin_ctz(om)];
+            for (int t = threadIdx.x; t < Sp * nb; t += BLOCK) {
+                const int kk = t / nb, jj = t - kk * nb;
+                ocs[(oi * Sp + kk) * nb + jj] = c2.csed[s1 + kk - 1][jj];
+            }
+        }
+    }
     __syncthreads();
     const int wave = threadIdx.x >> 6;
     for (int kk = 0; kk < Sp; ++kk) {
@@ -183,15 +194,23 @@ __global__ __launch_bounds__(BLOCK) void k_fullsky_stats(const Model* __restrict
                 }
             }
         }
-        if (fused && live)
-            for (unsigned om = others; om; om &= om - 1) {
+        if (fused && live) {
+            int oi = 0;
+            for (unsigned om = others; om; om &= om - 1, ++oi) {
                 const Comp& c2 = M.comp[__builtin_ctz(om)];
-                double t0, t1;
-                load_theta(M, c2, i, k, t0, t1);
-                const Prep p2 = sed_prep(c2, t0, t1);
                 const double a2 = c2.amp[(long long)(k - 1) * npix + i];
-                for (int j = 0; j < nb; ++j) col[j * BLOCK] = col[j * BLOCK] - comp_signal(M, c2, i, k, j, a2, p2);
+                if (c2.type >= DANGX_POWERLAW && c2.type <= DANGX_CMB && ((c2.const_planes >> (k - 1)) & 1)) {
+                    // comp_signal of a diffuse component with constant indices: amplitude * the host-evaluated row
+                    const double* row = ocs + (oi * Sp + kk) * nb;
+                    for (int j = 0; j < nb; ++j) col[j * BLOCK] = col[j * BLOCK] - a2 * row[j];
+                } else {
+                    double t0, t1;
+                    load_theta(M, c2, i, k, t0, t1);
+                    const Prep p2 = sed_prep(c2, t0, t1);
+                    for (int j = 0; j < nb; ++j) col[j * BLOCK] = col[j * BLOCK] - comp_signal(M, c2, i, k, j, a2, p2);
+                }
             }
+        }
         // ---- the three sums of every band
         for (int j0 = 0; j0 < nb; j0 += 5) {
             double rmt[5];
@@ -515,7 +534,7 @@ int dangx_fullsky_sums(dangx_ctx* ctx, int what, const double* theta, double* ou
     const unsigned nblk = nblocks(coarse ? ctx->fs_npc : ctx->hm.npix);
     if (what == 3) {   // the chisq statistics: one pass
         const long long nwp = nblk;
-        const size_t ldsz = ((size_t)ctx->hm.nbands * BLOCK + (size_t)rows * (BLOCK / 64)) * sizeof(double);
+        const size_t ldsz = ((size_t)ctx->hm.nbands * BLOCK + (size_t)rows * (BLOCK / 64) + (size_t)MAXC * Sp * ctx->hm.nbands) * sizeof(double);
         if (ensure_partial(ctx, (long long)rows * nwp)) return 1;
         hipLaunchKernelGGL(k_fullsky_stats, dim3(nblk), dim3(BLOCK), ldsz, ctx->stream, ctx->dm, ctx->fs_comp, ctx->fs_s1, ctx->fs_s2, theta[0], theta[1],
                            coarse ? ctx->cs_data : ctx->fs_data, ctx->fs_others, (!coarse && ctx->fs_lazy) ? 1 : 0,
