@@ -329,6 +329,50 @@ __global__ __launch_bounds__(BLOCK) void k_udgrade_planes(const double* __restri
         }
 }
 
+// The same degrade with the loads shared out over a wave: wave w of the block takes coarse pixel 4 * block + w, lane ip reads child
+// ip of every plane (QW planes in flight: the 64 children of a pixel are ~15 runs of neighbouring RING pixels, so a load
+// instruction touches half as many lines as one thread per coarse pixel did), the values go through LDS ([pixel][plane][child], one
+// pad word per row) and thread (pixel, plane) adds its 64 children in NESTED order as before.  ratio == 64 only.
+constexpr int UDG_QW = 10, UDG_G = BLOCK / 64;
+__global__ __launch_bounds__(BLOCK) void k_udgrade_wave(const double* __restrict__ in, double* __restrict__ out,
+                                                        const int* __restrict__ n2r_in, const int* __restrict__ r2n_out,
+                                                        long long npix_in, long long npix_out, int mode, double scale, int layout,
+                                                        int nb, int nmaps, int s1, int nplanes) {
+    __shared__ double sh[UDG_G][UDG_QW][65];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long o = (long long)blockIdx.x * UDG_G + wave;
+    const int q0 = blockIdx.y * UDG_QW;
+    if (o < npix_out) {
+        const long long c = n2r_in[(long long)r2n_out[o] * 64 + lane];
+        double x[UDG_QW];
+#pragma unroll
+        for (int t = 0; t < UDG_QW; ++t) {
+            const int q = (q0 + t < nplanes) ? q0 + t : nplanes - 1;
+            const long long off = (layout == 0) ? (long long)q * npix_in : ((long long)(q % nb) * nmaps + (s1 + q / nb - 1)) * npix_in;
+            x[t] = in[off + c];
+        }
+#pragma unroll
+        for (int t = 0; t < UDG_QW; ++t) sh[wave][t][lane] = x[t];
+    }
+    __syncthreads();
+    if (threadIdx.x < UDG_G * UDG_QW) {
+        const int g = threadIdx.x / UDG_QW, t = threadIdx.x - g * UDG_QW;
+        const long long og = (long long)blockIdx.x * UDG_G + g;
+        if (og < npix_out && q0 + t < nplanes) {
+            double total = 0.0;
+            int nobs = 0;
+            for (int ip = 0; ip < 64; ++ip) {
+                double v = sh[g][t][ip];
+                if (mode == 1) v = v * v;
+                if (fabs(v - MISSVAL) > fabs(1e-5 * MISSVAL)) { total = total + v; ++nobs; }
+            }
+            double v = nobs ? total / nobs : MISSVAL;
+            if (mode == 1) v = sqrt(v) * scale;
+            out[(long long)(q0 + t) * npix_out + og] = v;
+        }
+    }
+}
+
 // Pixel-sharded form of the degrade step: coarse pixel o collects, in NEST child order, only those of its children whose
 // RING index lies in this shard [pix0, pix0 + npix_loc); it emits the sum of the good ones and their number.  The sums
 // of all shards (added by the caller) are finished by k_udgrade_finish -- with one shard that is k_udgrade bit for bit.
@@ -656,8 +700,15 @@ static int coarse_stage(dangx_ctx* ctx, int comp, int map_n, int nside, int samp
     const dim3 gq(nblocks(npc), Sp * nb), g1(nblocks(npc), 1);
     const double scale = (double)sample_nside * 1.0 / nside;
     const dim3 gp(nblocks(npc), (Sp * nb + UDG_QC - 1) / UDG_QC);
-    hipLaunchKernelGGL(k_udgrade_planes, gp, dim3(BLOCK), 0, ctx->stream, ctx->fs_data, ctx->cs_data, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
-                       ratio, 0, scale, 0, nb, ctx->hm.nmaps, s1, Sp * nb);
+    static const bool wave_on = [] { const char* e = getenv("DANGX_UDGRADE_WAVE"); return !(e && e[0] == '0'); }();  // A/B switch
+    const bool by_wave = wave_on && ratio == 64;
+    const dim3 gw((unsigned)((npc + UDG_G - 1) / UDG_G), (Sp * nb + UDG_QW - 1) / UDG_QW);
+    if (by_wave)
+        hipLaunchKernelGGL(k_udgrade_wave, gw, dim3(BLOCK), 0, ctx->stream, ctx->fs_data, ctx->cs_data, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
+                           0, scale, 0, nb, ctx->hm.nmaps, s1, Sp * nb);
+    else
+        hipLaunchKernelGGL(k_udgrade_planes, gp, dim3(BLOCK), 0, ctx->stream, ctx->fs_data, ctx->cs_data, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
+                           ratio, 0, scale, 0, nb, ctx->hm.nmaps, s1, Sp * nb);
     // the degraded rms and mask: the kept copy of this plane set if the maps have not changed since, else degraded and kept
     static const bool keep_on = [] { const char* e = getenv("DANGX_COARSE_KEEP"); return !(e && e[0] == '0'); }();  // A/B switch
     dangx_ctx::CsKept* hit = nullptr;
@@ -669,8 +720,12 @@ static int coarse_stage(dangx_ctx* ctx, int comp, int map_n, int nside, int samp
         HIPCHK(ctx, hipMemcpyAsync(ctx->cs_mask, hit->mask, sizeof(double) * npc, hipMemcpyDeviceToDevice, ctx->stream));
         return 0;
     }
-    hipLaunchKernelGGL(k_udgrade_planes, gp, dim3(BLOCK), 0, ctx->stream, ctx->rms, ctx->cs_rms, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
-                       ratio, 1, scale, 1, nb, ctx->hm.nmaps, s1, Sp * nb);
+    if (by_wave)
+        hipLaunchKernelGGL(k_udgrade_wave, gw, dim3(BLOCK), 0, ctx->stream, ctx->rms, ctx->cs_rms, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
+                           1, scale, 1, nb, ctx->hm.nmaps, s1, Sp * nb);
+    else
+        hipLaunchKernelGGL(k_udgrade_planes, gp, dim3(BLOCK), 0, ctx->stream, ctx->rms, ctx->cs_rms, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
+                           ratio, 1, scale, 1, nb, ctx->hm.nmaps, s1, Sp * nb);
     hipLaunchKernelGGL(k_udgrade, g1, dim3(BLOCK), 0, ctx->stream, ctx->mask, ctx->cs_mask, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
                        ratio, 1, 2, scale, 0, nb, ctx->hm.nmaps, s1);
     HIPCHK(ctx, hipGetLastError());
