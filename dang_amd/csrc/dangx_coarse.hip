@@ -329,44 +329,60 @@ __global__ __launch_bounds__(BLOCK) void k_udgrade_planes(const double* __restri
         }
 }
 
-// The same degrade with the loads shared out over a wave: wave w of the block takes coarse pixel 4 * block + w, lane ip reads child
-// ip of every plane (QW planes in flight: the 64 children of a pixel are ~15 runs of neighbouring RING pixels, so a load
-// instruction touches half as many lines as one thread per coarse pixel did), the values go through LDS ([pixel][plane][child], one
-// pad word per row) and thread (pixel, plane) adds its 64 children in NESTED order as before.  ratio == 64 only.
+// The same degrade with the loads shared out over a wave: lane l of wave w reads one child of every plane (QW planes in flight) --
+// ratio <= 64: the wave takes 64 / ratio coarse pixels, lane l = child l % ratio of its pixel l / ratio; ratio > 64: one coarse pixel,
+// its children in rounds of 64.  The children of a coarse pixel are a few runs of neighbouring RING pixels, so a load instruction
+// touches far fewer lines than with one thread per coarse pixel (64 children: 0.5 ms against 2.07 ms per sweep at C3).  The values
+// go through LDS ([wave][plane][lane], one pad word per row) and one thread per (coarse pixel, plane) adds its children in NESTED
+// order as before.  ratio: a power of four.
 constexpr int UDG_QW = 10, UDG_G = BLOCK / 64;
 __global__ __launch_bounds__(BLOCK) void k_udgrade_wave(const double* __restrict__ in, double* __restrict__ out,
                                                         const int* __restrict__ n2r_in, const int* __restrict__ r2n_out,
-                                                        long long npix_in, long long npix_out, int mode, double scale, int layout,
-                                                        int nb, int nmaps, int s1, int nplanes) {
+                                                        long long npix_in, long long npix_out, int ratio, int mode, double scale,
+                                                        int layout, int nb, int nmaps, int s1, int nplanes) {
     __shared__ double sh[UDG_G][UDG_QW][65];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long long o = (long long)blockIdx.x * UDG_G + wave;
+    const int cpw = (ratio < 64) ? 64 / ratio : 1, rounds = (ratio > 64) ? ratio / 64 : 1, per = (ratio < 64) ? ratio : 64;
     const int q0 = blockIdx.y * UDG_QW;
-    if (o < npix_out) {
-        const long long c = n2r_in[(long long)r2n_out[o] * 64 + lane];
-        double x[UDG_QW];
+    const long long o0 = ((long long)blockIdx.x * UDG_G + wave) * cpw;          // first coarse pixel of the wave
+    const long long ol = o0 + lane / per;                                        // the lane's coarse pixel
+    // the summing threads: (wave g, pixel u of the wave, plane t), several rounds of the block when there are more than BLOCK of them
+    const int nsum = UDG_G * cpw * UDG_QW;
+    double total[3] = {0.0, 0.0, 0.0};
+    int nobs[3] = {0, 0, 0};
+    for (int rd = 0; rd < rounds; ++rd) {
+        if (ol < npix_out) {
+            const long long c = n2r_in[(long long)r2n_out[ol] * ratio + rd * 64 + lane % per];
+            double x[UDG_QW];
 #pragma unroll
-        for (int t = 0; t < UDG_QW; ++t) {
-            const int q = (q0 + t < nplanes) ? q0 + t : nplanes - 1;
-            const long long off = (layout == 0) ? (long long)q * npix_in : ((long long)(q % nb) * nmaps + (s1 + q / nb - 1)) * npix_in;
-            x[t] = in[off + c];
-        }
-#pragma unroll
-        for (int t = 0; t < UDG_QW; ++t) sh[wave][t][lane] = x[t];
-    }
-    __syncthreads();
-    if (threadIdx.x < UDG_G * UDG_QW) {
-        const int g = threadIdx.x / UDG_QW, t = threadIdx.x - g * UDG_QW;
-        const long long og = (long long)blockIdx.x * UDG_G + g;
-        if (og < npix_out && q0 + t < nplanes) {
-            double total = 0.0;
-            int nobs = 0;
-            for (int ip = 0; ip < 64; ++ip) {
-                double v = sh[g][t][ip];
-                if (mode == 1) v = v * v;
-                if (fabs(v - MISSVAL) > fabs(1e-5 * MISSVAL)) { total = total + v; ++nobs; }
+            for (int t = 0; t < UDG_QW; ++t) {
+                const int q = (q0 + t < nplanes) ? q0 + t : nplanes - 1;
+                const long long off = (layout == 0) ? (long long)q * npix_in : ((long long)(q % nb) * nmaps + (s1 + q / nb - 1)) * npix_in;
+                x[t] = in[off + c];
             }
-            double v = nobs ? total / nobs : MISSVAL;
+#pragma unroll
+            for (int t = 0; t < UDG_QW; ++t) sh[wave][t][lane] = x[t];
+        }
+        __syncthreads();
+        int slot = 0;
+        for (int a = threadIdx.x; a < nsum; a += BLOCK, ++slot) {
+            const int g = a / (cpw * UDG_QW), r = a - g * cpw * UDG_QW, u = r / UDG_QW, t = r - u * UDG_QW;
+            const long long og = ((long long)blockIdx.x * UDG_G + g) * cpw + u;
+            if (og < npix_out && q0 + t < nplanes)
+                for (int ip = 0; ip < per; ++ip) {
+                    double v = sh[g][t][u * per + ip];
+                    if (mode == 1) v = v * v;
+                    if (fabs(v - MISSVAL) > fabs(1e-5 * MISSVAL)) { total[slot] = total[slot] + v; ++nobs[slot]; }
+                }
+        }
+        __syncthreads();
+    }
+    int slot = 0;
+    for (int a = threadIdx.x; a < nsum; a += BLOCK, ++slot) {
+        const int g = a / (cpw * UDG_QW), r = a - g * cpw * UDG_QW, u = r / UDG_QW, t = r - u * UDG_QW;
+        const long long og = ((long long)blockIdx.x * UDG_G + g) * cpw + u;
+        if (og < npix_out && q0 + t < nplanes) {
+            double v = nobs[slot] ? total[slot] / nobs[slot] : MISSVAL;
             if (mode == 1) v = sqrt(v) * scale;
             out[(long long)(q0 + t) * npix_out + og] = v;
         }
@@ -701,11 +717,13 @@ static int coarse_stage(dangx_ctx* ctx, int comp, int map_n, int nside, int samp
     const double scale = (double)sample_nside * 1.0 / nside;
     const dim3 gp(nblocks(npc), (Sp * nb + UDG_QC - 1) / UDG_QC);
     static const bool wave_on = [] { const char* e = getenv("DANGX_UDGRADE_WAVE"); return !(e && e[0] == '0'); }();  // A/B switch
-    const bool by_wave = wave_on && ratio == 64;
-    const dim3 gw((unsigned)((npc + UDG_G - 1) / UDG_G), (Sp * nb + UDG_QW - 1) / UDG_QW);
+    // (ratio 4: 16 pixels x 4 waves x 10 planes = 640 summing threads, three rounds of the block: the kernel's three slots)
+    const bool by_wave = wave_on && ratio >= 4;
+    const long long per_block = (long long)UDG_G * ((ratio < 64) ? 64 / ratio : 1);
+    const dim3 gw((unsigned)((npc + per_block - 1) / per_block), (Sp * nb + UDG_QW - 1) / UDG_QW);
     if (by_wave)
         hipLaunchKernelGGL(k_udgrade_wave, gw, dim3(BLOCK), 0, ctx->stream, ctx->fs_data, ctx->cs_data, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
-                           0, scale, 0, nb, ctx->hm.nmaps, s1, Sp * nb);
+                           ratio, 0, scale, 0, nb, ctx->hm.nmaps, s1, Sp * nb);
     else
         hipLaunchKernelGGL(k_udgrade_planes, gp, dim3(BLOCK), 0, ctx->stream, ctx->fs_data, ctx->cs_data, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
                            ratio, 0, scale, 0, nb, ctx->hm.nmaps, s1, Sp * nb);
@@ -722,7 +740,7 @@ static int coarse_stage(dangx_ctx* ctx, int comp, int map_n, int nside, int samp
     }
     if (by_wave)
         hipLaunchKernelGGL(k_udgrade_wave, gw, dim3(BLOCK), 0, ctx->stream, ctx->rms, ctx->cs_rms, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
-                           1, scale, 1, nb, ctx->hm.nmaps, s1, Sp * nb);
+                           ratio, 1, scale, 1, nb, ctx->hm.nmaps, s1, Sp * nb);
     else
         hipLaunchKernelGGL(k_udgrade_planes, gp, dim3(BLOCK), 0, ctx->stream, ctx->rms, ctx->cs_rms, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
                            ratio, 1, scale, 1, nb, ctx->hm.nmaps, s1, Sp * nb);

@@ -27,7 +27,8 @@ def test_device_udgrade_matches_the_restatement(built):
 
 
 @pytest.mark.parametrize("lnl,ml_mode,cnside,prior", [("chisq", "sample", 4, None), ("chisq", "optimize", 8, None),
-                                                      ("chisq", "sample", 2, None),   # 64 children per coarse pixel: k_udgrade_wave
+                                                      ("chisq", "sample", 2, None),   # 64 children per coarse pixel: one round of k_udgrade_wave
+                                                      ("chisq", "sample", 1, None),   # 256: four rounds
                                                       ("marginal", "sample", 2, None), ("prior", "sample", 4, None),
                                                       ("chisq", "sample", 2, "jeffreys"), ("chisq", "optimize", 4, "jeffreys")])
 def test_coarse_index_sampling_matches_oracle(built, lnl, ml_mode, cnside, prior):
