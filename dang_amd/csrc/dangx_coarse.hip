@@ -336,7 +336,9 @@ __global__ __launch_bounds__(BLOCK) void k_udgrade_planes(const double* __restri
 // go through LDS ([wave][plane][lane], one pad word per row) and one thread per (coarse pixel, plane) adds its children in NESTED
 // order as before.  ratio: a power of four.
 constexpr int UDG_QW = 10, UDG_G = BLOCK / 64;
-__global__ __launch_bounds__(BLOCK) void k_udgrade_wave(const double* __restrict__ in, double* __restrict__ out,
+template <bool FUSED>
+__global__ __launch_bounds__(BLOCK) void k_udgrade_wave(const Model* __restrict__ Mp, int comp_unused, unsigned others, int Sp,
+                                                        const double* __restrict__ in, double* __restrict__ out,
                                                         const int* __restrict__ n2r_in, const int* __restrict__ r2n_out,
                                                         long long npix_in, long long npix_out, int ratio, int mode, double scale,
                                                         int layout, int nb, int nmaps, int s1, int nplanes) {
@@ -357,8 +359,33 @@ __global__ __launch_bounds__(BLOCK) void k_udgrade_wave(const double* __restrict
 #pragma unroll
             for (int t = 0; t < UDG_QW; ++t) {
                 const int q = (q0 + t < nplanes) ? q0 + t : nplanes - 1;
-                const long long off = (layout == 0) ? (long long)q * npix_in : ((long long)(q % nb) * nmaps + (s1 + q / nb - 1)) * npix_in;
+                // FUSED: the raw maps (plane q = Stokes q / nb, band q % nb), cleaned below; else the staged / rms maps
+                const long long off = (FUSED || layout != 0) ? ((long long)(q % nb) * nmaps + (s1 + q / nb - 1)) * npix_in : (long long)q * npix_in;
                 x[t] = in[off + c];
+            }
+            if (FUSED) {   // data_raw minus every other component at the child pixel, dangx_fullsky_prepare's expression and order (:173-196)
+                const Model& M = *Mp;
+#pragma unroll
+                for (int t = 0; t < UDG_QW; ++t) {
+                    const int q = (q0 + t < nplanes) ? q0 + t : nplanes - 1, j = q % nb;
+                    if (s1 + q / nb == 1) x[t] = (x[t] - M.offset[j]) / M.gain[j];
+                }
+                for (unsigned om = others; om; om &= om - 1) {
+                    const Comp& c2 = M.comp[__builtin_ctz(om)];
+                    Prep p2[2];
+                    double a2[2];
+                    for (int kk = 0; kk < Sp; ++kk) {
+                        double t0, t1;
+                        load_theta(M, c2, (int)c, s1 + kk, t0, t1);
+                        p2[kk] = sed_prep(c2, t0, t1);
+                        a2[kk] = c2.amp[(long long)(s1 + kk - 1) * npix_in + c];
+                    }
+#pragma unroll
+                    for (int t = 0; t < UDG_QW; ++t) {
+                        const int q = (q0 + t < nplanes) ? q0 + t : nplanes - 1, kk = q / nb, j = q - kk * nb;
+                        x[t] = x[t] - comp_signal(M, c2, (int)c, s1 + kk, j, a2[kk], p2[kk]);
+                    }
+                }
             }
 #pragma unroll
             for (int t = 0; t < UDG_QW; ++t) sh[wave][t][lane] = x[t];
@@ -699,11 +726,18 @@ int dangx_udgrade(dangx_ctx* ctx, int mode, const double* map_in, int nside_in, 
 static int coarse_stage(dangx_ctx* ctx, int comp, int map_n, int nside, int sample_nside) {
     const long long npix = ctx->dims.npix;
     if (hp_tables(ctx, nside, sample_nside)) return 1;
-    if (dangx_fullsky_prepare(ctx, comp, map_n)) return 1;
+    const int r1 = nside / sample_nside, ratio = r1 * r1;
+    // the degrade with its loads shared out over a wave (k_udgrade_wave; DANGX_UDGRADE_WAVE=0: a thread per coarse pixel).  It CAN form
+    // the cleaned data at the child pixels itself (no staging pass, no staging buffer traffic: DANGX_COARSE_FUSE=1) -- measured SLOWER,
+    // 24.7 against 16.8 ms per iteration at C3 / Nside 128: the other components' SEDs are then evaluated in a gather-shaped launch,
+    // once per ten-plane chunk -- so the staging pass stays.
+    static const bool wave_on = [] { const char* e = getenv("DANGX_UDGRADE_WAVE"); return !(e && e[0] == '0'); }();
+    static const bool fuse_on = [] { const char* e = getenv("DANGX_COARSE_FUSE"); return e && e[0] == '1'; }();
+    const bool by_wave = wave_on && ratio >= 4, fuse_stage = by_wave && fuse_on;
+    if (fuse_stage ? fullsky_prepare_impl(ctx, comp, map_n, true) : dangx_fullsky_prepare(ctx, comp, map_n)) return 1;
     const int s1 = ctx->fs_s1, s2 = ctx->fs_s2, Sp = s2 - s1 + 1, nb = ctx->hm.nbands;
     ctx->fs_comp = -1;  // the staging buffer is ours now
     const long long npc = 12LL * sample_nside * sample_nside;
-    const int r1 = nside / sample_nside, ratio = r1 * r1;
     const long long need = (long long)Sp * nb * npc;
     if (need > ctx->cs_cap) {
         for (double** b : {&ctx->cs_data, &ctx->cs_rms, &ctx->cs_mask, &ctx->cs_index}) { if (*b) (void)hipFree(*b); *b = nullptr; }
@@ -716,13 +750,14 @@ static int coarse_stage(dangx_ctx* ctx, int comp, int map_n, int nside, int samp
     const dim3 gq(nblocks(npc), Sp * nb), g1(nblocks(npc), 1);
     const double scale = (double)sample_nside * 1.0 / nside;
     const dim3 gp(nblocks(npc), (Sp * nb + UDG_QC - 1) / UDG_QC);
-    static const bool wave_on = [] { const char* e = getenv("DANGX_UDGRADE_WAVE"); return !(e && e[0] == '0'); }();  // A/B switch
     // (ratio 4: 16 pixels x 4 waves x 10 planes = 640 summing threads, three rounds of the block: the kernel's three slots)
-    const bool by_wave = wave_on && ratio >= 4;
     const long long per_block = (long long)UDG_G * ((ratio < 64) ? 64 / ratio : 1);
     const dim3 gw((unsigned)((npc + per_block - 1) / per_block), (Sp * nb + UDG_QW - 1) / UDG_QW);
-    if (by_wave)
-        hipLaunchKernelGGL(k_udgrade_wave, gw, dim3(BLOCK), 0, ctx->stream, ctx->fs_data, ctx->cs_data, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
+    if (by_wave && fuse_stage)   // the cleaned data are formed at the child pixels: the staging pass above was skipped
+        hipLaunchKernelGGL(k_udgrade_wave<true>, gw, dim3(BLOCK), 0, ctx->stream, ctx->dm, comp, ctx->fs_others, Sp, ctx->sig, ctx->cs_data,
+                           ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc, ratio, 0, scale, 0, nb, ctx->hm.nmaps, s1, Sp * nb);
+    else if (by_wave)
+        hipLaunchKernelGGL(k_udgrade_wave<false>, gw, dim3(BLOCK), 0, ctx->stream, ctx->dm, comp, 0u, Sp, ctx->fs_data, ctx->cs_data, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
                            ratio, 0, scale, 0, nb, ctx->hm.nmaps, s1, Sp * nb);
     else
         hipLaunchKernelGGL(k_udgrade_planes, gp, dim3(BLOCK), 0, ctx->stream, ctx->fs_data, ctx->cs_data, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
@@ -739,7 +774,7 @@ static int coarse_stage(dangx_ctx* ctx, int comp, int map_n, int nside, int samp
         return 0;
     }
     if (by_wave)
-        hipLaunchKernelGGL(k_udgrade_wave, gw, dim3(BLOCK), 0, ctx->stream, ctx->rms, ctx->cs_rms, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
+        hipLaunchKernelGGL(k_udgrade_wave<false>, gw, dim3(BLOCK), 0, ctx->stream, ctx->dm, comp, 0u, Sp, ctx->rms, ctx->cs_rms, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
                            ratio, 1, scale, 1, nb, ctx->hm.nmaps, s1, Sp * nb);
     else
         hipLaunchKernelGGL(k_udgrade_planes, gp, dim3(BLOCK), 0, ctx->stream, ctx->rms, ctx->cs_rms, ctx->hp_n2r_f, ctx->hp_r2n_c, npix, npc,
