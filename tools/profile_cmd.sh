@@ -8,7 +8,7 @@ tag=$1; shift
 R=$(pwd); out=$R/gpurun_out/prof_$tag; mkdir -p "$out"
 export TMPDIR=/tmp
 B="python3 $R/$*"
-RE="k_(amp|index|plane|schur|sky|cg|Ax|rhs|reduce)"
+RE="k_(amp|index|plane|schur|sky|cg|Ax|rhs|reduce|fullsky|udgrade|chisq|coarse)"
 echo "[$tag] plain run"; $B > "$out/$tag.txt" 2> "$out/run.err"
 echo "[$tag] kernel trace"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o run -- $B > /dev/null 2> "$out/trace.err"
