@@ -141,7 +141,8 @@ __global__ __launch_bounds__(BLOCK) void k_fullsky_rows(const Model* __restrict_
 // here -- data_raw minus every other component in dangx_fullsky_prepare's order (:173-196), a plane's bands in the thread's LDS
 // column, each other component's index values / amplitude read once per plane -- instead of read from the staging buffer, which is
 // then never written.  Dynamic LDS: nb * BLOCK doubles (the column) + 3 * nb * Sp * (BLOCK / 64) (the wave sums).
-__global__ __launch_bounds__(BLOCK) void k_fullsky_stats(const Model* __restrict__ Mp, int comp, int s1, int s2, double th0, double th1,
+constexpr int FS_B = 10;   // maps in flight per thread in k_fullsky_stats
+__global__ __launch_bounds__(BLOCK, 4) void k_fullsky_stats(const Model* __restrict__ Mp, int comp, int s1, int s2, double th0, double th1,
                                                          const double* __restrict__ data, unsigned others, int fused,
                                                          const double* __restrict__ crms, const double* __restrict__ cmask,
                                                          long long npix_c, double* __restrict__ partial) {
@@ -178,15 +179,15 @@ __global__ __launch_bounds__(BLOCK) void k_fullsky_stats(const Model* __restrict
         const int k = s1 + kk;
         const double amp = in ? c.amp[(long long)(k - 1) * M.npix + il] : 0.0;
         // ---- the plane's cleaned data -> the column
-        for (int j0 = 0; j0 < nb; j0 += 5) {   // five bands' maps in flight
-            double d[5];
+        for (int j0 = 0; j0 < nb; j0 += FS_B) {   // FS_B bands' maps in flight
+            double d[FS_B];
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
+            for (int t = 0; t < FS_B; ++t) {
                 const int j = (j0 + t < nb) ? j0 + t : nb - 1;
                 d[t] = fused ? M.sig[((long long)j * M.nmaps + (k - 1)) * npix + ic] : data[((long long)kk * nb + j) * npix + ic];
             }
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
+            for (int t = 0; t < FS_B; ++t) {
                 const int j = j0 + t;
                 if (j < nb) {
                     if (fused && k == 1) d[t] = (d[t] - M.offset[j]) / M.gain[j];
@@ -212,15 +213,15 @@ __global__ __launch_bounds__(BLOCK) void k_fullsky_stats(const Model* __restrict
             }
         }
         // ---- the three sums of every band
-        for (int j0 = 0; j0 < nb; j0 += 5) {
-            double rmt[5];
+        for (int j0 = 0; j0 < nb; j0 += FS_B) {
+            double rmt[FS_B];
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
+            for (int t = 0; t < FS_B; ++t) {
                 const int j = (j0 + t < nb) ? j0 + t : nb - 1;
                 rmt[t] = coarse ? crms[((long long)kk * nb + j) * npix + ic] : M.rms[((long long)j * M.nmaps + (k - 1)) * npix + ic];
             }
 #pragma unroll
-          for (int t = 0; t < 5; ++t) {
+          for (int t = 0; t < FS_B; ++t) {
             const int j = j0 + t;
             if (j >= nb) break;
             double v0 = 0.0, v1 = 0.0, v2 = 0.0;
