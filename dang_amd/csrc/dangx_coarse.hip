@@ -14,7 +14,9 @@ namespace {
 // chain itself (proposal, prior, accept) runs on the host between the all-reduces (dang_amd/api.py).
 
 // data_raw minus every other component for planes s1..s2 (:173-196, all pixels) -> out[(kk*nb + j)*npix + i]
-constexpr int FS_B = 10;   // maps in flight per thread in k_fullsky_prepare / k_fullsky_stats
+constexpr int FP_B = 10;   // maps in flight per thread in k_fullsky_prepare
+constexpr int FS_B = 5;    // ... in k_fullsky_stats: six waves per SIMD (80 registers, 19 of them spilled) beat four with ten maps in flight,
+                           // 11.3 against 11.8 ms per full-sky iteration at C3 on one device; eight waves spill 39
 __global__ __launch_bounds__(BLOCK) void k_fullsky_prepare(const Model* __restrict__ Mp, int comp, int s1, int s2,
                                                            unsigned others, double* __restrict__ out) {
     // a plane's bands in the thread's LDS column (dynamic LDS: nb * BLOCK doubles): five maps in flight, every other component's
@@ -27,15 +29,15 @@ __global__ __launch_bounds__(BLOCK) void k_fullsky_prepare(const Model* __restri
     const bool in = i < npix;
     const int ic = in ? i : 0;
     for (int k = s1; k <= s2; ++k) {
-        for (int j0 = 0; j0 < nb; j0 += FS_B) {
-            double d[FS_B];
+        for (int j0 = 0; j0 < nb; j0 += FP_B) {
+            double d[FP_B];
 #pragma unroll
-            for (int t = 0; t < FS_B; ++t) {
+            for (int t = 0; t < FP_B; ++t) {
                 const int j = (j0 + t < nb) ? j0 + t : nb - 1;
                 d[t] = M.sig[((long long)j * M.nmaps + (k - 1)) * npix + ic];
             }
 #pragma unroll
-            for (int t = 0; t < FS_B; ++t) {
+            for (int t = 0; t < FP_B; ++t) {
                 const int j = j0 + t;
                 if (j < nb) {
                     if (k == 1) d[t] = (d[t] - M.offset[j]) / M.gain[j];
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(BLOCK) void k_fullsky_rows(const Model* __restrict_
 // here -- data_raw minus every other component in dangx_fullsky_prepare's order (:173-196), a plane's bands in the thread's LDS
 // column, each other component's index values / amplitude read once per plane -- instead of read from the staging buffer, which is
 // then never written.  Dynamic LDS: nb * BLOCK doubles (the column) + 3 * nb * Sp * (BLOCK / 64) (the wave sums).
-__global__ __launch_bounds__(BLOCK, 4) void k_fullsky_stats(const Model* __restrict__ Mp, int comp, int s1, int s2, double th0, double th1,
+__global__ __launch_bounds__(BLOCK, 6) void k_fullsky_stats(const Model* __restrict__ Mp, int comp, int s1, int s2, double th0, double th1,
                                                          const double* __restrict__ data, unsigned others, int fused,
                                                          const double* __restrict__ crms, const double* __restrict__ cmask,
                                                          long long npix_c, double* __restrict__ partial) {
