@@ -339,6 +339,8 @@ int dangx_index_plain_sum(dangx_ctx *ctx, int comp, int nind, int map_n, double 
  *   dangx_fullsky_sums   : LOCAL sums at theta[2]: what = 0 evaluate_lnL (1 value); 1 evaluate_marginal_lnL
  *                          (2*nbands*Sp values: TNd(j,k), TNT(j,k) interleaved, j outer / k inner; the caller forms
  *                          sum -1/2 TNd^2/TNT after the all-reduce); 2 the jeffreys-prior sum (1 value).
+ *                          3 the chisq likelihood's sufficient statistics about theta (3*nbands*Sp values: W0, U, V of
+ *                          (band j, plane k) at 3*(j*Sp + k): sum r0^2, sum r0 a/sigma, sum a^2/sigma^2 with r0 = (d - a s_j(theta))/sigma).
  *   dangx_fill_index     : c%indices(:, s1:s2, nind) = value for every pixel (:329, :483).
  *   dangx_gain_sums      : out[0] = sum map2*N_inv*map1, out[1] = sum map1*N_inv*map1 of fit_band_gain (:606-607). */
 int dangx_fullsky_prepare(dangx_ctx *ctx, int comp, int map_n);
@@ -361,7 +363,10 @@ int dangx_fullsky_finish_coarse(dangx_ctx *ctx, int comp, int map_n, int nside, 
 
 /* ---- the SKY-WIDE steps of the Gibbs loop, chain included (dang_amd/csrc/dangx_sky.hip) --------------------------------
  * One number describes the whole sky in these steps: a Metropolis step is a pass over the maps that leaves a few sums, plus
- * a few scalar operations.  Each entry point runs the whole chain of the reference procedure it names, so the chain exists
+ * a few scalar operations -- or, for the chisq likelihood of a diffuse component (whose model of a band is amplitude(pixel) x
+ * one SED value), ONE pass per sweep that leaves the sufficient statistics W0, U, V per (band, plane) about the starting point:
+ * -2 lnL(theta) = sum [W0 - 2 ds U + ds^2 V], every proposal then costs nbands SED evaluations on the host (dangx_fullsky_sums
+ * selector 3; the same chain to rounding, DANGX_FULLSKY_STATS=0 for a pass per proposal).  Each entry point runs the whole chain of the reference procedure it names, so the chain exists
  * once for every host language.  ctxs[0..nctx) are the contexts of THIS process in shard order (nctx = 1: a whole-sky
  * context, or one context per process); a sky-wide sum is the contexts' sums added in shard order, then summed over the
  * ranks through ctxs[0]'s dangx_set_allreduce callback.  Random numbers: Philox4x32-10 keyed by (seed, stream, pixel label
